@@ -1,0 +1,202 @@
+/*
+ * smmhip.h — C ABI of libsmmhip.so: the MI355X (gfx950) backend for the BGP
+ * parallel-tempering hot path of floswald/SMM.jl.
+ *
+ * The reference has no FFI; its two seams are Julia dynamic dispatch:
+ *   (1) computeNextIteration!(algo::MAlgoBGP)      src/mopt/AlgoBGP.jl:589-640
+ *       (called once per iteration from run!       src/mopt/AlgoAbstract.jl:38-45)
+ *   (2) the objective contract f(ev::Eval)::Eval   src/mopt/mprob.jl:175-205
+ * A Julia maintainer binds the functions below with `ccall`;
+ * the Python host layer in smm.jl_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, <0 = smm_status_t error code;
+ *     smm_last_error(ctx) returns a human readable message (ctx may be NULL for
+ *     errors raised by smm_ctx_create).
+ *   - all pointers are HOST pointers unless the name ends in `_dev`.
+ *   - host buffers are borrowed for the duration of the call only.
+ *   - chain ids and iteration numbers in *downloaded* data are 1-based exactly
+ *     as in the reference (BGPChain.id, BGPChain.exchanged, BGPChain.best_id;
+ *     AlgoBGP.jl:42-110): exchanged==0 means "no exchange", best_id==-1 "unset".
+ *   - all floating point data is IEEE double (the reference is Float64 throughout).
+ *   - a ctx is single-threaded (one caller thread), like the reference's master task.
+ */
+#ifndef SMMHIP_H
+#define SMMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMMHIP_ABI_VERSION 1
+
+/* Numerical contract shared with the oracle (oracle/smm_oracle.c):
+ * the ns simulated draws of one moment are summed as SMM_REDUCE_LANES lane-strided
+ * sequential partial sums (lane l takes draws l, l+256, l+512, ...), each group of 64
+ * partials is combined by a halving tree (offsets 32,16,8,4,2,1) and the 4 group
+ * totals are added left to right.  Replaces mean(X,dims=2), ObjExamples.jl:79. */
+#define SMM_REDUCE_LANES 256
+
+typedef enum {
+    SMM_OK = 0,
+    SMM_ERR_INVALID_ARG = -1,
+    SMM_ERR_NO_DEVICE = -2,          /* no HIP device / HIP runtime failure          */
+    SMM_ERR_NEGATIVE_OBJECTIVE = -3, /* objective value <0 or NaN: AlgoBGP.jl:341     */
+    SMM_ERR_NO_DRAW_IN_SUPPORT = -4, /* mysample exhausted smpl_iters: AlgoBGP.jl:409 */
+    SMM_ERR_BAD_BATCH = -5,          /* batch_size not a divisor of np: AlgoBGP.jl:95-103 (quirk not replicated) */
+    SMM_ERR_MAXITER = -6,            /* step beyond opts.maxiter (history capacity)   */
+    SMM_ERR_HIP = -7,
+    SMM_ERR_STATE = -8
+} smm_status_t;
+
+/* objective_id: device objectives replacing MProb.objfunc (mprob.jl:159,182) */
+typedef enum {
+    SMM_OBJ_NORM = 0,   /* objfunc_norm, ObjExamples.jl:59-116 (requires np==nm)          */
+    SMM_OBJ_BANANA = 1, /* banana, ObjExamples.jl:251-265, generalised to np dims        */
+    SMM_OBJ_NORM_FAILBOX = 2 /* objfunc_norm that "throws" (status=-2, mprob.jl:183-186)
+                                when obj_params[0] <= theta_0 <= obj_params[1]; the role of
+                                Testobj_fails, ObjExamples.jl:27-32 */
+} smm_objective_t;
+
+/* MProb (mprob.jl:29-53) flattened: parameters to sample with bounds and start
+ * values (addSampledParam!, mprob.jl:81-98), data moments and weights
+ * (addMoment!, mprob.jl:123-155). */
+typedef struct {
+    int32_t np;              /* number of sampled parameters                              */
+    int32_t nm;              /* number of moments                                         */
+    int32_t ns;              /* simulated draws per moment (10000 in ObjExamples.jl:76)   */
+    int32_t objective_id;    /* smm_objective_t                                           */
+    const double* init;      /* [np] MProb.initial_value                                  */
+    const double* lb;        /* [np]                                                      */
+    const double* ub;        /* [np]                                                      */
+    const double* mom;       /* [nm] data moments                                         */
+    const double* w;         /* [nm] weights; NaN = no weight (ObjExamples.jl:96-97)      */
+    const double* obj_params;/* objective specific blob, may be NULL                      */
+    int32_t n_obj_params;
+    int32_t reserved;
+} smm_problem_t;
+
+/* opts Dict of MAlgoBGP (AlgoBGP.jl:505-537) flattened; per-chain vectors are
+ * supplied already expanded (sigma[i] = opts["sigma"]*temps[i], AlgoBGP.jl:508,518). */
+typedef struct {
+    int32_t N;               /* chains owned by THIS context (local shard)                */
+    int32_t maxiter;         /* history capacity T (BGPChain(n), AlgoBGP.jl:78)           */
+    const double* sigma;     /* [N] initial proposal std-dev in [0,1]-space               */
+    const double* acc_tuner; /* [N] AlgoBGP.jl:523                                        */
+    const double* min_improve;/* [N] AlgoBGP.jl:522                                       */
+    int32_t sigma_update_steps; /* AlgoBGP.jl:519                                         */
+    int32_t smpl_iters;         /* AlgoBGP.jl:521                                         */
+    double  sigma_adjust_by;    /* AlgoBGP.jl:520                                         */
+    int32_t batch_size;         /* AlgoBGP.jl:524; must divide np                         */
+    int32_t exchange_from_iter; /* 2 in the reference (AlgoBGP.jl:637)                    */
+    uint64_t seed;
+    int32_t chain_offset;    /* global id (0-based) of local chain 0                      */
+    int32_t N_global;        /* total chains over all shards (== N on one GPU)            */
+    int32_t device;          /* HIP device ordinal                                        */
+    int32_t reserved;
+} smm_bgp_opts_t;
+
+/* Injected randomness ("parity mode").  Any pointer may be NULL = use the built-in
+ * counter-based generator (Philox4x32-10 + Box-Muller, documented in DESIGN.md).
+ * Tables cover the LOCAL shard's chains, except `pairs` which is global. */
+typedef struct {
+    const double* probs_acc;   /* [T][N]  the MH uniforms, BGPChain.probs_acc AlgoBGP.jl:85    */
+    const double* prop_normals;/* [T][K][np][N] standard normals for try k of mysample         */
+    int32_t prop_tries;        /* K; tries beyond K raise SMM_ERR_NO_DRAW_IN_SUPPORT           */
+    int32_t n_pairs;           /* pairs per iteration in `pairs` (N_global, or N_global-1 <3)  */
+    const int32_t* pairs;      /* [T][n_pairs][2] 0-based global chain ids i<j, AlgoBGP.jl:656 */
+    const double* Z;           /* [nm][ns] shock matrix of objfunc_norm (seed-1234 draws)      */
+} smm_tables_t;
+
+/* Caller-allocated SoA download buffers for iterations t0..t1-1 (0-based t = iter-1).
+ * nt = t1-t0.  Any pointer may be NULL (skipped).  Mirrors history(c) AlgoBGP.jl:138-160
+ * plus the Eval fields read by params()/allAccepted() (:117-131). */
+typedef struct {
+    double* value;      /* [nt][N]      evals[t].value                         */
+    double* prob;       /* [nt][N]      evals[t].prob                          */
+    double* curr_val;   /* [nt][N]                                              */
+    double* best_val;   /* [nt][N]                                              */
+    double* params;     /* [nt][np][N]                                          */
+    double* sim_moments;/* [nt][nm][N]                                          */
+    int32_t* best_id;   /* [nt][N]      1-based iteration                      */
+    int32_t* exchanged; /* [nt][N]      1-based partner id, 0 none             */
+    uint8_t* accepted;  /* [nt][N]                                              */
+    int8_t*  status;    /* [nt][N]      evals[t].status                        */
+} smm_history_t;
+
+/* Per-chain scalar state (what save/readMalgo/restart! need besides history;
+ * AlgoAbstract.jl:83-102, AlgoBGP.jl:759-884). Caller-allocated, any may be NULL. */
+typedef struct {
+    int32_t iter;        /* out/in: completed iterations                        */
+    int32_t reserved;
+    double* sigma;       /* [N]                                                  */
+    double* accept_rate; /* [N]                                                  */
+    double* la_value;    /* [N] last accepted record (getLastAccepted :217)      */
+    double* la_prob;     /* [N]                                                  */
+    double* la_params;   /* [np][N]                                              */
+    double* la_sim_moments; /* [nm][N]                                           */
+    int8_t* la_status;   /* [N]                                                  */
+    int32_t* n_noex;     /* [N] iterations with exchanged==0 (set_acceptRate! :253-257) */
+    int32_t* n_acc_noex; /* [N] accepted among those                             */
+    double* best_val;    /* [N]                                                  */
+    int32_t* best_id;    /* [N]                                                  */
+} smm_state_t;
+
+typedef struct {
+    double step_ms;       /* device time of the last smm_bgp_step (hipEvent)           */
+    double iter_kernel_ms;/* summed device time of the per-iteration chain kernel       */
+    double exch_kernel_ms;/* summed device time of the exchange kernels                 */
+    int64_t chain_evals;  /* chain evaluations performed by the last smm_bgp_step      */
+    int32_t iters;
+    int32_t reserved;
+} smm_timing_t;
+
+int  smm_abi_version(void);
+int  smm_device_count(void);
+
+/* MAlgoBGP(m,opts) constructor, AlgoBGP.jl:505-537 + BGPChain ctor :78-109 */
+int  smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts,
+                    const smm_tables_t* tables /* may be NULL */, void** ctx_out);
+void smm_ctx_destroy(void* ctx);
+const char* smm_last_error(void* ctx);
+
+/* n_iters x computeNextIteration! (AlgoBGP.jl:589-640) incl. exchangeMoves!
+ * (:647-716); single shard only (N_global == N). Blocks until the device is done. */
+int  smm_bgp_step(void* ctx, int32_t n_iters);
+/* same, but returns after enqueueing; smm_sync waits and reports device errors. */
+int  smm_bgp_step_async(void* ctx, int32_t n_iters);
+int  smm_sync(void* ctx);
+
+/* Sharded form (one ctx per GPU), the three phases of one iteration:
+ *   smm_bgp_local_step : next_eval for the local chains (AlgoBGP.jl:272-294)
+ *   smm_bgp_export_records_dev : pack last-accepted records of the local chains into
+ *        rec_dev [(np+nm+3)][N] doubles (value, prob, status, params, simM) for the
+ *        RCCL all-gather
+ *   smm_bgp_exchange_dev : exchangeMoves! over all N_global chains given the gathered
+ *        records [G][(np+nm+3)][N] (identical on every rank), applied to local chains */
+int  smm_bgp_local_step(void* ctx);
+int  smm_bgp_record_doubles(void* ctx);
+int  smm_bgp_export_records_dev(void* ctx, void* rec_dev);
+int  smm_bgp_exchange_dev(void* ctx, const void* gathered_dev);
+/* the HIP stream all of the ctx's work is enqueued on (hipStream_t as void*) */
+void* smm_stream(void* ctx);
+
+/* batched evaluateObjective(m,p) (mprob.jl:175-188) for M parameter vectors
+ * params [np][M] -> value[M], sim_moments[nm][M], status[M].  Used by tests and by
+ * the other callers of evaluateObjective (slices.jl:153, econometrics.jl:42). */
+int  smm_eval_batch(void* ctx, const double* params, int32_t M,
+                    double* value, double* sim_moments, int8_t* status);
+
+int  smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out);
+int  smm_get_state(void* ctx, smm_state_t* out);
+int  smm_set_state(void* ctx, const smm_state_t* in, const smm_history_t* hist /* iterations 0..iter-1 */);
+int  smm_get_timing(void* ctx, smm_timing_t* out);
+/* copy of the shock matrix actually used, [nm][ns] */
+int  smm_get_Z(void* ctx, double* Z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMMHIP_H */

@@ -1,0 +1,86 @@
+"""Loader of the CPU oracle (oracle/smm_oracle.c). TEST INFRASTRUCTURE ONLY — imported by
+tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke(), never by smm.jl_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import smm_jl_amd as S
+from smm_jl_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmm_oracle.so")
+
+_ORC_ONLY = [
+    ("orc_bgp_export_records", None, [C.c_void_p, A.c_double_p]),
+    ("orc_bgp_exchange", C.c_int, [C.c_void_p, A.c_double_p]),
+    ("orc_set_mode", None, [C.c_void_p, C.c_int, C.c_int]),
+    ("orc_gen_Z", None, [C.c_uint64, C.c_int, C.c_int, A.c_double_p]),
+    ("orc_gen_pairs", None, [C.c_uint64, C.c_int32, C.c_int32, A.c_int32_p]),
+    ("orc_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("orc_max_threads", C.c_int, []),
+]
+_SHARED = ["smm_ctx_create", "smm_ctx_destroy", "smm_last_error", "smm_bgp_step", "smm_bgp_local_step",
+           "smm_bgp_record_doubles", "smm_eval_batch", "smm_get_history", "smm_get_state", "smm_get_Z"]
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or \
+            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "smm_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsmm_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(LIB_PATH)
+        A.bind(lib, [s for s in A.SYMBOLS if s[0] in _SHARED], "smm_", "orc_")
+        A.bind(lib, _ORC_ONLY)
+        _lib = lib
+    return _lib
+
+
+class OracleContext(S.BGPContext):
+    def __init__(self, problem, opts, tables=None, threads=1, regen_z=False):
+        super().__init__(load(), "orc_", problem, opts, tables)
+        self._lib.orc_set_mode(self._ctx, threads, int(regen_z))
+
+    def set_mode(self, threads=1, regen_z=False):
+        self._lib.orc_set_mode(self._ctx, threads, int(regen_z))
+
+    def export_records(self):
+        rec = np.empty((self.record_doubles(), self.N))
+        self._lib.orc_bgp_export_records(self._ctx, A.dptr(rec))
+        return rec
+
+    def exchange(self, gathered):
+        g = A.f64(gathered)
+        self._check(self._lib.orc_bgp_exchange(self._ctx, A.dptr(g)))
+
+
+def gen_Z(seed, nm, ns):
+    Z = np.empty((nm, ns))
+    load().orc_gen_Z(seed, nm, ns, A.dptr(Z))
+    return Z
+
+
+def gen_pairs(seed, t, Ng):
+    K = Ng - 1 if Ng < 3 else Ng
+    p = np.empty((max(K, 0), 2), np.int32)
+    if K > 0:
+        load().orc_gen_pairs(seed, t, Ng, p.ctypes.data_as(A.c_int32_p))
+    return p
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    load().orc_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def max_threads():
+    return load().orc_max_threads()

@@ -1,0 +1,721 @@
+/*
+ * smm_oracle.c — CPU restatement (plain C) of the BGP parallel-tempering hot path of
+ * floswald/SMM.jl.  TEST INFRASTRUCTURE ONLY: nothing in the product (smm.jl_amd/,
+ * libsmmhip.so) may link, import or call this file.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() use it, as the checker.
+ *
+ * PARITY STATUS: "parity unpinned" against the reference's own numbers.  The reference is
+ * Julia (no julia binary in the build container), its proposals draw from a non-seedable
+ * RandomDevice (src/SMM.jl:60, src/mopt/AlgoBGP.jl:404) and its tests hold no known-answer
+ * vector for this path.  What IS pinned here:
+ *   - the behavioural properties P1..P7 of test/test_BGPchain.jl, test/test_objfunc.jl,
+ *     test/test_algoBGP.jl (lifted into tests/test_oracle_properties.py),
+ *   - the analytic anchor of ObjExamples.jl:90-101 (Z == 0 => value = mean(((mu-mom)/w)^2)),
+ *   - Philox4x32-10 known-answer vectors (Random123 kat_vectors).
+ * Every function cites the reference lines it restates (paths relative to /root/reference).
+ *
+ * All randomness is either INJECTED (tables) or drawn from a counter-based generator
+ * (Philox4x32-10 + Box-Muller) whose definition is restated here independently of the
+ * HIP library.  Third-party arithmetic that the reference takes from Distributions.jl /
+ * Random (MvNormal rand, sample(..;replace=false), randn) cannot be reproduced bit-for-bit
+ * (unpinned dependency versions, Project.toml:28-29); only its distributional meaning is.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_OK 0
+#define ORC_ERR_INVALID_ARG (-1)
+#define ORC_ERR_NEGATIVE_OBJECTIVE (-3)
+#define ORC_ERR_NO_DRAW_IN_SUPPORT (-4)
+#define ORC_ERR_BAD_BATCH (-5)
+#define ORC_ERR_MAXITER (-6)
+
+#define ORC_OBJ_NORM 0
+#define ORC_OBJ_BANANA 1
+#define ORC_OBJ_NORM_FAILBOX 2
+
+#define ORC_REDUCE_LANES 256 /* numerical contract, see include/smmhip.h */
+
+/* same memory layout as smm_problem_t / smm_bgp_opts_t / smm_tables_t / smm_history_t /
+ * smm_state_t of include/smmhip.h so that one set of ctypes classes drives both. */
+typedef struct {
+    int32_t np, nm, ns, objective_id;
+    const double *init, *lb, *ub, *mom, *w, *obj_params;
+    int32_t n_obj_params, reserved;
+} orc_problem_t;
+
+typedef struct {
+    int32_t N, maxiter;
+    const double *sigma, *acc_tuner, *min_improve; /* [N_global] each */
+    int32_t sigma_update_steps, smpl_iters;
+    double sigma_adjust_by;
+    int32_t batch_size, exchange_from_iter;
+    uint64_t seed;
+    int32_t chain_offset, N_global, device, reserved;
+} orc_opts_t;
+
+typedef struct {
+    const double* probs_acc;
+    const double* prop_normals;
+    int32_t prop_tries, n_pairs;
+    const int32_t* pairs;
+    const double* Z;
+} orc_tables_t;
+
+typedef struct {
+    double *value, *prob, *curr_val, *best_val, *params, *sim_moments;
+    int32_t *best_id, *exchanged;
+    uint8_t* accepted;
+    int8_t* status;
+} orc_history_t;
+
+typedef struct {
+    int32_t iter, reserved;
+    double *sigma, *accept_rate, *la_value, *la_prob, *la_params, *la_sim_moments;
+    int8_t* la_status;
+    int32_t *n_noex, *n_acc_noex;
+    double* best_val;
+    int32_t* best_id;
+} orc_state_t;
+
+/* ------------------------------------------------------------------------------------ */
+/* Counter-based RNG: Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).                 */
+/* ------------------------------------------------------------------------------------ */
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void orc_philox4x32_10(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_10(ctr, key, out); }
+
+enum { STREAM_U = 1, STREAM_PROP = 2, STREAM_Z = 3, STREAM_PAIRS = 4 };
+
+static void stream_key(uint64_t seed, uint32_t stream, uint32_t key[2]) {
+    key[0] = (uint32_t)seed;
+    key[1] = (uint32_t)(seed >> 32) ^ (stream * 0x9E3779B9u);
+}
+
+/* uniform in [0,1): top 53 bits of a 64-bit word (the range of Julia's rand(), AlgoBGP.jl:85) */
+static double u53(uint32_t hi, uint32_t lo) {
+    uint64_t w = ((uint64_t)hi << 32) | lo;
+    return (double)(w >> 11) * 0x1.0p-53;
+}
+/* uniform in (0,1] for the log of Box-Muller */
+static double u53_open0(uint32_t hi, uint32_t lo) {
+    uint64_t w = ((uint64_t)hi << 32) | lo;
+    return (double)((w >> 11) + 1) * 0x1.0p-53;
+}
+/* Box-Muller: two standard normals from one Philox block */
+static void box_muller(const uint32_t x[4], double z[2]) {
+    double u1 = u53_open0(x[0], x[1]);
+    double u2 = u53(x[2], x[3]);
+    double r = sqrt(-2.0 * log(u1));
+    double a = 6.283185307179586476925286766559 * u2;
+    z[0] = r * cos(a);
+    z[1] = r * sin(a);
+}
+
+/* MH uniform of (global chain c, iteration t>=1): one entry of probs_acc = rand(n), AlgoBGP.jl:85 */
+static double rng_u(uint64_t seed, uint32_t c, uint32_t t) {
+    uint32_t key[2], ctr[4] = {c, t, 0, 0}, x[4];
+    stream_key(seed, STREAM_U, key);
+    philox4x32_10(ctr, key, x);
+    return u53(x[0], x[1]);
+}
+/* standard normal for (chain c, iteration t, try r, parameter k): rand(RAND,d), AlgoBGP.jl:404 */
+static double rng_prop_normal(uint64_t seed, uint32_t c, uint32_t t, uint32_t r, uint32_t k) {
+    uint32_t key[2], ctr[4] = {c, t, r, k >> 1}, x[4];
+    double z[2];
+    stream_key(seed, STREAM_PROP, key);
+    philox4x32_10(ctr, key, x);
+    box_muller(x, z);
+    return z[k & 1];
+}
+/* shock z[k][s] of the objective: the seed-1234 draw matrix of ObjExamples.jl:74-79 */
+static double rng_Z(uint64_t seed, uint32_t k, uint32_t s) {
+    uint32_t key[2], ctr[4] = {s, k >> 1, 0, 0}, x[4];
+    double z[2];
+    stream_key(seed, STREAM_Z, key);
+    philox4x32_10(ctr, key, x);
+    box_muller(x, z);
+    return z[k & 1];
+}
+void orc_gen_Z(uint64_t seed, int nm, int ns, double* Z) {
+    for (int k = 0; k < nm; ++k)
+        for (int s = 0; s < ns; ++s) Z[(size_t)k * ns + s] = rng_Z(seed, (uint32_t)k, (uint32_t)s);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Exchange-pair sampling: K distinct pairs, uniformly, in random order, out of           */
+/* props = [(i,j) for i in 1:N, j in 1:N if i<j]; sample(props,K,replace=false)           */
+/* (AlgoBGP.jl:653-656).  Restated as a keyed bijection (6-round Feistel network with     */
+/* cycle walking) of the linear pair index evaluated at 0..K-1, so that no O(N^2) array   */
+/* is ever materialised.  Linear index m <-> (i,j), i<j (0-based): m = j(j-1)/2 + i,       */
+/* i.e. i runs fastest, as in the reference's comprehension order.                        */
+/* ------------------------------------------------------------------------------------ */
+static uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+typedef struct { uint32_t k[6]; uint32_t half_bits; uint64_t M; } pair_perm_t;
+
+static void pair_perm_init(pair_perm_t* p, uint64_t seed, uint32_t t, uint64_t M) {
+    uint32_t key[2], x[4];
+    stream_key(seed, STREAM_PAIRS, key);
+    uint32_t c0[4] = {t, 0, 0, 0}, c1[4] = {t, 1, 0, 0};
+    philox4x32_10(c0, key, x);
+    p->k[0] = x[0]; p->k[1] = x[1]; p->k[2] = x[2]; p->k[3] = x[3];
+    philox4x32_10(c1, key, x);
+    p->k[4] = x[0]; p->k[5] = x[1];
+    uint32_t bits = 0;
+    while (bits < 62 && ((uint64_t)1 << bits) < M) ++bits; /* 2^bits >= M */
+    p->half_bits = (bits + 1) / 2;
+    if (p->half_bits == 0) p->half_bits = 1;
+    p->M = M;
+}
+static uint64_t pair_perm_eval(const pair_perm_t* p, uint64_t x) {
+    const uint32_t h = p->half_bits;
+    const uint32_t mask = (h >= 32) ? 0xFFFFFFFFu : ((1u << h) - 1u);
+    do {
+        uint32_t L = (uint32_t)(x >> h) & mask, R = (uint32_t)x & mask;
+        for (int r = 0; r < 6; ++r) {
+            uint32_t F = fmix32(R + p->k[r]) & mask;
+            uint32_t nL = R;
+            R = L ^ F;
+            L = nL;
+        }
+        x = ((uint64_t)L << h) | R;
+    } while (x >= p->M);
+    return x;
+}
+static void pair_unrank(uint64_t m, int32_t* i, int32_t* j) {
+    uint64_t jj = (uint64_t)((1.0 + sqrt(1.0 + 8.0 * (double)m)) * 0.5);
+    while (jj * (jj - 1) / 2 > m) --jj;
+    while ((jj + 1) * jj / 2 <= m) ++jj;
+    *j = (int32_t)jj;
+    *i = (int32_t)(m - jj * (jj - 1) / 2);
+}
+/* number of exchange proposals per iteration: AlgoBGP.jl:655 */
+static int n_exchange_pairs(int N) { return N < 3 ? N - 1 : N; }
+
+void orc_gen_pairs(uint64_t seed, int32_t t /*1-based iteration*/, int32_t Ng, int32_t* pairs /*[K][2]*/) {
+    int K = n_exchange_pairs(Ng);
+    if (K <= 0) return;
+    pair_perm_t p;
+    pair_perm_init(&p, seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
+    for (int q = 0; q < K; ++q) {
+        uint64_t m = pair_perm_eval(&p, (uint64_t)q);
+        pair_unrank(m, &pairs[2 * q], &pairs[2 * q + 1]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Objectives                                                                             */
+/* ------------------------------------------------------------------------------------ */
+
+/* canonical reduction of SMM_REDUCE_LANES partial sums (see include/smmhip.h) */
+static double reduce_partials(double* p /*[256], clobbered*/) {
+    double tot = 0.0;
+    for (int g = 0; g < ORC_REDUCE_LANES / 64; ++g) {
+        double* q = p + 64 * g;
+        for (int off = 32; off >= 1; off >>= 1)
+            for (int i = 0; i < off; ++i) q[i] = q[i] + q[i + off];
+        tot = (g == 0) ? q[0] : tot + q[0];
+    }
+    return tot;
+}
+
+/* objfunc_norm, ObjExamples.jl:59-116.
+ *   mu = params (:66); X[k,s] = mu_k + 1.0*z[k,s] (MvNormal(mu,PDiagMat(ones)), :76-78;
+ *   multiplying by sqrt(1.0) is exact so x = z + mu in one rounding);
+ *   simM = mean(X,dims=2) (:79); v_k = ((simM_k - mom_k)/w_k)^2, or without the division
+ *   when the moment has no weight (:90-100); value = mean(v) (:101); status = 1 (:110).
+ *   Z == the draws after Random.seed!(1234) (:74): identical for every evaluation.
+ *   regen != 0: regenerate every z from the counter RNG inside the evaluation (what the
+ *   reference's CPU path pays for: 20000 randn per call), bit-identical to a cached Z. */
+static void objfunc_norm(int nm, int ns, const double* theta, const double* Z, int regen, uint64_t seed,
+                         const double* mom, const double* w, double* simM, double* value, int8_t* status) {
+    double part[ORC_REDUCE_LANES];
+    double vsum = 0.0;
+    for (int k = 0; k < nm; ++k) {
+        const double mu = theta[k];
+        for (int l = 0; l < ORC_REDUCE_LANES; ++l) {
+            double acc = 0.0;
+            for (int s = l; s < ns; s += ORC_REDUCE_LANES) {
+                double z = regen ? rng_Z(seed, (uint32_t)k, (uint32_t)s) : Z[(size_t)k * ns + s];
+                double x = z + mu;
+                acc = acc + x;
+            }
+            part[l] = acc;
+        }
+        double tot = reduce_partials(part);
+        simM[k] = tot / (double)ns;
+        double d = simM[k] - mom[k];
+        if (!isnan(w[k])) d = d / w[k];
+        double v = d * d;
+        vsum = (k == 0) ? v : vsum + v;
+    }
+    *value = vsum / (double)nm;
+    *status = 1;
+}
+
+/* banana, ObjExamples.jl:251-265: value = 100*(b-a^2)^2 + (1-a)^2 (:255), simMoments_k =
+ * dataMoment_k + 2.2 (:259-261).  The reference function cannot run (String keys on a Symbol
+ * dict, never sets status); SURVEY.md §8d C4 defines the generalisation to np dimensions:
+ * value = sum_{i<np-1} 100*(x_{i+1}-x_i^2)^2 + (1-x_i)^2, status=1.  PARITY UNPINNED. */
+static void objfunc_banana(int np, int nm, const double* theta, const double* mom, double* simM, double* value,
+                           int8_t* status) {
+    double v = 0.0;
+    for (int i = 0; i + 1 < np; ++i) {
+        double a = theta[i], b = theta[i + 1];
+        double t1 = b - a * a;
+        double t2 = 1.0 - a;
+        double term = 100.0 * (t1 * t1) + t2 * t2;
+        v = (i == 0) ? term : v + term;
+    }
+    for (int k = 0; k < nm; ++k) simM[k] = mom[k] + 2.2;
+    *value = v;
+    *status = 1;
+}
+
+typedef struct {
+    orc_problem_t prob;
+    orc_opts_t opts;
+    int have_u, have_norm, have_pairs;
+    double *init, *lb, *ub, *mom, *w, *obj_params;
+    double *acc_tuner, *min_improve; /* [Ng] */
+    double *u_tab, *norm_tab, *Z;
+    int32_t* pair_tab;
+    int32_t prop_tries, n_pairs;
+    /* chain state [N] */
+    int32_t iter;
+    double *sigma, *accept_rate;
+    double *la_value, *la_prob, *la_params /*[np][N]*/, *la_simM /*[nm][N]*/;
+    int8_t* la_status;
+    int32_t *n_noex, *n_acc_noex;
+    double* best_val; int32_t* best_id;
+    /* history [T][...] */
+    orc_history_t h;
+    char err[256];
+    int regen_z, threads;
+} orc_t;
+
+/* evaluateObjective(m,p), mprob.jl:175-188: run the objective; an exception => status=-2
+ * with the Eval left at its constructor defaults value=-1.0 (Eval.jl:84), no simMoments. */
+static void evaluate_objective(const orc_t* o, const double* theta, double* simM, double* value, int8_t* status) {
+    const orc_problem_t* p = &o->prob;
+    switch (p->objective_id) {
+    case ORC_OBJ_NORM:
+        objfunc_norm(p->nm, p->ns, theta, o->Z, o->regen_z, o->opts.seed, o->mom, o->w, simM, value, status);
+        break;
+    case ORC_OBJ_BANANA:
+        objfunc_banana(p->np, p->nm, theta, o->mom, simM, value, status);
+        break;
+    case ORC_OBJ_NORM_FAILBOX:
+        if (o->obj_params && theta[0] >= o->obj_params[0] && theta[0] <= o->obj_params[1]) {
+            for (int k = 0; k < p->nm; ++k) simM[k] = NAN;
+            *value = -1.0;
+            *status = -2;
+        } else {
+            objfunc_norm(p->nm, p->ns, theta, o->Z, o->regen_z, o->opts.seed, o->mom, o->w, simM, value, status);
+        }
+        break;
+    default:
+        for (int k = 0; k < p->nm; ++k) simM[k] = NAN;
+        *value = -1.0;
+        *status = -2;
+    }
+}
+
+static double* dupd(const double* s, size_t n) {
+    double* d = (double*)malloc((n ? n : 1) * sizeof(double));
+    if (s && n) memcpy(d, s, n * sizeof(double));
+    return d;
+}
+
+void orc_ctx_destroy(void* v) {
+    orc_t* o = (orc_t*)v;
+    if (!o) return;
+    free(o->init); free(o->lb); free(o->ub); free(o->mom); free(o->w); free(o->obj_params);
+    free(o->acc_tuner); free(o->min_improve); free(o->u_tab); free(o->norm_tab); free(o->Z); free(o->pair_tab);
+    free(o->sigma); free(o->accept_rate); free(o->la_value); free(o->la_prob); free(o->la_params); free(o->la_simM);
+    free(o->la_status); free(o->n_noex); free(o->n_acc_noex); free(o->best_val); free(o->best_id);
+    free(o->h.value); free(o->h.prob); free(o->h.curr_val); free(o->h.best_val); free(o->h.params);
+    free(o->h.sim_moments); free(o->h.best_id); free(o->h.exchanged); free(o->h.accepted); free(o->h.status);
+    free(o);
+}
+
+/* MAlgoBGP(m,opts) + BGPChain(id,n;...) constructors: AlgoBGP.jl:505-537, :78-109.
+ * best_val = curr_val = Inf, best_id = -1, accepted = false, exchanged = 0, accept_rate = 0,
+ * iter = 0 (:82-92).  probs_acc = rand(n) (:85) is either injected or generated on demand. */
+int orc_ctx_create(const orc_problem_t* prob, const orc_opts_t* opts, const orc_tables_t* tab, void** out) {
+    if (!prob || !opts || !out) return ORC_ERR_INVALID_ARG;
+    const int np = prob->np, nm = prob->nm, ns = prob->ns, N = opts->N, T = opts->maxiter, Ng = opts->N_global;
+    if (np < 1 || nm < 1 || ns < 1 || N < 1 || T < 1 || Ng < N || opts->chain_offset < 0 ||
+        opts->chain_offset + N > Ng)
+        return ORC_ERR_INVALID_ARG;
+    if ((prob->objective_id == ORC_OBJ_NORM || prob->objective_id == ORC_OBJ_NORM_FAILBOX) && np != nm)
+        return ORC_ERR_INVALID_ARG; /* objfunc_norm pairs param k with moment k, ObjExamples.jl:66-78 */
+    if (opts->batch_size < 1 || opts->batch_size > np || np % opts->batch_size != 0) return ORC_ERR_BAD_BATCH;
+    orc_t* o = (orc_t*)calloc(1, sizeof(orc_t));
+    o->prob = *prob; o->opts = *opts;
+    o->init = dupd(prob->init, np); o->lb = dupd(prob->lb, np); o->ub = dupd(prob->ub, np);
+    o->mom = dupd(prob->mom, nm); o->w = dupd(prob->w, nm);
+    o->obj_params = prob->n_obj_params > 0 ? dupd(prob->obj_params, prob->n_obj_params) : NULL;
+    o->acc_tuner = dupd(opts->acc_tuner, Ng); o->min_improve = dupd(opts->min_improve, Ng);
+    o->sigma = dupd(opts->sigma + opts->chain_offset, N);
+    size_t TN = (size_t)T * N;
+    if (tab && tab->probs_acc) { o->u_tab = dupd(tab->probs_acc, TN); o->have_u = 1; }
+    if (tab && tab->prop_normals && tab->prop_tries > 0) {
+        o->prop_tries = tab->prop_tries;
+        o->norm_tab = dupd(tab->prop_normals, TN * (size_t)tab->prop_tries * np);
+        o->have_norm = 1;
+    }
+    if (tab && tab->pairs && tab->n_pairs > 0) {
+        o->n_pairs = tab->n_pairs;
+        size_t n = (size_t)T * tab->n_pairs * 2;
+        o->pair_tab = (int32_t*)malloc(n * sizeof(int32_t));
+        memcpy(o->pair_tab, tab->pairs, n * sizeof(int32_t));
+        o->have_pairs = 1;
+    }
+    o->Z = (double*)malloc((size_t)nm * ns * sizeof(double));
+    if (tab && tab->Z) memcpy(o->Z, tab->Z, (size_t)nm * ns * sizeof(double));
+    else orc_gen_Z(opts->seed, nm, ns, o->Z);
+    o->accept_rate = (double*)calloc(N, sizeof(double));
+    o->la_value = (double*)calloc(N, sizeof(double)); o->la_prob = (double*)calloc(N, sizeof(double));
+    o->la_params = (double*)calloc((size_t)np * N, sizeof(double));
+    o->la_simM = (double*)calloc((size_t)nm * N, sizeof(double));
+    o->la_status = (int8_t*)calloc(N, 1);
+    o->n_noex = (int32_t*)calloc(N, sizeof(int32_t)); o->n_acc_noex = (int32_t*)calloc(N, sizeof(int32_t));
+    o->best_val = (double*)malloc(N * sizeof(double)); o->best_id = (int32_t*)malloc(N * sizeof(int32_t));
+    for (int c = 0; c < N; ++c) { o->best_val[c] = INFINITY; o->best_id[c] = -1; o->la_value[c] = INFINITY; }
+    o->h.value = (double*)malloc(TN * 8); o->h.prob = (double*)malloc(TN * 8);
+    o->h.curr_val = (double*)malloc(TN * 8); o->h.best_val = (double*)malloc(TN * 8);
+    o->h.params = (double*)malloc(TN * np * 8); o->h.sim_moments = (double*)malloc(TN * nm * 8);
+    o->h.best_id = (int32_t*)malloc(TN * 4); o->h.exchanged = (int32_t*)calloc(TN, 4);
+    o->h.accepted = (uint8_t*)calloc(TN, 1); o->h.status = (int8_t*)calloc(TN, 1);
+    for (size_t i = 0; i < TN; ++i) { o->h.best_val[i] = INFINITY; o->h.curr_val[i] = INFINITY; o->h.best_id[i] = -1;
+        o->h.value[i] = NAN; o->h.prob[i] = NAN; }
+    for (size_t i = 0; i < TN * np; ++i) o->h.params[i] = NAN;
+    for (size_t i = 0; i < TN * nm; ++i) o->h.sim_moments[i] = NAN;
+    o->threads = 1;
+    *out = o;
+    return ORC_OK;
+}
+
+const char* orc_last_error(void* v) { return v ? ((orc_t*)v)->err : "null ctx"; }
+void orc_set_mode(void* v, int threads, int regen_z) {
+    orc_t* o = (orc_t*)v;
+    o->threads = threads < 1 ? 1 : threads;
+    o->regen_z = regen_z;
+}
+
+/* set_eval!(c,ev), AlgoBGP.jl:220-245, for chain c at iteration t (1-based), given the
+ * best_val/best_id of iteration t-1.  Writes history row t and the running best. */
+static void store_record(orc_t* o, int c, int t, const double* params, const double* simM, double value, double prob,
+                         int accepted, int8_t status, double best_prev, int32_t best_id_prev, double curr_prev) {
+    const int N = o->opts.N, np = o->prob.np, nm = o->prob.nm;
+    const size_t r = (size_t)(t - 1) * N + c;
+    o->h.value[r] = value; o->h.prob[r] = prob; o->h.accepted[r] = (uint8_t)accepted; o->h.status[r] = status;
+    for (int k = 0; k < np; ++k) o->h.params[((size_t)(t - 1) * np + k) * N + c] = params[k];
+    for (int k = 0; k < nm; ++k) o->h.sim_moments[((size_t)(t - 1) * nm + k) * N + c] = simM[k];
+    if (t == 1) {                                  /* :225-228 */
+        o->h.best_val[r] = value; o->h.curr_val[r] = value; o->h.best_id[r] = 1;
+    } else {
+        o->h.curr_val[r] = accepted ? value : curr_prev;      /* :231-235 */
+        if (value < best_prev) { o->h.best_val[r] = value; o->h.best_id[r] = t; }   /* :236-238 */
+        else { o->h.best_val[r] = best_prev; o->h.best_id[r] = best_id_prev; }      /* :239-243 */
+    }
+}
+
+/* next_eval(c), AlgoBGP.jl:272-294, for local chain c at iteration t:
+ * proposal (:424-471, mysample :400-410, mapto_01/ab mprob.jl:246-272) ->
+ * evaluateObjective (mprob.jl:175-188) -> doAcceptReject! (:324-392) -> set_eval! (:220-245).
+ * Returns 0 or an error code. */
+static int next_eval(orc_t* o, int c, int t, double* theta, double* simM, double* x01) {
+    const int N = o->opts.N, np = o->prob.np, nm = o->prob.nm, T = o->opts.maxiter;
+    const uint32_t gc = (uint32_t)(o->opts.chain_offset + c);
+    const uint64_t seed = o->opts.seed;
+    (void)T;
+    /* ---- proposal ---- */
+    if (t == 1) {
+        for (int k = 0; k < np; ++k) theta[k] = o->init[k];        /* :426-427 */
+    } else {
+        const double sig = o->sigma[c];
+        const int bs = o->opts.batch_size;
+        const int max_tries = o->have_norm ? (o->prop_tries < o->opts.smpl_iters ? o->prop_tries : o->opts.smpl_iters)
+                                           : o->opts.smpl_iters;
+        for (int b0 = 0; b0 < np; b0 += bs) {          /* one batch when bs==np (:441-442), else per batch (:444-453) */
+            int ok = 0;
+            for (int r = 0; r < max_tries && !ok; ++r) { /* mysample :403-408 */
+                ok = 1;
+                for (int k = b0; k < b0 + bs; ++k) {
+                    double mu01 = (o->la_params[(size_t)k * N + c] - o->lb[k]) / (o->ub[k] - o->lb[k]); /* mprob.jl:248 */
+                    double z = o->have_norm
+                                   ? o->norm_tab[((((size_t)(t - 1) * o->prop_tries + r) * np + k) * N) + c]
+                                   : rng_prop_normal(seed, gc, (uint32_t)t, (uint32_t)r, (uint32_t)k);
+                    double step = sig * z;              /* MvNormal(mu01, sigma::Float64): x = mu + sigma*z */
+                    double x = mu01 + step;
+                    x01[k] = x;
+                    if (!(x >= 0.0 && x <= 1.0)) ok = 0; /* inclusive bounds :405 */
+                }
+            }
+            if (!ok) {                                  /* :409 (batch mode: error raised, not swallowed) */
+                snprintf(o->err, sizeof o->err, "no draw in support after %d trials: chain %u iter %d", max_tries,
+                         gc + 1, t);
+                return ORC_ERR_NO_DRAW_IN_SUPPORT;
+            }
+        }
+        for (int k = 0; k < np; ++k) {
+            double span = o->ub[k] - o->lb[k];
+            double sc = x01[k] * span;
+            theta[k] = sc + o->lb[k];                   /* mapto_ab, mprob.jl:271 */
+        }
+    }
+    /* ---- objective ---- */
+    double value; int8_t status;
+    evaluate_objective(o, theta, simM, &value, &status);
+    /* ---- doAcceptReject! ---- */
+    double prob; int acc;
+    if (t == 1) {                                       /* :326-332 */
+        prob = 1.0; acc = 1; status = 1;
+    } else {
+        const double old = o->la_value[c];
+        if (status < 0) {                               /* :336-338 */
+            prob = 0.0; acc = 0;
+        } else {
+            if (!(value >= 0.0)) {                      /* :341 (NaN >= 0 is false => error as well) */
+                snprintf(o->err, sizeof o->err, "objective returned a negative or NaN value %g: chain %u iter %d",
+                         value, gc + 1, t);
+                return ORC_ERR_NEGATIVE_OBJECTIVE;
+            }
+            double e = exp(o->acc_tuner[gc] * (old - value));
+            prob = (e != e) ? e : (e < 1.0 ? e : 1.0);  /* minimum([1.0, e]) propagates NaN, :344 */
+            if (!isfinite(prob)) { prob = 0.0; acc = 0; status = -1; }            /* :350-353 */
+            else if (!isfinite(old)) { prob = 1.0; acc = 1; }                     /* :355-359 */
+            else {
+                status = 1;
+                double u = o->have_u ? o->u_tab[(size_t)(t - 1) * N + c] : rng_u(seed, gc, (uint32_t)t);
+                acc = (prob > u) ? 1 : 0;                                          /* strict >, :362-367 */
+            }
+        }
+    }
+    /* set_acceptRate!, :253-257: mean(accepted[1:iter][exchanged[1:iter].==0]); at this point
+     * exchanged[iter]==0, earlier iterations have their final exchanged status. */
+    o->accept_rate[c] = (double)(o->n_acc_noex[c] + acc) / (double)(o->n_noex[c] + 1);
+    if (t > 1 && (t % o->opts.sigma_update_steps) == 0) {                          /* :381-390 */
+        if (o->accept_rate[c] > 0.234) o->sigma[c] = o->sigma[c] * (1.0 + o->opts.sigma_adjust_by);
+        else o->sigma[c] = o->sigma[c] * (1.0 - o->opts.sigma_adjust_by);
+    }
+    /* ---- set_eval! ---- */
+    store_record(o, c, t, theta, simM, value, prob, acc, status, o->best_val[c], o->best_id[c], o->la_value[c]);
+    const size_t r = (size_t)(t - 1) * N + c;
+    o->best_val[c] = o->h.best_val[r]; o->best_id[c] = o->h.best_id[r];
+    if (acc) { /* the record becomes the chain's last accepted one (lastAccepted :209-215) */
+        o->la_value[c] = value; o->la_prob[c] = prob; o->la_status[c] = status;
+        for (int k = 0; k < np; ++k) o->la_params[(size_t)k * N + c] = theta[k];
+        for (int k = 0; k < nm; ++k) o->la_simM[(size_t)k * N + c] = simM[k];
+    }
+    return ORC_OK;
+}
+
+/* all local chains: map(next_eval, chains), AlgoBGP.jl:614 (or the pmap form :596-605) */
+int orc_bgp_local_step(void* v) {
+    orc_t* o = (orc_t*)v;
+    const int N = o->opts.N, np = o->prob.np, nm = o->prob.nm;
+    if (o->iter >= o->opts.maxiter) { snprintf(o->err, sizeof o->err, "maxiter reached"); return ORC_ERR_MAXITER; }
+    const int t = o->iter + 1;
+    int rc = ORC_OK;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(o->threads) if (o->threads > 1)
+#endif
+    for (int c = 0; c < N; ++c) {
+        double* buf = (double*)malloc((size_t)(2 * np + nm) * sizeof(double));
+        int e = next_eval(o, c, t, buf, buf + np, buf + np + nm);
+        if (e != ORC_OK) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            { if (rc == ORC_OK) rc = e; }
+        }
+        free(buf);
+    }
+    if (rc != ORC_OK) return rc;
+    o->iter = t;
+    return ORC_OK;
+}
+
+int orc_bgp_record_doubles(void* v) { orc_t* o = (orc_t*)v; return 3 + o->prob.np + o->prob.nm; }
+
+/* last-accepted records of the local chains, [(3+np+nm)][N]: value, prob, status, params, simM */
+void orc_bgp_export_records(void* v, double* rec) {
+    orc_t* o = (orc_t*)v;
+    const int N = o->opts.N, np = o->prob.np, nm = o->prob.nm;
+    for (int c = 0; c < N; ++c) {
+        rec[c] = o->la_value[c]; rec[(size_t)N + c] = o->la_prob[c]; rec[(size_t)2 * N + c] = (double)o->la_status[c];
+        for (int k = 0; k < np; ++k) rec[(size_t)(3 + k) * N + c] = o->la_params[(size_t)k * N + c];
+        for (int k = 0; k < nm; ++k) rec[(size_t)(3 + np + k) * N + c] = o->la_simM[(size_t)k * N + c];
+    }
+}
+
+/* after the exchange phase of iteration t: iterations with exchanged==0 count towards the
+ * acceptance rate (set_acceptRate!, :253-257) */
+static void close_iteration(orc_t* o) {
+    const int N = o->opts.N, t = o->iter;
+    for (int c = 0; c < N; ++c) {
+        const size_t r = (size_t)(t - 1) * N + c;
+        if (o->h.exchanged[r] == 0) { o->n_noex[c] += 1; o->n_acc_noex[c] += o->h.accepted[r]; }
+    }
+}
+
+/* exchangeMoves!(algo), AlgoBGP.jl:647-716 + swap_ev_ij! :734-749, over ALL N_global chains.
+ * gathered = records of every chain, [G][(3+np+nm)][N] with G = N_global/N shards (rank order);
+ * must be called after orc_local_step for the same iteration; applies swaps to local chains. */
+int orc_bgp_exchange(void* v, const double* gathered) {
+    orc_t* o = (orc_t*)v;
+    const int N = o->opts.N, Ng = o->opts.N_global, np = o->prob.np, nm = o->prob.nm, t = o->iter;
+    const int R = 3 + np + nm;
+    if (!(t >= o->opts.exchange_from_iter && Ng > 1)) { close_iteration(o); return ORC_OK; }   /* :637 */
+    const int K = o->have_pairs ? o->n_pairs : n_exchange_pairs(Ng);
+    int32_t* pairs = (int32_t*)malloc((size_t)(K > 0 ? K : 1) * 2 * sizeof(int32_t));
+    if (o->have_pairs) memcpy(pairs, o->pair_tab + (size_t)(t - 1) * K * 2, (size_t)K * 2 * sizeof(int32_t));
+    else orc_gen_pairs(o->opts.seed, t, Ng, pairs);
+    double* val = (double*)malloc((size_t)Ng * sizeof(double));
+    int32_t* src = (int32_t*)malloc((size_t)Ng * sizeof(int32_t));
+    int32_t* partner = (int32_t*)calloc((size_t)Ng, sizeof(int32_t));
+    for (int g = 0; g < Ng; ++g) {
+        int shard = g / N, l = g % N;
+        val[g] = gathered[((size_t)shard * R + 0) * N + l];
+        src[g] = g;
+    }
+    for (int q = 0; q < K; ++q) {                      /* sequential, order dependent: :662-691 */
+        int i = pairs[2 * q], j = pairs[2 * q + 1];
+        if (val[i] - val[j] > o->min_improve[i]) {     /* dist_fun = -, :688 */
+            double tv = val[i]; val[i] = val[j]; val[j] = tv;       /* swap_ev_ij! :739-744 */
+            int32_t ts = src[i]; src[i] = src[j]; src[j] = ts;
+            partner[i] = j + 1; partner[j] = i + 1;                  /* set_exchanged! :747-748 */
+        }
+    }
+    for (int c = 0; c < N; ++c) {
+        int g = o->opts.chain_offset + c;
+        if (partner[g] == 0) continue;
+        int s = src[g], shard = s / N, l = s % N;
+        const double* rec = gathered + (size_t)shard * R * N;
+        double value = rec[l], prob = rec[(size_t)N + l];
+        int8_t status = (int8_t)rec[(size_t)2 * N + l];
+        double* params = (double*)malloc((size_t)(np + nm) * sizeof(double));
+        double* simM = params + np;
+        for (int k = 0; k < np; ++k) params[k] = rec[(size_t)(3 + k) * N + l];
+        for (int k = 0; k < nm; ++k) simM[k] = rec[(size_t)(3 + np + k) * N + l];
+        /* set_eval!(ci, ej): overwrites the chain's record of iteration t; best/curr are
+         * recomputed against iteration t-1 (:231-243); ej.accepted is true. */
+        const size_t rp = (size_t)(t - 2) * N + c;
+        store_record(o, c, t, params, simM, value, prob, 1, status, o->h.best_val[rp], o->h.best_id[rp],
+                     o->h.curr_val[rp]);
+        const size_t r = (size_t)(t - 1) * N + c;
+        o->h.exchanged[r] = partner[g];
+        o->best_val[c] = o->h.best_val[r]; o->best_id[c] = o->h.best_id[r];
+        o->la_value[c] = value; o->la_prob[c] = prob; o->la_status[c] = status;
+        for (int k = 0; k < np; ++k) o->la_params[(size_t)k * N + c] = params[k];
+        for (int k = 0; k < nm; ++k) o->la_simM[(size_t)k * N + c] = simM[k];
+        free(params);
+    }
+    free(pairs); free(val); free(src); free(partner);
+    close_iteration(o);
+    return ORC_OK;
+}
+
+/* computeNextIteration!(algo), AlgoBGP.jl:589-640, n_iters times (run!, AlgoAbstract.jl:38-45);
+ * single shard only. */
+int orc_bgp_step(void* v, int n_iters) {
+    orc_t* o = (orc_t*)v;
+    if (o->opts.N != o->opts.N_global) { snprintf(o->err, sizeof o->err, "orc_bgp_step needs a single shard"); return ORC_ERR_INVALID_ARG; }
+    const int R = orc_bgp_record_doubles(v);
+    double* rec = (double*)malloc((size_t)R * o->opts.N * sizeof(double));
+    int rc = ORC_OK;
+    for (int it = 0; it < n_iters && rc == ORC_OK; ++it) {
+        rc = orc_bgp_local_step(v);
+        if (rc != ORC_OK) break;
+        orc_bgp_export_records(v, rec);
+        rc = orc_bgp_exchange(v, rec);
+    }
+    free(rec);
+    return rc;
+}
+
+/* batched evaluateObjective: params [np][M] -> value[M], simM[nm][M], status[M] */
+int orc_eval_batch(void* v, const double* params, int M, double* value, double* simM, int8_t* status) {
+    orc_t* o = (orc_t*)v;
+    const int np = o->prob.np, nm = o->prob.nm;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(o->threads) if (o->threads > 1)
+#endif
+    for (int i = 0; i < M; ++i) {
+        double* th = (double*)malloc((size_t)(np + nm) * sizeof(double));
+        double* sm = th + np;
+        for (int k = 0; k < np; ++k) th[k] = params[(size_t)k * M + i];
+        evaluate_objective(o, th, sm, &value[i], &status[i]);
+        for (int k = 0; k < nm; ++k) simM[(size_t)k * M + i] = sm[k];
+        free(th);
+    }
+    return ORC_OK;
+}
+
+#define CPY(dst, src, n, sz) do { if (dst) memcpy(dst, src, (size_t)(n) * (sz)); } while (0)
+
+int orc_get_history(void* v, int t0, int t1, orc_history_t* out) {
+    orc_t* o = (orc_t*)v;
+    const size_t N = o->opts.N, np = o->prob.np, nm = o->prob.nm;
+    if (t0 < 0 || t1 < t0 || t1 > o->opts.maxiter) return ORC_ERR_INVALID_ARG;
+    const size_t nt = (size_t)(t1 - t0), off = (size_t)t0 * N;
+    CPY(out->value, o->h.value + off, nt * N, 8); CPY(out->prob, o->h.prob + off, nt * N, 8);
+    CPY(out->curr_val, o->h.curr_val + off, nt * N, 8); CPY(out->best_val, o->h.best_val + off, nt * N, 8);
+    CPY(out->params, o->h.params + off * np, nt * N * np, 8);
+    CPY(out->sim_moments, o->h.sim_moments + off * nm, nt * N * nm, 8);
+    CPY(out->best_id, o->h.best_id + off, nt * N, 4); CPY(out->exchanged, o->h.exchanged + off, nt * N, 4);
+    CPY(out->accepted, o->h.accepted + off, nt * N, 1); CPY(out->status, o->h.status + off, nt * N, 1);
+    return ORC_OK;
+}
+
+int orc_get_state(void* v, orc_state_t* s) {
+    orc_t* o = (orc_t*)v;
+    const size_t N = o->opts.N, np = o->prob.np, nm = o->prob.nm;
+    s->iter = o->iter;
+    CPY(s->sigma, o->sigma, N, 8); CPY(s->accept_rate, o->accept_rate, N, 8);
+    CPY(s->la_value, o->la_value, N, 8); CPY(s->la_prob, o->la_prob, N, 8);
+    CPY(s->la_params, o->la_params, N * np, 8); CPY(s->la_sim_moments, o->la_simM, N * nm, 8);
+    CPY(s->la_status, o->la_status, N, 1); CPY(s->n_noex, o->n_noex, N, 4); CPY(s->n_acc_noex, o->n_acc_noex, N, 4);
+    CPY(s->best_val, o->best_val, N, 8); CPY(s->best_id, o->best_id, N, 4);
+    return ORC_OK;
+}
+
+int orc_get_Z(void* v, double* Z) {
+    orc_t* o = (orc_t*)v;
+    memcpy(Z, o->Z, (size_t)o->prob.nm * o->prob.ns * sizeof(double));
+    return ORC_OK;
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,187 @@
+"""Thin object wrapper over the C ABI of include/smmhip.h.
+
+`BGPContext` drives any shared library that exports that ABI under a symbol prefix; the
+package itself only ever instantiates it on libsmmhip.so (prefix "smm_") through
+`hip_context(...)`.  There is deliberately no CPU code path in here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+
+
+class Problem:
+    """Flattened MProb (mprob.jl:29-53): what smm_problem_t carries."""
+
+    def __init__(self, init, lb, ub, mom, w=None, ns=10000, objective_id=A.SMM_OBJ_NORM, obj_params=None):
+        self.init = A.f64(init); self.lb = A.f64(lb); self.ub = A.f64(ub)
+        self.mom = A.f64(mom)
+        self.w = A.f64(np.full(len(self.mom), np.nan) if w is None else w)
+        self.np = len(self.init); self.nm = len(self.mom); self.ns = int(ns)
+        self.objective_id = int(objective_id)
+        self.obj_params = None if obj_params is None else A.f64(obj_params)
+        assert len(self.lb) == self.np and len(self.ub) == self.np and len(self.w) == self.nm
+
+    def struct(self):
+        p = A.smm_problem_t()
+        p.np, p.nm, p.ns, p.objective_id = self.np, self.nm, self.ns, self.objective_id
+        p.init, p.lb, p.ub, p.mom, p.w = map(A.dptr, (self.init, self.lb, self.ub, self.mom, self.w))
+        p.obj_params = A.dptr(self.obj_params)
+        p.n_obj_params = 0 if self.obj_params is None else len(self.obj_params)
+        return p
+
+
+class BGPOpts:
+    """Flattened opts Dict of MAlgoBGP (AlgoBGP.jl:505-537). Per-chain vectors are GLOBAL
+    (length N_global); the context owns chains [chain_offset, chain_offset+N)."""
+
+    def __init__(self, N, maxiter, sigma, acc_tuner, min_improve, sigma_update_steps=10, sigma_adjust_by=0.01,
+                 smpl_iters=1000, batch_size=None, exchange_from_iter=2, seed=12, chain_offset=0, N_global=None,
+                 device=0):
+        self.N = int(N); self.maxiter = int(maxiter)
+        self.N_global = int(N if N_global is None else N_global)
+        self.sigma = A.f64(sigma, (self.N_global,)); self.acc_tuner = A.f64(acc_tuner, (self.N_global,))
+        self.min_improve = A.f64(min_improve, (self.N_global,))
+        self.sigma_update_steps = int(sigma_update_steps); self.sigma_adjust_by = float(sigma_adjust_by)
+        self.smpl_iters = int(smpl_iters); self.batch_size = batch_size
+        self.exchange_from_iter = int(exchange_from_iter); self.seed = int(seed)
+        self.chain_offset = int(chain_offset); self.device = int(device)
+
+    def struct(self, np_):
+        o = A.smm_bgp_opts_t()
+        o.N, o.maxiter = self.N, self.maxiter
+        o.sigma, o.acc_tuner, o.min_improve = map(A.dptr, (self.sigma, self.acc_tuner, self.min_improve))
+        o.sigma_update_steps, o.smpl_iters = self.sigma_update_steps, self.smpl_iters
+        o.sigma_adjust_by = self.sigma_adjust_by
+        o.batch_size = np_ if self.batch_size is None else int(self.batch_size)
+        o.exchange_from_iter = self.exchange_from_iter
+        o.seed = self.seed
+        o.chain_offset, o.N_global, o.device = self.chain_offset, self.N_global, self.device
+        return o
+
+
+class Tables:
+    """Injected randomness (smm_tables_t). All optional."""
+
+    def __init__(self, probs_acc=None, prop_normals=None, pairs=None, Z=None):
+        self.probs_acc = None if probs_acc is None else A.f64(probs_acc)          # [T][N]
+        self.prop_normals = None if prop_normals is None else A.f64(prop_normals)  # [T][K][np][N]
+        self.pairs = None if pairs is None else np.ascontiguousarray(pairs, dtype=np.int32)  # [T][K][2]
+        self.Z = None if Z is None else A.f64(Z)                                   # [nm][ns]
+
+    def struct(self):
+        t = A.smm_tables_t()
+        t.probs_acc = A.dptr(self.probs_acc)
+        t.prop_normals = A.dptr(self.prop_normals)
+        t.prop_tries = 0 if self.prop_normals is None else self.prop_normals.shape[1]
+        t.pairs = None if self.pairs is None else self.pairs.ctypes.data_as(A.c_int32_p)
+        t.n_pairs = 0 if self.pairs is None else self.pairs.shape[1]
+        t.Z = A.dptr(self.Z)
+        return t
+
+
+class BGPContext:
+    """One device context = the chains of one MAlgoBGP shard."""
+
+    def __init__(self, lib, prefix, problem, opts, tables=None):
+        self._lib = lib
+        self._p = prefix
+        self.problem, self.opts = problem, opts
+        self.tables = tables
+        self._ctx = C.c_void_p()
+        ps, os_ = problem.struct(), opts.struct(problem.np)
+        ts = tables.struct() if tables is not None else None
+        rc = self._fn("ctx_create")(C.byref(ps), C.byref(os_), C.byref(ts) if ts is not None else None,
+                                    C.byref(self._ctx))
+        if rc != 0:
+            msg = self._fn("last_error")(None)
+            raise A.SMMHipError(rc, msg.decode() if msg else "ctx_create failed")
+        self.N, self.np, self.nm = opts.N, problem.np, problem.nm
+
+    def _fn(self, name):
+        return getattr(self._lib, self._p + name)
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._fn("last_error")(self._ctx)
+            raise A.SMMHipError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if self._ctx:
+            self._fn("ctx_destroy")(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- the path ---------------------------------------------------------------------
+    def step(self, n_iters=1):
+        self._check(self._fn("bgp_step")(self._ctx, int(n_iters)))
+
+    def step_async(self, n_iters=1):
+        self._check(self._fn("bgp_step_async")(self._ctx, int(n_iters)))
+
+    def sync(self):
+        self._check(self._fn("sync")(self._ctx))
+
+    def local_step(self):
+        self._check(self._fn("bgp_local_step")(self._ctx))
+
+    def record_doubles(self):
+        return self._fn("bgp_record_doubles")(self._ctx)
+
+    def export_records_dev(self, ptr):
+        self._check(self._fn("bgp_export_records_dev")(self._ctx, C.c_void_p(ptr)))
+
+    def exchange_dev(self, ptr):
+        self._check(self._fn("bgp_exchange_dev")(self._ctx, C.c_void_p(ptr)))
+
+    def stream(self):
+        return self._fn("stream")(self._ctx)
+
+    def eval_batch(self, params):
+        params = A.f64(params)
+        assert params.shape[0] == self.np
+        M = params.shape[1]
+        value = np.empty(M); simM = np.empty((self.nm, M)); status = np.empty(M, np.int8)
+        self._check(self._fn("eval_batch")(self._ctx, A.dptr(params), M, A.dptr(value), A.dptr(simM),
+                                           status.ctypes.data_as(A.c_int8_p)))
+        return value, simM, status
+
+    # --- read back --------------------------------------------------------------------
+    def history(self, t0=0, t1=None):
+        t1 = self.state().iter if t1 is None else t1
+        hb = A.HistoryBuffers(t1 - t0, self.N, self.np, self.nm)
+        hs = hb.struct()
+        self._check(self._fn("get_history")(self._ctx, t0, t1, C.byref(hs)))
+        return hb
+
+    def state(self):
+        sb = A.StateBuffers(self.N, self.np, self.nm)
+        ss = sb.struct()
+        self._check(self._fn("get_state")(self._ctx, C.byref(ss)))
+        sb.iter = ss.iter
+        return sb
+
+    def set_state(self, sb, hb):
+        ss, hs = sb.struct(), hb.struct()
+        self._check(self._fn("set_state")(self._ctx, C.byref(ss), C.byref(hs)))
+
+    def timing(self):
+        t = A.smm_timing_t()
+        self._check(self._fn("get_timing")(self._ctx, C.byref(t)))
+        return t
+
+    def Z(self):
+        z = np.empty((self.nm, self.problem.ns))
+        self._check(self._fn("get_Z")(self._ctx, A.dptr(z)))
+        return z
+
+
+def hip_context(problem, opts, tables=None):
+    """The product constructor: a BGPContext on libsmmhip.so. Raises if the library is missing."""
+    return BGPContext(A.load(), "smm_", problem, opts, tables)
