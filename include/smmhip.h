@@ -79,13 +79,15 @@ typedef struct {
 } smm_problem_t;
 
 /* opts Dict of MAlgoBGP (AlgoBGP.jl:505-537) flattened; per-chain vectors are
- * supplied already expanded (sigma[i] = opts["sigma"]*temps[i], AlgoBGP.jl:508,518). */
+ * supplied already expanded (sigma[i] = opts["sigma"]*temps[i], AlgoBGP.jl:508,518) and
+ * GLOBAL (length N_global); the context uses entries [chain_offset, chain_offset+N). */
 typedef struct {
     int32_t N;               /* chains owned by THIS context (local shard)                */
     int32_t maxiter;         /* history capacity T (BGPChain(n), AlgoBGP.jl:78)           */
-    const double* sigma;     /* [N] initial proposal std-dev in [0,1]-space               */
-    const double* acc_tuner; /* [N] AlgoBGP.jl:523                                        */
-    const double* min_improve;/* [N] AlgoBGP.jl:522                                       */
+    const double* sigma;     /* [N_global] initial proposal std-dev in [0,1]-space        */
+    const double* acc_tuner; /* [N_global] AlgoBGP.jl:523                                 */
+    const double* min_improve;/* [N_global] AlgoBGP.jl:522 (the exchange test of pair (i,j)
+                                 reads chain i's threshold on every shard, :688)          */
     int32_t sigma_update_steps; /* AlgoBGP.jl:519                                         */
     int32_t smpl_iters;         /* AlgoBGP.jl:521                                         */
     double  sigma_adjust_by;    /* AlgoBGP.jl:520                                         */
@@ -193,6 +195,9 @@ int  smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out);
 int  smm_get_state(void* ctx, smm_state_t* out);
 int  smm_set_state(void* ctx, const smm_state_t* in, const smm_history_t* hist /* iterations 0..iter-1 */);
 int  smm_get_timing(void* ctx, smm_timing_t* out);
+/* on != 0: bracket every kernel of smm_bgp_step with hipEvents on the ctx stream so that
+ * smm_get_timing reports iter_kernel_ms / exch_kernel_ms (sums over the last step). */
+int  smm_set_profiling(void* ctx, int32_t on);
 /* copy of the shock matrix actually used, [nm][ns] */
 int  smm_get_Z(void* ctx, double* Z);
 

@@ -112,6 +112,7 @@ SYMBOLS = [
     ("smm_set_state", C.c_int, [C.c_void_p, C.POINTER(smm_state_t), C.POINTER(smm_history_t)]),
     ("smm_get_timing", C.c_int, [C.c_void_p, C.POINTER(smm_timing_t)]),
     ("smm_get_Z", C.c_int, [C.c_void_p, c_double_p]),
+    ("smm_set_profiling", C.c_int, [C.c_void_p, C.c_int32]),
 ]
 
 

@@ -176,6 +176,9 @@ class BGPContext:
         self._check(self._fn("get_timing")(self._ctx, C.byref(t)))
         return t
 
+    def set_profiling(self, on=True):
+        self._check(self._fn("set_profiling")(self._ctx, int(bool(on))))
+
     def Z(self):
         z = np.empty((self.nm, self.problem.ns))
         self._check(self._fn("get_Z")(self._ctx, A.dptr(z)))

@@ -1,0 +1,67 @@
+"""Sharding of the BGP chains over ranks (one process per GPU).
+
+Chains are independent inside an iteration (next_eval, AlgoBGP.jl:272-294); the only coupling
+is exchangeMoves! (AlgoBGP.jl:647-716), which needs every chain's last accepted record.  Each
+rank owns a contiguous block of chains; per iteration there is ONE collective — an all-gather of
+the fixed-size last-accepted records over RCCL/xGMI — after which every rank resolves the
+identical pair list redundantly and applies the swaps that touch its own chains.
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipShardEngine:
+    """adapter of a libsmmhip BGPContext to the ShardedBGP protocol (device tensors)"""
+
+    def __init__(self, ctx, device):
+        self.ctx = ctx
+        self.device = torch.device(device)
+        self.N = ctx.N
+        self.R = ctx.record_doubles()
+        # all torch work (the RCCL all-gather) is ordered on the library's own HIP stream
+        self.stream = torch.cuda.ExternalStream(ctx.stream(), device=self.device)
+
+    def new_tensor(self, shape):
+        return torch.empty(shape, dtype=torch.float64, device=self.device)
+
+    def local_step(self):
+        self.ctx.local_step()
+
+    def export_records(self, out):
+        self.ctx.export_records_dev(out.data_ptr())
+
+    def exchange(self, gathered):
+        self.ctx.exchange_dev(gathered.data_ptr())
+
+    def sync(self):
+        self.ctx.sync()
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
+
+
+class ShardedBGP:
+    """computeNextIteration! (AlgoBGP.jl:589-640) over world_size shards."""
+
+    def __init__(self, engine, group=None):
+        self.e = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.local = engine.new_tensor((engine.R, engine.N))
+        self.gathered = engine.new_tensor((self.world, engine.R, engine.N))
+
+    def step(self, n_iters=1):
+        e = self.e
+        with e.stream_ctx():
+            for _ in range(n_iters):
+                e.local_step()
+                if self.world == 1:
+                    e.export_records(self.gathered[0])
+                else:
+                    e.export_records(self.local)
+                    dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
+                e.exchange(self.gathered)
+
+    def sync(self):
+        self.e.sync()
