@@ -29,6 +29,18 @@ PEAK_FP64_ADD_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3: 256 CU x 4 SIMD x 16
 PEAK_HBM_GBS = 8000.0
 
 
+def host_cores():
+    """cores this process may really use: affinity mask and cgroup quota, not the machine total"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(threads):
     """the oracle (C port of the reference path) on the host cores, bounded sample, 'faithful' mode:
     every evaluation regenerates its 2 x 10000 normals like ObjExamples.jl:74-79."""
@@ -136,7 +148,7 @@ def main():
                         "note": "algorithmic 128 B per chain-eval; small by construction"}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(os.cpu_count() or 1)
+        cpu = cpu_baseline(host_cores())
 
     if rank == 0:
         out = {"metric": "chain-evals/sec (whole node), serialNormal 2p/2m, 4096 chains x 200 iters",

@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <algorithm>
 #include <string>
@@ -126,12 +127,56 @@ __device__ inline void simulate_tile(const KParams& P, const double* s_theta, do
             acc[c] = 0.0;
         }
         const double* __restrict__ Zk = P.Z + (size_t)k * P.ns;
-        for (int s = tid; s < P.ns; s += WG) {
-            const double z = Zk[s];
+        // lane `tid` sums its draws tid, tid+256, ... in that order (numerical contract).  U rows
+        // are loaded ahead of use so that U independent L2 reads are in flight per lane.
+        constexpr int U = 8;
+        int s = tid;
+        double zc[U];
+        bool have = (s + (U - 1) * WG) < P.ns;
+        if (have) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const double x = z + mu[c];
-                acc[c] = acc[c] + x;
+            for (int u = 0; u < U; ++u) zc[u] = Zk[s + u * WG];
+        }
+        while (have) {
+            const int sn = s + U * WG;
+            const bool have_next = (sn + (U - 1) * WG) < P.ns;
+            double zn[U];
+            if (have_next) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) zn[u] = Zk[sn + u * WG];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const double x = zc[u] + mu[c];
+                    acc[c] = acc[c] + x;
+                }
+            }
+            if (have_next) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) zc[u] = zn[u];
+            }
+            s = sn;
+            have = have_next;
+        }
+        {   // remaining (< U full rows + the ragged last row): masked
+            double zt[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = (s + u * WG) < P.ns;
+                zt[u] = ok[u] ? Zk[s + u * WG] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (ok[u]) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const double x = zt[u] + mu[c];
+                        acc[c] = acc[c] + x;
+                    }
+                }
             }
         }
         const double tot = wave_reduce_transposed<CT>(acc, lane);
@@ -422,6 +467,158 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve(const KParams P, const int
     }
 }
 
+// k_exch_resolve_lds: same result as k_exch_resolve, for K <= Ng <= XLDS_MAX, everything in LDS.
+// Instead of barrier-separated rounds the pair list is executed as a data-flow graph:
+//   1. per chain c, the list positions of the pairs touching c are bucketed (counting sort:
+//      LDS atomics + block scan) and every pair learns its rank r_i, r_j among the pairs of
+//      its two chains;
+//   2. ticket[c] counts the executed pairs of chain c; pair q may run exactly when
+//      ticket[i]==r_i && ticket[j]==r_j, i.e. when all its predecessors on both chains ran
+//      and none of its successors did: the sequential order of AlgoBGP.jl:662-691 per chain;
+//   3. after running it publishes ticket+1 on both chains (release/acquire, workgroup scope).
+// The critical path is the longest dependency chain (~ log N) times one LDS round trip.
+constexpr int XLDS_MAX = 4096;
+constexpr unsigned XSPIN_LIMIT = 1u << 22;
+
+__global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ng = P.Ng, N = P.N, R = 3 + P.np + P.nm;
+    const int K = P.pairtab ? P.n_pairs_tab : n_exchange_pairs(Ng);
+    double* val = (double*)xsm;                       // [Ng]   (aliases ep[2K] during the build)
+    uint32_t* ep = (uint32_t*)xsm;                    // [2K]
+    uint32_t* cnt = (uint32_t*)(val + Ng);            // [Ng]   histogram -> cursor -> ticket
+    uint16_t* src = (uint16_t*)(cnt + Ng);            // [Ng]
+    uint16_t* partner = src + Ng;                     // [Ng]
+    uint16_t* pi = partner + Ng;                      // [K]
+    uint16_t* pj = pi + K;                            // [K]
+    uint16_t* ri = pj + K;                            // [K]
+    uint16_t* rj = ri + K;                            // [K]
+    uint32_t* wsum = (uint32_t*)(rj + K);             // [16] (4 u16 arrays of K = 8K bytes: 4-byte aligned)
+
+    for (int c = tid; c < Ng; c += XWG) cnt[c] = 0;
+    if (P.pairtab) {
+        for (int q = tid; q < K; q += XWG) {
+            pi[q] = (uint16_t)P.pairtab[((size_t)(t - 1) * K + q) * 2];
+            pj[q] = (uint16_t)P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
+        }
+    } else {
+        PairPerm pp;
+        pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
+        for (int q = tid; q < K; q += XWG) {
+            int32_t i, j;
+            pair_unrank(pp.eval((uint64_t)q), i, j);
+            pi[q] = (uint16_t)i;
+            pj[q] = (uint16_t)j;
+        }
+    }
+    __syncthreads();
+    // 1a. histogram of endpoints
+    for (int q = tid; q < K; q += XWG) {
+        atomicAdd(&cnt[pi[q]], 1u);
+        atomicAdd(&cnt[pj[q]], 1u);
+    }
+    __syncthreads();
+    // 1b. exclusive scan of cnt[0..Ng) -> cursor (segment start)
+    {
+        const int per = (Ng + XWG - 1) / XWG;  // consecutive entries per thread (<= 4)
+        const int c0 = tid * per;
+        uint32_t loc[XLDS_MAX / XWG];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < XLDS_MAX / XWG; ++u) {
+            const int c = c0 + u;
+            const uint32_t v = (u < per && c < Ng) ? cnt[c] : 0u;
+            loc[u] = sum;
+            sum += v;
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const uint32_t excl = base + incl - sum;
+#pragma unroll
+        for (int u = 0; u < XLDS_MAX / XWG; ++u) {
+            const int c = c0 + u;
+            if (u < per && c < Ng) cnt[c] = excl + loc[u];
+        }
+    }
+    __syncthreads();
+    // 1c. scatter list positions into the chain buckets (order inside a bucket is arbitrary)
+    for (int q = tid; q < K; q += XWG) {
+        ep[atomicAdd(&cnt[pi[q]], 1u)] = (uint32_t)q;
+        ep[atomicAdd(&cnt[pj[q]], 1u)] = (uint32_t)q;
+    }
+    __syncthreads();  // now cnt[c] == end of chain c's bucket
+    // 1d. rank of each pair inside the buckets of its two chains = number of smaller positions
+    for (int q = tid; q < K; q += XWG) {
+        const int i = pi[q], j = pj[q];
+        uint32_t b = i ? cnt[i - 1] : 0u, e = cnt[i], r = 0;
+        for (uint32_t x = b; x < e; ++x) r += (ep[x] < (uint32_t)q) ? 1u : 0u;
+        ri[q] = (uint16_t)r;
+        b = j ? cnt[j - 1] : 0u; e = cnt[j]; r = 0;
+        for (uint32_t x = b; x < e; ++x) r += (ep[x] < (uint32_t)q) ? 1u : 0u;
+        rj[q] = (uint16_t)r;
+    }
+    __syncthreads();
+    // 2. state: values of the last accepted records, identity permutation, zero tickets
+    for (int g = tid; g < Ng; g += XWG) {
+        const int shard = g / N, l = g - shard * N;
+        val[g] = gathered[(size_t)shard * R * N + l];
+        src[g] = (uint16_t)g;
+        partner[g] = 0;
+        cnt[g] = 0;
+    }
+    __syncthreads();
+    // 3. data-flow execution
+    {
+        int q = tid;
+        double mi = (q < K) ? P.min_improve_g[pi[q]] : 0.0;
+        unsigned spins = 0;
+        while (true) {
+            bool progressed = false;
+            if (q < K) {
+                const int i = pi[q], j = pj[q];
+                const uint32_t ti = __hip_atomic_load(&cnt[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t tj = __hip_atomic_load(&cnt[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (ti == ri[q] && tj == rj[q]) {
+                    const double vi = val[i], vj = val[j];
+                    if (vi - vj > mi) {                         // dist_fun = -, AlgoBGP.jl:688
+                        val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744
+                        const uint16_t si = src[i];
+                        src[i] = src[j]; src[j] = si;
+                        partner[i] = (uint16_t)(j + 1); partner[j] = (uint16_t)(i + 1);  // :747-748
+                    }
+                    __hip_atomic_store(&cnt[i], ti + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&cnt[j], tj + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    q += XWG;
+                    if (q < K) mi = P.min_improve_g[pi[q]];
+                    progressed = true;
+                }
+            }
+            if (__all(q >= K)) break;
+            if (!__any(progressed)) {
+                if (++spins > XSPIN_LIMIT) {  // cannot happen (the smallest pending position is always runnable)
+                    if (lane == 0) report_error(P, 3, t, 0);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int g = tid; g < Ng; g += XWG) {
+        P.xsrc[g] = src[g];
+        P.xpartner[g] = partner[g];
+    }
+}
+
 // k_exch_apply: for local chains, set_eval!(ci, ej) (+ set_exchanged!) of swap_ev_ij!
 // (AlgoBGP.jl:734-749): the chain's record of iteration t is overwritten by the donor's last
 // accepted record; curr/best are recomputed against iteration t-1 (:231-243).  Also closes the
@@ -480,6 +677,7 @@ struct Ctx {
     smm_timing_t timing{};
     bool pending_timing = false;
     bool profiling = false;
+    bool force_generic_exchange = false;
     std::vector<hipEvent_t> pev;  // profiling events: 3 per iteration (before iter, after iter, after exchange)
     int pev_iters = 0;
 };
@@ -532,9 +730,17 @@ void launch_chain_iter(Ctx* c, int t, int close_iter) {
     }
 }
 
+size_t xlds_bytes(int Ng, int K) {
+    return (size_t)Ng * (8 + 4 + 2 + 2) + (size_t)(K + (K & 1)) * 2 * 4 + 16 * 4 + 16;
+}
+
 void launch_exchange(Ctx* c, int t, const double* gathered) {
     const KParams& P = c->P;
-    hipLaunchKernelGGL(k_exch_resolve, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
+    const int K = P.pairtab ? P.n_pairs_tab : n_exchange_pairs(P.Ng);
+    if (P.Ng <= XLDS_MAX && K <= P.Ng && !c->force_generic_exchange)
+        hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), xlds_bytes(P.Ng, K), c->stream, P, t, gathered);
+    else
+        hipLaunchKernelGGL(k_exch_resolve, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
     hipLaunchKernelGGL(k_exch_apply, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, t, gathered);
 }
 
@@ -546,6 +752,11 @@ int check_device_error(Ctx* c) {
     if (e == ERR_NONE) return SMM_OK;
     const int kind = (int)(e & 3), chain = (int)((e >> 2) & 0xffffffffu), it = (int)(e >> 34);
     char b[256];
+    if (kind == 3) {
+        snprintf(b, sizeof b, "internal error: exchange resolution did not converge (iteration %d)", it);
+        c->err = b;
+        return SMM_ERR_HIP;
+    }
     if (kind == 1) {
         snprintf(b, sizeof b, "AlgoBGP assumes that your objective function returns a non-negative number "
                  "(chain %d, iteration %d)", chain + 1, it);
@@ -619,6 +830,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         KParams& P = c->P;
         c->obj = prob->objective_id;
         c->exchange_from = opts->exchange_from_iter;
+        {
+            const char* e = getenv("SMMHIP_GENERIC_EXCHANGE");  // test hook: force the any-size resolution kernel
+            c->force_generic_exchange = e && e[0] == '1';
+        }
         P.np = np; P.nm = nm; P.ns = ns; P.obj = prob->objective_id;
         P.init = dupload(c, prob->init, np); P.lb = dupload(c, prob->lb, np); P.ub = dupload(c, prob->ub, np);
         P.mom = dupload(c, prob->mom, nm); P.w = dupload(c, prob->w, nm);
@@ -671,6 +886,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.h_acc = dalloc<uint8_t>(c, TN); dfill(c, P.h_acc, TN, (uint8_t)0);
         P.h_status = dalloc<int8_t>(c, TN); dfill(c, P.h_status, TN, (int8_t)0);
         P.err = dalloc<unsigned long long>(c, 1); dfill(c, P.err, 1, ERR_NONE);
+        HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)xlds_bytes(XLDS_MAX, XLDS_MAX)));
         HIPCHK(hipDeviceSynchronize());
     } catch (const std::string& m) {
         g_create_err = m;

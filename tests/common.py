@@ -39,7 +39,7 @@ def general_normal(npar, N, T, ns=1000, seed=7, batch_size=None, **kw):
     return prob, opts
 
 
-def random_tables(prob, opts, tries=4, seed=99, pairs=True, Z=True):
+def random_tables(prob, opts, tries=24, seed=99, pairs=True, Z=True):
     rng = np.random.default_rng(seed)
     T, N, Ng = opts.maxiter, opts.N, opts.N_global
     K = Ng - 1 if Ng < 3 else Ng

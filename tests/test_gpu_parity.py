@@ -10,30 +10,28 @@ from smm_jl_amd import _abi as A
 pytestmark = pytest.mark.gpu
 
 
-def run_both(S, O, prob, opts, tables, T=None, chunks=None):
-    T = opts.maxiter if T is None else T
+def make_pair(S, O, prob, opts, tables=None, **okw):
+    """a HIP context and an oracle context fed with identical inputs.  The shock matrix Z (the
+    seed-1234 draws of ObjExamples.jl:74-79) is injected randomness: when the caller gives none the
+    library's default Z is read back and handed to the oracle (host libm builds may differ by an ulp)."""
     h = S.hip_context(prob, opts, tables)
-    o = O.OracleContext(prob, opts, tables)
-    if chunks:
-        for n in chunks:
-            h.step(n); o.step(n)
-    else:
-        h.step(T); o.step(T)
+    t = tables if tables is not None else S.Tables()
+    to = S.Tables(probs_acc=t.probs_acc, prop_normals=t.prop_normals, pairs=t.pairs, Z=h.Z())
+    o = O.OracleContext(prob, opts, to, **okw)
     return h, o
 
 
-def inject_Z(S, O, prob, opts):
-    """make both sides use the very same shock matrix (the library's host-generated default)"""
-    h = S.hip_context(prob, opts)
-    Z = h.Z()
-    h.close()
-    return Z
+def run_both(S, O, prob, opts, tables, T=None):
+    T = opts.maxiter if T is None else T
+    h, o = make_pair(S, O, prob, opts, tables)
+    h.step(T); o.step(T)
+    return h, o
 
 
 def test_eval_batch_matches_oracle(S, O):
     prob, opts = cm.serial_normal(N=3, T=2)
-    h = S.hip_context(prob, opts); o = O.OracleContext(prob, opts)
-    np.testing.assert_array_equal(h.Z(), o.Z())  # host generated in both: same libm
+    h, o = make_pair(S, O, prob, opts)
+    np.testing.assert_allclose(h.Z(), O.gen_Z(opts.seed, 2, prob.ns), rtol=1e-14)  # same generator, libm builds differ by <= 1ulp
     rng = np.random.default_rng(0)
     for M in (1, 7, 8, 9, 100):
         p = np.stack([rng.uniform(-3, 3, M), rng.uniform(-20, 20, M)])
@@ -52,7 +50,7 @@ def test_eval_batch_analytic_anchor(S):
 @pytest.mark.parametrize("ns", [1, 63, 255, 256, 257, 1000, 10000])
 def test_eval_batch_ragged_ns(S, O, ns):
     prob, opts = cm.serial_normal(N=3, T=2, ns=ns)
-    h = S.hip_context(prob, opts); o = O.OracleContext(prob, opts)
+    h, o = make_pair(S, O, prob, opts)
     p = np.array([[0.2, -1.0, 2.5], [-0.2, 10.0, -19.0]])
     vh, mh, _ = h.eval_batch(p); vo, mo, _ = o.eval_batch(p)
     assert np.array_equal(vh, vo) and np.array_equal(mh, mo)
@@ -120,7 +118,7 @@ def test_banana(S, O):
 def test_error_negative_objective(S, O):
     # NaN data moment -> NaN value -> "AlgoBGP assumes ... non-negative" (AlgoBGP.jl:341)
     prob, opts = cm.serial_normal(N=4, T=5, ns=100, mom=(np.nan, 10.0))
-    h = S.hip_context(prob, opts); o = O.OracleContext(prob, opts)
+    h, o = make_pair(S, O, prob, opts)
     with pytest.raises(A.SMMHipError) as eh:
         h.step(3)
     with pytest.raises(A.SMMHipError) as eo:
@@ -131,7 +129,7 @@ def test_error_negative_objective(S, O):
 def test_error_no_draw_in_support(S, O):
     # mysample exhausts smpl_iters (AlgoBGP.jl:409)
     prob, opts = cm.serial_normal(N=4, T=5, ns=100, sigma0=1e6, smpl_iters=2)
-    h = S.hip_context(prob, opts); o = O.OracleContext(prob, opts)
+    h, o = make_pair(S, O, prob, opts)
     with pytest.raises(A.SMMHipError) as eh:
         h.step(3)
     with pytest.raises(A.SMMHipError) as eo:
@@ -214,9 +212,8 @@ def test_sharded_equals_single(S, O, G):
 def test_c2_full_size_against_oracle(S, O):
     # BASELINE config C2 (headline): 4096 chains x 200 iterations, ns = 10000
     prob, opts = cm.serial_normal(N=4096, T=200)
-    h = S.hip_context(prob, opts)
+    h, o = make_pair(S, O, prob, opts, threads=min(O.max_threads(), len(__import__("os").sched_getaffinity(0))))
     h.step(200)
-    o = O.OracleContext(prob, opts, threads=O.max_threads())
     o.step(200)
     hh, ho = h.history(), o.history()
     cm.assert_history_equal(hh, ho)
