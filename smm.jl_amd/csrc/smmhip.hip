@@ -1,16 +1,22 @@
 // smmhip.hip — libsmmhip.so: hand-written HIP (gfx950 / MI355X) implementation of the BGP
 // parallel-tempering iteration of floswald/SMM.jl behind the C ABI of include/smmhip.h.
 //
-// One iteration of computeNextIteration!(algo::MAlgoBGP) (src/mopt/AlgoBGP.jl:589-640) is
-//   k_chain_iter   : next_eval for every chain at once (proposal :424-471, objective
-//                    mprob.jl:175-188 -> ObjExamples.jl:59-116, doAcceptReject! :324-392,
-//                    set_eval! :220-245); a 256-lane workgroup owns a tile of CT chains,
-//                    the ns simulated draws are spread over the lanes, the shock matrix Z is
-//                    re-used CT times from registers, moments are reduced by a transposed
-//                    wave reduction + LDS.
-//   k_exch_resolve : exchangeMoves! (:647-716): pair sampling + ordered swap resolution by
-//                    ONE workgroup, exact sequential semantics via dependency rounds.
-//   k_exch_apply   : swap_ev_ij! (:734-749) + set_exchanged! for the local chains.
+// One iteration of computeNextIteration!(algo::MAlgoBGP) (src/mopt/AlgoBGP.jl:589-640) is two
+// dependent launches on one HIP stream:
+//   k_chain_iter      : next_eval for every chain at once — materialise the previous iteration's
+//                       exchange (swap_ev_ij! :734-749), proposal (:424-471), objective
+//                       (mprob.jl:175-188 -> ObjExamples.jl:59-116), doAcceptReject! (:324-392),
+//                       set_eval! (:220-245).  A 256-lane workgroup owns a tile of CT chains, the
+//                       ns simulated draws are spread over the lanes, every shock z is re-used CT
+//                       times from a register, moments are reduced by a transposed wave reduction
+//                       and combined through LDS.
+//   k_exch_resolve_*  : exchangeMoves! (:647-716): ordered swap resolution by ONE workgroup with
+//                       exact sequential semantics (data-flow over per-chain tickets in LDS).
+// Everything that does not depend on the chains' state is produced ahead of the dependent loop by
+// wide, latency-tolerant kernels, one window of iterations at a time:
+//   k_pregen_rng      : proposal normals (first tries) and the MH uniforms (probs_acc, :85)
+//   k_exch_plan       : the exchange pair list of every iteration and each pair's rank among the
+//                       pairs of its two chains (the dependency structure of the sequential walk)
 // Data layout: structure-of-arrays, chain index fastest (coalesced), FP64 throughout.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,10 +37,15 @@ using namespace smm;
 
 constexpr int WG = SMM_REDUCE_LANES;  // 256 lanes own one chain tile (numerical contract)
 constexpr int MAX_DIM = 64;           // np, nm <= 64
-constexpr int XWG = 1024;             // exchange-resolution workgroup
+constexpr int XWG = 1024;             // exchange workgroup
+constexpr int XLDS_MAX = 8192;        // largest N_global resolved in LDS (16 B per chain)
+constexpr int PRE_TRIES = 4;          // proposal tries generated ahead (later tries: in-kernel RNG)
+constexpr unsigned XSPIN_LIMIT = 1u << 22;
 
-// error word: min over (iter<<34 | chain<<2 | kind); kind 1 = negative objective, 2 = no draw
+// error word: min over (iter<<34 | chain<<2 | kind); 1 negative objective, 2 no draw, 3 internal
 constexpr unsigned long long ERR_NONE = ~0ull;
+
+enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2 };
 
 struct KParams {
     // problem
@@ -47,29 +58,31 @@ struct KParams {
     double sigma_adjust_by;
     uint64_t seed;
     const double *acc_tuner_g, *min_improve_g;  // [Ng]
-    // tables
-    const double* utab;   // [T][N] or null
-    const double* ntab;   // [T][K][np][N] or null
-    int ntries;
-    const int32_t* pairtab;  // [T][n_pairs][2] or null
+    // randomness tables: either injected for the whole run (t0 = 1) or the current window
+    const double* utab;  // [W][N]
+    int utab_t0;
+    const double* ntab;  // [W][ntries][np][N]
+    int ntab_t0, ntries, ntab_user;
+    const int32_t* pairtab;  // injected [T][n_pairs][2] or null
     int n_pairs_tab;
+    const unsigned long long* plan;  // [W][K]: pi | pj<<16 | ri<<32 | rj<<48
+    int plan_t0, plan_K;
     // chain state [N]
     double *sigma, *accept_rate;
-    double *la_value, *la_prob, *la_params, *la_simM;
-    int8_t* la_status;
     int32_t *n_noex, *n_acc;
-    double* best_val;
-    int32_t* best_id;
-    double* rec;  // [(3+np+nm)][N] last accepted records after the accept step
-    // exchange scratch [Ng]
-    double* xval;
+    uint8_t *last_acc, *was_exch;
+    double *best_val, *bestp_val;
+    int32_t *best_id, *bestp_id;
+    // exchange result [Ng] (+ scratch of the any-size kernel)
     int32_t *xsrc, *xpartner, *xnext, *xpairs;
+    double* xval;
     // history [T][..][N]
     double *h_value, *h_prob, *h_curr, *h_best, *h_params, *h_simM;
     int32_t *h_best_id, *h_exch;
     uint8_t* h_acc;
     int8_t* h_status;
     unsigned long long* err;
+    int dbg;  // SMMHIP_DBG timing experiments (results invalid when != 0)
 };
 
 __device__ inline void report_error(const KParams& P, int kind, int t, int gchain) {
@@ -77,9 +90,11 @@ __device__ inline void report_error(const KParams& P, int kind, int t, int gchai
     atomicMin(P.err, key);
 }
 
-// Transposed wave reduction: every lane holds CT partial sums a[0..CT); on return lane l holds
-// the 64-lane total of accumulator acc_index<CT>(l), combined by the canonical halving tree
-// (offsets 32,16,8,4,2,1; IEEE addition is commutative so both partners get the same bits).
+// ------------------------------------------------------------------------------------------
+// Transposed wave reduction: every lane holds CT partial sums a[0..CT); on return lane l holds the
+// 64-lane total of accumulator acc_index<CT>(l), combined by the canonical halving tree (offsets
+// 32,16,8,4,2,1; IEEE addition is commutative so both partners compute the same bits).
+// ------------------------------------------------------------------------------------------
 template <int CT, int NN, int OFF>
 __device__ inline void wave_reduce_step(double (&a)[CT], int lane) {
     if constexpr (NN > 1) {
@@ -103,8 +118,7 @@ __device__ inline double wave_reduce_transposed(double (&a)[CT], int lane) {
     return a[0];
 }
 template <int CT>
-__device__ inline int acc_index(int lane) {
-    // the log2(CT) top lane bits, most significant first
+__device__ inline int acc_index(int lane) {  // the log2(CT) top lane bits
     constexpr int LG = (CT == 1) ? 0 : (CT == 2) ? 1 : (CT == 4) ? 2 : (CT == 8) ? 3 : (CT == 16) ? 4 : (CT == 32) ? 5 : 6;
     return LG == 0 ? 0 : (lane >> (6 - LG));
 }
@@ -114,11 +128,15 @@ __device__ inline bool acc_writer(int lane) {
 }
 
 // The simulation of objfunc_norm (ObjExamples.jl:76-79) for a tile of CT chains:
-// X[k,s] = theta_c[k] + z[k,s]; partial sums over the draws of each lane; reduction.
-// s_theta [CT][np] (LDS), s_part [4][CT][nm] (LDS).
+// X[k,s] = theta_c[k] + z[k,s]; lane `tid` sums its draws tid, tid+256, ... in that order
+// (numerical contract); U rows are loaded ahead of use so that U independent reads of the
+// L2-resident shock matrix are in flight per lane.  s_theta [CT][np], s_part [4][CT][nm] in LDS.
 template <int CT>
 __device__ inline void simulate_tile(const KParams& P, const double* s_theta, double* s_part, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
+    constexpr int U = 8;
+    const int ns = P.ns;
+    const int nfull = ns / (U * WG);  // chunks of U rows in which every lane has a draw (uniform)
     for (int k = 0; k < P.nm; ++k) {
         double mu[CT], acc[CT];
 #pragma unroll
@@ -126,25 +144,17 @@ __device__ inline void simulate_tile(const KParams& P, const double* s_theta, do
             mu[c] = s_theta[c * P.np + k];
             acc[c] = 0.0;
         }
-        const double* __restrict__ Zk = P.Z + (size_t)k * P.ns;
-        // lane `tid` sums its draws tid, tid+256, ... in that order (numerical contract).  U rows
-        // are loaded ahead of use so that U independent L2 reads are in flight per lane.
-        constexpr int U = 8;
-        int s = tid;
+        const double* __restrict__ Zk = P.Z + (size_t)k * ns;
         double zc[U];
-        bool have = (s + (U - 1) * WG) < P.ns;
-        if (have) {
+        if (nfull > 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) zc[u] = Zk[s + u * WG];
+            for (int u = 0; u < U; ++u) zc[u] = Zk[tid + u * WG];
         }
-        while (have) {
-            const int sn = s + U * WG;
-            const bool have_next = (sn + (U - 1) * WG) < P.ns;
+        for (int ch = 0; ch < nfull; ++ch) {
             double zn[U];
-            if (have_next) {
+            const int base_n = (ch + 1 < nfull) ? (ch + 1) * U * WG : ch * U * WG;  // last trip: harmless reload
 #pragma unroll
-                for (int u = 0; u < U; ++u) zn[u] = Zk[sn + u * WG];
-            }
+            for (int u = 0; u < U; ++u) zn[u] = Zk[base_n + tid + u * WG];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -153,24 +163,17 @@ __device__ inline void simulate_tile(const KParams& P, const double* s_theta, do
                     acc[c] = acc[c] + x;
                 }
             }
-            if (have_next) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) zc[u] = zn[u];
-            }
-            s = sn;
-            have = have_next;
+            for (int u = 0; u < U; ++u) zc[u] = zn[u];
         }
-        {   // remaining (< U full rows + the ragged last row): masked
+        {   // remaining rows (< U full rows + the ragged last row): clamped loads, predicated adds
+            const int s0 = nfull * U * WG + tid;
             double zt[U];
-            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) zt[u] = Zk[min(s0 + u * WG, ns - 1)];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                ok[u] = (s + u * WG) < P.ns;
-                zt[u] = ok[u] ? Zk[s + u * WG] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (ok[u]) {
+                if (s0 + u * WG < ns) {
 #pragma unroll
                     for (int c = 0; c < CT; ++c) {
                         const double x = zt[u] + mu[c];
@@ -226,22 +229,70 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
     status = 1;
 }
 
+// Head of an iteration for local chain c: settle what iteration t-1 left open.
+//  - F_HAS_PENDING: the exchange of iteration t-1 was resolved (xsrc/xpartner) but not applied.
+//    set_eval!(ci, ej) of swap_ev_ij! (AlgoBGP.jl:734-749): the chain's record of iteration t-1 is
+//    overwritten by the donor's last accepted record (accepted = true, the donor's prob/status),
+//    curr = donor value, best recomputed against iteration t-2 (:231-243); exchanged = partner.
+//  - F_CLOSE_PREV: iteration t-1 counts towards accept_rate iff it was not exchanged
+//    (set_acceptRate!, :253-257).
+// Returns the local index s of the record (in rec_in) the chain continues from.
+__device__ inline int settle_previous(const KParams& P, int t, int c, const double* __restrict__ rec_in, int flags) {
+    const int N = P.N, np = P.np, nm = P.nm;
+    int s = c;
+    bool exch = false;
+    if (flags & F_HAS_PENDING) {
+        const int g = P.offset + c;
+        const int partner = P.xpartner[g];
+        if (partner != 0) {
+            exch = true;
+            s = P.xsrc[g] - P.offset;
+            const int tp = t - 1;
+            const double value = rec_in[s], prob = rec_in[(size_t)N + s];
+            const int8_t status = (int8_t)rec_in[(size_t)2 * N + s];
+            const double bp = P.bestp_val[c];
+            double bestv; int bestid;
+            if (value < bp) { bestv = value; bestid = tp; }
+            else { bestv = bp; bestid = P.bestp_id[c]; }
+            P.best_val[c] = bestv; P.best_id[c] = bestid;
+            const size_t row = (size_t)(tp - 1) * N + c;
+            P.h_value[row] = value; P.h_prob[row] = prob; P.h_curr[row] = value; P.h_best[row] = bestv;
+            P.h_best_id[row] = bestid; P.h_exch[row] = partner; P.h_acc[row] = 1; P.h_status[row] = status;
+            for (int k = 0; k < np; ++k) P.h_params[((size_t)(tp - 1) * np + k) * N + c] = rec_in[(size_t)(3 + k) * N + s];
+            for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(tp - 1) * nm + k) * N + c] = rec_in[(size_t)(3 + np + k) * N + s];
+        }
+    } else if (P.was_exch[c]) {  // sharded path: k_exch_apply already rewrote record and history
+        exch = true;
+        P.was_exch[c] = 0;
+    }
+    if ((flags & F_CLOSE_PREV) && !exch) {
+        P.n_noex[c] += 1;
+        P.n_acc[c] += P.last_acc[c];
+    }
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------
-// k_chain_iter: one next_eval (AlgoBGP.jl:272-294) for every local chain, iteration t (1-based)
+// k_chain_iter: one next_eval (AlgoBGP.jl:272-294) for every local chain, iteration t (1-based).
+// rec_in : last accepted records after iteration t-1's accept step   [(3+np+nm)][N]
+// rec_out: the same after iteration t's accept step (input of exchangeMoves!)
 // ------------------------------------------------------------------------------------------
 template <bool SIM, int CT>
-__global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t, const int close_iter) {
+__global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                   double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* s_theta = smem;                         // [CT][np]
-    double* s_simM = s_theta + CT * P.np;           // [CT][nm]
-    double* s_part = s_simM + CT * P.nm;            // [4][CT][nm]
+    double* s_theta = smem;                // [CT][np]
+    double* s_simM = s_theta + CT * P.np;  // [CT][nm]
+    double* s_part = s_simM + CT * P.nm;   // [4][CT][nm]
     const int tid = threadIdx.x;
     const int c = blockIdx.x * CT + tid;
     const bool chain_lane = (tid < CT) && (c < P.N);
     const int gc = P.offset + c;
     const int N = P.N, np = P.np, nm = P.nm;
+    int s = c;            // record the chain continues from
+    double old = INFINITY;
 
-    // ---- proposal(c), AlgoBGP.jl:424-471 ----
+    // ---- settle iteration t-1, then proposal(c), AlgoBGP.jl:424-471 ----
     if (tid < CT) {
         double* th = s_theta + tid * np;
         if (!chain_lane) {
@@ -249,41 +300,48 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
         } else if (t == 1) {
             for (int k = 0; k < np; ++k) th[k] = P.init[k];  // :426-427
         } else {
+            s = settle_previous(P, t, c, rec_in, flags);
+            old = rec_in[s];
             const double sig = P.sigma[c];
             const int bs = P.batch_size;
-            const int max_tries = P.ntab ? min(P.ntries, P.smpl_iters) : P.smpl_iters;
-            for (int b0 = 0; b0 < np; b0 += bs) {
-                bool ok = false;
-                for (int r = 0; r < max_tries && !ok; ++r) {  // mysample, :400-410
-                    ok = true;
-                    double zc0 = 0.0, zc1 = 0.0;
-                    int zq = -1;
-                    for (int k = b0; k < b0 + bs; ++k) {
-                        const double lbk = P.lb[k], ubk = P.ub[k];
-                        const double mu01 = (P.la_params[(size_t)k * N + c] - lbk) / (ubk - lbk);  // mprob.jl:248
-                        double z;
-                        if (P.ntab) {
-                            z = P.ntab[((((size_t)(t - 1) * P.ntries + r) * np + k) * N) + c];
-                        } else {
-                            if ((k >> 1) != zq) {
-                                zq = k >> 1;
-                                rng_prop_normal2(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)r, (uint32_t)zq, zc0, zc1);
+            const int max_tries = P.ntab_user ? min(P.ntries, P.smpl_iters) : P.smpl_iters;
+            const size_t wrow = (size_t)(t - P.ntab_t0) * P.ntries;
+            if (P.dbg & 1) {
+                for (int k = 0; k < np; ++k) th[k] = rec_in[(size_t)(3 + k) * N + s];
+            } else {
+                for (int b0 = 0; b0 < np; b0 += bs) {
+                    bool ok = false;
+                    for (int r = 0; r < max_tries && !ok; ++r) {  // mysample, :400-410
+                        ok = true;
+                        double zc0 = 0.0, zc1 = 0.0;
+                        int zq = -1;
+                        for (int k = b0; k < b0 + bs; ++k) {
+                            const double lbk = P.lb[k], ubk = P.ub[k];
+                            const double mu01 = (rec_in[(size_t)(3 + k) * N + s] - lbk) / (ubk - lbk);  // mprob.jl:248
+                            double z;
+                            if (r < P.ntries) {
+                                z = P.ntab[((wrow + r) * np + k) * N + c];
+                            } else {
+                                if ((k >> 1) != zq) {
+                                    zq = k >> 1;
+                                    rng_prop_normal2(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)r, (uint32_t)zq, zc0, zc1);
+                                }
+                                z = (k & 1) ? zc1 : zc0;
                             }
-                            z = (k & 1) ? zc1 : zc0;
+                            const double step = sig * z;  // MvNormal(mu01, sigma): x = mu + sigma*z
+                            const double x = mu01 + step;
+                            th[k] = x;
+                            if (!(x >= 0.0 && x <= 1.0)) ok = false;  // inclusive bounds, :405
                         }
-                        const double step = sig * z;  // MvNormal(mu01, sigma): x = mu + sigma*z
-                        const double x = mu01 + step;
-                        th[k] = x;
-                        if (!(x >= 0.0 && x <= 1.0)) ok = false;  // inclusive bounds, :405
                     }
+                    if (!ok) report_error(P, 2, t, gc);  // :409
                 }
-                if (!ok) report_error(P, 2, t, gc);  // :409
-            }
-            for (int k = 0; k < np; ++k) {
-                const double lbk = P.lb[k];
-                const double span = P.ub[k] - lbk;
-                const double sc = th[k] * span;
-                th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
+                for (int k = 0; k < np; ++k) {
+                    const double lbk = P.lb[k];
+                    const double span = P.ub[k] - lbk;
+                    const double sc = th[k] * span;
+                    th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
+                }
             }
         }
     }
@@ -291,9 +349,10 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
 
     // ---- simulation: all 256 lanes, ns draws x nm moments x CT chains ----
     if constexpr (SIM) {
-        simulate_tile<CT>(P, s_theta, s_part, tid);
+        if (!(P.dbg & 2)) simulate_tile<CT>(P, s_theta, s_part, tid);
         __syncthreads();
     }
+    if (P.dbg & 4) return;
 
     // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245) ----
     if (chain_lane) {
@@ -305,7 +364,6 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
 
         double prob;
         bool acc;
-        const double old = P.la_value[c];
         if (t == 1) {  // :326-332
             prob = 1.0; acc = true; status = 1;
         } else if (status < 0) {  // :336-338
@@ -318,7 +376,7 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
             else if (!isfinite(old)) { prob = 1.0; acc = true; }            // :355-359
             else {
                 status = 1;
-                const double u = P.utab ? P.utab[(size_t)(t - 1) * N + c] : rng_u(P.seed, (uint32_t)gc, (uint32_t)t);
+                const double u = P.utab[(size_t)(t - P.utab_t0) * N + c];  // probs_acc[iter], :85
                 acc = prob > u;  // strict, :362-367
             }
         }
@@ -326,6 +384,7 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
         const int nn = P.n_noex[c], na = P.n_acc[c];
         const double rate = (double)(na + (acc ? 1 : 0)) / (double)(nn + 1);
         P.accept_rate[c] = rate;
+        P.last_acc[c] = acc ? 1 : 0;
         if (t > 1 && (t % P.sigma_update_steps) == 0) {  // :381-390
             const double s0 = P.sigma[c];
             P.sigma[c] = (rate > 0.234) ? s0 * (1.0 + P.sigma_adjust_by) : s0 * (1.0 - P.sigma_adjust_by);
@@ -338,32 +397,37 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
         else {
             currv = acc ? value : old;  // curr_val[t-1] == value of the last accepted record
             const double bp = P.best_val[c];
+            const int bpid = P.best_id[c];
+            P.bestp_val[c] = bp; P.bestp_id[c] = bpid;  // best after t-1: needed if iteration t gets exchanged
             if (value < bp) { bestv = value; bestid = t; }
-            else { bestv = bp; bestid = P.best_id[c]; }
+            else { bestv = bp; bestid = bpid; }
         }
         P.best_val[c] = bestv; P.best_id[c] = bestid;
         P.h_value[row] = value; P.h_prob[row] = prob; P.h_curr[row] = currv; P.h_best[row] = bestv;
         P.h_best_id[row] = bestid; P.h_exch[row] = 0; P.h_acc[row] = acc ? 1 : 0; P.h_status[row] = (int8_t)status;
         for (int k = 0; k < np; ++k) P.h_params[((size_t)(t - 1) * np + k) * N + c] = th[k];
         for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(t - 1) * nm + k) * N + c] = sm[k];
-        // last accepted record (lastAccepted :209-215) + its export row for the exchange step
-        double rv, rp; int rs;
+        // the chain's last accepted record (lastAccepted :209-215) = input of the exchange step
         if (acc) {
-            rv = value; rp = prob; rs = status;
-            P.la_value[c] = value; P.la_prob[c] = prob; P.la_status[c] = (int8_t)status;
-            for (int k = 0; k < np; ++k) P.la_params[(size_t)k * N + c] = th[k];
-            for (int k = 0; k < nm; ++k) P.la_simM[(size_t)k * N + c] = sm[k];
+            rec_out[c] = value; rec_out[(size_t)N + c] = prob; rec_out[(size_t)2 * N + c] = (double)status;
+            for (int k = 0; k < np; ++k) rec_out[(size_t)(3 + k) * N + c] = th[k];
+            for (int k = 0; k < nm; ++k) rec_out[(size_t)(3 + np + k) * N + c] = sm[k];
         } else {
-            rv = old; rp = P.la_prob[c]; rs = P.la_status[c];
-        }
-        P.rec[c] = rv; P.rec[(size_t)N + c] = rp; P.rec[(size_t)2 * N + c] = (double)rs;
-        for (int k = 0; k < np; ++k) P.rec[(size_t)(3 + k) * N + c] = acc ? th[k] : P.la_params[(size_t)k * N + c];
-        for (int k = 0; k < nm; ++k) P.rec[(size_t)(3 + np + k) * N + c] = acc ? sm[k] : P.la_simM[(size_t)k * N + c];
-        if (close_iter) {  // no exchange phase follows: this iteration counts towards accept_rate
-            P.n_noex[c] = nn + 1;
-            P.n_acc[c] = na + (acc ? 1 : 0);
+            const int R = 3 + np + nm;
+            for (int f = 0; f < R; ++f) rec_out[(size_t)f * N + c] = rec_in[(size_t)f * N + s];
         }
     }
+}
+
+// k_flush: settle the last iteration (pending exchange + accept-rate counters) without starting a
+// new one, so that state/history can be read back or saved (save/readMalgo, AlgoAbstract.jl:83-102).
+__global__ void k_flush(const KParams P, const int t_next, const double* __restrict__ rec_in, double* __restrict__ rec_out,
+                        const int flags) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.N) return;
+    const int s = settle_previous(P, t_next, c, rec_in, flags);
+    const int R = 3 + P.np + P.nm;
+    for (int f = 0; f < R; ++f) rec_out[(size_t)f * P.N + c] = rec_in[(size_t)f * P.N + s];
 }
 
 // batched evaluateObjective(m,p), mprob.jl:175-188: params [np][M] -> value, simM [nm][M], status
@@ -397,16 +461,200 @@ __global__ __launch_bounds__(WG) void k_eval_batch(const KParams P, const double
 }
 
 // ------------------------------------------------------------------------------------------
-// k_exch_resolve: exchangeMoves! (AlgoBGP.jl:647-716) over all Ng chains, one workgroup.
-// The reference walks the K sampled pairs in order and swaps the two chains' last accepted
-// records when value_i - value_j > min_improve_i (:688).  Pairs that share no chain commute,
-// so the list is executed in dependency rounds: in each round every not-yet-executed pair
-// bids (atomicMin of its list position) on both of its chains; a pair that wins both bids has
-// no unexecuted predecessor touching either chain and is executed.  Result == sequential walk.
-// Outputs: xsrc[g] = chain whose post-accept record chain g ends up with, xpartner[g] = last
-// exchange partner (1-based) or 0.
+// k_pregen_rng: the state-independent randomness of iterations t0 .. t0+W-1:
+//   ntab [W][PRE_TRIES][np][N]  standard normals of mysample's first tries (rand(RAND,d), :404)
+//   utab [W][N]                 the MH uniforms (probs_acc = rand(n), :85)
+// one thread per (iteration, try, parameter pair, chain).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(XWG) void k_exch_resolve(const KParams P, const int t, const double* __restrict__ gathered) {
+__global__ void k_pregen_rng(const KParams P, const int t0, const int W, double* __restrict__ ntab, double* __restrict__ utab) {
+    const int N = P.N, np = P.np;
+    const int Q = (np + 1) / 2;
+    const size_t total = (size_t)W * PRE_TRIES * Q * N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % N);
+    size_t rest = i / N;
+    const int q = (int)(rest % Q); rest /= Q;
+    const int r = (int)(rest % PRE_TRIES);
+    const int w = (int)(rest / PRE_TRIES);
+    const int t = t0 + w;
+    const uint32_t gc = (uint32_t)(P.offset + c);
+    if (t > 1) {  // iteration 1 proposes the initial value (:426-427)
+        double z0, z1;
+        rng_prop_normal2(P.seed, gc, (uint32_t)t, (uint32_t)r, (uint32_t)q, z0, z1);
+        const size_t base = (((size_t)w * PRE_TRIES + r) * np) * N + c;
+        ntab[base + (size_t)(2 * q) * N] = z0;
+        if (2 * q + 1 < np) ntab[base + (size_t)(2 * q + 1) * N] = z1;
+    }
+    if (r == 0 && q == 0) utab[(size_t)w * N + c] = rng_u(P.seed, gc, (uint32_t)t);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_exch_plan: one workgroup per iteration t = t0 + blockIdx.x.  Samples the exchange pair list
+// (sample(props, K, replace=false), AlgoBGP.jl:653-656) and derives the dependency structure of
+// the ordered walk (:662-691): for pair q = (i,j), r_i / r_j = number of earlier pairs touching
+// chain i / chain j (counting sort of the 2K endpoints by chain: LDS atomics + block scan).
+// plan[t-t0][q] = i | j<<16 | r_i<<32 | r_j<<48.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0, unsigned long long* __restrict__ plan) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = t0 + blockIdx.x;
+    const int Ng = P.Ng, K = P.plan_K;
+    uint32_t* cnt = (uint32_t*)xsm;          // [Ng]  histogram -> cursor
+    uint32_t* ep = cnt + Ng;                 // [2K]  list positions bucketed by chain
+    uint16_t* pi = (uint16_t*)(ep + 2 * K);  // [K]
+    uint16_t* pj = pi + K;                   // [K]
+    uint32_t* wsum = (uint32_t*)(pj + K);    // [16] (pi,pj: 4K bytes from a 4-byte aligned base)
+    unsigned long long* out = plan + (size_t)blockIdx.x * K;
+
+    for (int c = tid; c < Ng; c += XWG) cnt[c] = 0;
+    if (P.pairtab) {
+        for (int q = tid; q < K; q += XWG) {
+            pi[q] = (uint16_t)P.pairtab[((size_t)(t - 1) * K + q) * 2];
+            pj[q] = (uint16_t)P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
+        }
+    } else {
+        PairPerm pp;
+        pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
+        for (int q = tid; q < K; q += XWG) {
+            int32_t i, j;
+            pair_unrank(pp.eval((uint64_t)q), i, j);
+            pi[q] = (uint16_t)i;
+            pj[q] = (uint16_t)j;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) {  // histogram of endpoints
+        atomicAdd(&cnt[pi[q]], 1u);
+        atomicAdd(&cnt[pj[q]], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of cnt[0..Ng) -> bucket start
+        constexpr int PER = XLDS_MAX / XWG;
+        const int per = (Ng + XWG - 1) / XWG;
+        const int c0 = tid * per;
+        uint32_t loc[PER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u;
+            const uint32_t v = (u < per && c < Ng) ? cnt[c] : 0u;
+            loc[u] = sum;
+            sum += v;
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const uint32_t excl = base + incl - sum;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u;
+            if (u < per && c < Ng) cnt[c] = excl + loc[u];
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) {  // scatter (order inside a bucket is arbitrary)
+        ep[atomicAdd(&cnt[pi[q]], 1u)] = (uint32_t)q;
+        ep[atomicAdd(&cnt[pj[q]], 1u)] = (uint32_t)q;
+    }
+    __syncthreads();  // now cnt[c] == end of chain c's bucket
+    for (int q = tid; q < K; q += XWG) {  // rank = number of smaller list positions in the bucket
+        const uint32_t i = pi[q], j = pj[q];
+        uint32_t b = i ? cnt[i - 1] : 0u, e = cnt[i], ri = 0, rj = 0;
+        for (uint32_t x = b; x < e; ++x) ri += (ep[x] < (uint32_t)q) ? 1u : 0u;
+        b = j ? cnt[j - 1] : 0u; e = cnt[j];
+        for (uint32_t x = b; x < e; ++x) rj += (ep[x] < (uint32_t)q) ? 1u : 0u;
+        out[q] = (unsigned long long)i | ((unsigned long long)j << 16) | ((unsigned long long)ri << 32) |
+                 ((unsigned long long)rj << 48);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_exch_resolve_lds: exchangeMoves! (AlgoBGP.jl:647-716) for N_global <= XLDS_MAX, one workgroup,
+// all state in LDS.  The reference walks the K sampled pairs in order and swaps the two chains'
+// last accepted records when value_i - value_j > min_improve_i (:688).  Pairs that share no chain
+// commute, so the list is executed as a data-flow graph: ticket[c] counts the executed pairs of
+// chain c and pair q = (i,j) runs exactly when ticket[i]==r_i && ticket[j]==r_j (all of its
+// predecessors on both chains ran, none of its successors did); then it publishes ticket+1 on both
+// chains (release/acquire at workgroup scope).  Critical path = longest dependency chain of the
+// list (~log N) x one LDS round trip.  Outputs xsrc[g] (whose record chain g ends up with) and
+// xpartner[g] (last exchange partner, 1-based, 0 = none).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Ng = P.Ng, N = P.N, R = 3 + P.np + P.nm, K = P.plan_K;
+    double* val = (double*)xsm;               // [Ng]
+    uint32_t* ticket = (uint32_t*)(val + Ng);  // [Ng]
+    uint16_t* src = (uint16_t*)(ticket + Ng);  // [Ng]
+    uint16_t* partner = src + Ng;              // [Ng]
+    const unsigned long long* __restrict__ plan = P.plan + (size_t)(t - P.plan_t0) * K;
+
+    int q = tid;
+    unsigned long long pw = (q < K) ? plan[q] : 0ull;
+    double mi = (q < K) ? P.min_improve_g[pw & 0xffff] : 0.0;
+    for (int g = tid; g < Ng; g += XWG) {
+        const int shard = g / N, l = g - shard * N;
+        val[g] = gathered[(size_t)shard * R * N + l];
+        ticket[g] = 0;
+        src[g] = (uint16_t)g;
+        partner[g] = 0;
+    }
+    __syncthreads();
+    unsigned spins = 0;
+    while (true) {
+        bool progressed = false;
+        if (q < K) {
+            const uint32_t i = (uint32_t)(pw & 0xffff), j = (uint32_t)((pw >> 16) & 0xffff);
+            const uint32_t ri = (uint32_t)((pw >> 32) & 0xffff), rj = (uint32_t)(pw >> 48);
+            const uint32_t ti = __hip_atomic_load(&ticket[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t tj = __hip_atomic_load(&ticket[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ti == ri && tj == rj) {
+                const double vi = val[i], vj = val[j];
+                if (vi - vj > mi) {                         // dist_fun = -, :688
+                    val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744
+                    const uint16_t si = src[i];
+                    src[i] = src[j]; src[j] = si;
+                    partner[i] = (uint16_t)(j + 1); partner[j] = (uint16_t)(i + 1);  // set_exchanged!, :747-748
+                }
+                __hip_atomic_store(&ticket[i], ti + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&ticket[j], tj + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                q += XWG;
+                if (q < K) {
+                    pw = plan[q];
+                    mi = P.min_improve_g[pw & 0xffff];
+                }
+                progressed = true;
+            }
+        }
+        if (__all(q >= K)) break;
+        if (!__any(progressed)) {
+            if (++spins > XSPIN_LIMIT) {  // cannot happen: the smallest pending list position is always runnable
+                if (lane == 0) report_error(P, 3, t, 0);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    for (int g = tid; g < Ng; g += XWG) {
+        P.xsrc[g] = src[g];
+        P.xpartner[g] = partner[g];
+    }
+}
+
+// k_exch_resolve_any: the same result for any N_global, state in global memory, executed in
+// barrier-separated dependency rounds: every pending pair bids (atomicMin of its list position) on
+// both of its chains; a pair that wins both bids has no pending predecessor and is executed.
+__global__ __launch_bounds__(XWG) void k_exch_resolve_any(const KParams P, const int t, const double* __restrict__ gathered) {
     const int tid = threadIdx.x;
     const int Ng = P.Ng, N = P.N, R = 3 + P.np + P.nm;
     const int K = P.pairtab ? P.n_pairs_tab : n_exchange_pairs(Ng);
@@ -467,198 +715,33 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve(const KParams P, const int
     }
 }
 
-// k_exch_resolve_lds: same result as k_exch_resolve, for K <= Ng <= XLDS_MAX, everything in LDS.
-// Instead of barrier-separated rounds the pair list is executed as a data-flow graph:
-//   1. per chain c, the list positions of the pairs touching c are bucketed (counting sort:
-//      LDS atomics + block scan) and every pair learns its rank r_i, r_j among the pairs of
-//      its two chains;
-//   2. ticket[c] counts the executed pairs of chain c; pair q may run exactly when
-//      ticket[i]==r_i && ticket[j]==r_j, i.e. when all its predecessors on both chains ran
-//      and none of its successors did: the sequential order of AlgoBGP.jl:662-691 per chain;
-//   3. after running it publishes ticket+1 on both chains (release/acquire, workgroup scope).
-// The critical path is the longest dependency chain (~ log N) times one LDS round trip.
-constexpr int XLDS_MAX = 4096;
-constexpr unsigned XSPIN_LIMIT = 1u << 22;
-
-__global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const int t, const double* __restrict__ gathered) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Ng = P.Ng, N = P.N, R = 3 + P.np + P.nm;
-    const int K = P.pairtab ? P.n_pairs_tab : n_exchange_pairs(Ng);
-    double* val = (double*)xsm;                       // [Ng]   (aliases ep[2K] during the build)
-    uint32_t* ep = (uint32_t*)xsm;                    // [2K]
-    uint32_t* cnt = (uint32_t*)(val + Ng);            // [Ng]   histogram -> cursor -> ticket
-    uint16_t* src = (uint16_t*)(cnt + Ng);            // [Ng]
-    uint16_t* partner = src + Ng;                     // [Ng]
-    uint16_t* pi = partner + Ng;                      // [K]
-    uint16_t* pj = pi + K;                            // [K]
-    uint16_t* ri = pj + K;                            // [K]
-    uint16_t* rj = ri + K;                            // [K]
-    uint32_t* wsum = (uint32_t*)(rj + K);             // [16] (4 u16 arrays of K = 8K bytes: 4-byte aligned)
-
-    for (int c = tid; c < Ng; c += XWG) cnt[c] = 0;
-    if (P.pairtab) {
-        for (int q = tid; q < K; q += XWG) {
-            pi[q] = (uint16_t)P.pairtab[((size_t)(t - 1) * K + q) * 2];
-            pj[q] = (uint16_t)P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
-        }
-    } else {
-        PairPerm pp;
-        pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
-        for (int q = tid; q < K; q += XWG) {
-            int32_t i, j;
-            pair_unrank(pp.eval((uint64_t)q), i, j);
-            pi[q] = (uint16_t)i;
-            pj[q] = (uint16_t)j;
-        }
-    }
-    __syncthreads();
-    // 1a. histogram of endpoints
-    for (int q = tid; q < K; q += XWG) {
-        atomicAdd(&cnt[pi[q]], 1u);
-        atomicAdd(&cnt[pj[q]], 1u);
-    }
-    __syncthreads();
-    // 1b. exclusive scan of cnt[0..Ng) -> cursor (segment start)
-    {
-        const int per = (Ng + XWG - 1) / XWG;  // consecutive entries per thread (<= 4)
-        const int c0 = tid * per;
-        uint32_t loc[XLDS_MAX / XWG];
-        uint32_t sum = 0;
-#pragma unroll
-        for (int u = 0; u < XLDS_MAX / XWG; ++u) {
-            const int c = c0 + u;
-            const uint32_t v = (u < per && c < Ng) ? cnt[c] : 0u;
-            loc[u] = sum;
-            sum += v;
-        }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t base = 0;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        const uint32_t excl = base + incl - sum;
-#pragma unroll
-        for (int u = 0; u < XLDS_MAX / XWG; ++u) {
-            const int c = c0 + u;
-            if (u < per && c < Ng) cnt[c] = excl + loc[u];
-        }
-    }
-    __syncthreads();
-    // 1c. scatter list positions into the chain buckets (order inside a bucket is arbitrary)
-    for (int q = tid; q < K; q += XWG) {
-        ep[atomicAdd(&cnt[pi[q]], 1u)] = (uint32_t)q;
-        ep[atomicAdd(&cnt[pj[q]], 1u)] = (uint32_t)q;
-    }
-    __syncthreads();  // now cnt[c] == end of chain c's bucket
-    // 1d. rank of each pair inside the buckets of its two chains = number of smaller positions
-    for (int q = tid; q < K; q += XWG) {
-        const int i = pi[q], j = pj[q];
-        uint32_t b = i ? cnt[i - 1] : 0u, e = cnt[i], r = 0;
-        for (uint32_t x = b; x < e; ++x) r += (ep[x] < (uint32_t)q) ? 1u : 0u;
-        ri[q] = (uint16_t)r;
-        b = j ? cnt[j - 1] : 0u; e = cnt[j]; r = 0;
-        for (uint32_t x = b; x < e; ++x) r += (ep[x] < (uint32_t)q) ? 1u : 0u;
-        rj[q] = (uint16_t)r;
-    }
-    __syncthreads();
-    // 2. state: values of the last accepted records, identity permutation, zero tickets
-    for (int g = tid; g < Ng; g += XWG) {
-        const int shard = g / N, l = g - shard * N;
-        val[g] = gathered[(size_t)shard * R * N + l];
-        src[g] = (uint16_t)g;
-        partner[g] = 0;
-        cnt[g] = 0;
-    }
-    __syncthreads();
-    // 3. data-flow execution
-    {
-        int q = tid;
-        double mi = (q < K) ? P.min_improve_g[pi[q]] : 0.0;
-        unsigned spins = 0;
-        while (true) {
-            bool progressed = false;
-            if (q < K) {
-                const int i = pi[q], j = pj[q];
-                const uint32_t ti = __hip_atomic_load(&cnt[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t tj = __hip_atomic_load(&cnt[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (ti == ri[q] && tj == rj[q]) {
-                    const double vi = val[i], vj = val[j];
-                    if (vi - vj > mi) {                         // dist_fun = -, AlgoBGP.jl:688
-                        val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744
-                        const uint16_t si = src[i];
-                        src[i] = src[j]; src[j] = si;
-                        partner[i] = (uint16_t)(j + 1); partner[j] = (uint16_t)(i + 1);  // :747-748
-                    }
-                    __hip_atomic_store(&cnt[i], ti + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&cnt[j], tj + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    q += XWG;
-                    if (q < K) mi = P.min_improve_g[pi[q]];
-                    progressed = true;
-                }
-            }
-            if (__all(q >= K)) break;
-            if (!__any(progressed)) {
-                if (++spins > XSPIN_LIMIT) {  // cannot happen (the smallest pending position is always runnable)
-                    if (lane == 0) report_error(P, 3, t, 0);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-    }
-    __syncthreads();
-    for (int g = tid; g < Ng; g += XWG) {
-        P.xsrc[g] = src[g];
-        P.xpartner[g] = partner[g];
-    }
-}
-
-// k_exch_apply: for local chains, set_eval!(ci, ej) (+ set_exchanged!) of swap_ev_ij!
-// (AlgoBGP.jl:734-749): the chain's record of iteration t is overwritten by the donor's last
-// accepted record; curr/best are recomputed against iteration t-1 (:231-243).  Also closes the
-// iteration's acceptance-rate counters (set_acceptRate!, :253-257).
-__global__ void k_exch_apply(const KParams P, const int t, const double* __restrict__ gathered) {
+// k_exch_apply (sharded path): set_eval!(ci, ej) + set_exchanged! of swap_ev_ij! (AlgoBGP.jl:734-749)
+// for the local chains, reading the donor records from the all-gathered buffer:
+// gathered [G][(3+np+nm)][N]; rec = this shard's own post-accept records, updated in place.
+__global__ void k_exch_apply(const KParams P, const int t, const double* __restrict__ gathered, double* __restrict__ rec) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.N) return;
     const int N = P.N, np = P.np, nm = P.nm, R = 3 + np + nm;
     const int g = P.offset + c;
     const int partner = P.xpartner[g];
-    const size_t row = (size_t)(t - 1) * N + c;
-    if (partner == 0) {
-        P.n_noex[c] += 1;
-        P.n_acc[c] += P.h_acc[row];
-        return;
-    }
+    if (partner == 0) return;
     const int s = P.xsrc[g];
     const int shard = s / N, l = s - shard * N;
-    const double* rec = gathered + (size_t)shard * R * N;
-    const double value = rec[l], prob = rec[(size_t)N + l];
-    const int8_t status = (int8_t)rec[(size_t)2 * N + l];
-    const size_t prow = (size_t)(t - 2) * N + c;
-    const double bp = P.h_best[prow];
+    const double* __restrict__ src = gathered + (size_t)shard * R * N;
+    const double value = src[l], prob = src[(size_t)N + l];
+    const int8_t status = (int8_t)src[(size_t)2 * N + l];
+    const double bp = P.bestp_val[c];
     double bestv; int bestid;
     if (value < bp) { bestv = value; bestid = t; }
-    else { bestv = bp; bestid = P.h_best_id[prow]; }
+    else { bestv = bp; bestid = P.bestp_id[c]; }
     P.best_val[c] = bestv; P.best_id[c] = bestid;
+    const size_t row = (size_t)(t - 1) * N + c;
     P.h_value[row] = value; P.h_prob[row] = prob; P.h_curr[row] = value; P.h_best[row] = bestv;
     P.h_best_id[row] = bestid; P.h_exch[row] = partner; P.h_acc[row] = 1; P.h_status[row] = status;
-    P.la_value[c] = value; P.la_prob[c] = prob; P.la_status[c] = status;
-    for (int k = 0; k < np; ++k) {
-        const double v = rec[(size_t)(3 + k) * N + l];
-        P.h_params[((size_t)(t - 1) * np + k) * N + c] = v;
-        P.la_params[(size_t)k * N + c] = v;
-    }
-    for (int k = 0; k < nm; ++k) {
-        const double v = rec[(size_t)(3 + np + k) * N + l];
-        P.h_simM[((size_t)(t - 1) * nm + k) * N + c] = v;
-        P.la_simM[(size_t)k * N + c] = v;
-    }
+    for (int k = 0; k < np; ++k) P.h_params[((size_t)(t - 1) * np + k) * N + c] = src[(size_t)(3 + k) * N + l];
+    for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(t - 1) * nm + k) * N + c] = src[(size_t)(3 + np + k) * N + l];
+    for (int f = 0; f < R; ++f) rec[(size_t)f * N + c] = src[(size_t)f * N + l];
+    P.was_exch[c] = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -677,9 +760,23 @@ struct Ctx {
     smm_timing_t timing{};
     bool pending_timing = false;
     bool profiling = false;
-    bool force_generic_exchange = false;
-    std::vector<hipEvent_t> pev;  // profiling events: 3 per iteration (before iter, after iter, after exchange)
+    bool force_any_exchange = false;
+    std::vector<hipEvent_t> pev;  // profiling events: 3 per iteration
     int pev_iters = 0;
+    // double-buffered last-accepted records
+    double* rec[2] = {nullptr, nullptr};
+    int cur = 0;               // rec[cur] holds the records after the last accept step
+    bool pending = false;      // exchange of iteration `iter` resolved but not applied
+    bool prev_open = false;    // accept-rate counters of iteration `iter` not closed yet
+    // look-ahead windows
+    int win_cap = 0;           // iterations per window
+    double *win_ntab = nullptr, *win_utab = nullptr;
+    unsigned long long* win_plan = nullptr;
+    int rng_t0 = 0, rng_w = 0;    // window currently held: iterations [t0, t0+w)
+    int plan_t0 = 0, plan_w = 0;
+    bool user_u = false, user_n = false;
+    bool lds_exchange = false;
+    int ct = 8;
 };
 
 #define HIPCHK(call)                                                                                  \
@@ -707,6 +804,7 @@ T* dupload(Ctx* c, const T* h, size_t n) {
 }
 template <class T>
 void dfill(Ctx* c, T* d, size_t n, T v) {
+    (void)c;
     std::vector<T> h(n, v);
     if (n) HIPCHK(hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
 }
@@ -716,35 +814,73 @@ bool is_sim(int obj) { return obj == SMM_OBJ_NORM || obj == SMM_OBJ_NORM_FAILBOX
 size_t tile_smem(const Ctx* c, int ct) {
     return (size_t)(ct * c->P.np + ct * c->P.nm + (is_sim(c->obj) ? (WG / 64) * ct * c->P.nm : 0)) * sizeof(double);
 }
+size_t plan_lds_bytes(int Ng, int K) { return (size_t)Ng * 4 + (size_t)K * 8 + (size_t)(K + (K & 1)) * 4 + 64 + 16; }
+size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
 
-void launch_chain_iter(Ctx* c, int t, int close_iter) {
-    const KParams& P = c->P;
-    if (is_sim(c->obj)) {
-        constexpr int CT = 8;
-        const int grid = (P.N + CT - 1) / CT;
-        hipLaunchKernelGGL((k_chain_iter<true, CT>), dim3(grid), dim3(WG), tile_smem(c, CT), c->stream, P, t, close_iter);
-    } else {
-        constexpr int CT = 64;
-        const int grid = (P.N + CT - 1) / CT;
-        hipLaunchKernelGGL((k_chain_iter<false, CT>), dim3(grid), dim3(WG), tile_smem(c, CT), c->stream, P, t, close_iter);
+int exchange_K(const Ctx* c) { return c->P.pairtab ? c->P.n_pairs_tab : n_exchange_pairs(c->P.Ng); }
+bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P.Ng > 1; }  // AlgoBGP.jl:637
+
+// make the look-ahead tables cover iteration t (1-based); windows never straddle a call that
+// needs them twice: a new window simply starts at t.
+void ensure_windows(Ctx* c, int t) {
+    KParams& P = c->P;
+    const bool need_rng = !(c->user_u && c->user_n);
+    if (need_rng && !(t >= c->rng_t0 && t < c->rng_t0 + c->rng_w)) {
+        const int W = std::min(c->win_cap, P.T - t + 1);
+        const size_t Q = (size_t)(P.np + 1) / 2;
+        const size_t total = (size_t)W * PRE_TRIES * Q * P.N;
+        hipLaunchKernelGGL(k_pregen_rng, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, P, t, W, c->win_ntab,
+                           c->win_utab);
+        c->rng_t0 = t; c->rng_w = W;
+        if (!c->user_n) { P.ntab = c->win_ntab; P.ntab_t0 = t; P.ntries = PRE_TRIES; P.ntab_user = 0; }
+        if (!c->user_u) { P.utab = c->win_utab; P.utab_t0 = t; }
+    }
+    if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
+        const int W = std::min(c->win_cap, P.T - t + 1);
+        hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan);
+        c->plan_t0 = t; c->plan_w = W;
+        P.plan = c->win_plan; P.plan_t0 = t;
     }
 }
 
-size_t xlds_bytes(int Ng, int K) {
-    return (size_t)Ng * (8 + 4 + 2 + 2) + (size_t)(K + (K & 1)) * 2 * 4 + 16 * 4 + 16;
-}
-
-void launch_exchange(Ctx* c, int t, const double* gathered) {
+void launch_chain_iter(Ctx* c, int t, int flags) {
     const KParams& P = c->P;
-    const int K = P.pairtab ? P.n_pairs_tab : n_exchange_pairs(P.Ng);
-    if (P.Ng <= XLDS_MAX && K <= P.Ng && !c->force_generic_exchange)
-        hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), xlds_bytes(P.Ng, K), c->stream, P, t, gathered);
-    else
-        hipLaunchKernelGGL(k_exch_resolve, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
-    hipLaunchKernelGGL(k_exch_apply, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, t, gathered);
+    const double* rin = c->rec[c->cur];
+    double* rout = c->rec[c->cur ^ 1];
+    if (is_sim(c->obj)) {
+        if (c->ct == 4) {
+            hipLaunchKernelGGL((k_chain_iter<true, 4>), dim3((P.N + 3) / 4), dim3(WG), tile_smem(c, 4), c->stream, P, t, rin, rout, flags);
+        } else if (c->ct == 16) {
+            hipLaunchKernelGGL((k_chain_iter<true, 16>), dim3((P.N + 15) / 16), dim3(WG), tile_smem(c, 16), c->stream, P, t, rin, rout, flags);
+        } else {
+            hipLaunchKernelGGL((k_chain_iter<true, 8>), dim3((P.N + 7) / 8), dim3(WG), tile_smem(c, 8), c->stream, P, t, rin, rout, flags);
+        }
+    } else {
+        constexpr int CT = 64;
+        hipLaunchKernelGGL((k_chain_iter<false, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, t, rin, rout, flags);
+    }
+    c->cur ^= 1;
 }
 
-bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P.Ng > 1; }  // AlgoBGP.jl:637
+void launch_resolve(Ctx* c, int t, const double* gathered) {
+    const KParams& P = c->P;
+    if (c->lds_exchange)
+        hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), resolve_lds_bytes(P.Ng), c->stream, P, t, gathered);
+    else
+        hipLaunchKernelGGL(k_exch_resolve_any, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
+}
+
+// settle the open end of the last iteration (no-op when nothing is open)
+void flush(Ctx* c) {
+    if (!c->pending && !c->prev_open) return;
+    const KParams& P = c->P;
+    const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
+    hipLaunchKernelGGL(k_flush, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter + 1, c->rec[c->cur],
+                       c->rec[c->cur ^ 1], flags);
+    c->cur ^= 1;
+    c->pending = false;
+    c->prev_open = false;
+}
 
 int check_device_error(Ctx* c) {
     unsigned long long e = ERR_NONE;
@@ -764,7 +900,7 @@ int check_device_error(Ctx* c) {
         return SMM_ERR_NEGATIVE_OBJECTIVE;
     }
     snprintf(b, sizeof b, "no draw in support after %d trials (chain %d, iteration %d): increase smpl_iters",
-             c->P.ntab ? (c->P.ntries < c->P.smpl_iters ? c->P.ntries : c->P.smpl_iters) : c->P.smpl_iters, chain + 1, it);
+             c->P.ntab_user ? std::min(c->P.ntries, c->P.smpl_iters) : c->P.smpl_iters, chain + 1, it);
     c->err = b;
     return SMM_ERR_NO_DRAW_IN_SUPPORT;
 }
@@ -809,10 +945,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         return fail(nullptr, SMM_ERR_INVALID_ARG, "need 1 <= np,nm <= 64 and ns >= 1");
     if (N < 1 || T < 1 || Ng < N || opts->chain_offset < 0 || opts->chain_offset + N > Ng || (Ng % N) != 0)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "bad N / N_global / chain_offset / maxiter");
-    if (is_sim(prob->objective_id) && np != nm)
-        return fail(nullptr, SMM_ERR_INVALID_ARG, "objfunc_norm needs one moment per parameter (ObjExamples.jl:66-78)");
     if (prob->objective_id < 0 || prob->objective_id > SMM_OBJ_NORM_FAILBOX)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "unknown objective_id");
+    if (is_sim(prob->objective_id) && np != nm)
+        return fail(nullptr, SMM_ERR_INVALID_ARG, "objfunc_norm needs one moment per parameter (ObjExamples.jl:66-78)");
     if (opts->batch_size < 1 || opts->batch_size > np || (np % opts->batch_size) != 0)
         return fail(nullptr, SMM_ERR_BAD_BATCH, "batch_size must divide the number of parameters (AlgoBGP.jl:95-103)");
     if (opts->sigma_update_steps < 1) return fail(nullptr, SMM_ERR_INVALID_ARG, "sigma_update_steps < 1");
@@ -831,8 +967,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         c->obj = prob->objective_id;
         c->exchange_from = opts->exchange_from_iter;
         {
-            const char* e = getenv("SMMHIP_GENERIC_EXCHANGE");  // test hook: force the any-size resolution kernel
-            c->force_generic_exchange = e && e[0] == '1';
+            const char* e = getenv("SMMHIP_ANY_EXCHANGE");  // test hook: force the any-size resolution kernel
+            c->force_any_exchange = e && e[0] == '1';
+            const char* d = getenv("SMMHIP_DBG");
+            P.dbg = d ? atoi(d) : 0;
+            const char* ct = getenv("SMMHIP_CT");  // tuning hook: chains per tile (4, 8, 16); numerics unaffected
+            c->ct = ct ? atoi(ct) : 8;
         }
         P.np = np; P.nm = nm; P.ns = ns; P.obj = prob->objective_id;
         P.init = dupload(c, prob->init, np); P.lb = dupload(c, prob->lb, np); P.ub = dupload(c, prob->ub, np);
@@ -851,30 +991,52 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.batch_size = opts->batch_size; P.sigma_adjust_by = opts->sigma_adjust_by; P.seed = opts->seed;
         P.acc_tuner_g = dupload(c, opts->acc_tuner, Ng); P.min_improve_g = dupload(c, opts->min_improve, Ng);
         const size_t TN = (size_t)T * N;
-        P.utab = (tab && tab->probs_acc) ? dupload(c, tab->probs_acc, TN) : nullptr;
+        if (tab && tab->probs_acc) { P.utab = dupload(c, tab->probs_acc, TN); P.utab_t0 = 1; c->user_u = true; }
         if (tab && tab->prop_normals && tab->prop_tries > 0) {
-            P.ntries = tab->prop_tries;
+            P.ntries = tab->prop_tries; P.ntab_t0 = 1; P.ntab_user = 1; c->user_n = true;
             P.ntab = dupload(c, tab->prop_normals, TN * (size_t)tab->prop_tries * np);
         }
         if (tab && tab->pairs && tab->n_pairs > 0) {
             P.n_pairs_tab = tab->n_pairs;
             P.pairtab = dupload(c, tab->pairs, (size_t)T * tab->n_pairs * 2);
         }
+        const int K = exchange_K(c);
+        P.plan_K = K;
+        c->lds_exchange = Ng > 1 && Ng <= XLDS_MAX && K >= 1 && K <= Ng && !c->force_any_exchange;
+        // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
+        {
+            const size_t per_iter = (size_t)PRE_TRIES * np * N * 8 + (size_t)N * 8 + (size_t)K * 8;
+            c->win_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)192 << 20) / per_iter));
+            c->win_cap = std::min(c->win_cap, T);
+            if (!(c->user_u && c->user_n)) {
+                c->win_ntab = dalloc<double>(c, (size_t)c->win_cap * PRE_TRIES * np * N);
+                c->win_utab = dalloc<double>(c, (size_t)c->win_cap * N);
+            }
+            if (c->lds_exchange) c->win_plan = dalloc<unsigned long long>(c, (size_t)c->win_cap * K);
+        }
         P.sigma = dupload(c, opts->sigma + opts->chain_offset, N);
         P.accept_rate = dalloc<double>(c, N); dfill(c, P.accept_rate, N, 0.0);
-        P.la_value = dalloc<double>(c, N); dfill(c, P.la_value, N, (double)INFINITY);
-        P.la_prob = dalloc<double>(c, N); dfill(c, P.la_prob, N, 0.0);
-        P.la_params = dalloc<double>(c, (size_t)np * N); dfill(c, P.la_params, (size_t)np * N, 0.0);
-        P.la_simM = dalloc<double>(c, (size_t)nm * N); dfill(c, P.la_simM, (size_t)nm * N, 0.0);
-        P.la_status = dalloc<int8_t>(c, N); dfill(c, P.la_status, N, (int8_t)0);
         P.n_noex = dalloc<int32_t>(c, N); dfill(c, P.n_noex, N, 0);
         P.n_acc = dalloc<int32_t>(c, N); dfill(c, P.n_acc, N, 0);
+        P.last_acc = dalloc<uint8_t>(c, N); dfill(c, P.last_acc, N, (uint8_t)0);
+        P.was_exch = dalloc<uint8_t>(c, N); dfill(c, P.was_exch, N, (uint8_t)0);
         P.best_val = dalloc<double>(c, N); dfill(c, P.best_val, N, (double)INFINITY);
         P.best_id = dalloc<int32_t>(c, N); dfill(c, P.best_id, N, -1);
-        P.rec = dalloc<double>(c, (size_t)(3 + np + nm) * N);
-        const int Kmax = std::max(std::max(n_exchange_pairs(Ng), P.n_pairs_tab), 1);
-        P.xval = dalloc<double>(c, Ng); P.xsrc = dalloc<int32_t>(c, Ng); P.xpartner = dalloc<int32_t>(c, Ng);
-        P.xnext = dalloc<int32_t>(c, Ng); P.xpairs = dalloc<int32_t>(c, (size_t)Kmax * 2);
+        P.bestp_val = dalloc<double>(c, N); dfill(c, P.bestp_val, N, (double)INFINITY);
+        P.bestp_id = dalloc<int32_t>(c, N); dfill(c, P.bestp_id, N, -1);
+        const size_t RN = (size_t)(3 + np + nm) * N;
+        for (int b = 0; b < 2; ++b) {
+            c->rec[b] = dalloc<double>(c, RN);
+            std::vector<double> h(RN, 0.0);
+            for (int i = 0; i < N; ++i) h[i] = INFINITY;  // value row: Inf until the first accept
+            HIPCHK(hipMemcpy(c->rec[b], h.data(), RN * 8, hipMemcpyHostToDevice));
+        }
+        const int Kmax = std::max(K, 1);
+        P.xsrc = dalloc<int32_t>(c, Ng); P.xpartner = dalloc<int32_t>(c, Ng);
+        dfill(c, P.xpartner, Ng, 0);
+        if (!c->lds_exchange) {
+            P.xval = dalloc<double>(c, Ng); P.xnext = dalloc<int32_t>(c, Ng); P.xpairs = dalloc<int32_t>(c, (size_t)Kmax * 2);
+        }
         P.h_value = dalloc<double>(c, TN); dfill(c, P.h_value, TN, (double)NAN);
         P.h_prob = dalloc<double>(c, TN); dfill(c, P.h_prob, TN, (double)NAN);
         P.h_curr = dalloc<double>(c, TN); dfill(c, P.h_curr, TN, (double)INFINITY);
@@ -886,8 +1048,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.h_acc = dalloc<uint8_t>(c, TN); dfill(c, P.h_acc, TN, (uint8_t)0);
         P.h_status = dalloc<int8_t>(c, TN); dfill(c, P.h_status, TN, (int8_t)0);
         P.err = dalloc<unsigned long long>(c, 1); dfill(c, P.err, 1, ERR_NONE);
-        HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)xlds_bytes(XLDS_MAX, XLDS_MAX)));
+        if (c->lds_exchange) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_lds_bytes(XLDS_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_plan, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)plan_lds_bytes(XLDS_MAX, XLDS_MAX)));
+        }
         HIPCHK(hipDeviceSynchronize());
     } catch (const std::string& m) {
         g_create_err = m;
@@ -946,17 +1112,23 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         for (int it = 0; it < n_iters; ++it) {
             const int t = c->iter + 1;
-            const bool ex = exchange_active(c, t);
+            ensure_windows(c, t);
+            const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
             if (c->profiling) HIPCHK(hipEventRecord(c->pev[3 * it], c->stream));
-            launch_chain_iter(c, t, ex ? 0 : 1);
+            launch_chain_iter(c, t, flags);
             if (c->profiling) HIPCHK(hipEventRecord(c->pev[3 * it + 1], c->stream));
-            if (ex) launch_exchange(c, t, c->P.rec);
+            c->prev_open = true;
+            c->pending = false;
+            if (exchange_active(c, t)) {
+                launch_resolve(c, t, c->rec[c->cur]);
+                c->pending = true;
+            }
             if (c->profiling) HIPCHK(hipEventRecord(c->pev[3 * it + 2], c->stream));
             c->iter = t;
         }
-        if (c->profiling) c->pev_iters = n_iters;
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         HIPCHK(hipGetLastError());
+        if (c->profiling) c->pev_iters = n_iters;
         c->pending_timing = true;
         c->timing.iters = n_iters;
         c->timing.chain_evals = (int64_t)n_iters * c->P.N;
@@ -979,8 +1151,12 @@ int smm_bgp_local_step(void* ctx) {
     try {
         HIPCHK(hipSetDevice(c->device));
         const int t = c->iter + 1;
-        launch_chain_iter(c, t, exchange_active(c, t) ? 0 : 1);
+        ensure_windows(c, t);
+        const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
+        launch_chain_iter(c, t, flags);
         HIPCHK(hipGetLastError());
+        c->prev_open = true;
+        c->pending = false;
         c->iter = t;
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
@@ -998,7 +1174,7 @@ int smm_bgp_export_records_dev(void* ctx, void* rec_dev) {
     if (!c || !rec_dev) return SMM_ERR_INVALID_ARG;
     try {
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipMemcpyAsync(rec_dev, c->P.rec, (size_t)(3 + c->P.np + c->P.nm) * c->P.N * sizeof(double),
+        HIPCHK(hipMemcpyAsync(rec_dev, c->rec[c->cur], (size_t)(3 + c->P.np + c->P.nm) * c->P.N * sizeof(double),
                               hipMemcpyDeviceToDevice, c->stream));
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
@@ -1010,9 +1186,15 @@ int smm_bgp_exchange_dev(void* ctx, const void* gathered_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !gathered_dev) return SMM_ERR_INVALID_ARG;
     if (c->iter < 1) return fail(c, SMM_ERR_STATE, "exchange before the first local step");
+    if (c->pending) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
     try {
         HIPCHK(hipSetDevice(c->device));
-        if (exchange_active(c, c->iter)) launch_exchange(c, c->iter, (const double*)gathered_dev);
+        if (exchange_active(c, c->iter)) {
+            const KParams& P = c->P;
+            launch_resolve(c, c->iter, (const double*)gathered_dev);
+            hipLaunchKernelGGL(k_exch_apply, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter,
+                               (const double*)gathered_dev, c->rec[c->cur]);
+        }
         HIPCHK(hipGetLastError());
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
@@ -1061,6 +1243,7 @@ int smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out) {
     if (!c || !out || t0 < 0 || t1 < t0 || t1 > c->P.T) return SMM_ERR_INVALID_ARG;
     try {
         HIPCHK(hipSetDevice(c->device));
+        flush(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         const KParams& P = c->P;
         const size_t N = P.N, nt = (size_t)(t1 - t0), off = (size_t)t0 * N;
@@ -1081,14 +1264,21 @@ int smm_get_state(void* ctx, smm_state_t* s) {
     if (!c || !s) return SMM_ERR_INVALID_ARG;
     try {
         HIPCHK(hipSetDevice(c->device));
+        flush(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         const KParams& P = c->P;
         const size_t N = P.N;
+        const double* rec = c->rec[c->cur];
         s->iter = c->iter;
         D2H(s->sigma, P.sigma, N, 8); D2H(s->accept_rate, P.accept_rate, N, 8);
-        D2H(s->la_value, P.la_value, N, 8); D2H(s->la_prob, P.la_prob, N, 8);
-        D2H(s->la_params, P.la_params, N * P.np, 8); D2H(s->la_sim_moments, P.la_simM, N * P.nm, 8);
-        D2H(s->la_status, P.la_status, N, 1); D2H(s->n_noex, P.n_noex, N, 4); D2H(s->n_acc_noex, P.n_acc, N, 4);
+        D2H(s->la_value, rec, N, 8); D2H(s->la_prob, rec + N, N, 8);
+        D2H(s->la_params, rec + 3 * N, N * P.np, 8); D2H(s->la_sim_moments, rec + (3 + P.np) * N, N * P.nm, 8);
+        if (s->la_status) {
+            std::vector<double> st(N);
+            HIPCHK(hipMemcpy(st.data(), rec + 2 * N, N * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < N; ++i) s->la_status[i] = (int8_t)st[i];
+        }
+        D2H(s->n_noex, P.n_noex, N, 4); D2H(s->n_acc_noex, P.n_acc, N, 4);
         D2H(s->best_val, P.best_val, N, 8); D2H(s->best_id, P.best_id, N, 4);
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
@@ -1105,10 +1295,16 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         HIPCHK(hipStreamSynchronize(c->stream));
         KParams& P = c->P;
         const size_t N = P.N, nt = (size_t)s->iter;
+        double* rec = c->rec[c->cur];
         H2D(P.sigma, s->sigma, N, 8); H2D(P.accept_rate, s->accept_rate, N, 8);
-        H2D(P.la_value, s->la_value, N, 8); H2D(P.la_prob, s->la_prob, N, 8);
-        H2D(P.la_params, s->la_params, N * P.np, 8); H2D(P.la_simM, s->la_sim_moments, N * P.nm, 8);
-        H2D(P.la_status, s->la_status, N, 1); H2D(P.n_noex, s->n_noex, N, 4); H2D(P.n_acc, s->n_acc_noex, N, 4);
+        H2D(rec, s->la_value, N, 8); H2D(rec + N, s->la_prob, N, 8);
+        H2D(rec + 3 * N, s->la_params, N * P.np, 8); H2D(rec + (3 + P.np) * N, s->la_sim_moments, N * P.nm, 8);
+        if (s->la_status) {
+            std::vector<double> st(N);
+            for (size_t i = 0; i < N; ++i) st[i] = (double)s->la_status[i];
+            HIPCHK(hipMemcpy(rec + 2 * N, st.data(), N * 8, hipMemcpyHostToDevice));
+        }
+        H2D(P.n_noex, s->n_noex, N, 4); H2D(P.n_acc, s->n_acc_noex, N, 4);
         H2D(P.best_val, s->best_val, N, 8); H2D(P.best_id, s->best_id, N, 4);
         if (h && nt) {
             H2D(P.h_value, h->value, nt * N, 8); H2D(P.h_prob, h->prob, nt * N, 8);
@@ -1117,7 +1313,10 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
             H2D(P.h_best_id, h->best_id, nt * N, 4); H2D(P.h_exch, h->exchanged, nt * N, 4);
             H2D(P.h_acc, h->accepted, nt * N, 1); H2D(P.h_status, h->status, nt * N, 1);
         }
+        dfill(c, P.was_exch, N, (uint8_t)0);
         c->iter = s->iter;
+        c->pending = false;
+        c->prev_open = false;
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }

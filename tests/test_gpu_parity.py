@@ -225,3 +225,23 @@ def test_c2_full_size_against_oracle(S, O):
     t, c = np.nonzero(ex)
     assert np.array_equal(ex[t, ex[t, c] - 1] != 0, np.ones(len(t), bool))  # partners are marked too
     assert (ex[0] == 0).all()  # no exchange in iteration 1 (AlgoBGP.jl:637)
+
+
+@pytest.mark.parametrize("N", [2, 3, 50, 1000])
+def test_any_size_exchange_kernel_matches(S, O, N, monkeypatch):
+    # the barrier-round resolution kernel (used above N_global = 8192) against the LDS data-flow one
+    prob, opts = cm.serial_normal(N=N, T=30, ns=200)
+    a, o = run_both(S, O, prob, opts, None)
+    monkeypatch.setenv("SMMHIP_ANY_EXCHANGE", "1")
+    b = S.hip_context(prob, opts)
+    b.step(30)
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_history_equal(a.history(), o.history())
+
+
+def test_window_boundaries(S, O):
+    # look-ahead tables are produced window by window (256 iterations): cross two boundaries
+    prob, opts = cm.serial_normal(N=40, T=600, ns=64)
+    h, o = run_both(S, O, prob, opts, None)
+    cm.assert_history_equal(h.history(), o.history())
+    cm.assert_state_equal(h.state(), o.state())
