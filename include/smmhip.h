@@ -34,10 +34,10 @@ extern "C" {
 
 /* Numerical contract shared with the oracle (oracle/smm_oracle.c):
  * the ns simulated draws of one moment are summed as SMM_REDUCE_LANES lane-strided
- * sequential partial sums (lane l takes draws l, l+256, l+512, ...), each group of 64
- * partials is combined by a halving tree (offsets 32,16,8,4,2,1) and the 4 group
+ * sequential partial sums (lane l takes draws l, l+512, l+1024, ...), each group of 64
+ * partials is combined by a halving tree (offsets 32,16,8,4,2,1) and the 8 group
  * totals are added left to right.  Replaces mean(X,dims=2), ObjExamples.jl:79. */
-#define SMM_REDUCE_LANES 256
+#define SMM_REDUCE_LANES 512
 
 typedef enum {
     SMM_OK = 0,

@@ -40,7 +40,7 @@
 #define ORC_OBJ_BANANA 1
 #define ORC_OBJ_NORM_FAILBOX 2
 
-#define ORC_REDUCE_LANES 256 /* numerical contract, see include/smmhip.h */
+#define ORC_REDUCE_LANES 512 /* numerical contract, see include/smmhip.h */
 
 /* same memory layout as smm_problem_t / smm_bgp_opts_t / smm_tables_t / smm_history_t /
  * smm_state_t of include/smmhip.h so that one set of ctypes classes drives both. */
@@ -231,7 +231,7 @@ void orc_gen_pairs(uint64_t seed, int32_t t /*1-based iteration*/, int32_t Ng, i
 /* ------------------------------------------------------------------------------------ */
 
 /* canonical reduction of SMM_REDUCE_LANES partial sums (see include/smmhip.h) */
-static double reduce_partials(double* p /*[256], clobbered*/) {
+static double reduce_partials(double* p /*[512], clobbered*/) {
     double tot = 0.0;
     for (int g = 0; g < ORC_REDUCE_LANES / 64; ++g) {
         double* q = p + 64 * g;

@@ -32,7 +32,7 @@ SMM_OBJ_NORM = 0
 SMM_OBJ_BANANA = 1
 SMM_OBJ_NORM_FAILBOX = 2
 
-SMM_REDUCE_LANES = 256
+SMM_REDUCE_LANES = 512
 
 
 class smm_problem_t(C.Structure):

@@ -35,11 +35,11 @@ namespace {
 
 using namespace smm;
 
-constexpr int WG = SMM_REDUCE_LANES;  // 256 lanes own one chain tile (numerical contract)
+constexpr int WG = SMM_REDUCE_LANES;  // 512 lanes own one chain tile (numerical contract)
 constexpr int MAX_DIM = 64;           // np, nm <= 64
 constexpr int XWG = 1024;             // exchange workgroup
 constexpr int XLDS_MAX = 8192;        // largest N_global resolved in LDS (16 B per chain)
-constexpr int PRE_TRIES = 4;          // proposal tries generated ahead (later tries: in-kernel RNG)
+constexpr int PRE_TRIES = 8;          // proposal tries generated ahead (later tries: in-kernel RNG)
 constexpr unsigned XSPIN_LIMIT = 1u << 22;
 
 // error word: min over (iter<<34 | chain<<2 | kind); 1 negative objective, 2 no draw, 3 internal
@@ -83,7 +83,10 @@ struct KParams {
     int8_t* h_status;
     unsigned long long* err;
     int dbg;  // SMMHIP_DBG timing experiments (results invalid when != 0)
+    unsigned long long* ts;  // SMMHIP_TS=1: per-workgroup phase timestamps of k_chain_iter (tools/)
 };
+
+#define TS_MARK(i) do { if (P.ts && threadIdx.x == 0) P.ts[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 
 __device__ inline void report_error(const KParams& P, int kind, int t, int gchain) {
     const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)gchain << 2) | (unsigned)kind;
@@ -128,35 +131,42 @@ __device__ inline bool acc_writer(int lane) {
 }
 
 // The simulation of objfunc_norm (ObjExamples.jl:76-79) for a tile of CT chains:
-// X[k,s] = theta_c[k] + z[k,s]; lane `tid` sums its draws tid, tid+256, ... in that order
-// (numerical contract); U rows are loaded ahead of use so that U independent reads of the
-// L2-resident shock matrix are in flight per lane.  s_theta [CT][np], s_part [4][CT][nm] in LDS.
+// X[k,s] = theta_c[k] + z[k,s]; lane `tid` of the 512 sums its draws tid, tid+512, ... of moment k
+// in that order (numerical contract).  Rows are processed in chunks of ZU; the shocks of the next
+// chunk (of this or of the next moment) are loaded from the L2-resident matrix while the current
+// chunk is added up.  Chunk 0 of moment 0 is loaded by the caller before its serial prologue.
+constexpr int ZU = 8;
+
+__device__ inline void sim_load_chunk(const double* __restrict__ Zk, int ns, int ch, int tid, double (&z)[ZU], int dbg) {
+    const int s0 = (dbg & 8) ? tid : ch * ZU * WG + tid;  // dbg 8: timing experiment, every chunk re-reads chunk 0
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) z[u] = Zk[min(s0 + u * WG, ns - 1)];
+}
+
+// zc: chunk 0 of moment 0 (already loaded).  s_theta [CT][np], s_part [WG/64][CT][nm] in LDS.
 template <int CT>
-__device__ inline void simulate_tile(const KParams& P, const double* s_theta, double* s_part, int tid) {
+__device__ inline void simulate_tile(const KParams& P, const double* s_theta, double* s_part, int tid, double (&zc)[ZU]) {
     const int lane = tid & 63, wave = tid >> 6;
-    constexpr int U = 8;
-    const int ns = P.ns;
-    const int nfull = ns / (U * WG);  // chunks of U rows in which every lane has a draw (uniform)
-    for (int k = 0; k < P.nm; ++k) {
-        double mu[CT], acc[CT];
+    const int ns = P.ns, nm = P.nm;
+    const int nfull = ns / (ZU * WG);  // chunks in which every lane has all ZU draws (uniform)
+    for (int k = 0; k < nm; ++k) {
+        const double* __restrict__ Zk = P.Z + (size_t)k * ns;
+        double mu[CT], acc[CT], zt[ZU];
+        // the ragged rest (< ZU rows): loaded now, used after the full chunks
+        sim_load_chunk(Zk, ns, nfull, tid, zt, P.dbg);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             mu[c] = s_theta[c * P.np + k];
             acc[c] = 0.0;
         }
-        const double* __restrict__ Zk = P.Z + (size_t)k * ns;
-        double zc[U];
-        if (nfull > 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) zc[u] = Zk[tid + u * WG];
-        }
         for (int ch = 0; ch < nfull; ++ch) {
-            double zn[U];
-            const int base_n = (ch + 1 < nfull) ? (ch + 1) * U * WG : ch * U * WG;  // last trip: harmless reload
+            double zn[ZU];
+            // next chunk of this moment, or chunk 0 of the next moment (last moment: harmless reload)
+            const bool last = (ch + 1 == nfull);
+            const double* __restrict__ Zn = (last && k + 1 < nm) ? Zk + ns : Zk;
+            sim_load_chunk(Zn, ns, last ? 0 : ch + 1, tid, zn, P.dbg);
 #pragma unroll
-            for (int u = 0; u < U; ++u) zn[u] = Zk[base_n + tid + u * WG];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < ZU; ++u) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     const double x = zc[u] + mu[c];
@@ -164,15 +174,12 @@ __device__ inline void simulate_tile(const KParams& P, const double* s_theta, do
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) zc[u] = zn[u];
+            for (int u = 0; u < ZU; ++u) zc[u] = zn[u];
         }
-        {   // remaining rows (< U full rows + the ragged last row): clamped loads, predicated adds
-            const int s0 = nfull * U * WG + tid;
-            double zt[U];
+        {
+            const int s0 = nfull * ZU * WG + tid;
 #pragma unroll
-            for (int u = 0; u < U; ++u) zt[u] = Zk[min(s0 + u * WG, ns - 1)];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < ZU; ++u) {
                 if (s0 + u * WG < ns) {
 #pragma unroll
                     for (int c = 0; c < CT; ++c) {
@@ -183,15 +190,17 @@ __device__ inline void simulate_tile(const KParams& P, const double* s_theta, do
             }
         }
         const double tot = wave_reduce_transposed<CT>(acc, lane);
-        if (acc_writer<CT>(lane)) s_part[(wave * CT + acc_index<CT>(lane)) * P.nm + k] = tot;
+        if (acc_writer<CT>(lane)) s_part[(wave * CT + acc_index<CT>(lane)) * nm + k] = tot;
     }
 }
 
 // value / simulated moments / status for one chain from its reduced sums
 // (ObjExamples.jl:79-110; banana :251-265; "exception" -> status -2, mprob.jl:183-186).
+// s_mom / s_w: data moments and weights staged in LDS.
 template <int CT>
 __device__ inline void finish_objective(const KParams& P, const double* theta /*LDS [np]*/, const double* s_part,
-                                        int ci, double* simM /*[nm] out, LDS*/, double& value, int& status) {
+                                        const double* s_mom, const double* s_w, int ci, double* simM /*[nm] out, LDS*/,
+                                        double& value, int& status) {
     if (P.obj == SMM_OBJ_BANANA) {
         double v = 0.0;
         for (int i = 0; i + 1 < P.np; ++i) {
@@ -201,7 +210,7 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
             const double term = 100.0 * (t1 * t1) + t2 * t2;
             v = (i == 0) ? term : v + term;
         }
-        for (int k = 0; k < P.nm; ++k) simM[k] = P.mom[k] + 2.2;
+        for (int k = 0; k < P.nm; ++k) simM[k] = s_mom[k] + 2.2;
         value = v;
         status = 1;
         return;
@@ -219,8 +228,8 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
         for (int wv = 1; wv < WG / 64; ++wv) tot = tot + s_part[(wv * CT + ci) * P.nm + k];
         const double m = tot / (double)P.ns;
         simM[k] = m;
-        double d = m - P.mom[k];
-        const double wk = P.w[k];
+        double d = m - s_mom[k];
+        const double wk = s_w[k];
         if (!isnan(wk)) d = d / wk;
         const double v = d * d;
         vsum = (k == 0) ? v : vsum + v;
@@ -229,7 +238,8 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
     status = 1;
 }
 
-// Head of an iteration for local chain c: settle what iteration t-1 left open.
+// What iteration t-1 left open for local chain c (used by k_flush; k_chain_iter inlines the same
+// logic with its loads hoisted):
 //  - F_HAS_PENDING: the exchange of iteration t-1 was resolved (xsrc/xpartner) but not applied.
 //    set_eval!(ci, ej) of swap_ev_ij! (AlgoBGP.jl:734-749): the chain's record of iteration t-1 is
 //    overwritten by the donor's last accepted record (accepted = true, the donor's prob/status),
@@ -237,8 +247,22 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
 //  - F_CLOSE_PREV: iteration t-1 counts towards accept_rate iff it was not exchanged
 //    (set_acceptRate!, :253-257).
 // Returns the local index s of the record (in rec_in) the chain continues from.
-__device__ inline int settle_previous(const KParams& P, int t, int c, const double* __restrict__ rec_in, int flags) {
+__device__ inline void write_swapped_history(const KParams& P, int tp, int c, int partner, const double* recv /*[R]*/,
+                                             double bp, int bpid, double& bestv, int& bestid) {
     const int N = P.N, np = P.np, nm = P.nm;
+    const double value = recv[0], prob = recv[1];
+    const int8_t status = (int8_t)recv[2];
+    if (value < bp) { bestv = value; bestid = tp; }
+    else { bestv = bp; bestid = bpid; }
+    const size_t row = (size_t)(tp - 1) * N + c;
+    P.h_value[row] = value; P.h_prob[row] = prob; P.h_curr[row] = value; P.h_best[row] = bestv;
+    P.h_best_id[row] = bestid; P.h_exch[row] = partner; P.h_acc[row] = 1; P.h_status[row] = status;
+    for (int k = 0; k < np; ++k) P.h_params[((size_t)(tp - 1) * np + k) * N + c] = recv[3 + k];
+    for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(tp - 1) * nm + k) * N + c] = recv[3 + np + k];
+}
+
+__device__ inline int settle_previous(const KParams& P, int t, int c, const double* __restrict__ rec_in, int flags) {
+    const int N = P.N, R = 3 + P.np + P.nm;
     int s = c;
     bool exch = false;
     if (flags & F_HAS_PENDING) {
@@ -247,19 +271,11 @@ __device__ inline int settle_previous(const KParams& P, int t, int c, const doub
         if (partner != 0) {
             exch = true;
             s = P.xsrc[g] - P.offset;
-            const int tp = t - 1;
-            const double value = rec_in[s], prob = rec_in[(size_t)N + s];
-            const int8_t status = (int8_t)rec_in[(size_t)2 * N + s];
-            const double bp = P.bestp_val[c];
+            double recv[3 + 2 * MAX_DIM];
+            for (int f = 0; f < R; ++f) recv[f] = rec_in[(size_t)f * N + s];
             double bestv; int bestid;
-            if (value < bp) { bestv = value; bestid = tp; }
-            else { bestv = bp; bestid = P.bestp_id[c]; }
+            write_swapped_history(P, t - 1, c, partner, recv, P.bestp_val[c], P.bestp_id[c], bestv, bestid);
             P.best_val[c] = bestv; P.best_id[c] = bestid;
-            const size_t row = (size_t)(tp - 1) * N + c;
-            P.h_value[row] = value; P.h_prob[row] = prob; P.h_curr[row] = value; P.h_best[row] = bestv;
-            P.h_best_id[row] = bestid; P.h_exch[row] = partner; P.h_acc[row] = 1; P.h_status[row] = status;
-            for (int k = 0; k < np; ++k) P.h_params[((size_t)(tp - 1) * np + k) * N + c] = rec_in[(size_t)(3 + k) * N + s];
-            for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(tp - 1) * nm + k) * N + c] = rec_in[(size_t)(3 + np + k) * N + s];
         }
     } else if (P.was_exch[c]) {  // sharded path: k_exch_apply already rewrote record and history
         exch = true;
@@ -276,92 +292,198 @@ __device__ inline int settle_previous(const KParams& P, int t, int c, const doub
 // k_chain_iter: one next_eval (AlgoBGP.jl:272-294) for every local chain, iteration t (1-based).
 // rec_in : last accepted records after iteration t-1's accept step   [(3+np+nm)][N]
 // rec_out: the same after iteration t's accept step (input of exchangeMoves!)
+// A 512-lane workgroup owns CT chains.  Lanes 0..CT-1 of wave 0 are the "chain lanes" that do the
+// per-chain serial work; wave 1 stages the problem constants; every lane pre-loads its first
+// shocks.  All per-chain global reads are issued up front in two dependent levels (state +
+// exchange result, then the record the chain continues from) and staged in LDS.
 // ------------------------------------------------------------------------------------------
+constexpr int NPF_MAX = 8;  // proposal tries whose normals are staged in LDS
+
+struct TileSmem {
+    double *theta, *simM, *rec, *z, *sig, *lb, *ub, *mom, *w, *part;
+    __device__ inline void carve(double* base, int CT, int np, int nm) {
+        const int R = 3 + np + nm;
+        theta = base;                 // [CT][np]
+        simM = theta + CT * np;       // [CT][nm]
+        rec = simM + CT * nm;         // [CT][R]
+        z = rec + CT * R;             // [CT][NPF_MAX][np]
+        sig = z + CT * NPF_MAX * np;  // [CT]
+        lb = sig + CT;                // [np]
+        ub = lb + np;                 // [np]
+        mom = ub + np;                // [nm]
+        w = mom + nm;                 // [nm]
+        part = w + nm;                // [WG/64][CT][nm]
+    }
+};
+
 template <bool SIM, int CT>
-__global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
-                                                   double* __restrict__ rec_out, const int flags) {
+__global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                      double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* s_theta = smem;                // [CT][np]
-    double* s_simM = s_theta + CT * P.np;  // [CT][nm]
-    double* s_part = s_simM + CT * P.nm;   // [4][CT][nm]
+    const int np = P.np, nm = P.nm, N = P.N, R = 3 + np + nm;
+    TileSmem S;
+    S.carve(smem, CT, np, nm);
     const int tid = threadIdx.x;
     const int c = blockIdx.x * CT + tid;
-    const bool chain_lane = (tid < CT) && (c < P.N);
+    const bool chain_lane = (tid < CT) && (c < N);
     const int gc = P.offset + c;
-    const int N = P.N, np = P.np, nm = P.nm;
-    int s = c;            // record the chain continues from
-    double old = INFINITY;
+    const int npf = min(P.ntries, NPF_MAX);
 
-    // ---- settle iteration t-1, then proposal(c), AlgoBGP.jl:424-471 ----
-    if (tid < CT) {
-        double* th = s_theta + tid * np;
-        if (!chain_lane) {
-            for (int k = 0; k < np; ++k) th[k] = 0.0;
-        } else if (t == 1) {
-            for (int k = 0; k < np; ++k) th[k] = P.init[k];  // :426-427
+    // per-chain state, live in registers from the prologue to the epilogue
+    int partner = 0, s = c, nn = 0, na = 0, bpid = -1, bppid = -1, lacc = 0, wasx = 0;
+    double sig = 0.0, bp = INFINITY, bpp = INFINITY, atun = 0.0, u = 0.0;
+    TS_MARK(0);
+
+    // ---- global reads, all issued before anything waits ----
+    double za[ZU];
+    if constexpr (SIM) sim_load_chunk(P.Z, P.ns, 0, tid, za, P.dbg);
+    if (tid >= 64 && tid < 128) {  // wave 1: problem constants
+        for (int k = tid - 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; }
+        for (int k = tid - 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
+    }
+    if (chain_lane) {
+        double* rc = S.rec + tid * R;
+        // level 1: everything indexed by the chain itself
+        if (flags & F_HAS_PENDING) { partner = P.xpartner[gc]; s = P.xsrc[gc] - P.offset; }
+        else wasx = P.was_exch[c];
+        sig = P.sigma[c]; nn = P.n_noex[c]; na = P.n_acc[c]; lacc = P.last_acc[c];
+        S.sig[tid] = sig;
+        bp = P.best_val[c]; bpid = P.best_id[c]; bpp = P.bestp_val[c]; bppid = P.bestp_id[c];
+        atun = P.acc_tuner_g[gc];
+        if (t > 1) {
+            u = P.utab[(size_t)(t - P.utab_t0) * N + c];  // probs_acc[iter], :85
+            const size_t wrow = (size_t)(t - P.ntab_t0) * P.ntries;
+            double* zz = S.z + tid * NPF_MAX * np;
+            const int nz = npf * np;
+#pragma unroll 8
+            for (int i = 0; i < nz; ++i) zz[i] = P.ntab[(wrow * np + i) * N + c];
+        }
+        // level 2: the record the chain continues from (its own, or the donor's)
+#pragma unroll 8
+        for (int f = 0; f < R; ++f) rc[f] = rec_in[(size_t)f * N + s];
+    }
+    TS_MARK(1);
+    __syncthreads();
+
+    // ---- settle iteration t-1 (registers only; its history stores are issued in the epilogue) ----
+    bool exch_prev = false;
+    if (chain_lane && t > 1) {
+        if (partner != 0) exch_prev = true;  // swap_ev_ij!, :734-749
+        else if (wasx) { exch_prev = true; P.was_exch[c] = 0; }
+        if ((flags & F_CLOSE_PREV) && !exch_prev) { nn += 1; na += lacc; }  // set_acceptRate!, :253-257
+        if (partner != 0) {  // best after t-1 recomputed against t-2 for the donor's record (:231-243)
+            const double dv = S.rec[tid * R];
+            if (dv < bpp) { bp = dv; bpid = t - 1; }
+            else { bp = bpp; bpid = bppid; }
+        }
+    }
+    TS_MARK(5);
+    // ---- proposal(c), AlgoBGP.jl:424-471: wave 0, lane = r*CT + cl evaluates try r of chain cl ----
+    if (tid < 64) {
+        constexpr int NR = 64 / CT;  // tries evaluated side by side
+        const int cl = tid % CT, r0 = tid / CT;
+        const int cc = blockIdx.x * CT + cl;
+        const bool valid = cc < N;
+        double* th = S.theta + cl * np;
+        const double* rc = S.rec + cl * R;
+        if (t == 1 || !valid || (P.dbg & 1)) {
+            if (r0 == 0)
+                for (int k = 0; k < np; ++k) th[k] = !valid ? 0.0 : (t == 1 ? P.init[k] : rc[3 + k]);  // :426-427
         } else {
-            s = settle_previous(P, t, c, rec_in, flags);
-            old = rec_in[s];
-            const double sig = P.sigma[c];
             const int bs = P.batch_size;
             const int max_tries = P.ntab_user ? min(P.ntries, P.smpl_iters) : P.smpl_iters;
-            const size_t wrow = (size_t)(t - P.ntab_t0) * P.ntries;
-            if (P.dbg & 1) {
-                for (int k = 0; k < np; ++k) th[k] = rec_in[(size_t)(3 + k) * N + s];
-            } else {
-                for (int b0 = 0; b0 < np; b0 += bs) {
-                    bool ok = false;
-                    for (int r = 0; r < max_tries && !ok; ++r) {  // mysample, :400-410
-                        ok = true;
+            const int npar = min(min(NR, npf), max_tries);  // tries done in parallel from LDS-staged normals
+            const double sg = S.sig[cl];
+            const double* zz = S.z + cl * NPF_MAX * np;
+            for (int b0 = 0; b0 < np; b0 += bs) {
+                bool ok = r0 < npar;
+                if (ok) {
+                    for (int k = b0; k < b0 + bs; ++k) {  // mysample, :400-410, try r0
+                        const double lbk = S.lb[k];
+                        const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);  // mapto_01, mprob.jl:248
+                        const double step = sg * zz[r0 * np + k];  // MvNormal(mu01, sigma): x = mu + sigma*z
+                        const double x = mu01 + step;
+                        if (!(x >= 0.0 && x <= 1.0)) ok = false;  // inclusive bounds, :405
+                    }
+                }
+                // first successful try of every chain
+                const unsigned long long m = __ballot(ok);
+                unsigned long long pat = 0;
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) pat |= ((m >> (rr * CT + cl)) & 1ull) << rr;
+                const int rwin = pat ? (__ffsll((long long)pat) - 1) : -1;
+                if (rwin == r0) {
+                    for (int k = b0; k < b0 + bs; ++k) {
+                        const double lbk = S.lb[k];
+                        const double span = S.ub[k] - lbk;
+                        const double mu01 = (rc[3 + k] - lbk) / span;
+                        const double step = sg * zz[r0 * np + k];
+                        const double x = mu01 + step;
+                        const double sc = x * span;
+                        th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
+                    }
+                } else if (rwin < 0 && r0 == 0) {  // rare: continue one try at a time (table, then the in-kernel generator)
+                    const int gcc = P.offset + cc;
+                    const size_t wrow = (size_t)(t - P.ntab_t0) * P.ntries;
+                    bool ok2 = false;
+                    for (int r = npar; r < max_tries && !ok2; ++r) {
+                        ok2 = true;
                         double zc0 = 0.0, zc1 = 0.0;
                         int zq = -1;
                         for (int k = b0; k < b0 + bs; ++k) {
-                            const double lbk = P.lb[k], ubk = P.ub[k];
-                            const double mu01 = (rec_in[(size_t)(3 + k) * N + s] - lbk) / (ubk - lbk);  // mprob.jl:248
+                            const double lbk = S.lb[k];
+                            const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);
                             double z;
-                            if (r < P.ntries) {
-                                z = P.ntab[((wrow + r) * np + k) * N + c];
+                            if (r < npf) {
+                                z = zz[r * np + k];
+                            } else if (r < P.ntries) {
+                                z = P.ntab[((wrow + r) * np + k) * N + cc];
                             } else {
                                 if ((k >> 1) != zq) {
                                     zq = k >> 1;
-                                    rng_prop_normal2(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)r, (uint32_t)zq, zc0, zc1);
+                                    rng_prop_normal2(P.seed, (uint32_t)gcc, (uint32_t)t, (uint32_t)r, (uint32_t)zq, zc0, zc1);
                                 }
                                 z = (k & 1) ? zc1 : zc0;
                             }
-                            const double step = sig * z;  // MvNormal(mu01, sigma): x = mu + sigma*z
+                            const double step = sg * z;
                             const double x = mu01 + step;
                             th[k] = x;
-                            if (!(x >= 0.0 && x <= 1.0)) ok = false;  // inclusive bounds, :405
+                            if (!(x >= 0.0 && x <= 1.0)) ok2 = false;
                         }
                     }
-                    if (!ok) report_error(P, 2, t, gc);  // :409
-                }
-                for (int k = 0; k < np; ++k) {
-                    const double lbk = P.lb[k];
-                    const double span = P.ub[k] - lbk;
-                    const double sc = th[k] * span;
-                    th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
+                    if (!ok2) report_error(P, 2, t, gcc);  // :409
+                    for (int k = b0; k < b0 + bs; ++k) {
+                        const double lbk = S.lb[k];
+                        const double span = S.ub[k] - lbk;
+                        const double sc = th[k] * span;
+                        th[k] = sc + lbk;
+                    }
                 }
             }
         }
     }
+    TS_MARK(6);
     __syncthreads();
+    TS_MARK(2);
 
-    // ---- simulation: all 256 lanes, ns draws x nm moments x CT chains ----
+    // ---- simulation: all 512 lanes, ns draws x nm moments x CT chains ----
     if constexpr (SIM) {
-        if (!(P.dbg & 2)) simulate_tile<CT>(P, s_theta, s_part, tid);
+        if (!(P.dbg & 2)) simulate_tile<CT>(P, S.theta, S.part, tid, za);
         __syncthreads();
     }
+    TS_MARK(3);
     if (P.dbg & 4) return;
 
     // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245) ----
     if (chain_lane) {
-        const double* th = s_theta + tid * np;
-        double* sm = s_simM + tid * nm;
+        const double* th = S.theta + tid * np;
+        const double* rc = S.rec + tid * R;
+        double* sm = S.simM + tid * nm;
         double value;
         int status;
-        finish_objective<CT>(P, th, s_part, tid, sm, value, status);
+        finish_objective<CT>(P, th, S.part, S.mom, S.w, tid, sm, value, status);
 
+        const double old = rc[0];
         double prob;
         bool acc;
         if (t == 1) {  // :326-332
@@ -370,25 +492,20 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
             prob = 0.0; acc = false;
         } else {
             if (!(value >= 0.0)) report_error(P, 1, t, gc);  // :341
-            const double e = exp(P.acc_tuner_g[gc] * (old - value));
+            const double e = exp(atun * (old - value));
             prob = (e != e) ? e : (e < 1.0 ? e : 1.0);  // minimum([1.0,e]), NaN propagates (:344)
             if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }  // :350-353
             else if (!isfinite(old)) { prob = 1.0; acc = true; }            // :355-359
-            else {
-                status = 1;
-                const double u = P.utab[(size_t)(t - P.utab_t0) * N + c];  // probs_acc[iter], :85
-                acc = prob > u;  // strict, :362-367
-            }
+            else { status = 1; acc = prob > u; }                            // strict >, :362-367
         }
+        TS_MARK(7);
         // set_acceptRate!, :253-257 (iteration t has exchanged==0 at this point)
-        const int nn = P.n_noex[c], na = P.n_acc[c];
         const double rate = (double)(na + (acc ? 1 : 0)) / (double)(nn + 1);
         P.accept_rate[c] = rate;
         P.last_acc[c] = acc ? 1 : 0;
-        if (t > 1 && (t % P.sigma_update_steps) == 0) {  // :381-390
-            const double s0 = P.sigma[c];
-            P.sigma[c] = (rate > 0.234) ? s0 * (1.0 + P.sigma_adjust_by) : s0 * (1.0 - P.sigma_adjust_by);
-        }
+        P.n_noex[c] = nn; P.n_acc[c] = na;
+        if (t > 1 && (t % P.sigma_update_steps) == 0)  // :381-390
+            P.sigma[c] = (rate > 0.234) ? sig * (1.0 + P.sigma_adjust_by) : sig * (1.0 - P.sigma_adjust_by);
         // set_eval!, :220-245
         const size_t row = (size_t)(t - 1) * N + c;
         double bestv, currv;
@@ -396,8 +513,6 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
         if (t == 1) { bestv = value; currv = value; bestid = 1; }
         else {
             currv = acc ? value : old;  // curr_val[t-1] == value of the last accepted record
-            const double bp = P.best_val[c];
-            const int bpid = P.best_id[c];
             P.bestp_val[c] = bp; P.bestp_id[c] = bpid;  // best after t-1: needed if iteration t gets exchanged
             if (value < bp) { bestv = value; bestid = t; }
             else { bestv = bp; bestid = bpid; }
@@ -407,16 +522,20 @@ __global__ __launch_bounds__(WG) void k_chain_iter(const KParams P, const int t,
         P.h_best_id[row] = bestid; P.h_exch[row] = 0; P.h_acc[row] = acc ? 1 : 0; P.h_status[row] = (int8_t)status;
         for (int k = 0; k < np; ++k) P.h_params[((size_t)(t - 1) * np + k) * N + c] = th[k];
         for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(t - 1) * nm + k) * N + c] = sm[k];
+        if (partner != 0) {  // iteration t-1 was exchanged: its record is the donor's (swap_ev_ij!, :734-749)
+            double bv; int bi;
+            write_swapped_history(P, t - 1, c, partner, rc, bpp, bppid, bv, bi);
+        }
         // the chain's last accepted record (lastAccepted :209-215) = input of the exchange step
         if (acc) {
             rec_out[c] = value; rec_out[(size_t)N + c] = prob; rec_out[(size_t)2 * N + c] = (double)status;
             for (int k = 0; k < np; ++k) rec_out[(size_t)(3 + k) * N + c] = th[k];
             for (int k = 0; k < nm; ++k) rec_out[(size_t)(3 + np + k) * N + c] = sm[k];
         } else {
-            const int R = 3 + np + nm;
-            for (int f = 0; f < R; ++f) rec_out[(size_t)f * N + c] = rec_in[(size_t)f * N + s];
+            for (int f = 0; f < R; ++f) rec_out[(size_t)f * N + c] = rc[f];
         }
     }
+    TS_MARK(4);
 }
 
 // k_flush: settle the last iteration (pending exchange + accept-rate counters) without starting a
@@ -432,28 +551,31 @@ __global__ void k_flush(const KParams P, const int t_next, const double* __restr
 
 // batched evaluateObjective(m,p), mprob.jl:175-188: params [np][M] -> value, simM [nm][M], status
 template <bool SIM, int CT>
-__global__ __launch_bounds__(WG) void k_eval_batch(const KParams P, const double* __restrict__ params, const int M,
-                                                   double* __restrict__ value, double* __restrict__ simM,
-                                                   int8_t* __restrict__ status) {
+__global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const double* __restrict__ params, const int M,
+                                                      double* __restrict__ value, double* __restrict__ simM,
+                                                      int8_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* s_theta = smem;
-    double* s_simM = s_theta + CT * P.np;
-    double* s_part = s_simM + CT * P.nm;
+    TileSmem S;
+    S.carve(smem, CT, P.np, P.nm);
     const int tid = threadIdx.x;
     const int i = blockIdx.x * CT + tid;
     const bool chain_lane = (tid < CT) && (i < M);
+    double za[ZU];
+    if constexpr (SIM) sim_load_chunk(P.Z, P.ns, 0, tid, za, P.dbg);
+    if (tid >= 64 && tid < 128)
+        for (int k = tid - 64; k < P.nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
     if (tid < CT)
-        for (int k = 0; k < P.np; ++k) s_theta[tid * P.np + k] = chain_lane ? params[(size_t)k * M + i] : 0.0;
+        for (int k = 0; k < P.np; ++k) S.theta[tid * P.np + k] = chain_lane ? params[(size_t)k * M + i] : 0.0;
     __syncthreads();
     if constexpr (SIM) {
-        simulate_tile<CT>(P, s_theta, s_part, tid);
+        simulate_tile<CT>(P, S.theta, S.part, tid, za);
         __syncthreads();
     }
     if (chain_lane) {
         double v;
         int st;
-        double* sm = s_simM + tid * P.nm;
-        finish_objective<CT>(P, s_theta + tid * P.np, s_part, tid, sm, v, st);
+        double* sm = S.simM + tid * P.nm;
+        finish_objective<CT>(P, S.theta + tid * P.np, S.part, S.mom, S.w, tid, sm, v, st);
         value[i] = v;
         status[i] = (int8_t)st;
         for (int k = 0; k < P.nm; ++k) simM[(size_t)k * M + i] = sm[k];
@@ -811,8 +933,10 @@ void dfill(Ctx* c, T* d, size_t n, T v) {
 
 bool is_sim(int obj) { return obj == SMM_OBJ_NORM || obj == SMM_OBJ_NORM_FAILBOX; }
 
-size_t tile_smem(const Ctx* c, int ct) {
-    return (size_t)(ct * c->P.np + ct * c->P.nm + (is_sim(c->obj) ? (WG / 64) * ct * c->P.nm : 0)) * sizeof(double);
+size_t tile_smem(const Ctx* c, int ct) {  // TileSmem::carve
+    const size_t np = c->P.np, nm = c->P.nm;
+    return ((size_t)ct * (1 + np + nm + (3 + np + nm) + NPF_MAX * np + (is_sim(c->obj) ? (WG / 64) * nm : 0)) + 2 * np + 2 * nm) *
+           sizeof(double);
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)Ng * 4 + (size_t)K * 8 + (size_t)(K + (K & 1)) * 4 + 64 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
@@ -855,9 +979,10 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
         } else {
             hipLaunchKernelGGL((k_chain_iter<true, 8>), dim3((P.N + 7) / 8), dim3(WG), tile_smem(c, 8), c->stream, P, t, rin, rout, flags);
         }
+    } else if (tile_smem(c, 64) <= (size_t)60 * 1024) {
+        hipLaunchKernelGGL((k_chain_iter<false, 64>), dim3((P.N + 63) / 64), dim3(WG), tile_smem(c, 64), c->stream, P, t, rin, rout, flags);
     } else {
-        constexpr int CT = 64;
-        hipLaunchKernelGGL((k_chain_iter<false, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, t, rin, rout, flags);
+        hipLaunchKernelGGL((k_chain_iter<false, 8>), dim3((P.N + 7) / 8), dim3(WG), tile_smem(c, 8), c->stream, P, t, rin, rout, flags);
     }
     c->cur ^= 1;
 }
@@ -971,6 +1096,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             c->force_any_exchange = e && e[0] == '1';
             const char* d = getenv("SMMHIP_DBG");
             P.dbg = d ? atoi(d) : 0;
+            const char* tsv = getenv("SMMHIP_TS");
+            if (tsv && tsv[0] == '1') { P.ts = dalloc<unsigned long long>(c, (size_t)8 * 65536); }
             const char* ct = getenv("SMMHIP_CT");  // tuning hook: chains per tile (4, 8, 16); numerics unaffected
             c->ct = ct ? atoi(ct) : 8;
         }
@@ -1334,6 +1461,14 @@ int smm_set_profiling(void* ctx, int32_t on) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return SMM_ERR_INVALID_ARG;
     c->profiling = on != 0;
+    return SMM_OK;
+}
+
+// debug (not part of the public header): per-workgroup wall_clock64 stamps of the last k_chain_iter
+int smm_debug_ts(void* ctx, unsigned long long* out, int n_wg) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !c->P.ts) return SMM_ERR_INVALID_ARG;
+    if (hipMemcpy(out, c->P.ts, (size_t)n_wg * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
     return SMM_OK;
 }
 

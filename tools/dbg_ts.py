@@ -1,0 +1,32 @@
+import sys, os, ctypes as C
+import numpy as np
+os.environ["SMMHIP_TS"] = "1"
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import smm_jl_amd as S, common as cm
+prob, opts = cm.serial_normal(N=4096, T=700)
+ctx = S.hip_context(prob, opts)
+ctx.step(150)
+lib = S._abi.load()
+nwg = 512
+buf = np.zeros((nwg, 8), np.uint64)
+lib.smm_debug_ts(ctx._ctx, buf.ctypes.data_as(C.c_void_p), nwg)
+ts = buf.astype(np.float64) / 100.0  # wall_clock64 = 100 MHz -> us
+t0 = ts[:, 0].min()
+print("phase stamps relative to first WG start (us): mean / min / max over %d WGs" % nwg)
+for i, name in enumerate(["start", "after loads", "after proposal+barrier", "after sim", "end"]):
+    v = ts[:, i] - t0
+    print("%-24s %7.2f %7.2f %7.2f" % (name, v.mean(), v.min(), v.max()))
+seq = [0, 1, 5, 6, 2, 3, 7, 4]
+names2 = ["loads(L1+L2)+LDS stage+barrier1", "settle prev", "proposal", "barrier2", "sim", "objective+accept", "stores issued"]
+tt = ts[:, seq]
+dd = np.diff(tt, axis=1)
+print("fine phases (us) mean/min/max:")
+for i, nme in enumerate(names2):
+    print("%-34s %7.2f %7.2f %7.2f" % (nme, dd[:, i].mean(), dd[:, i].min(), dd[:, i].max()))
+d = np.diff(ts[:, :5], axis=1)
+print("per-WG phase durations (us) mean/min/max:")
+for i, name in enumerate(["loads", "settle+proposal", "sim", "finish"]):
+    print("%-18s %7.2f %7.2f %7.2f" % (name, d[:, i].mean(), d[:, i].min(), d[:, i].max()))
+slow = np.argsort(-d[:, 1])[:8]
+print("slowest proposal WGs:", [(int(i), round(float(d[i,1]),1)) for i in slow])
+print("kernel span %.2f us" % (ts[:, 4].max() - t0))
