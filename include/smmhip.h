@@ -173,11 +173,12 @@ int  smm_sync(void* ctx);
 
 /* Sharded form (one ctx per GPU), the three phases of one iteration:
  *   smm_bgp_local_step : next_eval for the local chains (AlgoBGP.jl:272-294)
- *   smm_bgp_export_records_dev : pack last-accepted records of the local chains into
- *        rec_dev [(np+nm+3)][N] doubles (value, prob, status, params, simM) for the
- *        RCCL all-gather
+ *   smm_bgp_export_records_dev : copy the last-accepted records of the local chains into
+ *        rec_dev [N][RW] doubles, RW = smm_bgp_record_doubles(ctx) (value, prob, status,
+ *        params[np], simM[nm], zero padded to an even count) — the RCCL all-gather payload
  *   smm_bgp_exchange_dev : exchangeMoves! over all N_global chains given the gathered
- *        records [G][(np+nm+3)][N] (identical on every rank), applied to local chains */
+ *        records [N_global][RW] in global chain order (identical on every rank), applied
+ *        to the local chains */
 int  smm_bgp_local_step(void* ctx);
 int  smm_bgp_record_doubles(void* ctx);
 int  smm_bgp_export_records_dev(void* ctx, void* rec_dev);

@@ -53,7 +53,7 @@ class OracleContext(S.BGPContext):
         self._lib.orc_set_mode(self._ctx, threads, int(regen_z))
 
     def export_records(self):
-        rec = np.empty((self.record_doubles(), self.N))
+        rec = np.empty((self.N, self.record_doubles()))
         self._lib.orc_bgp_export_records(self._ctx, A.dptr(rec))
         return rec
 

@@ -562,16 +562,19 @@ int orc_bgp_local_step(void* v) {
     return ORC_OK;
 }
 
-int orc_bgp_record_doubles(void* v) { orc_t* o = (orc_t*)v; return 3 + o->prob.np + o->prob.nm; }
+/* doubles per exported record: value, prob, status, params[np], simM[nm], padded to an even count */
+int orc_bgp_record_doubles(void* v) { orc_t* o = (orc_t*)v; return (3 + o->prob.np + o->prob.nm + 1) & ~1; }
 
-/* last-accepted records of the local chains, [(3+np+nm)][N]: value, prob, status, params, simM */
+/* last-accepted records of the local chains, [N][RW] */
 void orc_bgp_export_records(void* v, double* rec) {
     orc_t* o = (orc_t*)v;
-    const int N = o->opts.N, np = o->prob.np, nm = o->prob.nm;
+    const int N = o->opts.N, np = o->prob.np, nm = o->prob.nm, RW = orc_bgp_record_doubles(v);
     for (int c = 0; c < N; ++c) {
-        rec[c] = o->la_value[c]; rec[(size_t)N + c] = o->la_prob[c]; rec[(size_t)2 * N + c] = (double)o->la_status[c];
-        for (int k = 0; k < np; ++k) rec[(size_t)(3 + k) * N + c] = o->la_params[(size_t)k * N + c];
-        for (int k = 0; k < nm; ++k) rec[(size_t)(3 + np + k) * N + c] = o->la_simM[(size_t)k * N + c];
+        double* r = rec + (size_t)c * RW;
+        for (int f = 0; f < RW; ++f) r[f] = 0.0;
+        r[0] = o->la_value[c]; r[1] = o->la_prob[c]; r[2] = (double)o->la_status[c];
+        for (int k = 0; k < np; ++k) r[3 + k] = o->la_params[(size_t)k * N + c];
+        for (int k = 0; k < nm; ++k) r[3 + np + k] = o->la_simM[(size_t)k * N + c];
     }
 }
 
@@ -586,12 +589,12 @@ static void close_iteration(orc_t* o) {
 }
 
 /* exchangeMoves!(algo), AlgoBGP.jl:647-716 + swap_ev_ij! :734-749, over ALL N_global chains.
- * gathered = records of every chain, [G][(3+np+nm)][N] with G = N_global/N shards (rank order);
- * must be called after orc_local_step for the same iteration; applies swaps to local chains. */
+ * gathered = records of every chain in global id order, [N_global][RW] (shards concatenated);
+ * must be called after orc_bgp_local_step for the same iteration; applies swaps to local chains. */
 int orc_bgp_exchange(void* v, const double* gathered) {
     orc_t* o = (orc_t*)v;
     const int N = o->opts.N, Ng = o->opts.N_global, np = o->prob.np, nm = o->prob.nm, t = o->iter;
-    const int R = 3 + np + nm;
+    const int RW = orc_bgp_record_doubles(v);
     if (!(t >= o->opts.exchange_from_iter && Ng > 1)) { close_iteration(o); return ORC_OK; }   /* :637 */
     const int K = o->have_pairs ? o->n_pairs : n_exchange_pairs(Ng);
     int32_t* pairs = (int32_t*)malloc((size_t)(K > 0 ? K : 1) * 2 * sizeof(int32_t));
@@ -600,11 +603,7 @@ int orc_bgp_exchange(void* v, const double* gathered) {
     double* val = (double*)malloc((size_t)Ng * sizeof(double));
     int32_t* src = (int32_t*)malloc((size_t)Ng * sizeof(int32_t));
     int32_t* partner = (int32_t*)calloc((size_t)Ng, sizeof(int32_t));
-    for (int g = 0; g < Ng; ++g) {
-        int shard = g / N, l = g % N;
-        val[g] = gathered[((size_t)shard * R + 0) * N + l];
-        src[g] = g;
-    }
+    for (int g = 0; g < Ng; ++g) { val[g] = gathered[(size_t)g * RW]; src[g] = g; }
     for (int q = 0; q < K; ++q) {                      /* sequential, order dependent: :662-691 */
         int i = pairs[2 * q], j = pairs[2 * q + 1];
         if (val[i] - val[j] > o->min_improve[i]) {     /* dist_fun = -, :688 */
@@ -616,14 +615,11 @@ int orc_bgp_exchange(void* v, const double* gathered) {
     for (int c = 0; c < N; ++c) {
         int g = o->opts.chain_offset + c;
         if (partner[g] == 0) continue;
-        int s = src[g], shard = s / N, l = s % N;
-        const double* rec = gathered + (size_t)shard * R * N;
-        double value = rec[l], prob = rec[(size_t)N + l];
-        int8_t status = (int8_t)rec[(size_t)2 * N + l];
-        double* params = (double*)malloc((size_t)(np + nm) * sizeof(double));
-        double* simM = params + np;
-        for (int k = 0; k < np; ++k) params[k] = rec[(size_t)(3 + k) * N + l];
-        for (int k = 0; k < nm; ++k) simM[k] = rec[(size_t)(3 + np + k) * N + l];
+        const double* rec = gathered + (size_t)src[g] * RW;
+        double value = rec[0], prob = rec[1];
+        int8_t status = (int8_t)rec[2];
+        const double* params = rec + 3;
+        const double* simM = rec + 3 + np;
         /* set_eval!(ci, ej): overwrites the chain's record of iteration t; best/curr are
          * recomputed against iteration t-1 (:231-243); ej.accepted is true. */
         const size_t rp = (size_t)(t - 2) * N + c;
@@ -635,7 +631,6 @@ int orc_bgp_exchange(void* v, const double* gathered) {
         o->la_value[c] = value; o->la_prob[c] = prob; o->la_status[c] = status;
         for (int k = 0; k < np; ++k) o->la_params[(size_t)k * N + c] = params[k];
         for (int k = 0; k < nm; ++k) o->la_simM[(size_t)k * N + c] = simM[k];
-        free(params);
     }
     free(pairs); free(val); free(src); free(partner);
     close_iteration(o);

@@ -6,7 +6,7 @@
 //   k_chain_iter      : next_eval for every chain at once — materialise the previous iteration's
 //                       exchange (swap_ev_ij! :734-749), proposal (:424-471), objective
 //                       (mprob.jl:175-188 -> ObjExamples.jl:59-116), doAcceptReject! (:324-392),
-//                       set_eval! (:220-245).  A 256-lane workgroup owns a tile of CT chains, the
+//                       set_eval! (:220-245).  A 512-lane workgroup owns a tile of CT chains, the
 //                       ns simulated draws are spread over the lanes, every shock z is re-used CT
 //                       times from a register, moments are reduced by a transposed wave reduction
 //                       and combined through LDS.
@@ -17,7 +17,16 @@
 //   k_pregen_rng      : proposal normals (first tries) and the MH uniforms (probs_acc, :85)
 //   k_exch_plan       : the exchange pair list of every iteration and each pair's rank among the
 //                       pairs of its two chains (the dependency structure of the sequential walk)
-// Data layout: structure-of-arrays, chain index fastest (coalesced), FP64 throughout.
+//
+// Data layout in HBM (FP64 throughout): everything a chain needs per iteration sits in a few
+// 16-byte aligned per-chain blocks (array-of-structures), so that the 64 lanes of a tile's
+// control wave move a whole tile's state with a handful of dwordx4 instructions:
+//   cs   [N][16]          chain state block (sigma, accept-rate counters, best/bestp, acc_tuner)
+//   rec  [2][N][RW]       last accepted record: value, prob, status, params[np], simM[nm]
+//   rb   [W][N][RBW]      randomness block of one iteration: u, normals[tries][np]
+//   hrec [T][N][HW]       history record: value, prob, curr, best, best_id, exch, acc, status,
+//                         params[np], simM[nm]   (transposed to the ABI's SoA on download)
+//   xres [Ng]             exchange result: src | partner<<32
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -39,8 +48,14 @@ constexpr int WG = SMM_REDUCE_LANES;  // 512 lanes own one chain tile (numerical
 constexpr int MAX_DIM = 64;           // np, nm <= 64
 constexpr int XWG = 1024;             // exchange workgroup
 constexpr int XLDS_MAX = 8192;        // largest N_global resolved in LDS (16 B per chain)
-constexpr int PRE_TRIES = 8;          // proposal tries generated ahead (later tries: in-kernel RNG)
 constexpr unsigned XSPIN_LIMIT = 1u << 22;
+
+// chain state block
+constexpr int CSW = 16;
+enum : int { CS_SIGMA = 0, CS_RATE, CS_NNOEX, CS_NACC, CS_LACC, CS_WASX, CS_BEST, CS_BESTID, CS_BESTP, CS_BESTPID, CS_ATUN,
+             CS_PARTNER /* LDS only */ };
+// history record
+enum : int { H_VALUE = 0, H_PROB, H_CURR, H_BEST, H_BESTID, H_EXCH, H_ACC, H_STATUS, H_PARAMS };
 
 // error word: min over (iter<<34 | chain<<2 | kind); 1 negative objective, 2 no draw, 3 internal
 constexpr unsigned long long ERR_NONE = ~0ull;
@@ -57,32 +72,32 @@ struct KParams {
     int sigma_update_steps, smpl_iters, batch_size;
     double sigma_adjust_by;
     uint64_t seed;
-    const double *acc_tuner_g, *min_improve_g;  // [Ng]
-    // randomness tables: either injected for the whole run (t0 = 1) or the current window
-    const double* utab;  // [W][N]
-    int utab_t0;
-    const double* ntab;  // [W][ntries][np][N]
-    int ntab_t0, ntries, ntab_user;
-    const int32_t* pairtab;  // injected [T][n_pairs][2] or null
+    const double* min_improve_g;  // [Ng]
+    // block widths (doubles, even)
+    int RW, HW, RBW;
+    int rb_tries;  // proposal tries held in a randomness block
+    int user_n;    // normals are injected: tries beyond rb_tries are an error, not the generator's
+    const double* rb;  // [W][N][RBW] window of randomness blocks
+    int rb_t0;
+    // injected tables in the ABI's layout (device copies), consumed by k_pregen_rng / k_exch_plan
+    const double* user_utab;  // [T][N]
+    const double* user_ntab;  // [T][K][np][N]
+    const int32_t* pairtab;   // [T][n_pairs][2]
     int n_pairs_tab;
+    // exchange plan window
     const unsigned long long* plan;  // [W][K]: pi | pj<<16 | ri<<32 | rj<<48
+    const double* plan_mi;           // [W][K]: min_improve of chain pi
     int plan_t0, plan_K;
-    // chain state [N]
-    double *sigma, *accept_rate;
-    int32_t *n_noex, *n_acc;
-    uint8_t *last_acc, *was_exch;
-    double *best_val, *bestp_val;
-    int32_t *best_id, *bestp_id;
-    // exchange result [Ng] (+ scratch of the any-size kernel)
+    // state
+    double* cs;                // [N][CSW]
+    unsigned long long* xres;  // [Ng]
+    // scratch of the any-size exchange kernel
     int32_t *xsrc, *xpartner, *xnext, *xpairs;
     double* xval;
-    // history [T][..][N]
-    double *h_value, *h_prob, *h_curr, *h_best, *h_params, *h_simM;
-    int32_t *h_best_id, *h_exch;
-    uint8_t* h_acc;
-    int8_t* h_status;
+    // history
+    double* hrec;  // [T][N][HW]
     unsigned long long* err;
-    int dbg;  // SMMHIP_DBG timing experiments (results invalid when != 0)
+    int dbg;                 // SMMHIP_DBG timing experiments (results invalid when != 0)
     unsigned long long* ts;  // SMMHIP_TS=1: per-workgroup phase timestamps of k_chain_iter (tools/)
 };
 
@@ -92,6 +107,8 @@ __device__ inline void report_error(const KParams& P, int kind, int t, int gchai
     const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)gchain << 2) | (unsigned)kind;
     atomicMin(P.err, key);
 }
+
+__host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
 
 // ------------------------------------------------------------------------------------------
 // Transposed wave reduction: every lane holds CT partial sums a[0..CT); on return lane l holds the
@@ -238,195 +255,175 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
     status = 1;
 }
 
-// What iteration t-1 left open for local chain c (used by k_flush; k_chain_iter inlines the same
-// logic with its loads hoisted):
-//  - F_HAS_PENDING: the exchange of iteration t-1 was resolved (xsrc/xpartner) but not applied.
-//    set_eval!(ci, ej) of swap_ev_ij! (AlgoBGP.jl:734-749): the chain's record of iteration t-1 is
-//    overwritten by the donor's last accepted record (accepted = true, the donor's prob/status),
-//    curr = donor value, best recomputed against iteration t-2 (:231-243); exchanged = partner.
-//  - F_CLOSE_PREV: iteration t-1 counts towards accept_rate iff it was not exchanged
-//    (set_acceptRate!, :253-257).
-// Returns the local index s of the record (in rec_in) the chain continues from.
-__device__ inline void write_swapped_history(const KParams& P, int tp, int c, int partner, const double* recv /*[R]*/,
-                                             double bp, int bpid, double& bestv, int& bestid) {
-    const int N = P.N, np = P.np, nm = P.nm;
-    const double value = recv[0], prob = recv[1];
-    const int8_t status = (int8_t)recv[2];
-    if (value < bp) { bestv = value; bestid = tp; }
-    else { bestv = bp; bestid = bpid; }
-    const size_t row = (size_t)(tp - 1) * N + c;
-    P.h_value[row] = value; P.h_prob[row] = prob; P.h_curr[row] = value; P.h_best[row] = bestv;
-    P.h_best_id[row] = bestid; P.h_exch[row] = partner; P.h_acc[row] = 1; P.h_status[row] = status;
-    for (int k = 0; k < np; ++k) P.h_params[((size_t)(tp - 1) * np + k) * N + c] = recv[3 + k];
-    for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(tp - 1) * nm + k) * N + c] = recv[3 + np + k];
+// ------------------------------------------------------------------------------------------
+// Tile shared memory and wave-cooperative block moves
+// ------------------------------------------------------------------------------------------
+struct TileSmem {
+    double *cs, *rb, *rec, *rout, *h, *hp, *theta, *lb, *ub, *init, *mom, *w, *part;
+    __device__ inline void carve(double* base, int CT, int np, int nm, int RW, int HW, int RBW, bool sim) {
+        cs = base;                  // [CT][CSW]
+        rb = cs + CT * CSW;         // [CT][RBW]
+        rec = rb + CT * RBW;        // [CT][RW]   record the chain continues from
+        rout = rec + CT * RW;       // [CT][RW]   record after this iteration's accept step
+        h = rout + CT * RW;         // [CT][HW]   history record of iteration t
+        hp = h + CT * HW;           // [CT][HW]   rewritten history record of iteration t-1 (exchanged chains)
+        theta = hp + CT * HW;       // [CT][np]
+        lb = theta + CT * np;       // [np] ...
+        ub = lb + np;
+        init = ub + np;
+        mom = init + np;            // [nm]
+        w = mom + nm;
+        part = w + nm;              // [WG/64][CT][nm]
+        (void)sim;
+    }
+};
+__host__ __device__ inline size_t tile_smem_doubles(int CT, int np, int nm, int RW, int HW, int RBW, bool sim) {
+    return (size_t)CT * (CSW + RBW + 2 * RW + 2 * HW + np) + 3 * np + 2 * nm + (sim ? (size_t)(WG / 64) * CT * nm : 0) + 2;
 }
 
-__device__ inline int settle_previous(const KParams& P, int t, int c, const double* __restrict__ rec_in, int flags) {
-    const int N = P.N, R = 3 + P.np + P.nm;
-    int s = c;
-    bool exch = false;
-    if (flags & F_HAS_PENDING) {
-        const int g = P.offset + c;
-        const int partner = P.xpartner[g];
-        if (partner != 0) {
-            exch = true;
-            s = P.xsrc[g] - P.offset;
-            double recv[3 + 2 * MAX_DIM];
-            for (int f = 0; f < R; ++f) recv[f] = rec_in[(size_t)f * N + s];
-            double bestv; int bestid;
-            write_swapped_history(P, t - 1, c, partner, recv, P.bestp_val[c], P.bestp_id[c], bestv, bestid);
-            P.best_val[c] = bestv; P.best_id[c] = bestid;
-        }
-    } else if (P.was_exch[c]) {  // sharded path: k_exch_apply already rewrote record and history
-        exch = true;
-        P.was_exch[c] = 0;
-    }
-    if ((flags & F_CLOSE_PREV) && !exch) {
-        P.n_noex[c] += 1;
-        P.n_acc[c] += P.last_acc[c];
-    }
-    return s;
+// lanes (cl, r) of the control wave move chain cl's block of W doubles (W even) in 16-byte pieces
+template <int CT>
+__device__ inline void coop_load(double* lds_blk, const double* __restrict__ g, int W, int r) {
+    constexpr int NR = 64 / CT;
+    const double2* __restrict__ gs = (const double2*)g;
+    double2* ld = (double2*)lds_blk;
+#pragma unroll 2
+    for (int i = r; i < W / 2; i += NR) ld[i] = gs[i];
+}
+template <int CT>
+__device__ inline void coop_store(double* __restrict__ g, const double* lds_blk, int W, int r) {
+    constexpr int NR = 64 / CT;
+    double2* __restrict__ gd = (double2*)g;
+    const double2* ld = (const double2*)lds_blk;
+#pragma unroll 2
+    for (int i = r; i < W / 2; i += NR) gd[i] = ld[i];
+}
+
+// set_eval!(ci, ej) of swap_ev_ij! (AlgoBGP.jl:734-749) as a history record: the chain's record of
+// the exchanged iteration tp is the donor's last accepted one (accepted = true, the donor's
+// prob/status), curr = donor value, best recomputed against iteration tp-1 (:231-243).
+__device__ inline void make_swapped_history(const KParams& P, double* hrec /*[HW]*/, const double* donor /*[RW]*/, int tp,
+                                            int partner, double bpp, double bppid, double& bestv, double& bestid) {
+    const double value = donor[0];
+    if (value < bpp) { bestv = value; bestid = (double)tp; }
+    else { bestv = bpp; bestid = bppid; }
+    hrec[H_VALUE] = value; hrec[H_PROB] = donor[1]; hrec[H_CURR] = value; hrec[H_BEST] = bestv;
+    hrec[H_BESTID] = bestid; hrec[H_EXCH] = (double)partner; hrec[H_ACC] = 1.0; hrec[H_STATUS] = donor[2];
+    const int nv = P.np + P.nm;
+    for (int k = 0; k < nv; ++k) hrec[H_PARAMS + k] = donor[3 + k];
 }
 
 // ------------------------------------------------------------------------------------------
 // k_chain_iter: one next_eval (AlgoBGP.jl:272-294) for every local chain, iteration t (1-based).
-// rec_in : last accepted records after iteration t-1's accept step   [(3+np+nm)][N]
+// rec_in : last accepted records after iteration t-1's accept step   [N][RW]
 // rec_out: the same after iteration t's accept step (input of exchangeMoves!)
-// A 512-lane workgroup owns CT chains.  Lanes 0..CT-1 of wave 0 are the "chain lanes" that do the
-// per-chain serial work; wave 1 stages the problem constants; every lane pre-loads its first
-// shocks.  All per-chain global reads are issued up front in two dependent levels (state +
-// exchange result, then the record the chain continues from) and staged in LDS.
+// Wave 0 is the tile's control wave: lane = r*CT + cl works for chain cl.  It moves the per-chain
+// blocks with 16-byte pieces (two dependent levels: state/randomness/exchange result, then the
+// record the chain continues from), evaluates the proposal tries side by side, and after the
+// simulation lanes r == 0 run the accept step and the wave stores the result blocks.
 // ------------------------------------------------------------------------------------------
-constexpr int NPF_MAX = 8;  // proposal tries whose normals are staged in LDS
-
-struct TileSmem {
-    double *theta, *simM, *rec, *z, *sig, *lb, *ub, *mom, *w, *part;
-    __device__ inline void carve(double* base, int CT, int np, int nm) {
-        const int R = 3 + np + nm;
-        theta = base;                 // [CT][np]
-        simM = theta + CT * np;       // [CT][nm]
-        rec = simM + CT * nm;         // [CT][R]
-        z = rec + CT * R;             // [CT][NPF_MAX][np]
-        sig = z + CT * NPF_MAX * np;  // [CT]
-        lb = sig + CT;                // [np]
-        ub = lb + np;                 // [np]
-        mom = ub + np;                // [nm]
-        w = mom + nm;                 // [nm]
-        part = w + nm;                // [WG/64][CT][nm]
-    }
-};
-
 template <bool SIM, int CT>
 __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
                                                       double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int np = P.np, nm = P.nm, N = P.N, R = 3 + np + nm;
+    constexpr int NR = 64 / CT;
+    const int np = P.np, nm = P.nm, N = P.N, RW = P.RW, HW = P.HW, RBW = P.RBW;
     TileSmem S;
-    S.carve(smem, CT, np, nm);
+    S.carve(smem, CT, np, nm, RW, HW, RBW, SIM);
     const int tid = threadIdx.x;
-    const int c = blockIdx.x * CT + tid;
-    const bool chain_lane = (tid < CT) && (c < N);
+    const int cl = tid % CT, r = (tid % 64) / CT;
+    const int c = blockIdx.x * CT + cl;       // chain served by this lane (control wave only)
+    const bool ctl = tid < 64;
+    const bool valid = ctl && (c < N);
+    const bool chain_lane = valid && r == 0;
     const int gc = P.offset + c;
-    const int npf = min(P.ntries, NPF_MAX);
-
-    // per-chain state, live in registers from the prologue to the epilogue
-    int partner = 0, s = c, nn = 0, na = 0, bpid = -1, bppid = -1, lacc = 0, wasx = 0;
-    double sig = 0.0, bp = INFINITY, bpp = INFINITY, atun = 0.0, u = 0.0;
     TS_MARK(0);
 
     // ---- global reads, all issued before anything waits ----
     double za[ZU];
     if constexpr (SIM) sim_load_chunk(P.Z, P.ns, 0, tid, za, P.dbg);
     if (tid >= 64 && tid < 128) {  // wave 1: problem constants
-        for (int k = tid - 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; }
+        for (int k = tid - 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; S.init[k] = P.init[k]; }
         for (int k = tid - 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
     }
-    if (chain_lane) {
-        double* rc = S.rec + tid * R;
-        // level 1: everything indexed by the chain itself
-        if (flags & F_HAS_PENDING) { partner = P.xpartner[gc]; s = P.xsrc[gc] - P.offset; }
-        else wasx = P.was_exch[c];
-        sig = P.sigma[c]; nn = P.n_noex[c]; na = P.n_acc[c]; lacc = P.last_acc[c];
-        S.sig[tid] = sig;
-        bp = P.best_val[c]; bpid = P.best_id[c]; bpp = P.bestp_val[c]; bppid = P.bestp_id[c];
-        atun = P.acc_tuner_g[gc];
-        if (t > 1) {
-            u = P.utab[(size_t)(t - P.utab_t0) * N + c];  // probs_acc[iter], :85
-            const size_t wrow = (size_t)(t - P.ntab_t0) * P.ntries;
-            double* zz = S.z + tid * NPF_MAX * np;
-            const int nz = npf * np;
-#pragma unroll 8
-            for (int i = 0; i < nz; ++i) zz[i] = P.ntab[(wrow * np + i) * N + c];
-        }
+    int partner = 0;
+    if (valid) {
+        // level 1: exchange result, chain state block, this iteration's randomness block
+        unsigned long long xr = (unsigned long long)(unsigned)gc;
+        if (flags & F_HAS_PENDING) xr = P.xres[gc];
+        coop_load<CT>(S.cs + cl * CSW, P.cs + (size_t)c * CSW, CSW, r);
+        if (t > 1) coop_load<CT>(S.rb + cl * RBW, P.rb + ((size_t)(t - P.rb_t0) * N + c) * RBW, RBW, r);
         // level 2: the record the chain continues from (its own, or the donor's)
-#pragma unroll 8
-        for (int f = 0; f < R; ++f) rc[f] = rec_in[(size_t)f * N + s];
+        const int s = (int)(unsigned)(xr & 0xffffffffu) - P.offset;
+        partner = (int)(xr >> 32);
+        coop_load<CT>(S.rec + cl * RW, rec_in + (size_t)s * RW, RW, r);
     }
     TS_MARK(1);
     __syncthreads();
 
-    // ---- settle iteration t-1 (registers only; its history stores are issued in the epilogue) ----
-    bool exch_prev = false;
-    if (chain_lane && t > 1) {
-        if (partner != 0) exch_prev = true;  // swap_ev_ij!, :734-749
-        else if (wasx) { exch_prev = true; P.was_exch[c] = 0; }
-        if ((flags & F_CLOSE_PREV) && !exch_prev) { nn += 1; na += lacc; }  // set_acceptRate!, :253-257
-        if (partner != 0) {  // best after t-1 recomputed against t-2 for the donor's record (:231-243)
-            const double dv = S.rec[tid * R];
-            if (dv < bpp) { bp = dv; bpid = t - 1; }
-            else { bp = bpp; bpid = bppid; }
+    // ---- settle iteration t-1 (chain lanes; registers + LDS only) ----
+    double sig = 0.0, bp = INFINITY, bpid = -1.0, atun = 0.0, u = 0.0;
+    int nn = 0, na = 0;
+    if (chain_lane) {
+        const double* csb = S.cs + cl * CSW;
+        sig = csb[CS_SIGMA]; nn = (int)csb[CS_NNOEX]; na = (int)csb[CS_NACC];
+        bp = csb[CS_BEST]; bpid = csb[CS_BESTID]; atun = csb[CS_ATUN];
+        if (t > 1) {
+            u = S.rb[cl * RBW];  // probs_acc[iter], :85
+            bool exch_prev = false;
+            if (partner != 0) {  // swap_ev_ij!, :734-749: iteration t-1's record becomes the donor's
+                exch_prev = true;
+                make_swapped_history(P, S.hp + cl * HW, S.rec + cl * RW, t - 1, partner, csb[CS_BESTP], csb[CS_BESTPID], bp, bpid);
+            } else if (csb[CS_WASX] != 0.0) {  // sharded path: k_exch_apply already rewrote record and history
+                exch_prev = true;
+            }
+            if ((flags & F_CLOSE_PREV) && !exch_prev) { nn += 1; na += (int)csb[CS_LACC]; }  // set_acceptRate!, :253-257
         }
+        S.cs[cl * CSW + CS_PARTNER] = (double)partner;
     }
     TS_MARK(5);
-    // ---- proposal(c), AlgoBGP.jl:424-471: wave 0, lane = r*CT + cl evaluates try r of chain cl ----
-    if (tid < 64) {
-        constexpr int NR = 64 / CT;  // tries evaluated side by side
-        const int cl = tid % CT, r0 = tid / CT;
-        const int cc = blockIdx.x * CT + cl;
-        const bool valid = cc < N;
+    // ---- proposal(c), AlgoBGP.jl:424-471: lane (cl, r) evaluates try r of chain cl ----
+    if (ctl) {
         double* th = S.theta + cl * np;
-        const double* rc = S.rec + cl * R;
+        const double* rc = S.rec + cl * RW;
         if (t == 1 || !valid || (P.dbg & 1)) {
-            if (r0 == 0)
-                for (int k = 0; k < np; ++k) th[k] = !valid ? 0.0 : (t == 1 ? P.init[k] : rc[3 + k]);  // :426-427
+            if (r == 0)
+                for (int k = 0; k < np; ++k) th[k] = !valid ? 0.0 : (t == 1 ? S.init[k] : rc[3 + k]);  // :426-427
         } else {
             const int bs = P.batch_size;
-            const int max_tries = P.ntab_user ? min(P.ntries, P.smpl_iters) : P.smpl_iters;
-            const int npar = min(min(NR, npf), max_tries);  // tries done in parallel from LDS-staged normals
-            const double sg = S.sig[cl];
-            const double* zz = S.z + cl * NPF_MAX * np;
+            const int max_tries = P.user_n ? min(P.rb_tries, P.smpl_iters) : P.smpl_iters;
+            const int npar = min(min(NR, P.rb_tries), max_tries);  // tries evaluated side by side
+            const double sg = S.cs[cl * CSW + CS_SIGMA];
+            const double* zz = S.rb + cl * RBW + 1;  // [tries][np]
             for (int b0 = 0; b0 < np; b0 += bs) {
-                bool ok = r0 < npar;
+                bool ok = r < npar;
                 if (ok) {
-                    for (int k = b0; k < b0 + bs; ++k) {  // mysample, :400-410, try r0
+                    for (int k = b0; k < b0 + bs; ++k) {  // mysample, :400-410, try r
                         const double lbk = S.lb[k];
                         const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);  // mapto_01, mprob.jl:248
-                        const double step = sg * zz[r0 * np + k];  // MvNormal(mu01, sigma): x = mu + sigma*z
+                        const double step = sg * zz[r * np + k];  // MvNormal(mu01, sigma): x = mu + sigma*z
                         const double x = mu01 + step;
                         if (!(x >= 0.0 && x <= 1.0)) ok = false;  // inclusive bounds, :405
                     }
                 }
-                // first successful try of every chain
-                const unsigned long long m = __ballot(ok);
+                const unsigned long long m = __ballot(ok);  // first successful try of every chain
                 unsigned long long pat = 0;
 #pragma unroll
                 for (int rr = 0; rr < NR; ++rr) pat |= ((m >> (rr * CT + cl)) & 1ull) << rr;
                 const int rwin = pat ? (__ffsll((long long)pat) - 1) : -1;
-                if (rwin == r0) {
+                if (rwin == r) {
                     for (int k = b0; k < b0 + bs; ++k) {
                         const double lbk = S.lb[k];
                         const double span = S.ub[k] - lbk;
                         const double mu01 = (rc[3 + k] - lbk) / span;
-                        const double step = sg * zz[r0 * np + k];
+                        const double step = sg * zz[r * np + k];
                         const double x = mu01 + step;
                         const double sc = x * span;
                         th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
                     }
-                } else if (rwin < 0 && r0 == 0) {  // rare: continue one try at a time (table, then the in-kernel generator)
-                    const int gcc = P.offset + cc;
-                    const size_t wrow = (size_t)(t - P.ntab_t0) * P.ntries;
+                } else if (rwin < 0 && r == 0) {  // rare: one try at a time (block, then the in-kernel generator)
                     bool ok2 = false;
-                    for (int r = npar; r < max_tries && !ok2; ++r) {
+                    for (int rr = npar; rr < max_tries && !ok2; ++rr) {
                         ok2 = true;
                         double zc0 = 0.0, zc1 = 0.0;
                         int zq = -1;
@@ -434,14 +431,12 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
                             const double lbk = S.lb[k];
                             const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);
                             double z;
-                            if (r < npf) {
-                                z = zz[r * np + k];
-                            } else if (r < P.ntries) {
-                                z = P.ntab[((wrow + r) * np + k) * N + cc];
+                            if (rr < P.rb_tries) {
+                                z = zz[rr * np + k];
                             } else {
                                 if ((k >> 1) != zq) {
                                     zq = k >> 1;
-                                    rng_prop_normal2(P.seed, (uint32_t)gcc, (uint32_t)t, (uint32_t)r, (uint32_t)zq, zc0, zc1);
+                                    rng_prop_normal2(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)rr, (uint32_t)zq, zc0, zc1);
                                 }
                                 z = (k & 1) ? zc1 : zc0;
                             }
@@ -451,7 +446,7 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
                             if (!(x >= 0.0 && x <= 1.0)) ok2 = false;
                         }
                     }
-                    if (!ok2) report_error(P, 2, t, gcc);  // :409
+                    if (!ok2) report_error(P, 2, t, gc);  // :409
                     for (int k = b0; k < b0 + bs; ++k) {
                         const double lbk = S.lb[k];
                         const double span = S.ub[k] - lbk;
@@ -474,14 +469,17 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
     TS_MARK(3);
     if (P.dbg & 4) return;
 
-    // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245) ----
+    // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245): chain lanes ----
     if (chain_lane) {
-        const double* th = S.theta + tid * np;
-        const double* rc = S.rec + tid * R;
-        double* sm = S.simM + tid * nm;
+        const double* th = S.theta + cl * np;
+        const double* rc = S.rec + cl * RW;
+        double* hr = S.h + cl * HW;
+        double* ro = S.rout + cl * RW;
+        double* csb = S.cs + cl * CSW;
+        double* sm = hr + H_PARAMS + np;
         double value;
         int status;
-        finish_objective<CT>(P, th, S.part, S.mom, S.w, tid, sm, value, status);
+        finish_objective<CT>(P, th, S.part, S.mom, S.w, cl, sm, value, status);
 
         const double old = rc[0];
         double prob;
@@ -501,39 +499,40 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
         TS_MARK(7);
         // set_acceptRate!, :253-257 (iteration t has exchanged==0 at this point)
         const double rate = (double)(na + (acc ? 1 : 0)) / (double)(nn + 1);
-        P.accept_rate[c] = rate;
-        P.last_acc[c] = acc ? 1 : 0;
-        P.n_noex[c] = nn; P.n_acc[c] = na;
+        double nsig = sig;
         if (t > 1 && (t % P.sigma_update_steps) == 0)  // :381-390
-            P.sigma[c] = (rate > 0.234) ? sig * (1.0 + P.sigma_adjust_by) : sig * (1.0 - P.sigma_adjust_by);
+            nsig = (rate > 0.234) ? sig * (1.0 + P.sigma_adjust_by) : sig * (1.0 - P.sigma_adjust_by);
         // set_eval!, :220-245
-        const size_t row = (size_t)(t - 1) * N + c;
-        double bestv, currv;
-        int bestid;
-        if (t == 1) { bestv = value; currv = value; bestid = 1; }
+        double bestv, currv, bestid;
+        if (t == 1) { bestv = value; currv = value; bestid = 1.0; }
         else {
             currv = acc ? value : old;  // curr_val[t-1] == value of the last accepted record
-            P.bestp_val[c] = bp; P.bestp_id[c] = bpid;  // best after t-1: needed if iteration t gets exchanged
-            if (value < bp) { bestv = value; bestid = t; }
+            if (value < bp) { bestv = value; bestid = (double)t; }
             else { bestv = bp; bestid = bpid; }
         }
-        P.best_val[c] = bestv; P.best_id[c] = bestid;
-        P.h_value[row] = value; P.h_prob[row] = prob; P.h_curr[row] = currv; P.h_best[row] = bestv;
-        P.h_best_id[row] = bestid; P.h_exch[row] = 0; P.h_acc[row] = acc ? 1 : 0; P.h_status[row] = (int8_t)status;
-        for (int k = 0; k < np; ++k) P.h_params[((size_t)(t - 1) * np + k) * N + c] = th[k];
-        for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(t - 1) * nm + k) * N + c] = sm[k];
-        if (partner != 0) {  // iteration t-1 was exchanged: its record is the donor's (swap_ev_ij!, :734-749)
-            double bv; int bi;
-            write_swapped_history(P, t - 1, c, partner, rc, bpp, bppid, bv, bi);
-        }
+        csb[CS_SIGMA] = nsig; csb[CS_RATE] = rate; csb[CS_NNOEX] = (double)nn; csb[CS_NACC] = (double)na;
+        csb[CS_LACC] = acc ? 1.0 : 0.0; csb[CS_WASX] = 0.0; csb[CS_BEST] = bestv; csb[CS_BESTID] = bestid;
+        csb[CS_BESTP] = bp; csb[CS_BESTPID] = bpid;  // best after t-1: needed if iteration t gets exchanged
+        hr[H_VALUE] = value; hr[H_PROB] = prob; hr[H_CURR] = currv; hr[H_BEST] = bestv; hr[H_BESTID] = bestid;
+        hr[H_EXCH] = 0.0; hr[H_ACC] = acc ? 1.0 : 0.0; hr[H_STATUS] = (double)status;
+        for (int k = 0; k < np; ++k) hr[H_PARAMS + k] = th[k];
         // the chain's last accepted record (lastAccepted :209-215) = input of the exchange step
         if (acc) {
-            rec_out[c] = value; rec_out[(size_t)N + c] = prob; rec_out[(size_t)2 * N + c] = (double)status;
-            for (int k = 0; k < np; ++k) rec_out[(size_t)(3 + k) * N + c] = th[k];
-            for (int k = 0; k < nm; ++k) rec_out[(size_t)(3 + np + k) * N + c] = sm[k];
+            ro[0] = value; ro[1] = prob; ro[2] = (double)status;
+            for (int k = 0; k < np; ++k) ro[3 + k] = th[k];
+            for (int k = 0; k < nm; ++k) ro[3 + np + k] = sm[k];
         } else {
-            for (int f = 0; f < R; ++f) rec_out[(size_t)f * N + c] = rc[f];
+            for (int f = 0; f < RW; ++f) ro[f] = rc[f];
         }
+    }
+    // ---- the control wave stores the tile's result blocks ----
+    if (valid) {
+        __builtin_amdgcn_wave_barrier();
+        coop_store<CT>(P.cs + (size_t)c * CSW, S.cs + cl * CSW, CSW, r);
+        coop_store<CT>(rec_out + (size_t)c * RW, S.rout + cl * RW, RW, r);
+        coop_store<CT>(P.hrec + ((size_t)(t - 1) * N + c) * HW, S.h + cl * HW, HW, r);
+        if (t > 1 && S.cs[cl * CSW + CS_PARTNER] != 0.0)
+            coop_store<CT>(P.hrec + ((size_t)(t - 2) * N + c) * HW, S.hp + cl * HW, HW, r);
     }
     TS_MARK(4);
 }
@@ -544,9 +543,37 @@ __global__ void k_flush(const KParams P, const int t_next, const double* __restr
                         const int flags) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.N) return;
-    const int s = settle_previous(P, t_next, c, rec_in, flags);
-    const int R = 3 + P.np + P.nm;
-    for (int f = 0; f < R; ++f) rec_out[(size_t)f * P.N + c] = rec_in[(size_t)f * P.N + s];
+    const int RW = P.RW, HW = P.HW, N = P.N;
+    double* csb = P.cs + (size_t)c * CSW;
+    int s = c;
+    bool exch = false;
+    if (flags & F_HAS_PENDING) {
+        const unsigned long long xr = P.xres[P.offset + c];
+        const int partner = (int)(xr >> 32);
+        if (partner != 0) {
+            exch = true;
+            s = (int)(unsigned)(xr & 0xffffffffu) - P.offset;
+            const int tp = t_next - 1;
+            const double* donor = rec_in + (size_t)s * RW;
+            double* hrec = P.hrec + ((size_t)(tp - 1) * N + c) * HW;
+            const double value = donor[0];
+            double bestv, bestid;
+            if (value < csb[CS_BESTP]) { bestv = value; bestid = (double)tp; }
+            else { bestv = csb[CS_BESTP]; bestid = csb[CS_BESTPID]; }
+            hrec[H_VALUE] = value; hrec[H_PROB] = donor[1]; hrec[H_CURR] = value; hrec[H_BEST] = bestv;
+            hrec[H_BESTID] = bestid; hrec[H_EXCH] = (double)partner; hrec[H_ACC] = 1.0; hrec[H_STATUS] = donor[2];
+            for (int k = 0; k < P.np + P.nm; ++k) hrec[H_PARAMS + k] = donor[3 + k];
+            csb[CS_BEST] = bestv; csb[CS_BESTID] = bestid;
+        }
+    } else if (csb[CS_WASX] != 0.0) {
+        exch = true;
+        csb[CS_WASX] = 0.0;
+    }
+    if ((flags & F_CLOSE_PREV) && !exch) {
+        csb[CS_NNOEX] += 1.0;
+        csb[CS_NACC] += csb[CS_LACC];
+    }
+    for (int f = 0; f < RW; ++f) rec_out[(size_t)c * RW + f] = rec_in[(size_t)s * RW + f];
 }
 
 // batched evaluateObjective(m,p), mprob.jl:175-188: params [np][M] -> value, simM [nm][M], status
@@ -556,7 +583,7 @@ __global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const dou
                                                       int8_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     TileSmem S;
-    S.carve(smem, CT, P.np, P.nm);
+    S.carve(smem, CT, P.np, P.nm, P.RW, P.HW, P.RBW, SIM);
     const int tid = threadIdx.x;
     const int i = blockIdx.x * CT + tid;
     const bool chain_lane = (tid < CT) && (i < M);
@@ -574,7 +601,7 @@ __global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const dou
     if (chain_lane) {
         double v;
         int st;
-        double* sm = S.simM + tid * P.nm;
+        double* sm = S.h + tid * P.HW;
         finish_objective<CT>(P, S.theta + tid * P.np, S.part, S.mom, S.w, tid, sm, v, st);
         value[i] = v;
         status[i] = (int8_t)st;
@@ -583,32 +610,38 @@ __global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const dou
 }
 
 // ------------------------------------------------------------------------------------------
-// k_pregen_rng: the state-independent randomness of iterations t0 .. t0+W-1:
-//   ntab [W][PRE_TRIES][np][N]  standard normals of mysample's first tries (rand(RAND,d), :404)
-//   utab [W][N]                 the MH uniforms (probs_acc = rand(n), :85)
+// k_pregen_rng: the state-independent randomness of iterations t0 .. t0+W-1 as per-chain blocks
+//   rb[w][c] = { u, z[try][k] }:  u = the MH uniform (probs_acc = rand(n), AlgoBGP.jl:85),
+//   z = standard normals of mysample's first tries (rand(RAND,d), :404) — injected or generated.
 // one thread per (iteration, try, parameter pair, chain).
 // ------------------------------------------------------------------------------------------
-__global__ void k_pregen_rng(const KParams P, const int t0, const int W, double* __restrict__ ntab, double* __restrict__ utab) {
-    const int N = P.N, np = P.np;
+__global__ void k_pregen_rng(const KParams P, const int t0, const int W, double* __restrict__ rb) {
+    const int N = P.N, np = P.np, TR = P.rb_tries;
     const int Q = (np + 1) / 2;
-    const size_t total = (size_t)W * PRE_TRIES * Q * N;
+    const size_t total = (size_t)W * TR * Q * N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % N);
-    size_t rest = i / N;
-    const int q = (int)(rest % Q); rest /= Q;
-    const int r = (int)(rest % PRE_TRIES);
-    const int w = (int)(rest / PRE_TRIES);
+    const int q = (int)(i % Q);
+    size_t rest = i / Q;
+    const int r = (int)(rest % TR); rest /= TR;
+    const int c = (int)(rest % N);
+    const int w = (int)(rest / N);
     const int t = t0 + w;
     const uint32_t gc = (uint32_t)(P.offset + c);
+    double* blk = rb + ((size_t)w * N + c) * P.RBW;
     if (t > 1) {  // iteration 1 proposes the initial value (:426-427)
-        double z0, z1;
-        rng_prop_normal2(P.seed, gc, (uint32_t)t, (uint32_t)r, (uint32_t)q, z0, z1);
-        const size_t base = (((size_t)w * PRE_TRIES + r) * np) * N + c;
-        ntab[base + (size_t)(2 * q) * N] = z0;
-        if (2 * q + 1 < np) ntab[base + (size_t)(2 * q + 1) * N] = z1;
+        double z0, z1 = 0.0;
+        if (P.user_ntab) {
+            const size_t base = (((size_t)(t - 1) * TR + r) * np) * N + c;
+            z0 = P.user_ntab[base + (size_t)(2 * q) * N];
+            if (2 * q + 1 < np) z1 = P.user_ntab[base + (size_t)(2 * q + 1) * N];
+        } else {
+            rng_prop_normal2(P.seed, gc, (uint32_t)t, (uint32_t)r, (uint32_t)q, z0, z1);
+        }
+        blk[1 + r * np + 2 * q] = z0;
+        if (2 * q + 1 < np) blk[1 + r * np + 2 * q + 1] = z1;
     }
-    if (r == 0 && q == 0) utab[(size_t)w * N + c] = rng_u(P.seed, gc, (uint32_t)t);
+    if (r == 0 && q == 0) blk[0] = P.user_utab ? P.user_utab[(size_t)(t - 1) * N + c] : rng_u(P.seed, gc, (uint32_t)t);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -616,9 +649,10 @@ __global__ void k_pregen_rng(const KParams P, const int t0, const int W, double*
 // (sample(props, K, replace=false), AlgoBGP.jl:653-656) and derives the dependency structure of
 // the ordered walk (:662-691): for pair q = (i,j), r_i / r_j = number of earlier pairs touching
 // chain i / chain j (counting sort of the 2K endpoints by chain: LDS atomics + block scan).
-// plan[t-t0][q] = i | j<<16 | r_i<<32 | r_j<<48.
+// plan[t-t0][q] = i | j<<16 | r_i<<32 | r_j<<48, plan_mi[t-t0][q] = min_improve[i].
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0, unsigned long long* __restrict__ plan) {
+__global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0, unsigned long long* __restrict__ plan,
+                                                   double* __restrict__ plan_mi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = t0 + blockIdx.x;
@@ -629,6 +663,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
     uint16_t* pj = pi + K;                   // [K]
     uint32_t* wsum = (uint32_t*)(pj + K);    // [16] (pi,pj: 4K bytes from a 4-byte aligned base)
     unsigned long long* out = plan + (size_t)blockIdx.x * K;
+    double* out_mi = plan_mi + (size_t)blockIdx.x * K;
 
     for (int c = tid; c < Ng; c += XWG) cnt[c] = 0;
     if (P.pairtab) {
@@ -696,6 +731,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         for (uint32_t x = b; x < e; ++x) rj += (ep[x] < (uint32_t)q) ? 1u : 0u;
         out[q] = (unsigned long long)i | ((unsigned long long)j << 16) | ((unsigned long long)ri << 32) |
                  ((unsigned long long)rj << 48);
+        out_mi[q] = P.min_improve_g[i];  // the threshold of the pair's colder chain, AlgoBGP.jl:688
     }
 }
 
@@ -707,25 +743,26 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
 // chain c and pair q = (i,j) runs exactly when ticket[i]==r_i && ticket[j]==r_j (all of its
 // predecessors on both chains ran, none of its successors did); then it publishes ticket+1 on both
 // chains (release/acquire at workgroup scope).  Critical path = longest dependency chain of the
-// list (~log N) x one LDS round trip.  Outputs xsrc[g] (whose record chain g ends up with) and
-// xpartner[g] (last exchange partner, 1-based, 0 = none).
+// list (~log N) x one LDS round trip.  Output xres[g] = src | partner<<32: whose record chain g
+// ends up with, and its last exchange partner (1-based, 0 = none).
+// gathered: last accepted records of all chains, [Ng][RW].
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const int t, const double* __restrict__ gathered) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int Ng = P.Ng, N = P.N, R = 3 + P.np + P.nm, K = P.plan_K;
+    const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
     double* val = (double*)xsm;               // [Ng]
     uint32_t* ticket = (uint32_t*)(val + Ng);  // [Ng]
     uint16_t* src = (uint16_t*)(ticket + Ng);  // [Ng]
     uint16_t* partner = src + Ng;              // [Ng]
     const unsigned long long* __restrict__ plan = P.plan + (size_t)(t - P.plan_t0) * K;
+    const double* __restrict__ plan_mi = P.plan_mi + (size_t)(t - P.plan_t0) * K;
 
     int q = tid;
     unsigned long long pw = (q < K) ? plan[q] : 0ull;
-    double mi = (q < K) ? P.min_improve_g[pw & 0xffff] : 0.0;
+    double mi = (q < K) ? plan_mi[q] : 0.0;
     for (int g = tid; g < Ng; g += XWG) {
-        const int shard = g / N, l = g - shard * N;
-        val[g] = gathered[(size_t)shard * R * N + l];
+        val[g] = gathered[(size_t)g * RW];
         ticket[g] = 0;
         src[g] = (uint16_t)g;
         partner[g] = 0;
@@ -752,7 +789,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
                 q += XWG;
                 if (q < K) {
                     pw = plan[q];
-                    mi = P.min_improve_g[pw & 0xffff];
+                    mi = plan_mi[q];
                 }
                 progressed = true;
             }
@@ -767,10 +804,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
         }
     }
     __syncthreads();
-    for (int g = tid; g < Ng; g += XWG) {
-        P.xsrc[g] = src[g];
-        P.xpartner[g] = partner[g];
-    }
+    for (int g = tid; g < Ng; g += XWG) P.xres[g] = (unsigned long long)src[g] | ((unsigned long long)partner[g] << 32);
 }
 
 // k_exch_resolve_any: the same result for any N_global, state in global memory, executed in
@@ -778,11 +812,10 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
 // both of its chains; a pair that wins both bids has no pending predecessor and is executed.
 __global__ __launch_bounds__(XWG) void k_exch_resolve_any(const KParams P, const int t, const double* __restrict__ gathered) {
     const int tid = threadIdx.x;
-    const int Ng = P.Ng, N = P.N, R = 3 + P.np + P.nm;
+    const int Ng = P.Ng, RW = P.RW;
     const int K = P.pairtab ? P.n_pairs_tab : n_exchange_pairs(Ng);
     for (int g = tid; g < Ng; g += XWG) {
-        const int shard = g / N, l = g - shard * N;
-        P.xval[g] = gathered[(size_t)shard * R * N + l];
+        P.xval[g] = gathered[(size_t)g * RW];
         P.xsrc[g] = g;
         P.xpartner[g] = 0;
         P.xnext[g] = 0x7fffffff;
@@ -835,35 +868,33 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_any(const KParams P, const
         }
         remaining = __syncthreads_or(mine);
     }
+    for (int g = tid; g < Ng; g += XWG)
+        P.xres[g] = (unsigned long long)(unsigned)P.xsrc[g] | ((unsigned long long)(unsigned)P.xpartner[g] << 32);
 }
 
 // k_exch_apply (sharded path): set_eval!(ci, ej) + set_exchanged! of swap_ev_ij! (AlgoBGP.jl:734-749)
-// for the local chains, reading the donor records from the all-gathered buffer:
-// gathered [G][(3+np+nm)][N]; rec = this shard's own post-accept records, updated in place.
+// for the local chains, reading the donor records from the all-gathered buffer [Ng][RW];
+// rec = this shard's own post-accept records [N][RW], updated in place.
 __global__ void k_exch_apply(const KParams P, const int t, const double* __restrict__ gathered, double* __restrict__ rec) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.N) return;
-    const int N = P.N, np = P.np, nm = P.nm, R = 3 + np + nm;
-    const int g = P.offset + c;
-    const int partner = P.xpartner[g];
+    const int N = P.N, RW = P.RW, HW = P.HW;
+    const unsigned long long xr = P.xres[P.offset + c];
+    const int partner = (int)(xr >> 32);
     if (partner == 0) return;
-    const int s = P.xsrc[g];
-    const int shard = s / N, l = s - shard * N;
-    const double* __restrict__ src = gathered + (size_t)shard * R * N;
-    const double value = src[l], prob = src[(size_t)N + l];
-    const int8_t status = (int8_t)src[(size_t)2 * N + l];
-    const double bp = P.bestp_val[c];
-    double bestv; int bestid;
-    if (value < bp) { bestv = value; bestid = t; }
-    else { bestv = bp; bestid = P.bestp_id[c]; }
-    P.best_val[c] = bestv; P.best_id[c] = bestid;
-    const size_t row = (size_t)(t - 1) * N + c;
-    P.h_value[row] = value; P.h_prob[row] = prob; P.h_curr[row] = value; P.h_best[row] = bestv;
-    P.h_best_id[row] = bestid; P.h_exch[row] = partner; P.h_acc[row] = 1; P.h_status[row] = status;
-    for (int k = 0; k < np; ++k) P.h_params[((size_t)(t - 1) * np + k) * N + c] = src[(size_t)(3 + k) * N + l];
-    for (int k = 0; k < nm; ++k) P.h_simM[((size_t)(t - 1) * nm + k) * N + c] = src[(size_t)(3 + np + k) * N + l];
-    for (int f = 0; f < R; ++f) rec[(size_t)f * N + c] = src[(size_t)f * N + l];
-    P.was_exch[c] = 1;
+    const int s = (int)(unsigned)(xr & 0xffffffffu);
+    const double* __restrict__ donor = gathered + (size_t)s * RW;
+    double* csb = P.cs + (size_t)c * CSW;
+    double* hrec = P.hrec + ((size_t)(t - 1) * N + c) * HW;
+    const double value = donor[0];
+    double bestv, bestid;
+    if (value < csb[CS_BESTP]) { bestv = value; bestid = (double)t; }
+    else { bestv = csb[CS_BESTP]; bestid = csb[CS_BESTPID]; }
+    csb[CS_BEST] = bestv; csb[CS_BESTID] = bestid; csb[CS_WASX] = 1.0;
+    hrec[H_VALUE] = value; hrec[H_PROB] = donor[1]; hrec[H_CURR] = value; hrec[H_BEST] = bestv;
+    hrec[H_BESTID] = bestid; hrec[H_EXCH] = (double)partner; hrec[H_ACC] = 1.0; hrec[H_STATUS] = donor[2];
+    for (int k = 0; k < P.np + P.nm; ++k) hrec[H_PARAMS + k] = donor[3 + k];
+    for (int f = 0; f < RW; ++f) rec[(size_t)c * RW + f] = donor[f];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -885,18 +916,18 @@ struct Ctx {
     bool force_any_exchange = false;
     std::vector<hipEvent_t> pev;  // profiling events: 3 per iteration
     int pev_iters = 0;
-    // double-buffered last-accepted records
+    // double-buffered last-accepted records [N][RW]
     double* rec[2] = {nullptr, nullptr};
     int cur = 0;               // rec[cur] holds the records after the last accept step
     bool pending = false;      // exchange of iteration `iter` resolved but not applied
     bool prev_open = false;    // accept-rate counters of iteration `iter` not closed yet
     // look-ahead windows
     int win_cap = 0;           // iterations per window
-    double *win_ntab = nullptr, *win_utab = nullptr;
+    double* win_rb = nullptr;
     unsigned long long* win_plan = nullptr;
+    double* win_plan_mi = nullptr;
     int rng_t0 = 0, rng_w = 0;    // window currently held: iterations [t0, t0+w)
     int plan_t0 = 0, plan_w = 0;
-    bool user_u = false, user_n = false;
     bool lds_exchange = false;
     int ct = 8;
 };
@@ -924,65 +955,55 @@ T* dupload(Ctx* c, const T* h, size_t n) {
     if (h && n) HIPCHK(hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice));
     return d;
 }
-template <class T>
-void dfill(Ctx* c, T* d, size_t n, T v) {
-    (void)c;
-    std::vector<T> h(n, v);
-    if (n) HIPCHK(hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
-}
 
 bool is_sim(int obj) { return obj == SMM_OBJ_NORM || obj == SMM_OBJ_NORM_FAILBOX; }
 
-size_t tile_smem(const Ctx* c, int ct) {  // TileSmem::carve
-    const size_t np = c->P.np, nm = c->P.nm;
-    return ((size_t)ct * (1 + np + nm + (3 + np + nm) + NPF_MAX * np + (is_sim(c->obj) ? (WG / 64) * nm : 0)) + 2 * np + 2 * nm) *
-           sizeof(double);
+size_t tile_smem(const Ctx* c, int ct) {
+    const KParams& P = c->P;
+    return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, is_sim(c->obj)) * sizeof(double);
 }
-size_t plan_lds_bytes(int Ng, int K) { return (size_t)Ng * 4 + (size_t)K * 8 + (size_t)(K + (K & 1)) * 4 + 64 + 16; }
+size_t plan_lds_bytes(int Ng, int K) { return (size_t)Ng * 4 + (size_t)K * 8 + (size_t)K * 4 + 64 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
 
 int exchange_K(const Ctx* c) { return c->P.pairtab ? c->P.n_pairs_tab : n_exchange_pairs(c->P.Ng); }
 bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P.Ng > 1; }  // AlgoBGP.jl:637
 
-// make the look-ahead tables cover iteration t (1-based); windows never straddle a call that
-// needs them twice: a new window simply starts at t.
+// make the look-ahead tables cover iteration t (1-based): a new window simply starts at t
 void ensure_windows(Ctx* c, int t) {
     KParams& P = c->P;
-    const bool need_rng = !(c->user_u && c->user_n);
-    if (need_rng && !(t >= c->rng_t0 && t < c->rng_t0 + c->rng_w)) {
+    if (!(t >= c->rng_t0 && t < c->rng_t0 + c->rng_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
         const size_t Q = (size_t)(P.np + 1) / 2;
-        const size_t total = (size_t)W * PRE_TRIES * Q * P.N;
-        hipLaunchKernelGGL(k_pregen_rng, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, P, t, W, c->win_ntab,
-                           c->win_utab);
+        const size_t total = (size_t)W * P.rb_tries * Q * P.N;
+        hipLaunchKernelGGL(k_pregen_rng, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, P, t, W, c->win_rb);
         c->rng_t0 = t; c->rng_w = W;
-        if (!c->user_n) { P.ntab = c->win_ntab; P.ntab_t0 = t; P.ntries = PRE_TRIES; P.ntab_user = 0; }
-        if (!c->user_u) { P.utab = c->win_utab; P.utab_t0 = t; }
+        P.rb = c->win_rb; P.rb_t0 = t;
     }
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
-        hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan);
+        hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
+                           c->win_plan_mi);
         c->plan_t0 = t; c->plan_w = W;
-        P.plan = c->win_plan; P.plan_t0 = t;
+        P.plan = c->win_plan; P.plan_mi = c->win_plan_mi; P.plan_t0 = t;
     }
 }
 
-void launch_chain_iter(Ctx* c, int t, int flags) {
+template <bool SIM, int CT>
+void launch_chain_iter_ct(Ctx* c, int t, int flags) {
     const KParams& P = c->P;
-    const double* rin = c->rec[c->cur];
-    double* rout = c->rec[c->cur ^ 1];
+    hipLaunchKernelGGL((k_chain_iter<SIM, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, t,
+                       (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
+}
+
+void launch_chain_iter(Ctx* c, int t, int flags) {
     if (is_sim(c->obj)) {
-        if (c->ct == 4) {
-            hipLaunchKernelGGL((k_chain_iter<true, 4>), dim3((P.N + 3) / 4), dim3(WG), tile_smem(c, 4), c->stream, P, t, rin, rout, flags);
-        } else if (c->ct == 16) {
-            hipLaunchKernelGGL((k_chain_iter<true, 16>), dim3((P.N + 15) / 16), dim3(WG), tile_smem(c, 16), c->stream, P, t, rin, rout, flags);
-        } else {
-            hipLaunchKernelGGL((k_chain_iter<true, 8>), dim3((P.N + 7) / 8), dim3(WG), tile_smem(c, 8), c->stream, P, t, rin, rout, flags);
-        }
+        if (c->ct == 4) launch_chain_iter_ct<true, 4>(c, t, flags);
+        else if (c->ct == 16) launch_chain_iter_ct<true, 16>(c, t, flags);
+        else launch_chain_iter_ct<true, 8>(c, t, flags);
     } else if (tile_smem(c, 64) <= (size_t)60 * 1024) {
-        hipLaunchKernelGGL((k_chain_iter<false, 64>), dim3((P.N + 63) / 64), dim3(WG), tile_smem(c, 64), c->stream, P, t, rin, rout, flags);
+        launch_chain_iter_ct<false, 64>(c, t, flags);
     } else {
-        hipLaunchKernelGGL((k_chain_iter<false, 8>), dim3((P.N + 7) / 8), dim3(WG), tile_smem(c, 8), c->stream, P, t, rin, rout, flags);
+        launch_chain_iter_ct<false, 8>(c, t, flags);
     }
     c->cur ^= 1;
 }
@@ -1000,7 +1021,7 @@ void flush(Ctx* c) {
     if (!c->pending && !c->prev_open) return;
     const KParams& P = c->P;
     const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
-    hipLaunchKernelGGL(k_flush, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter + 1, c->rec[c->cur],
+    hipLaunchKernelGGL(k_flush, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter + 1, (const double*)c->rec[c->cur],
                        c->rec[c->cur ^ 1], flags);
     c->cur ^= 1;
     c->pending = false;
@@ -1025,7 +1046,7 @@ int check_device_error(Ctx* c) {
         return SMM_ERR_NEGATIVE_OBJECTIVE;
     }
     snprintf(b, sizeof b, "no draw in support after %d trials (chain %d, iteration %d): increase smpl_iters",
-             c->P.ntab_user ? std::min(c->P.ntries, c->P.smpl_iters) : c->P.smpl_iters, chain + 1, it);
+             c->P.user_n ? std::min(c->P.rb_tries, c->P.smpl_iters) : c->P.smpl_iters, chain + 1, it);
     c->err = b;
     return SMM_ERR_NO_DRAW_IN_SUPPORT;
 }
@@ -1097,7 +1118,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* d = getenv("SMMHIP_DBG");
             P.dbg = d ? atoi(d) : 0;
             const char* tsv = getenv("SMMHIP_TS");
-            if (tsv && tsv[0] == '1') { P.ts = dalloc<unsigned long long>(c, (size_t)8 * 65536); }
+            if (tsv && tsv[0] == '1') P.ts = dalloc<unsigned long long>(c, (size_t)8 * 65536);
             const char* ct = getenv("SMMHIP_CT");  // tuning hook: chains per tile (4, 8, 16); numerics unaffected
             c->ct = ct ? atoi(ct) : 8;
         }
@@ -1116,70 +1137,85 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.N = N; P.Ng = Ng; P.offset = opts->chain_offset; P.T = T;
         P.sigma_update_steps = opts->sigma_update_steps; P.smpl_iters = opts->smpl_iters;
         P.batch_size = opts->batch_size; P.sigma_adjust_by = opts->sigma_adjust_by; P.seed = opts->seed;
-        P.acc_tuner_g = dupload(c, opts->acc_tuner, Ng); P.min_improve_g = dupload(c, opts->min_improve, Ng);
+        P.min_improve_g = dupload(c, opts->min_improve, Ng);
         const size_t TN = (size_t)T * N;
-        if (tab && tab->probs_acc) { P.utab = dupload(c, tab->probs_acc, TN); P.utab_t0 = 1; c->user_u = true; }
+        if (tab && tab->probs_acc) P.user_utab = dupload(c, tab->probs_acc, TN);
         if (tab && tab->prop_normals && tab->prop_tries > 0) {
-            P.ntries = tab->prop_tries; P.ntab_t0 = 1; P.ntab_user = 1; c->user_n = true;
-            P.ntab = dupload(c, tab->prop_normals, TN * (size_t)tab->prop_tries * np);
+            P.rb_tries = tab->prop_tries; P.user_n = 1;
+            P.user_ntab = dupload(c, tab->prop_normals, TN * (size_t)tab->prop_tries * np);
+        } else {
+            P.rb_tries = np <= 8 ? 8 : (np <= 32 ? 4 : 2);
         }
         if (tab && tab->pairs && tab->n_pairs > 0) {
             P.n_pairs_tab = tab->n_pairs;
             P.pairtab = dupload(c, tab->pairs, (size_t)T * tab->n_pairs * 2);
         }
+        P.RW = even_up(3 + np + nm);
+        P.HW = even_up(H_PARAMS + np + nm);
+        P.RBW = even_up(1 + P.rb_tries * np);
         const int K = exchange_K(c);
         P.plan_K = K;
         c->lds_exchange = Ng > 1 && Ng <= XLDS_MAX && K >= 1 && K <= Ng && !c->force_any_exchange;
-        // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
-        {
-            const size_t per_iter = (size_t)PRE_TRIES * np * N * 8 + (size_t)N * 8 + (size_t)K * 8;
+        {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
+            const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 16;
             c->win_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)192 << 20) / per_iter));
             c->win_cap = std::min(c->win_cap, T);
-            if (!(c->user_u && c->user_n)) {
-                c->win_ntab = dalloc<double>(c, (size_t)c->win_cap * PRE_TRIES * np * N);
-                c->win_utab = dalloc<double>(c, (size_t)c->win_cap * N);
+            c->win_rb = dalloc<double>(c, (size_t)c->win_cap * N * P.RBW);
+            HIPCHK(hipMemset(c->win_rb, 0, (size_t)c->win_cap * N * P.RBW * 8));
+            if (c->lds_exchange) {
+                c->win_plan = dalloc<unsigned long long>(c, (size_t)c->win_cap * K);
+                c->win_plan_mi = dalloc<double>(c, (size_t)c->win_cap * K);
             }
-            if (c->lds_exchange) c->win_plan = dalloc<unsigned long long>(c, (size_t)c->win_cap * K);
         }
-        P.sigma = dupload(c, opts->sigma + opts->chain_offset, N);
-        P.accept_rate = dalloc<double>(c, N); dfill(c, P.accept_rate, N, 0.0);
-        P.n_noex = dalloc<int32_t>(c, N); dfill(c, P.n_noex, N, 0);
-        P.n_acc = dalloc<int32_t>(c, N); dfill(c, P.n_acc, N, 0);
-        P.last_acc = dalloc<uint8_t>(c, N); dfill(c, P.last_acc, N, (uint8_t)0);
-        P.was_exch = dalloc<uint8_t>(c, N); dfill(c, P.was_exch, N, (uint8_t)0);
-        P.best_val = dalloc<double>(c, N); dfill(c, P.best_val, N, (double)INFINITY);
-        P.best_id = dalloc<int32_t>(c, N); dfill(c, P.best_id, N, -1);
-        P.bestp_val = dalloc<double>(c, N); dfill(c, P.bestp_val, N, (double)INFINITY);
-        P.bestp_id = dalloc<int32_t>(c, N); dfill(c, P.bestp_id, N, -1);
-        const size_t RN = (size_t)(3 + np + nm) * N;
-        for (int b = 0; b < 2; ++b) {
-            c->rec[b] = dalloc<double>(c, RN);
-            std::vector<double> h(RN, 0.0);
-            for (int i = 0; i < N; ++i) h[i] = INFINITY;  // value row: Inf until the first accept
-            HIPCHK(hipMemcpy(c->rec[b], h.data(), RN * 8, hipMemcpyHostToDevice));
+        {   // chain state blocks and records (BGPChain ctor, AlgoBGP.jl:78-109: best = Inf, best_id = -1, ...)
+            std::vector<double> cs((size_t)N * CSW, 0.0);
+            for (int i = 0; i < N; ++i) {
+                double* b = cs.data() + (size_t)i * CSW;
+                b[CS_SIGMA] = opts->sigma[opts->chain_offset + i];
+                b[CS_BEST] = INFINITY; b[CS_BESTID] = -1.0; b[CS_BESTP] = INFINITY; b[CS_BESTPID] = -1.0;
+                b[CS_ATUN] = opts->acc_tuner[opts->chain_offset + i];
+            }
+            P.cs = dupload(c, cs.data(), cs.size());
+            std::vector<double> rec((size_t)N * P.RW, 0.0);
+            for (int i = 0; i < N; ++i) rec[(size_t)i * P.RW] = INFINITY;  // value: Inf until the first accept
+            for (int b = 0; b < 2; ++b) c->rec[b] = dupload(c, rec.data(), rec.size());
         }
-        const int Kmax = std::max(K, 1);
-        P.xsrc = dalloc<int32_t>(c, Ng); P.xpartner = dalloc<int32_t>(c, Ng);
-        dfill(c, P.xpartner, Ng, 0);
+        P.xres = dalloc<unsigned long long>(c, Ng);
         if (!c->lds_exchange) {
+            const int Kmax = std::max(K, 1);
             P.xval = dalloc<double>(c, Ng); P.xnext = dalloc<int32_t>(c, Ng); P.xpairs = dalloc<int32_t>(c, (size_t)Kmax * 2);
+            P.xsrc = dalloc<int32_t>(c, Ng); P.xpartner = dalloc<int32_t>(c, Ng);
         }
-        P.h_value = dalloc<double>(c, TN); dfill(c, P.h_value, TN, (double)NAN);
-        P.h_prob = dalloc<double>(c, TN); dfill(c, P.h_prob, TN, (double)NAN);
-        P.h_curr = dalloc<double>(c, TN); dfill(c, P.h_curr, TN, (double)INFINITY);
-        P.h_best = dalloc<double>(c, TN); dfill(c, P.h_best, TN, (double)INFINITY);
-        P.h_params = dalloc<double>(c, TN * np); dfill(c, P.h_params, TN * np, (double)NAN);
-        P.h_simM = dalloc<double>(c, TN * nm); dfill(c, P.h_simM, TN * nm, (double)NAN);
-        P.h_best_id = dalloc<int32_t>(c, TN); dfill(c, P.h_best_id, TN, -1);
-        P.h_exch = dalloc<int32_t>(c, TN); dfill(c, P.h_exch, TN, 0);
-        P.h_acc = dalloc<uint8_t>(c, TN); dfill(c, P.h_acc, TN, (uint8_t)0);
-        P.h_status = dalloc<int8_t>(c, TN); dfill(c, P.h_status, TN, (int8_t)0);
-        P.err = dalloc<unsigned long long>(c, 1); dfill(c, P.err, 1, ERR_NONE);
+        {   // history: NaN values, curr/best = Inf, best_id = -1, exchanged = accepted = status = 0
+            std::vector<double> row((size_t)N * P.HW, NAN);
+            for (int i = 0; i < N; ++i) {
+                double* h = row.data() + (size_t)i * P.HW;
+                h[H_CURR] = INFINITY; h[H_BEST] = INFINITY; h[H_BESTID] = -1.0; h[H_EXCH] = 0.0; h[H_ACC] = 0.0; h[H_STATUS] = 0.0;
+            }
+            P.hrec = dalloc<double>(c, TN * P.HW);
+            for (int t = 0; t < T; ++t)
+                HIPCHK(hipMemcpy(P.hrec + (size_t)t * N * P.HW, row.data(), row.size() * 8, hipMemcpyHostToDevice));
+        }
+        P.err = dalloc<unsigned long long>(c, 1);
+        {
+            const unsigned long long e = ERR_NONE;
+            HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
+        }
         if (c->lds_exchange) {
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lds_bytes(XLDS_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_plan, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)plan_lds_bytes(XLDS_MAX, XLDS_MAX)));
+        }
+        {   // tiles of problems with many parameters need more than the default 64 KiB of dynamic LDS
+            const int lim = 160 * 1024;
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            if (tile_smem(c, is_sim(c->obj) ? c->ct : 8) > (size_t)lim) throw std::string("tile does not fit the 160 KiB LDS");
         }
         HIPCHK(hipDeviceSynchronize());
     } catch (const std::string& m) {
@@ -1293,7 +1329,7 @@ int smm_bgp_local_step(void* ctx) {
 
 int smm_bgp_record_doubles(void* ctx) {
     Ctx* c = (Ctx*)ctx;
-    return c ? 3 + c->P.np + c->P.nm : SMM_ERR_INVALID_ARG;
+    return c ? c->P.RW : SMM_ERR_INVALID_ARG;
 }
 
 int smm_bgp_export_records_dev(void* ctx, void* rec_dev) {
@@ -1301,8 +1337,8 @@ int smm_bgp_export_records_dev(void* ctx, void* rec_dev) {
     if (!c || !rec_dev) return SMM_ERR_INVALID_ARG;
     try {
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipMemcpyAsync(rec_dev, c->rec[c->cur], (size_t)(3 + c->P.np + c->P.nm) * c->P.N * sizeof(double),
-                              hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(rec_dev, c->rec[c->cur], (size_t)c->P.RW * c->P.N * sizeof(double), hipMemcpyDeviceToDevice,
+                              c->stream));
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
@@ -1343,13 +1379,11 @@ int smm_eval_batch(void* ctx, const double* params, int32_t M, double* value, do
         HIPCHK(hipMalloc((void**)&dm, (size_t)P.nm * M * 8));
         HIPCHK(hipMalloc((void**)&ds, (size_t)M));
         HIPCHK(hipMemcpyAsync(dp, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
-        if (is_sim(c->obj)) {
-            constexpr int CT = 8;
+        constexpr int CT = 8;
+        if (is_sim(c->obj))
             hipLaunchKernelGGL((k_eval_batch<true, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp, M, dv, dm, ds);
-        } else {
-            constexpr int CT = 64;
+        else
             hipLaunchKernelGGL((k_eval_batch<false, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp, M, dv, dm, ds);
-        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(value, dv, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(sim_moments, dm, (size_t)P.nm * M * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1362,9 +1396,8 @@ int smm_eval_batch(void* ctx, const double* params, int32_t M, double* value, do
     return SMM_OK;
 }
 
-#define D2H(dst, src, n, sz) do { if (dst) HIPCHK(hipMemcpy(dst, src, (size_t)(n) * (sz), hipMemcpyDeviceToHost)); } while (0)
-#define H2D(dst, src, n, sz) do { if (src) HIPCHK(hipMemcpy(dst, src, (size_t)(n) * (sz), hipMemcpyHostToDevice)); } while (0)
-
+// history(c) (AlgoBGP.jl:138-160): download iterations t0..t1-1 and transpose the per-chain history
+// records into the ABI's structure-of-arrays buffers.
 int smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !out || t0 < 0 || t1 < t0 || t1 > c->P.T) return SMM_ERR_INVALID_ARG;
@@ -1373,13 +1406,27 @@ int smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out) {
         flush(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         const KParams& P = c->P;
-        const size_t N = P.N, nt = (size_t)(t1 - t0), off = (size_t)t0 * N;
-        D2H(out->value, P.h_value + off, nt * N, 8); D2H(out->prob, P.h_prob + off, nt * N, 8);
-        D2H(out->curr_val, P.h_curr + off, nt * N, 8); D2H(out->best_val, P.h_best + off, nt * N, 8);
-        D2H(out->params, P.h_params + off * P.np, nt * N * P.np, 8);
-        D2H(out->sim_moments, P.h_simM + off * P.nm, nt * N * P.nm, 8);
-        D2H(out->best_id, P.h_best_id + off, nt * N, 4); D2H(out->exchanged, P.h_exch + off, nt * N, 4);
-        D2H(out->accepted, P.h_acc + off, nt * N, 1); D2H(out->status, P.h_status + off, nt * N, 1);
+        const size_t N = P.N, HW = P.HW, np = P.np, nm = P.nm;
+        std::vector<double> row(N * HW);
+        for (int t = t0; t < t1; ++t) {
+            HIPCHK(hipMemcpy(row.data(), P.hrec + (size_t)t * N * HW, row.size() * 8, hipMemcpyDeviceToHost));
+            const size_t o = (size_t)(t - t0) * N;
+            for (size_t i = 0; i < N; ++i) {
+                const double* h = row.data() + i * HW;
+                if (out->value) out->value[o + i] = h[H_VALUE];
+                if (out->prob) out->prob[o + i] = h[H_PROB];
+                if (out->curr_val) out->curr_val[o + i] = h[H_CURR];
+                if (out->best_val) out->best_val[o + i] = h[H_BEST];
+                if (out->best_id) out->best_id[o + i] = (int32_t)h[H_BESTID];
+                if (out->exchanged) out->exchanged[o + i] = (int32_t)h[H_EXCH];
+                if (out->accepted) out->accepted[o + i] = (uint8_t)h[H_ACC];
+                if (out->status) out->status[o + i] = (int8_t)h[H_STATUS];
+                if (out->params)
+                    for (size_t k = 0; k < np; ++k) out->params[((size_t)(t - t0) * np + k) * N + i] = h[H_PARAMS + k];
+                if (out->sim_moments)
+                    for (size_t k = 0; k < nm; ++k) out->sim_moments[((size_t)(t - t0) * nm + k) * N + i] = h[H_PARAMS + np + k];
+            }
+        }
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
@@ -1394,53 +1441,80 @@ int smm_get_state(void* ctx, smm_state_t* s) {
         flush(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         const KParams& P = c->P;
-        const size_t N = P.N;
-        const double* rec = c->rec[c->cur];
+        const size_t N = P.N, RW = P.RW, np = P.np, nm = P.nm;
+        std::vector<double> cs(N * CSW), rec(N * RW);
+        HIPCHK(hipMemcpy(cs.data(), P.cs, cs.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(rec.data(), c->rec[c->cur], rec.size() * 8, hipMemcpyDeviceToHost));
         s->iter = c->iter;
-        D2H(s->sigma, P.sigma, N, 8); D2H(s->accept_rate, P.accept_rate, N, 8);
-        D2H(s->la_value, rec, N, 8); D2H(s->la_prob, rec + N, N, 8);
-        D2H(s->la_params, rec + 3 * N, N * P.np, 8); D2H(s->la_sim_moments, rec + (3 + P.np) * N, N * P.nm, 8);
-        if (s->la_status) {
-            std::vector<double> st(N);
-            HIPCHK(hipMemcpy(st.data(), rec + 2 * N, N * 8, hipMemcpyDeviceToHost));
-            for (size_t i = 0; i < N; ++i) s->la_status[i] = (int8_t)st[i];
+        for (size_t i = 0; i < N; ++i) {
+            const double* b = cs.data() + i * CSW;
+            const double* r = rec.data() + i * RW;
+            if (s->sigma) s->sigma[i] = b[CS_SIGMA];
+            if (s->accept_rate) s->accept_rate[i] = b[CS_RATE];
+            if (s->n_noex) s->n_noex[i] = (int32_t)b[CS_NNOEX];
+            if (s->n_acc_noex) s->n_acc_noex[i] = (int32_t)b[CS_NACC];
+            if (s->best_val) s->best_val[i] = b[CS_BEST];
+            if (s->best_id) s->best_id[i] = (int32_t)b[CS_BESTID];
+            if (s->la_value) s->la_value[i] = r[0];
+            if (s->la_prob) s->la_prob[i] = r[1];
+            if (s->la_status) s->la_status[i] = (int8_t)r[2];
+            if (s->la_params)
+                for (size_t k = 0; k < np; ++k) s->la_params[k * N + i] = r[3 + k];
+            if (s->la_sim_moments)
+                for (size_t k = 0; k < nm; ++k) s->la_sim_moments[k * N + i] = r[3 + np + k];
         }
-        D2H(s->n_noex, P.n_noex, N, 4); D2H(s->n_acc_noex, P.n_acc, N, 4);
-        D2H(s->best_val, P.best_val, N, 8); D2H(s->best_id, P.best_id, N, 4);
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
     return SMM_OK;
 }
 
+// restart! (AlgoBGP.jl:804-884) with clean resume semantics: continue at iteration iter+1
 int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !s || s->iter < 0 || s->iter > c->P.T) return SMM_ERR_INVALID_ARG;
     if (s->iter > 0 && !h) return fail(c, SMM_ERR_INVALID_ARG, "history of iterations 0..iter-1 required");
+    if (!s->sigma || !s->accept_rate || !s->n_noex || !s->n_acc_noex || !s->best_val || !s->best_id || !s->la_value ||
+        !s->la_prob || !s->la_status || !s->la_params || !s->la_sim_moments)
+        return fail(c, SMM_ERR_INVALID_ARG, "smm_set_state needs every field of smm_state_t");
+    if (s->iter > 0 && (!h->value || !h->prob || !h->curr_val || !h->best_val || !h->params || !h->sim_moments ||
+                        !h->best_id || !h->exchanged || !h->accepted || !h->status))
+        return fail(c, SMM_ERR_INVALID_ARG, "smm_set_state needs every field of smm_history_t");
     try {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamSynchronize(c->stream));
         KParams& P = c->P;
-        const size_t N = P.N, nt = (size_t)s->iter;
-        double* rec = c->rec[c->cur];
-        H2D(P.sigma, s->sigma, N, 8); H2D(P.accept_rate, s->accept_rate, N, 8);
-        H2D(rec, s->la_value, N, 8); H2D(rec + N, s->la_prob, N, 8);
-        H2D(rec + 3 * N, s->la_params, N * P.np, 8); H2D(rec + (3 + P.np) * N, s->la_sim_moments, N * P.nm, 8);
-        if (s->la_status) {
-            std::vector<double> st(N);
-            for (size_t i = 0; i < N; ++i) st[i] = (double)s->la_status[i];
-            HIPCHK(hipMemcpy(rec + 2 * N, st.data(), N * 8, hipMemcpyHostToDevice));
+        const size_t N = P.N, RW = P.RW, HW = P.HW, np = P.np, nm = P.nm;
+        std::vector<double> cs(N * CSW), rec(N * RW, 0.0);
+        HIPCHK(hipMemcpy(cs.data(), P.cs, cs.size() * 8, hipMemcpyDeviceToHost));  // keeps acc_tuner
+        for (size_t i = 0; i < N; ++i) {
+            double* b = cs.data() + i * CSW;
+            double* r = rec.data() + i * RW;
+            b[CS_SIGMA] = s->sigma[i]; b[CS_RATE] = s->accept_rate[i];
+            b[CS_NNOEX] = (double)s->n_noex[i]; b[CS_NACC] = (double)s->n_acc_noex[i];
+            b[CS_LACC] = 0.0; b[CS_WASX] = 0.0;
+            b[CS_BEST] = s->best_val[i]; b[CS_BESTID] = (double)s->best_id[i];
+            b[CS_BESTP] = s->best_val[i]; b[CS_BESTPID] = (double)s->best_id[i];
+            r[0] = s->la_value[i]; r[1] = s->la_prob[i]; r[2] = (double)s->la_status[i];
+            for (size_t k = 0; k < np; ++k) r[3 + k] = s->la_params[k * N + i];
+            for (size_t k = 0; k < nm; ++k) r[3 + np + k] = s->la_sim_moments[k * N + i];
         }
-        H2D(P.n_noex, s->n_noex, N, 4); H2D(P.n_acc, s->n_acc_noex, N, 4);
-        H2D(P.best_val, s->best_val, N, 8); H2D(P.best_id, s->best_id, N, 4);
-        if (h && nt) {
-            H2D(P.h_value, h->value, nt * N, 8); H2D(P.h_prob, h->prob, nt * N, 8);
-            H2D(P.h_curr, h->curr_val, nt * N, 8); H2D(P.h_best, h->best_val, nt * N, 8);
-            H2D(P.h_params, h->params, nt * N * P.np, 8); H2D(P.h_simM, h->sim_moments, nt * N * P.nm, 8);
-            H2D(P.h_best_id, h->best_id, nt * N, 4); H2D(P.h_exch, h->exchanged, nt * N, 4);
-            H2D(P.h_acc, h->accepted, nt * N, 1); H2D(P.h_status, h->status, nt * N, 1);
+        HIPCHK(hipMemcpy(P.cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->rec[c->cur], rec.data(), rec.size() * 8, hipMemcpyHostToDevice));
+        std::vector<double> row(N * HW, 0.0);
+        for (int t = 0; t < s->iter; ++t) {
+            const size_t o = (size_t)t * N;
+            for (size_t i = 0; i < N; ++i) {
+                double* hr = row.data() + i * HW;
+                hr[H_VALUE] = h->value[o + i]; hr[H_PROB] = h->prob[o + i]; hr[H_CURR] = h->curr_val[o + i];
+                hr[H_BEST] = h->best_val[o + i]; hr[H_BESTID] = (double)h->best_id[o + i];
+                hr[H_EXCH] = (double)h->exchanged[o + i]; hr[H_ACC] = (double)h->accepted[o + i];
+                hr[H_STATUS] = (double)h->status[o + i];
+                for (size_t k = 0; k < np; ++k) hr[H_PARAMS + k] = h->params[((size_t)t * np + k) * N + i];
+                for (size_t k = 0; k < nm; ++k) hr[H_PARAMS + np + k] = h->sim_moments[((size_t)t * nm + k) * N + i];
+            }
+            HIPCHK(hipMemcpy(P.hrec + (size_t)t * N * HW, row.data(), row.size() * 8, hipMemcpyHostToDevice));
         }
-        dfill(c, P.was_exch, N, (uint8_t)0);
         c->iter = s->iter;
         c->pending = false;
         c->prev_open = false;

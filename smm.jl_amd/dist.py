@@ -48,8 +48,8 @@ class ShardedBGP:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.local = engine.new_tensor((engine.R, engine.N))
-        self.gathered = engine.new_tensor((self.world, engine.R, engine.N))
+        self.local = engine.new_tensor((engine.N, engine.R))
+        self.gathered = engine.new_tensor((self.world, engine.N, engine.R))  # == [N_global][R] in global chain order
 
     def step(self, n_iters=1):
         e = self.e

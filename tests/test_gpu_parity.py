@@ -181,7 +181,7 @@ def sharded_run(S, prob, opts_full, G, T):
                     N_global=opts_full.N_global)
         ctxs.append(S.hip_context(prob, o))
     R = ctxs[0].record_doubles()
-    gathered = torch.empty((G, R, N), dtype=torch.float64, device="cuda")
+    gathered = torch.empty((G, N, R), dtype=torch.float64, device="cuda")
     for _ in range(T):
         for r, c in enumerate(ctxs):
             c.local_step()
