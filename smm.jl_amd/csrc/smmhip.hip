@@ -758,9 +758,18 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
     const unsigned long long* __restrict__ plan = P.plan + (size_t)(t - P.plan_t0) * K;
     const double* __restrict__ plan_mi = P.plan_mi + (size_t)(t - P.plan_t0) * K;
 
-    int q = tid;
-    unsigned long long pw = (q < K) ? plan[q] : 0ull;
-    double mi = (q < K) ? plan_mi[q] : 0.0;
+#define XTS(i) do { if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + (i)] = wall_clock64(); } while (0)
+    XTS(0);
+    // this thread's pairs (list positions tid, tid+1024, ...): plan words and thresholds up front
+    constexpr int MAXPP = XLDS_MAX / XWG;
+    unsigned long long pws[MAXPP];
+    double mis[MAXPP];
+#pragma unroll
+    for (int m = 0; m < MAXPP; ++m) {
+        const int qq = tid + m * XWG;
+        pws[m] = (qq < K) ? plan[qq] : 0ull;
+        mis[m] = (qq < K) ? plan_mi[qq] : 0.0;
+    }
     for (int g = tid; g < Ng; g += XWG) {
         val[g] = gathered[(size_t)g * RW];
         ticket[g] = 0;
@@ -768,15 +777,20 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
         partner[g] = 0;
     }
     __syncthreads();
+    XTS(1);
+    int q = tid, m = 0;
+    unsigned long long pw = pws[0];
+    double mi = mis[0];
     unsigned spins = 0;
     while (true) {
         bool progressed = false;
         if (q < K) {
             const uint32_t i = (uint32_t)(pw & 0xffff), j = (uint32_t)((pw >> 16) & 0xffff);
             const uint32_t ri = (uint32_t)((pw >> 32) & 0xffff), rj = (uint32_t)(pw >> 48);
-            const uint32_t ti = __hip_atomic_load(&ticket[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t tj = __hip_atomic_load(&ticket[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t ti = __hip_atomic_load(&ticket[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t tj = __hip_atomic_load(&ticket[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ti == ri && tj == rj) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const double vi = val[i], vj = val[j];
                 if (vi - vj > mi) {                         // dist_fun = -, :688
                     val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744
@@ -784,13 +798,14 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
                     src[i] = src[j]; src[j] = si;
                     partner[i] = (uint16_t)(j + 1); partner[j] = (uint16_t)(i + 1);  // set_exchanged!, :747-748
                 }
-                __hip_atomic_store(&ticket[i], ti + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&ticket[j], tj + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&ticket[i], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&ticket[j], tj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 q += XWG;
-                if (q < K) {
-                    pw = plan[q];
-                    mi = plan_mi[q];
-                }
+                ++m;
+#pragma unroll
+                for (int k = 1; k < MAXPP; ++k)
+                    if (m == k) { pw = pws[k]; mi = mis[k]; }
                 progressed = true;
             }
         }
@@ -800,11 +815,14 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
                 if (lane == 0) report_error(P, 3, t, 0);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (!(P.dbg & 16)) __builtin_amdgcn_s_sleep(1);
         }
     }
+    XTS(2);
     __syncthreads();
+    XTS(3);
     for (int g = tid; g < Ng; g += XWG) P.xres[g] = (unsigned long long)src[g] | ((unsigned long long)partner[g] << 32);
+    XTS(4);
 }
 
 // k_exch_resolve_any: the same result for any N_global, state in global memory, executed in
@@ -1542,6 +1560,10 @@ int smm_set_profiling(void* ctx, int32_t on) {
 int smm_debug_ts(void* ctx, unsigned long long* out, int n_wg) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !c->P.ts) return SMM_ERR_INVALID_ARG;
+    if (n_wg < 0) {  // the exchange kernel's stamps
+        if (hipMemcpy(out, c->P.ts + (size_t)8 * 60000, 64, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
+        return SMM_OK;
+    }
     if (hipMemcpy(out, c->P.ts, (size_t)n_wg * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
     return SMM_OK;
 }

@@ -1,0 +1,245 @@
+"""The behavioural pins the reference's own tests hold for the path, lifted
+onto the CPU oracle, plus hand-derivable anchors and the edge cases of Appendix A."""
+import numpy as np
+import pytest
+
+import common as cm
+from smm_jl_amd import _abi as A, BGPOpts, Problem, Tables
+
+
+def run(O, prob, opts, tables=None, T=None):
+    o = O.OracleContext(prob, opts, tables)
+    o.step(opts.maxiter if T is None else T)
+    return o
+
+
+def test_P1_first_iteration(O):
+    # test_BGPchain.jl:49-51,95-111: proposal at iter 1 is the initial value, accepted, prob == 1, status 1
+    prob, opts = cm.serial_normal(N=3, T=5)
+    h = run(O, prob, opts).history()
+    assert np.array_equal(h.params[0], np.tile(prob.init[:, None], (1, 3)))
+    assert h.accepted[0].all() and (h.prob[0] == 1.0).all() and (h.status[0] == 1).all()
+    assert (h.best_id[0] == 1).all() and np.array_equal(h.best_val[0], h.value[0]) and np.array_equal(h.curr_val[0], h.value[0])
+    own = h.exchanged[1] == 0  # (an exchanged chain shows its donor's record, possibly the initial one)
+    assert (h.params[1][:, own] != h.params[0][:, own]).all()  # :60-62 later proposals differ
+
+
+def test_P2_P3_accept_rule(O):
+    # test_BGPchain.jl:130-144: better => prob == 1 and accepted; worse => prob < 1, accepted iff prob > probs_acc[iter]
+    prob, opts = cm.serial_normal(N=8, T=120, ns=300)
+    tab = cm.random_tables(prob, opts, pairs=False)
+    h = run(O, prob, opts, tab).history()
+    u = tab.probs_acc
+    for t in range(1, 120):
+        own = h.exchanged[t] == 0  # a swapped record is the donor's, not this chain's proposal
+        old = h.curr_val[t - 1]
+        new = h.value[t]
+        better = own & (new <= old)
+        worse = own & (new > old)
+        assert (h.prob[t][better] == 1.0).all() and h.accepted[t][better].all()
+        assert (h.prob[t][worse] < 1.0).all()
+        assert np.array_equal(h.accepted[t][worse].astype(bool), h.prob[t][worse] > u[t][worse])
+
+
+def test_P4_high_dimensional_batch_proposals_differ(O):
+    # test_BGPchain.jl:67-90: 18 parameters, batch_size = 1
+    prob, opts = cm.general_normal(18, N=2, T=23, ns=50, batch_size=1)
+    h = run(O, prob, opts).history()
+    p = h.params[:, :, 0]
+    assert all(not np.array_equal(p[t], p[t - 1]) for t in range(1, 23))
+    assert (p >= prob.lb).all() and (p <= prob.ub).all()
+
+
+def test_P5_objfunc_norm_at_truth(O):
+    # test_objfunc.jl:22-29: mu = 0, data moments 0, no weights: |simM| < 0.1
+    prob = Problem(init=[0, 0], lb=[-1, -1], ub=[1, 1], mom=[0, 0], w=None, ns=10000)
+    opts = BGPOpts(N=1, maxiter=1, sigma=[0.05], acc_tuner=[2.0], min_improve=[0.0])
+    o = O.OracleContext(prob, opts)
+    v, sm, st = o.eval_batch(np.zeros((2, 1)))
+    assert (np.abs(sm) < 0.1).all() and st[0] == 1
+    assert v[0] == pytest.approx(np.mean(sm[:, 0] ** 2), rel=1e-15)  # unweighted branch, ObjExamples.jl:96-97
+
+
+def test_analytic_anchor_zero_shocks(O):
+    # Z == 0 => value = mean(((mu - mom)/w)^2); serialNormal start: (1.44 + 104.04)/2 = 52.74
+    prob, opts = cm.serial_normal(N=3, T=1)
+    o = O.OracleContext(prob, opts, Tables(Z=np.zeros((2, prob.ns))))
+    v, sm, _ = o.eval_batch(np.array([[0.2, 1.0], [-0.2, 3.0]]))
+    assert v[0] == pytest.approx(52.74, abs=1e-12)
+    assert v[1] == pytest.approx((4.0 + 49.0) / 2, abs=1e-12)
+    prob2, _ = cm.serial_normal(N=3, T=1, w=(2.0, 4.0))
+    v2, _, _ = O.OracleContext(prob2, opts, Tables(Z=np.zeros((2, prob.ns)))).eval_batch(np.array([[0.2], [-0.2]]))
+    assert v2[0] == pytest.approx((1.44 / 4 + 104.04 / 16) / 2, abs=1e-12)
+
+
+def test_P6_history_shape(O):
+    # test_algoBGP.jl:30-38: serialNormal(2,20) history is 20 x (7 + np)
+    prob, opts = cm.serial_normal(N=3, T=20)
+    h = run(O, prob, opts).history()
+    assert h.value.shape == (20, 3) and h.params.shape == (20, 2, 3) and h.sim_moments.shape == (20, 2, 3)
+
+
+def test_P7_statistical_recovery(O):
+    # test_algoBGP.jl:57-121: N=2, 200 iterations, p2 in [-2,2], moments (-1,1), acc_tuners [5,1]:
+    # median of the accepted draws of chain 1 within 1.0 of the truth
+    prob, opts = cm.serial_normal(N=2, T=200, acc_tuners=[5.0, 1.0], p2_bounds=(-2.0, 2.0), mom=(-1.0, 1.0),
+                                  sigma_update_steps=201)
+    h = run(O, prob, opts).history()
+    acc = h.accepted[:, 0].astype(bool)
+    med = np.median(h.params[acc, :, 0], axis=0)
+    assert abs(med[0] - (-1.0)) < 1.0 and abs(med[1] - 1.0) < 1.0
+    # :123-193: batch_size = 1, sigma adaptation every 10, min_improve .05, default acc_tuners: within 0.7
+    prob, opts = cm.serial_normal(N=2, T=200, acc_tuners=[2.0, 2.0], p2_bounds=(-2.0, 2.0), mom=(-1.0, 1.0),
+                                  min_improve=0.05, batch_size=1)
+    h = run(O, prob, opts).history()
+    acc = h.accepted[:, 0].astype(bool)
+    med = np.median(h.params[acc, :, 0], axis=0)
+    assert abs(med[0] - (-1.0)) < 0.7 and abs(med[1] - 1.0) < 0.7
+
+
+def test_P9_readme_envelope(O):
+    # README.md:47-53: acc_rate 0.08-0.16, perc_exchanged 2-8.5 %, best value of chain 1 ~ 2e-3 (sanity envelope only)
+    prob, opts = cm.serial_normal(N=3, T=200)
+    o = run(O, prob, opts)
+    h, s = o.history(), o.state()
+    assert 0.03 < s.accept_rate.min() and s.accept_rate.max() < 0.4
+    assert (h.exchanged != 0).mean() < 0.2
+    assert h.best_val[-1, 0] < 0.05
+
+
+def test_bookkeeping_invariants(O):
+    prob, opts = cm.serial_normal(N=16, T=80, ns=200)
+    o = run(O, prob, opts)
+    h, s = o.history(), o.state()
+    assert (np.diff(h.best_val, axis=0) <= 0).all()
+    # best_id points at the iteration whose recorded best it is (AlgoBGP.jl:236-243)
+    for c in range(16):
+        for t in range(80):
+            bid = h.best_id[t, c]
+            assert 1 <= bid <= t + 1
+    # exchanged is symmetric and the swapped records are marked accepted (swap_ev_ij!, :734-749)
+    t, c = np.nonzero(h.exchanged)
+    assert (h.accepted[t, c] == 1).all()
+    assert (h.exchanged[0] == 0).all()
+    # accept_rate = mean(accepted[noex]) (set_acceptRate!, :253-257)
+    for c in range(16):
+        noex = h.exchanged[:, c] == 0
+        assert s.n_noex[c] == noex.sum() and s.n_acc_noex[c] == h.accepted[noex, c].sum()
+    # curr_val is the value of the last accepted record
+    np.testing.assert_array_equal(s.la_value, h.curr_val[-1])
+
+
+def test_sigma_adaptation_crossing_threshold(O):
+    # :381-390: every sigma_update_steps iterations sigma *= 1 +- adj depending on accept_rate > 0.234
+    prob, opts = cm.serial_normal(N=4, T=40, ns=200, sigma_update_steps=10, sigma_adjust_by=0.5)
+    tab = cm.random_tables(prob, opts)
+    o = O.OracleContext(prob, opts, tab)
+    sig0 = opts.sigma.copy()
+    o.step(9)
+    assert np.array_equal(o.state().sigma, sig0)  # not before iteration 10
+    o.step(1)
+    s = o.state()
+    up = s.accept_rate > 0.234
+    np.testing.assert_allclose(s.sigma, np.where(up, sig0 * 1.5, sig0 * 0.5), rtol=1e-15)
+
+
+def test_exchange_is_order_dependent_and_forwards_records(O):
+    # G3: chain 0 appears in three pairs of one iteration; the walk is sequential (AlgoBGP.jl:662-691)
+    N, T = 4, 3
+    prob, opts = cm.serial_normal(N=N, T=T, ns=100, acc_tuners=[2.0] * 4, min_improve=0.0)
+    rng = np.random.default_rng(5)
+    u = np.zeros((T, N))  # u = 0: every proposal with prob > 0 is accepted -> distinct values per chain
+    normals = rng.standard_normal((T, 8, 2, N))
+    pairs = np.zeros((T, 4, 2), np.int32)
+    pairs[:] = [[0, 1], [0, 2], [0, 3], [1, 2]]
+    tab = Tables(probs_acc=u, prop_normals=normals, pairs=pairs, Z=rng.standard_normal((2, 100)))
+    o = O.OracleContext(prob, opts, tab)
+    o.step(1)
+    ref = O.OracleContext(prob, opts, Tables(probs_acc=u, prop_normals=normals, pairs=pairs[:, :0].copy().reshape(T, 0, 2) if False else pairs, Z=tab.Z))
+    o.step(1)
+    h = o.history(0, 2)
+    # replay iteration 2's exchange by hand on the post-accept values
+    no_ex_prob, no_ex_opts = cm.serial_normal(N=N, T=T, ns=100, acc_tuners=[2.0] * 4, min_improve=1e300)
+    o2 = O.OracleContext(no_ex_prob, no_ex_opts, tab)
+    o2.step(2)
+    v = o2.history(0, 2).curr_val[1].copy()  # values after accept, before any exchange
+    slot = list(range(N)); partner = [0] * N
+    for i, j in pairs[1]:
+        if v[i] - v[j] > 0.0:
+            v[i], v[j] = v[j], v[i]
+            slot[i], slot[j] = slot[j], slot[i]
+            partner[i], partner[j] = j + 1, i + 1
+    np.testing.assert_array_equal(h.exchanged[1], partner)
+    np.testing.assert_array_equal(h.curr_val[1], v)
+    p2 = o2.history(0, 2)
+    for c in range(N):
+        if partner[c]:
+            la = p2.params[1, :, slot[c]] if p2.accepted[1, slot[c]] else p2.params[0, :, slot[c]]
+            np.testing.assert_array_equal(h.params[1, :, c], la)  # the donor's last accepted record was forwarded
+
+
+def test_status_minus2_is_a_rejection_with_value_minus1(O):
+    # mprob.jl:183-186 + AlgoBGP.jl:336-338; set_eval! still compares the Eval's default value -1 (:236)
+    prob, opts = cm.serial_normal(N=6, T=60, ns=100, objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[-0.2, 0.1])
+    h = run(O, prob, opts).history()
+    bad = h.status == -2
+    assert bad.sum() > 0
+    own = bad & (h.exchanged == 0)
+    assert (h.prob[own] == 0).all() and (h.accepted[own] == 0).all() and (h.value[own] == -1.0).all()
+    t, c = np.nonzero(own)
+    assert (h.best_val[t, c] == -1.0).all()  # the reference's quirk: the failed Eval's value -1 becomes "best"
+
+
+def test_errors(O):
+    prob, opts = cm.serial_normal(N=3, T=5, ns=50, mom=(np.nan, 1.0))
+    with pytest.raises(A.SMMHipError) as e:
+        run(O, prob, opts)
+    assert e.value.code == A.SMM_ERR_NEGATIVE_OBJECTIVE  # AlgoBGP.jl:341 (NaN >= 0 is false)
+    prob, opts = cm.serial_normal(N=3, T=5, ns=50, sigma0=1e6, smpl_iters=3)
+    with pytest.raises(A.SMMHipError) as e:
+        run(O, prob, opts)
+    assert e.value.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT  # AlgoBGP.jl:409
+    prob, opts = cm.general_normal(4, N=3, T=5, batch_size=3)
+    with pytest.raises(A.SMMHipError) as e:
+        O.OracleContext(prob, opts)
+    assert e.value.code == A.SMM_ERR_BAD_BATCH
+    prob, opts = cm.serial_normal(N=3, T=2, ns=50)
+    o = run(O, prob, opts)
+    with pytest.raises(A.SMMHipError) as e:
+        o.step(1)
+    assert e.value.code == A.SMM_ERR_MAXITER
+
+
+def test_single_chain_has_no_exchange(O):
+    prob, opts = cm.serial_normal(N=1, T=30, ns=100, acc_tuners=[2.0])
+    h = run(O, prob, opts).history()
+    assert (h.exchanged == 0).all()
+
+
+def test_regenerated_shocks_are_bit_identical_to_cached(O):
+    # the "faithful" CPU mode (draw the ns x nm normals inside every evaluation) changes cost, not results
+    prob, opts = cm.serial_normal(N=4, T=6, ns=1000)
+    a = O.OracleContext(prob, opts, regen_z=False); a.step(6)
+    b = O.OracleContext(prob, opts, regen_z=True, threads=2); b.step(6)
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+
+
+def test_sharded_oracle_equals_single(O):
+    N, G, T = 12, 3, 25
+    prob, opts = cm.serial_normal(N=N, T=T, ns=100)
+    single = run(O, prob, opts)
+    shards = []
+    for r in range(G):
+        _, o = cm.serial_normal(N=N, T=T, ns=100, N_local=N // G, chain_offset=r * (N // G))
+        shards.append(O.OracleContext(prob, o))
+    for _ in range(T):
+        for s in shards:
+            s.local_step()
+        g = np.concatenate([s.export_records() for s in shards], axis=0)
+        for s in shards:
+            s.exchange(g)
+    hs = single.history()
+    for r, s in enumerate(shards):
+        hr = s.history()
+        for f in A.HistoryBuffers.FIELDS:
+            assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * 4:(r + 1) * 4], equal_nan=True), f

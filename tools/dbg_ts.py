@@ -30,3 +30,8 @@ for i, name in enumerate(["loads", "settle+proposal", "sim", "finish"]):
 slow = np.argsort(-d[:, 1])[:8]
 print("slowest proposal WGs:", [(int(i), round(float(d[i,1]),1)) for i in slow])
 print("kernel span %.2f us" % (ts[:, 4].max() - t0))
+
+x = np.zeros(8, np.uint64)
+lib.smm_debug_ts(ctx._ctx, x.ctypes.data_as(C.c_void_p), -1)
+xs = x.astype(np.float64) / 100.0
+print("resolve kernel (thread 0): loads+init %.2f  flow %.2f  barrier %.2f  store %.2f us" % tuple(np.diff(xs[:5])))
