@@ -83,8 +83,10 @@ def main():
     import common as cm
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("SMM_BENCH_FORCE_SHARDED") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_loc = args.chains
@@ -98,7 +100,8 @@ def main():
         if world > 1:
             dist.barrier()
 
-    if world == 1:
+    force_sharded = os.environ.get("SMM_BENCH_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU
+    if world == 1 and not force_sharded:
         def run_step():
             ctx.step_async(ITERS_PER_STEP)
         sync = ctx.sync
@@ -127,7 +130,7 @@ def main():
 
     # roofline of the dominant kernel (k_chain_iter), HIP events on the library's stream
     roof = None
-    if world == 1:
+    if world == 1 and not force_sharded:
         ctx.set_profiling(True)
         ctx.step(ITERS_PER_STEP)
         tm = ctx.timing()
@@ -162,7 +165,7 @@ def main():
                           "exchange": "every iteration >= 2, N pairs" + (", RCCL all-gather" if world > 1 else "")},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
