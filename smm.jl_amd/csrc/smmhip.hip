@@ -87,6 +87,10 @@ struct KParams {
     // exchange plan window
     const unsigned long long* plan;  // [W][K]: pi | pj<<16 | ri<<32 | rj<<48
     const double* plan_mi;           // [W][K]: min_improve of chain pi
+    // the same list grouped by dependency level (pairs of one level touch disjoint chains)
+    const uint32_t* lv_pairs;        // [W][K]: pi | pj<<16, level by level
+    const double* lv_mi;             // [W][K]: min_improve of chain pi, same order
+    const uint32_t* lv_off;          // [W][K+2]: lv_off[l] = first position of level l; entry K+1 = number of levels
     int plan_t0, plan_K;
     // state
     double* cs;                // [N][CSW]
@@ -652,16 +656,17 @@ __global__ void k_pregen_rng(const KParams P, const int t0, const int W, double*
 // plan[t-t0][q] = i | j<<16 | r_i<<32 | r_j<<48, plan_mi[t-t0][q] = min_improve[i].
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0, unsigned long long* __restrict__ plan,
-                                                   double* __restrict__ plan_mi) {
+                                                   double* __restrict__ plan_mi, uint32_t* __restrict__ lv_pairs,
+                                                   double* __restrict__ lv_mi, uint32_t* __restrict__ lv_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = t0 + blockIdx.x;
     const int Ng = P.Ng, K = P.plan_K;
-    uint32_t* cnt = (uint32_t*)xsm;          // [Ng]  histogram -> cursor
-    uint32_t* ep = cnt + Ng;                 // [2K]  list positions bucketed by chain
+    uint32_t* cnt = (uint32_t*)xsm;          // [Ng+2]  histogram -> cursor (later: level histogram)
+    uint32_t* ep = cnt + Ng + 2;             // [2K]  list positions bucketed by chain (later: levels)
     uint16_t* pi = (uint16_t*)(ep + 2 * K);  // [K]
     uint16_t* pj = pi + K;                   // [K]
-    uint32_t* wsum = (uint32_t*)(pj + K);    // [16] (pi,pj: 4K bytes from a 4-byte aligned base)
+    uint32_t* wsum = (uint32_t*)(pj + K);    // [32] (pi,pj: 4K bytes from a 4-byte aligned base)
     unsigned long long* out = plan + (size_t)blockIdx.x * K;
     double* out_mi = plan_mi + (size_t)blockIdx.x * K;
 
@@ -723,15 +728,136 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         ep[atomicAdd(&cnt[pj[q]], 1u)] = (uint32_t)q;
     }
     __syncthreads();  // now cnt[c] == end of chain c's bucket
-    for (int q = tid; q < K; q += XWG) {  // rank = number of smaller list positions in the bucket
+    // rank = number of smaller list positions in the bucket; kept in registers for the level pass
+    constexpr int MAXPP = XLDS_MAX / XWG;
+    uint16_t rri[MAXPP], rrj[MAXPP];
+#pragma unroll
+    for (int m = 0; m < MAXPP; ++m) {
+        const int q = tid + m * XWG;
+        rri[m] = 0; rrj[m] = 0;
+        if (q < K) {
+            const uint32_t i = pi[q], j = pj[q];
+            uint32_t b = i ? cnt[i - 1] : 0u, e = cnt[i], ri = 0, rj = 0;
+            for (uint32_t x = b; x < e; ++x) ri += (ep[x] < (uint32_t)q) ? 1u : 0u;
+            b = j ? cnt[j - 1] : 0u; e = cnt[j];
+            for (uint32_t x = b; x < e; ++x) rj += (ep[x] < (uint32_t)q) ? 1u : 0u;
+            out[q] = (unsigned long long)i | ((unsigned long long)j << 16) | ((unsigned long long)ri << 32) |
+                     ((unsigned long long)rj << 48);
+            out_mi[q] = P.min_improve_g[i];  // the threshold of the pair's colder chain, AlgoBGP.jl:688
+            rri[m] = (uint16_t)ri; rrj[m] = (uint16_t)rj;
+        }
+    }
+    __syncthreads();
+    // ---- dependency levels: level(q) = 1 + max(level of q's predecessor on chain i, on chain j) ----
+    // buckets re-written in rank order, so that the predecessor of rank r is the entry of rank r-1
+#pragma unroll
+    for (int m = 0; m < MAXPP; ++m) {
+        const int q = tid + m * XWG;
+        if (q < K) {
+            const uint32_t i = pi[q], j = pj[q];
+            ep[(i ? cnt[i - 1] : 0u) + rri[m]] = (uint32_t)q;
+            ep[(j ? cnt[j - 1] : 0u) + rrj[m]] = (uint32_t)q;
+        }
+    }
+    __syncthreads();
+    int prei[MAXPP], prej[MAXPP];
+#pragma unroll
+    for (int m = 0; m < MAXPP; ++m) {
+        const int q = tid + m * XWG;
+        prei[m] = -1; prej[m] = -1;
+        if (q < K) {
+            const uint32_t i = pi[q], j = pj[q];
+            if (rri[m]) prei[m] = (int)ep[(i ? cnt[i - 1] : 0u) + rri[m] - 1];
+            if (rrj[m]) prej[m] = (int)ep[(j ? cnt[j - 1] : 0u) + rrj[m] - 1];
+        }
+    }
+    __syncthreads();  // cnt / ep are free from here on
+    uint16_t* lvl = (uint16_t*)ep;          // [K]
+    uint32_t* lhist = cnt;                   // [nlev+1] <= Ng+2 entries
+    for (int q = tid; q < K; q += XWG) lvl[q] = 0;
+    __syncthreads();
+    int changed = 1;
+    while (changed) {  // Jacobi sweeps: converges after (number of levels) sweeps
+        int mine = 0;
+        uint16_t nl[MAXPP];
+#pragma unroll
+        for (int m = 0; m < MAXPP; ++m) {
+            const int q = tid + m * XWG;
+            nl[m] = 0;
+            if (q < K) {
+                const uint32_t a = prei[m] >= 0 ? lvl[prei[m]] : 0u, b = prej[m] >= 0 ? lvl[prej[m]] : 0u;
+                const bool known = (prei[m] < 0 || a) && (prej[m] < 0 || b);
+                nl[m] = known ? (uint16_t)(1u + (a > b ? a : b)) : (uint16_t)0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MAXPP; ++m) {
+            const int q = tid + m * XWG;
+            if (q < K && nl[m] != lvl[q]) { lvl[q] = nl[m]; mine = 1; }
+        }
+        changed = __syncthreads_or(mine);
+    }
+    // counting sort of the pairs by level
+    for (int c = tid; c < Ng + 2; c += XWG) lhist[c] = 0;
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) atomicAdd(&lhist[lvl[q]], 1u);  // lhist[l] = size of level l (1-based), lhist[0] = 0
+    __syncthreads();
+    uint32_t* wsum2 = wsum + 16;
+    __shared__ uint32_t s_nlev;
+    if (tid == 0) s_nlev = 0;
+    __syncthreads();
+    {
+        uint32_t mx = 0;
+        for (int q = tid; q < K; q += XWG) mx = lvl[q] > mx ? lvl[q] : mx;
+        atomicMax(&s_nlev, mx);
+    }
+    __syncthreads();
+    const int nlev = (int)s_nlev;
+    {   // exclusive scan of lhist[0..nlev] -> first position of level l (stored at lhist[l-1] after the shift below)
+        constexpr int PER = XLDS_MAX / XWG + 1;
+        const int n = nlev + 1;
+        const int per = (n + XWG - 1) / XWG;
+        const int c0 = tid * per;
+        uint32_t loc[PER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u;
+            const uint32_t v = (u < per && c < n) ? lhist[c] : 0u;
+            loc[u] = sum;
+            sum += v;
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum2[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum2[w];
+        const uint32_t excl = base + incl - sum;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u;
+            if (u < per && c < n) lhist[c] = excl + loc[u];  // = number of pairs in levels < c  (level c starts here)
+        }
+    }
+    __syncthreads();
+    uint32_t* o_off = lv_off + (size_t)blockIdx.x * (K + 2);
+    // o_off[l] = end of the l-th level (0-based) = start of 1-based level l+2
+    for (int l = tid; l < nlev; l += XWG) o_off[l] = (l + 2 <= nlev) ? lhist[l + 2] : (uint32_t)K;
+    if (tid == 0) o_off[K + 1] = (uint32_t)nlev;
+    __syncthreads();
+    uint32_t* o_pairs = lv_pairs + (size_t)blockIdx.x * K;
+    double* o_mi = lv_mi + (size_t)blockIdx.x * K;
+    for (int q = tid; q < K; q += XWG) {
+        const uint32_t pos = atomicAdd(&lhist[lvl[q]], 1u);
         const uint32_t i = pi[q], j = pj[q];
-        uint32_t b = i ? cnt[i - 1] : 0u, e = cnt[i], ri = 0, rj = 0;
-        for (uint32_t x = b; x < e; ++x) ri += (ep[x] < (uint32_t)q) ? 1u : 0u;
-        b = j ? cnt[j - 1] : 0u; e = cnt[j];
-        for (uint32_t x = b; x < e; ++x) rj += (ep[x] < (uint32_t)q) ? 1u : 0u;
-        out[q] = (unsigned long long)i | ((unsigned long long)j << 16) | ((unsigned long long)ri << 32) |
-                 ((unsigned long long)rj << 48);
-        out_mi[q] = P.min_improve_g[i];  // the threshold of the pair's colder chain, AlgoBGP.jl:688
+        o_pairs[pos] = i | (j << 16);
+        o_mi[pos] = P.min_improve_g[i];
     }
 }
 
@@ -823,6 +949,72 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
     XTS(3);
     for (int g = tid; g < Ng; g += XWG) P.xres[g] = (unsigned long long)src[g] | ((unsigned long long)partner[g] << 32);
     XTS(4);
+}
+
+// k_exch_resolve_lvl: the same result for N_global <= XLVL_MAX, executed level by level: the plan
+// groups the pair list by dependency level (k_exch_plan); the pairs of one level touch pairwise
+// disjoint chains, so a level is one parallel step and the walk needs (number of levels ~ log N)
+// barriers.  Plan, values and thresholds are staged in LDS with coalesced loads up front.
+constexpr int XLVL_MAX = 4096;
+template <int LWG>
+__global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x;
+    const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
+    const int w = t - P.plan_t0;
+    double* val = (double*)xsm;                 // [Ng]
+    double* mi = val + Ng;                      // [K]
+    uint32_t* pairs = (uint32_t*)(mi + K);      // [K]
+    uint32_t* loff = pairs + K;                 // [K+2]
+    uint16_t* src = (uint16_t*)(loff + K + 2);  // [Ng]
+    uint16_t* partner = src + Ng;               // [Ng]
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    XTS(0);
+    const unsigned long long cyc0 = clock64();
+    // one level of global loads: values, plan, level offsets (the first 1024 unconditionally)
+    const uint32_t nlev_w = g_off[K + 1];
+    if (tid < K) loff[tid] = g_off[tid];
+    for (int g = tid; g < Ng; g += LWG) {
+        val[g] = gathered[(size_t)g * RW];
+        src[g] = (uint16_t)g;
+        partner[g] = 0;
+    }
+    for (int q = tid; q < K; q += LWG) { pairs[q] = g_pairs[q]; mi[q] = g_mi[q]; }
+    const int nlev = (int)nlev_w;
+    for (int l = tid + LWG; l < nlev; l += LWG) loff[l] = g_off[l];  // only for very deep lists
+    __syncthreads();
+    XTS(1);
+    uint32_t b = 0;
+    uint32_t e = nlev > 0 ? loff[0] : 0u;
+    uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
+    double m = (b + tid < e) ? mi[b + tid] : 0.0;
+    for (int l = 0; l < nlev; ++l) {
+        // fetch the next level's first pair of this thread while this level is processed
+        const uint32_t e2 = (l + 1 < nlev) ? loff[l + 1] : e;
+        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+        const double m2 = (e + tid < e2) ? mi[e + tid] : 0.0;
+        for (uint32_t pos = b + tid; pos < e; pos += LWG) {
+            if (pos != b + tid) { pw = pairs[pos]; m = mi[pos]; }
+            const uint32_t i = pw & 0xffffu, j = pw >> 16;
+            const double vi = val[i], vj = val[j];
+            if (vi - vj > m) {                          // dist_fun = -, AlgoBGP.jl:688
+                val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744
+                const uint16_t si = src[i];
+                src[i] = src[j]; src[j] = si;
+                partner[i] = (uint16_t)(j + 1); partner[j] = (uint16_t)(i + 1);  // set_exchanged!, :747-748
+            }
+        }
+        b = e; e = e2; pw = pw2; m = m2;
+        if (P.ts && tid == 0 && l < 40) P.ts[(size_t)8 * 60000 + 16 + l] = clock64() - cyc0;
+        __syncthreads();
+        if (P.ts && tid == 0 && l < 40) P.ts[(size_t)8 * 60000 + 56 + l] = clock64() - cyc0;
+    }
+    XTS(3);
+    for (int g = tid; g < Ng; g += LWG) P.xres[g] = (unsigned long long)src[g] | ((unsigned long long)partner[g] << 32);
+    XTS(4);
+    if (P.ts && tid == 0) { P.ts[(size_t)8 * 60000 + 6] = clock64() - cyc0; P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev; }
 }
 
 // k_exch_resolve_any: the same result for any N_global, state in global memory, executed in
@@ -944,6 +1136,10 @@ struct Ctx {
     double* win_rb = nullptr;
     unsigned long long* win_plan = nullptr;
     double* win_plan_mi = nullptr;
+    uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr;
+    double* win_lv_mi = nullptr;
+    bool lvl_exchange = false;
+    int lvl_wg = 1024;
     int rng_t0 = 0, rng_w = 0;    // window currently held: iterations [t0, t0+w)
     int plan_t0 = 0, plan_w = 0;
     bool lds_exchange = false;
@@ -980,8 +1176,9 @@ size_t tile_smem(const Ctx* c, int ct) {
     const KParams& P = c->P;
     return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, is_sim(c->obj)) * sizeof(double);
 }
-size_t plan_lds_bytes(int Ng, int K) { return (size_t)Ng * 4 + (size_t)K * 8 + (size_t)K * 4 + 64 + 16; }
+size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
+size_t resolve_lvl_bytes(int Ng, int K) { return (size_t)Ng * 12 + (size_t)K * 16 + 64; }
 
 int exchange_K(const Ctx* c) { return c->P.pairtab ? c->P.n_pairs_tab : n_exchange_pairs(c->P.Ng); }
 bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P.Ng > 1; }  // AlgoBGP.jl:637
@@ -1000,9 +1197,10 @@ void ensure_windows(Ctx* c, int t) {
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
         hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
-                           c->win_plan_mi);
+                           c->win_plan_mi, c->win_lv_pairs, c->win_lv_mi, c->win_lv_off);
         c->plan_t0 = t; c->plan_w = W;
         P.plan = c->win_plan; P.plan_mi = c->win_plan_mi; P.plan_t0 = t;
+        P.lv_pairs = c->win_lv_pairs; P.lv_mi = c->win_lv_mi; P.lv_off = c->win_lv_off;
     }
 }
 
@@ -1028,7 +1226,14 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
 
 void launch_resolve(Ctx* c, int t, const double* gathered) {
     const KParams& P = c->P;
-    if (c->lds_exchange)
+    if (c->lvl_exchange)
+        if (c->lvl_wg == 256)
+            hipLaunchKernelGGL(k_exch_resolve_lvl<256>, dim3(1), dim3(256), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+        else if (c->lvl_wg == 512)
+            hipLaunchKernelGGL(k_exch_resolve_lvl<512>, dim3(1), dim3(512), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+        else
+            hipLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+    else if (c->lds_exchange)
         hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), resolve_lds_bytes(P.Ng), c->stream, P, t, gathered);
     else
         hipLaunchKernelGGL(k_exch_resolve_any, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
@@ -1174,8 +1379,14 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         const int K = exchange_K(c);
         P.plan_K = K;
         c->lds_exchange = Ng > 1 && Ng <= XLDS_MAX && K >= 1 && K <= Ng && !c->force_any_exchange;
+        {
+            const char* e = getenv("SMMHIP_DATAFLOW_EXCHANGE");  // test hook: force the ticket (data-flow) resolution kernel
+            c->lvl_exchange = c->lds_exchange && Ng <= XLVL_MAX && !(e && e[0] == '1');
+            const char* lw = getenv("SMMHIP_LVL_WG");  // tuning hook
+            if (lw) c->lvl_wg = atoi(lw);
+        }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
-            const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 16;
+            const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 36;
             c->win_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)192 << 20) / per_iter));
             c->win_cap = std::min(c->win_cap, T);
             c->win_rb = dalloc<double>(c, (size_t)c->win_cap * N * P.RBW);
@@ -1183,6 +1394,9 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             if (c->lds_exchange) {
                 c->win_plan = dalloc<unsigned long long>(c, (size_t)c->win_cap * K);
                 c->win_plan_mi = dalloc<double>(c, (size_t)c->win_cap * K);
+                c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->win_cap * K);
+                c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
+                c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
             }
         }
         {   // chain state blocks and records (BGPChain ctor, AlgoBGP.jl:78-109: best = Inf, best_id = -1, ...)
@@ -1224,6 +1438,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (int)resolve_lds_bytes(XLDS_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_plan, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)plan_lds_bytes(XLDS_MAX, XLDS_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<512>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
         }
         {   // tiles of problems with many parameters need more than the default 64 KiB of dynamic LDS
             const int lim = 160 * 1024;
@@ -1561,7 +1781,7 @@ int smm_debug_ts(void* ctx, unsigned long long* out, int n_wg) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !c->P.ts) return SMM_ERR_INVALID_ARG;
     if (n_wg < 0) {  // the exchange kernel's stamps
-        if (hipMemcpy(out, c->P.ts + (size_t)8 * 60000, 64, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
+        if (hipMemcpy(out, c->P.ts + (size_t)8 * 60000, 8 * 100, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
         return SMM_OK;
     }
     if (hipMemcpy(out, c->P.ts, (size_t)n_wg * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;

@@ -239,6 +239,38 @@ def test_any_size_exchange_kernel_matches(S, O, N, monkeypatch):
     cm.assert_history_equal(a.history(), o.history())
 
 
+@pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096])
+def test_dataflow_exchange_kernel_matches(S, O, N, monkeypatch):
+    # the ticket (data-flow) resolution kernel (4096 < N_global <= 8192) against the level-synchronous one
+    prob, opts = cm.serial_normal(N=N, T=12, ns=64)
+    a, o = run_both(S, O, prob, opts, None)
+    monkeypatch.setenv("SMMHIP_DATAFLOW_EXCHANGE", "1")
+    b = S.hip_context(prob, opts)
+    b.step(12)
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_history_equal(a.history(), o.history())
+
+
+def test_exchange_worst_case_star_pairs(S, O):
+    # injected pair list in which every pair touches chain 0: dependency depth == number of pairs
+    N, T = 40, 6
+    prob, opts = cm.serial_normal(N=N, T=T, ns=64, acc_tuners=np.ones(N), min_improve=0.0)
+    tab = cm.random_tables(prob, opts)
+    tab.pairs[:, :, 0] = 0
+    tab.pairs[:, :, 1] = 1 + (np.arange(N)[None, :] * 7 + np.arange(T)[:, None]) % (N - 1)
+    tab.probs_acc[:] *= 0.1
+    h, o = run_both(S, O, prob, opts, tab)
+    assert (h.history().exchanged != 0).sum() > 0
+    cm.assert_history_equal(h.history(), o.history(), rtol=1e-12)
+
+
+def test_n_global_between_4096_and_8192(S, O):
+    prob, opts = cm.serial_normal(N=5000, T=6, ns=32)
+    h, o = make_pair(S, O, prob, opts, threads=8)
+    h.step(6); o.step(6)
+    cm.assert_history_equal(h.history(), o.history())
+
+
 def test_window_boundaries(S, O):
     # look-ahead tables are produced window by window (256 iterations): cross two boundaries
     prob, opts = cm.serial_normal(N=40, T=600, ns=64)

@@ -31,7 +31,10 @@ slow = np.argsort(-d[:, 1])[:8]
 print("slowest proposal WGs:", [(int(i), round(float(d[i,1]),1)) for i in slow])
 print("kernel span %.2f us" % (ts[:, 4].max() - t0))
 
-x = np.zeros(8, np.uint64)
+x = np.zeros(100, np.uint64)
 lib.smm_debug_ts(ctx._ctx, x.ctypes.data_as(C.c_void_p), -1)
 xs = x.astype(np.float64) / 100.0
-print("resolve kernel (thread 0): loads+init %.2f  flow %.2f  barrier %.2f  store %.2f us" % tuple(np.diff(xs[:5])))
+print("resolve kernel (thread 0): loads+init %.2f  levels %.2f  store %.2f us" % (xs[1]-xs[0], xs[3]-xs[1], xs[4]-xs[3]))
+print("resolve: %d levels, %d shader cycles over %.2f us -> %.0f MHz" % (int(x[7]), int(x[6]), xs[4]-xs[0], x[6]/(xs[4]-xs[0])))
+nl = int(x[7])
+print("per level (cycles): before-barrier, after-barrier:", [(int(x[16+l]), int(x[56+l])) for l in range(min(nl, 16))])
