@@ -66,7 +66,8 @@ struct KParams {
     // problem
     int np, nm, ns, obj;
     const double *init, *lb, *ub, *mom, *w, *objp;
-    const double* Z;  // [nm][ns]
+    const double* Z;  // [nm][zstride]: the shock matrix, every moment padded to whole chunks of ZU rows x 512 lanes
+    int zstride;
     // opts
     int N, Ng, offset, T;
     int sigma_update_steps, smpl_iters, batch_size;
@@ -158,60 +159,75 @@ __device__ inline bool acc_writer(int lane) {
 // chunk is added up.  Chunk 0 of moment 0 is loaded by the caller before its serial prologue.
 constexpr int ZU = 8;
 
-__device__ inline void sim_load_chunk(const double* __restrict__ Zk, int ns, int ch, int tid, double (&z)[ZU], int dbg) {
-    const int s0 = (dbg & 8) ? tid : ch * ZU * WG + tid;  // dbg 8: timing experiment, every chunk re-reads chunk 0
+__device__ inline void sim_load_chunk(const double* __restrict__ Zk, int ch, int tid, double (&z)[ZU], int dbg) {
+    // uniform row base + lane offset: no per-load address arithmetic (the padding makes every row loadable)
+    const double* __restrict__ base = Zk + (size_t)((dbg & 8) ? 0 : ch) * (ZU * WG) + tid;  // dbg 8: timing experiment
 #pragma unroll
-    for (int u = 0; u < ZU; ++u) z[u] = Zk[min(s0 + u * WG, ns - 1)];
+    for (int u = 0; u < ZU; ++u) z[u] = base[u * WG];
 }
 
 // zc: chunk 0 of moment 0 (already loaded).  s_theta [CT][np], s_part [WG/64][CT][nm] in LDS.
+// Moments are reduced in groups of G = 16/CT: one transposed reduction of G*CT accumulators has the
+// same number of dependent shuffle steps as one of CT, so grouping halves that latency for CT = 8.
 template <int CT>
 __device__ inline void simulate_tile(const KParams& P, const double* s_theta, double* s_part, int tid, double (&zc)[ZU]) {
+    constexpr int G = (CT >= 16) ? 1 : 16 / CT;
     const int lane = tid & 63, wave = tid >> 6;
     const int ns = P.ns, nm = P.nm;
     const int nfull = ns / (ZU * WG);  // chunks in which every lane has all ZU draws (uniform)
-    for (int k = 0; k < nm; ++k) {
-        const double* __restrict__ Zk = P.Z + (size_t)k * ns;
-        double mu[CT], acc[CT], zt[ZU];
-        // the ragged rest (< ZU rows): loaded now, used after the full chunks
-        sim_load_chunk(Zk, ns, nfull, tid, zt, P.dbg);
+    for (int k0 = 0; k0 < nm; k0 += G) {
+        double acc[G * CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            mu[c] = s_theta[c * P.np + k];
-            acc[c] = 0.0;
-        }
-        for (int ch = 0; ch < nfull; ++ch) {
-            double zn[ZU];
-            // next chunk of this moment, or chunk 0 of the next moment (last moment: harmless reload)
-            const bool last = (ch + 1 == nfull);
-            const double* __restrict__ Zn = (last && k + 1 < nm) ? Zk + ns : Zk;
-            sim_load_chunk(Zn, ns, last ? 0 : ch + 1, tid, zn, P.dbg);
+        for (int i = 0; i < G * CT; ++i) acc[i] = 0.0;
 #pragma unroll
-            for (int u = 0; u < ZU; ++u) {
+        for (int kk = 0; kk < G; ++kk) {
+            const int k = k0 + kk;
+            if (k < nm) {
+                const double* __restrict__ Zk = P.Z + (size_t)k * P.zstride;
+                double mu[CT], zt[ZU];
+                // the ragged rest (< ZU rows): loaded now, used after the full chunks
+                sim_load_chunk(Zk, nfull, tid, zt, P.dbg);
 #pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const double x = zc[u] + mu[c];
-                    acc[c] = acc[c] + x;
+                for (int c = 0; c < CT; ++c) mu[c] = s_theta[c * P.np + k];
+                for (int ch = 0; ch < nfull; ++ch) {
+                    double zn[ZU];
+                    // next chunk of this moment, or chunk 0 of the next moment (last moment: harmless reload)
+                    const bool last = (ch + 1 == nfull);
+                    const double* __restrict__ Zn = (last && k + 1 < nm) ? Zk + P.zstride : Zk;
+                    sim_load_chunk(Zn, last ? 0 : ch + 1, tid, zn, P.dbg);
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u) {
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            const double x = zc[u] + mu[c];
+                            acc[kk * CT + c] = acc[kk * CT + c] + x;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u) zc[u] = zn[u];
                 }
-            }
+                {
+                    const int s0 = nfull * ZU * WG + tid;
 #pragma unroll
-            for (int u = 0; u < ZU; ++u) zc[u] = zn[u];
-        }
-        {
-            const int s0 = nfull * ZU * WG + tid;
+                    for (int u = 0; u < ZU; ++u) {
+                        if (s0 + u * WG < ns) {
 #pragma unroll
-            for (int u = 0; u < ZU; ++u) {
-                if (s0 + u * WG < ns) {
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        const double x = zt[u] + mu[c];
-                        acc[c] = acc[c] + x;
+                            for (int c = 0; c < CT; ++c) {
+                                const double x = zt[u] + mu[c];
+                                acc[kk * CT + c] = acc[kk * CT + c] + x;
+                            }
+                        }
                     }
                 }
+                if (nfull == 0 && k + 1 < nm) sim_load_chunk(Zk + P.zstride, 0, tid, zc, P.dbg);  // keeps zc defined (unused)
             }
         }
-        const double tot = wave_reduce_transposed<CT>(acc, lane);
-        if (acc_writer<CT>(lane)) s_part[(wave * CT + acc_index<CT>(lane)) * nm + k] = tot;
+        const double tot = wave_reduce_transposed<G * CT>(acc, lane);
+        if (acc_writer<G * CT>(lane)) {
+            const int a = acc_index<G * CT>(lane);
+            const int kk = a / CT, c = a - kk * CT;
+            if (k0 + kk < nm) s_part[(wave * CT + c) * nm + k0 + kk] = tot;
+        }
     }
 }
 
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
 
     // ---- global reads, all issued before anything waits ----
     double za[ZU];
-    if constexpr (SIM) sim_load_chunk(P.Z, P.ns, 0, tid, za, P.dbg);
+    if constexpr (SIM) sim_load_chunk(P.Z, 0, tid, za, P.dbg);
     if (tid >= 64 && tid < 128) {  // wave 1: problem constants
         for (int k = tid - 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; S.init[k] = P.init[k]; }
         for (int k = tid - 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
@@ -592,7 +608,7 @@ __global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const dou
     const int i = blockIdx.x * CT + tid;
     const bool chain_lane = (tid < CT) && (i < M);
     double za[ZU];
-    if constexpr (SIM) sim_load_chunk(P.Z, P.ns, 0, tid, za, P.dbg);
+    if constexpr (SIM) sim_load_chunk(P.Z, 0, tid, za, P.dbg);
     if (tid >= 64 && tid < 128)
         for (int k = tid - 64; k < P.nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
     if (tid < CT)
@@ -1350,11 +1366,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.mom = dupload(c, prob->mom, nm); P.w = dupload(c, prob->w, nm);
         P.objp = prob->n_obj_params > 0 ? dupload(c, prob->obj_params, prob->n_obj_params) : nullptr;
         {
-            std::vector<double> Z((size_t)nm * ns);
-            if (tab && tab->Z) memcpy(Z.data(), tab->Z, Z.size() * sizeof(double));
-            else
-                for (int k = 0; k < nm; ++k)
-                    for (int s = 0; s < ns; ++s) Z[(size_t)k * ns + s] = rng_Z(opts->seed, (uint32_t)k, (uint32_t)s);
+            const int rows = (ns + WG - 1) / WG;
+            P.zstride = ((rows + ZU) / ZU) * ZU * WG;  // at least one chunk beyond the last full one
+            std::vector<double> Z((size_t)nm * P.zstride, 0.0);
+            for (int k = 0; k < nm; ++k)
+                for (int s = 0; s < ns; ++s)
+                    Z[(size_t)k * P.zstride + s] = (tab && tab->Z) ? tab->Z[(size_t)k * ns + s] : rng_Z(opts->seed, (uint32_t)k, (uint32_t)s);
             P.Z = dupload(c, Z.data(), Z.size());
         }
         P.N = N; P.Ng = Ng; P.offset = opts->chain_offset; P.T = T;
@@ -1793,7 +1810,9 @@ int smm_get_Z(void* ctx, double* Z) {
     if (!c || !Z) return SMM_ERR_INVALID_ARG;
     try {
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipMemcpy(Z, c->P.Z, (size_t)c->P.nm * c->P.ns * sizeof(double), hipMemcpyDeviceToHost));
+        for (int k = 0; k < c->P.nm; ++k)
+            HIPCHK(hipMemcpy(Z + (size_t)k * c->P.ns, c->P.Z + (size_t)k * c->P.zstride, (size_t)c->P.ns * sizeof(double),
+                             hipMemcpyDeviceToHost));
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
