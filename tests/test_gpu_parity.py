@@ -271,6 +271,21 @@ def test_n_global_between_4096_and_8192(S, O):
     cm.assert_history_equal(h.history(), o.history())
 
 
+def test_c4_banana_8192_chains(S, O):
+    # BASELINE config 4: banana objective generalised to 10 params / 10 moments, 8192 chains, 1 GPU
+    from smm_jl_amd import Problem, BGPOpts
+    npar, N, T = 10, 8192, 60
+    prob = Problem(init=np.zeros(npar), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar),
+                   w=np.ones(npar), ns=1, objective_id=A.SMM_OBJ_BANANA)
+    # min_improve < 0: exchange also when chain i gets (slightly) worse, AlgoBGP.jl:682-688
+    opts = BGPOpts(N=N, maxiter=T, sigma=0.02 * cm.temps(N, 5), acc_tuner=np.geomspace(20, 1, N), min_improve=-0.05 * np.ones(N))
+    h, o = run_both(S, O, prob, opts, None)
+    hh = h.history()
+    cm.assert_history_equal(hh, o.history())
+    cm.assert_state_equal(h.state(), o.state())
+    assert (hh.exchanged != 0).mean() > 0.01 and (np.diff(hh.best_val, axis=0) <= 0).all()
+
+
 def test_window_boundaries(S, O):
     # look-ahead tables are produced window by window (256 iterations): cross two boundaries
     prob, opts = cm.serial_normal(N=40, T=600, ns=64)
