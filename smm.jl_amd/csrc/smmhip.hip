@@ -1033,6 +1033,200 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const
     if (P.ts && tid == 0) { P.ts[(size_t)8 * 60000 + 6] = clock64() - cyc0; P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev; }
 }
 
+// ------------------------------------------------------------------------------------------
+// Large populations (8192 < N_global <= 65535, e.g. 8 GPUs x 4096 chains): the same level plan and
+// level-synchronous walk with their working sets in global memory (the LDS of one CU is too small).
+// k_exch_plan_big: one workgroup per iteration, scratch [blockIdx] in global memory; speed is not
+// critical (runs ahead of the dependent loop, one window at a time).
+// ------------------------------------------------------------------------------------------
+struct BigPlanScratch {  // per workgroup
+    uint32_t *cnt, *ep, *pi, *pj, *ri, *rj, *prei, *prej, *lvl, *nl;
+    __host__ __device__ static size_t words(int Ng, int K) { return (size_t)(Ng + 4) + (size_t)K * 10; }
+    __device__ void carve(uint32_t* base, int Ng, int K) {
+        cnt = base; ep = cnt + Ng + 4; pi = ep + 2 * K; pj = pi + K; ri = pj + K; rj = ri + K;
+        prei = rj + K; prej = prei + K; lvl = prej + K; nl = lvl + K;
+    }
+};
+
+__device__ inline uint32_t block_excl_scan_step(uint32_t v, uint32_t* wsum, int tid, uint32_t& total) {
+    // exclusive scan of one value per thread over the 1024-thread block
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    total = 0;
+    for (int w = 0; w < XWG / 64; ++w) total += wsum[w];
+    return base + incl - v;
+}
+
+// in-place exclusive scan of a[0..n) (n arbitrary), returns nothing; all threads must call
+__device__ inline void block_excl_scan(uint32_t* a, int n, uint32_t* wsum, int tid) {
+    uint32_t carry = 0;
+    for (int b = 0; b < n; b += XWG) {
+        const int i = b + tid;
+        const uint32_t v = i < n ? a[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan_step(v, wsum, tid, total);
+        if (i < n) a[i] = carry + ex;
+        carry += total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(XWG) void k_exch_plan_big(const KParams P, const int t0, uint32_t* __restrict__ scratch,
+                                                       uint32_t* __restrict__ lv_pairs, double* __restrict__ lv_mi,
+                                                       uint32_t* __restrict__ lv_off) {
+    __shared__ uint32_t wsum[XWG / 64];
+    __shared__ uint32_t s_nlev;
+    const int tid = threadIdx.x;
+    const int t = t0 + blockIdx.x;
+    const int Ng = P.Ng, K = P.plan_K;
+    BigPlanScratch S;
+    S.carve(scratch + (size_t)blockIdx.x * BigPlanScratch::words(Ng, K), Ng, K);
+    for (int c = tid; c < Ng + 4; c += XWG) S.cnt[c] = 0;
+    if (P.pairtab) {
+        for (int q = tid; q < K; q += XWG) {
+            S.pi[q] = (uint32_t)P.pairtab[((size_t)(t - 1) * K + q) * 2];
+            S.pj[q] = (uint32_t)P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
+        }
+    } else {
+        PairPerm pp;
+        pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
+        for (int q = tid; q < K; q += XWG) {
+            int32_t i, j;
+            pair_unrank(pp.eval((uint64_t)q), i, j);
+            S.pi[q] = (uint32_t)i;
+            S.pj[q] = (uint32_t)j;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) { atomicAdd(&S.cnt[S.pi[q]], 1u); atomicAdd(&S.cnt[S.pj[q]], 1u); }
+    __syncthreads();
+    block_excl_scan(S.cnt, Ng, wsum, tid);  // bucket starts
+    for (int q = tid; q < K; q += XWG) {   // scatter (arbitrary order inside a bucket)
+        S.ep[atomicAdd(&S.cnt[S.pi[q]], 1u)] = (uint32_t)q;
+        S.ep[atomicAdd(&S.cnt[S.pj[q]], 1u)] = (uint32_t)q;
+    }
+    __syncthreads();  // cnt[c] == end of bucket c
+    for (int q = tid; q < K; q += XWG) {   // ranks
+        const uint32_t i = S.pi[q], j = S.pj[q];
+        uint32_t b = i ? S.cnt[i - 1] : 0u, e = S.cnt[i], ri = 0, rj = 0;
+        for (uint32_t x = b; x < e; ++x) ri += (S.ep[x] < (uint32_t)q) ? 1u : 0u;
+        b = j ? S.cnt[j - 1] : 0u; e = S.cnt[j];
+        for (uint32_t x = b; x < e; ++x) rj += (S.ep[x] < (uint32_t)q) ? 1u : 0u;
+        S.ri[q] = ri; S.rj[q] = rj;
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) {   // buckets in rank order
+        const uint32_t i = S.pi[q], j = S.pj[q];
+        S.ep[(i ? S.cnt[i - 1] : 0u) + S.ri[q]] = (uint32_t)q;
+        S.ep[(j ? S.cnt[j - 1] : 0u) + S.rj[q]] = (uint32_t)q;
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) {   // predecessors
+        const uint32_t i = S.pi[q], j = S.pj[q];
+        S.prei[q] = S.ri[q] ? S.ep[(i ? S.cnt[i - 1] : 0u) + S.ri[q] - 1] : 0xffffffffu;
+        S.prej[q] = S.rj[q] ? S.ep[(j ? S.cnt[j - 1] : 0u) + S.rj[q] - 1] : 0xffffffffu;
+        S.lvl[q] = 0;
+    }
+    __syncthreads();
+    int changed = 1;
+    while (changed) {  // Jacobi sweeps
+        for (int q = tid; q < K; q += XWG) {
+            const uint32_t pa = S.prei[q], pb = S.prej[q];
+            const uint32_t a = pa != 0xffffffffu ? S.lvl[pa] : 0u, b = pb != 0xffffffffu ? S.lvl[pb] : 0u;
+            const bool known = (pa == 0xffffffffu || a) && (pb == 0xffffffffu || b);
+            S.nl[q] = known ? 1u + (a > b ? a : b) : 0u;
+        }
+        __syncthreads();
+        int mine = 0;
+        for (int q = tid; q < K; q += XWG)
+            if (S.nl[q] != S.lvl[q]) { S.lvl[q] = S.nl[q]; mine = 1; }
+        changed = __syncthreads_or(mine);
+    }
+    // counting sort by level (cnt is free now)
+    for (int c = tid; c < Ng + 4; c += XWG) S.cnt[c] = 0;
+    if (tid == 0) s_nlev = 0;
+    __syncthreads();
+    {
+        uint32_t mx = 0;
+        for (int q = tid; q < K; q += XWG) { atomicAdd(&S.cnt[S.lvl[q]], 1u); mx = S.lvl[q] > mx ? S.lvl[q] : mx; }
+        atomicMax(&s_nlev, mx);
+    }
+    __syncthreads();
+    const int nlev = (int)s_nlev;
+    block_excl_scan(S.cnt, nlev + 1, wsum, tid);  // cnt[l] = pairs in levels < l (1-based l)
+    uint32_t* o_off = lv_off + (size_t)blockIdx.x * (K + 2);
+    for (int l = tid; l < nlev; l += XWG) o_off[l] = (l + 2 <= nlev) ? S.cnt[l + 2] : (uint32_t)K;
+    if (tid == 0) o_off[K + 1] = (uint32_t)nlev;
+    __syncthreads();
+    uint32_t* o_pairs = lv_pairs + (size_t)blockIdx.x * K;
+    double* o_mi = lv_mi + (size_t)blockIdx.x * K;
+    for (int q = tid; q < K; q += XWG) {
+        const uint32_t pos = atomicAdd(&S.cnt[S.lvl[q]], 1u);
+        const uint32_t i = S.pi[q], j = S.pj[q];
+        o_pairs[pos] = i | (j << 16);
+        o_mi[pos] = P.min_improve_g[i];
+    }
+}
+
+// k_exch_resolve_lvl_big: level-synchronous walk with values / sources / partners in global memory
+// (agent-scope relaxed atomics: the lines are shared between the waves of the workgroup through L2).
+__global__ __launch_bounds__(XWG) void k_exch_resolve_lvl_big(const KParams P, const int t, const double* __restrict__ gathered) {
+    const int tid = threadIdx.x;
+    const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
+    const int w = t - P.plan_t0;
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    double* val = P.xval;
+    int32_t* src = P.xsrc;
+    int32_t* partner = P.xpartner;
+    const int nlev = (int)g_off[K + 1];
+    for (int g = tid; g < Ng; g += XWG) {
+        __hip_atomic_store(&val[g], gathered[(size_t)g * RW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&src[g], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partner[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    uint32_t b = 0;
+    for (int l = 0; l < nlev; ++l) {
+        const uint32_t e = g_off[l];
+        for (uint32_t pos = b + tid; pos < e; pos += XWG) {
+            const uint32_t pw = g_pairs[pos];
+            const double m = g_mi[pos];
+            const uint32_t i = pw & 0xffffu, j = pw >> 16;
+            const double vi = __hip_atomic_load(&val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double vj = __hip_atomic_load(&val[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (vi - vj > m) {                          // dist_fun = -, AlgoBGP.jl:688
+                __hip_atomic_store(&val[i], vj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // swap_ev_ij!, :739-744
+                __hip_atomic_store(&val[j], vi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int si = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int sj = __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&src[i], sj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&src[j], si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&partner[i], (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :747-748
+                __hip_atomic_store(&partner[j], (int)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        b = e;
+        __syncthreads();
+    }
+    for (int g = tid; g < Ng; g += XWG) {
+        const unsigned s_ = (unsigned)__hip_atomic_load(&src[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned p_ = (unsigned)__hip_atomic_load(&partner[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        P.xres[g] = (unsigned long long)s_ | ((unsigned long long)p_ << 32);
+    }
+}
+
 // k_exch_resolve_any: the same result for any N_global, state in global memory, executed in
 // barrier-separated dependency rounds: every pending pair bids (atomicMin of its list position) on
 // both of its chains; a pair that wins both bids has no pending predecessor and is executed.
@@ -1155,6 +1349,8 @@ struct Ctx {
     uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr;
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
+    bool big_exchange = false;   // 8192 < N_global <= 65535: level plan and walk in global memory
+    uint32_t* big_scratch = nullptr;
     int lvl_wg = 1024;
     int rng_t0 = 0, rng_w = 0;    // window currently held: iterations [t0, t0+w)
     int plan_t0 = 0, plan_w = 0;
@@ -1210,6 +1406,14 @@ void ensure_windows(Ctx* c, int t) {
         c->rng_t0 = t; c->rng_w = W;
         P.rb = c->win_rb; P.rb_t0 = t;
     }
+    if (c->big_exchange && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
+        const int W = std::min(c->win_cap, P.T - t + 1);
+        hipLaunchKernelGGL(k_exch_plan_big, dim3(W), dim3(XWG), 0, c->stream, P, t, c->big_scratch, c->win_lv_pairs, c->win_lv_mi,
+                           c->win_lv_off);
+        c->plan_t0 = t; c->plan_w = W;
+        P.plan_t0 = t;
+        P.lv_pairs = c->win_lv_pairs; P.lv_mi = c->win_lv_mi; P.lv_off = c->win_lv_off;
+    }
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
         hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
@@ -1251,6 +1455,8 @@ void launch_resolve(Ctx* c, int t, const double* gathered) {
             hipLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
     else if (c->lds_exchange)
         hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), resolve_lds_bytes(P.Ng), c->stream, P, t, gathered);
+    else if (c->big_exchange)
+        hipLaunchKernelGGL(k_exch_resolve_lvl_big, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
     else
         hipLaunchKernelGGL(k_exch_resolve_any, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
 }
@@ -1401,13 +1607,23 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             c->lvl_exchange = c->lds_exchange && Ng <= XLVL_MAX && !(e && e[0] == '1');
             const char* lw = getenv("SMMHIP_LVL_WG");  // tuning hook
             if (lw) c->lvl_wg = atoi(lw);
+            const char* be = getenv("SMMHIP_BIG_EXCHANGE");  // test hook: force the global-memory level kernels
+            const bool force_big = be && be[0] == '1';
+            c->big_exchange = Ng > 1 && Ng <= 65535 && K >= 1 && K <= Ng && !c->force_any_exchange && (force_big || !c->lds_exchange);
+            if (c->big_exchange) { c->lds_exchange = false; c->lvl_exchange = false; }
         }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
-            const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 36;
+            const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 : 0);
             c->win_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)192 << 20) / per_iter));
             c->win_cap = std::min(c->win_cap, T);
             c->win_rb = dalloc<double>(c, (size_t)c->win_cap * N * P.RBW);
             HIPCHK(hipMemset(c->win_rb, 0, (size_t)c->win_cap * N * P.RBW * 8));
+            if (c->big_exchange) {
+                c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->win_cap * K);
+                c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
+                c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
+                c->big_scratch = dalloc<uint32_t>(c, (size_t)c->win_cap * BigPlanScratch::words(Ng, K));
+            }
             if (c->lds_exchange) {
                 c->win_plan = dalloc<unsigned long long>(c, (size_t)c->win_cap * K);
                 c->win_plan_mi = dalloc<double>(c, (size_t)c->win_cap * K);

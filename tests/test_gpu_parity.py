@@ -251,6 +251,27 @@ def test_dataflow_exchange_kernel_matches(S, O, N, monkeypatch):
     cm.assert_history_equal(a.history(), o.history())
 
 
+@pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096])
+def test_big_exchange_kernels_match(S, O, N, monkeypatch):
+    # the global-memory level plan + walk (8192 < N_global <= 65535) forced at small sizes
+    prob, opts = cm.serial_normal(N=N, T=12, ns=64)
+    a, o = run_both(S, O, prob, opts, None)
+    monkeypatch.setenv("SMMHIP_BIG_EXCHANGE", "1")
+    b = S.hip_context(prob, opts)
+    b.step(12)
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_history_equal(a.history(), o.history())
+
+
+def test_n_global_above_8192(S, O):
+    # 8-GPU-sized population resolved on one GPU: 20000 chains
+    prob, opts = cm.serial_normal(N=20000, T=5, ns=32)
+    h, o = make_pair(S, O, prob, opts, threads=8)
+    h.step(5); o.step(5)
+    cm.assert_history_equal(h.history(), o.history())
+    assert (h.history().exchanged != 0).sum() > 0
+
+
 def test_exchange_worst_case_star_pairs(S, O):
     # injected pair list in which every pair touches chain 0: dependency depth == number of pairs
     N, T = 40, 6
@@ -262,6 +283,12 @@ def test_exchange_worst_case_star_pairs(S, O):
     h, o = run_both(S, O, prob, opts, tab)
     assert (h.history().exchanged != 0).sum() > 0
     cm.assert_history_equal(h.history(), o.history(), rtol=1e-12)
+    for env in ("SMMHIP_BIG_EXCHANGE", "SMMHIP_DATAFLOW_EXCHANGE", "SMMHIP_ANY_EXCHANGE"):
+        with pytest.MonkeyPatch.context() as mp:
+            mp.setenv(env, "1")
+            b = S.hip_context(prob, opts, tab)
+            b.step(T)
+            cm.assert_history_equal(h.history(), b.history(), exact_floats=True)
 
 
 def test_n_global_between_4096_and_8192(S, O):
