@@ -55,10 +55,17 @@ typedef enum {
 typedef enum {
     SMM_OBJ_NORM = 0,   /* objfunc_norm, ObjExamples.jl:59-116 (requires np==nm)          */
     SMM_OBJ_BANANA = 1, /* banana, ObjExamples.jl:251-265, generalised to np dims        */
-    SMM_OBJ_NORM_FAILBOX = 2 /* objfunc_norm that "throws" (status=-2, mprob.jl:183-186)
+    SMM_OBJ_NORM_FAILBOX = 2, /* objfunc_norm that "throws" (status=-2, mprob.jl:183-186)
                                 when obj_params[0] <= theta_0 <= obj_params[1]; the role of
                                 Testobj_fails, ObjExamples.jl:27-32 */
+    SMM_OBJ_DENSE = 3   /* synthetic dense simulation (BASELINE config 5, no reference counterpart):
+                           x = B*theta (B: SMM_DENSE_D x np), h = tanh(x), y = A*h (A: nm x SMM_DENSE_D),
+                           simM = y, value = mean(((simM-mom)/w)^2).  obj_params = [B row-major, A row-major]
+                           (SMM_DENSE_D*np + nm*SMM_DENSE_D doubles) or empty = generated from the seed.
+                           Summation order (numerical contract): x_d = fma chain over p; y_k = 8 fma chains
+                           over d in [32w, 32w+32), added left to right.  FP64 MFMA on the device. */
 } smm_objective_t;
+#define SMM_DENSE_D 256
 
 /* MProb (mprob.jl:29-53) flattened: parameters to sample with bounds and start
  * values (addSampledParam!, mprob.jl:81-98), data moments and weights

@@ -20,6 +20,7 @@ _ORC_ONLY = [
     ("orc_gen_pairs", None, [C.c_uint64, C.c_int32, C.c_int32, A.c_int32_p]),
     ("orc_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("orc_max_threads", C.c_int, []),
+    ("orc_gen_dense", None, [C.c_uint64, C.c_int, C.c_int, A.c_double_p]),
 ]
 _SHARED = ["smm_ctx_create", "smm_ctx_destroy", "smm_last_error", "smm_bgp_step", "smm_bgp_local_step",
            "smm_bgp_record_doubles", "smm_eval_batch", "smm_get_history", "smm_get_state", "smm_get_Z"]
@@ -84,3 +85,9 @@ def philox(ctr, key):
 
 def max_threads():
     return load().orc_max_threads()
+
+
+def gen_dense(seed, np_, nm):
+    out = np.empty(A.SMM_DENSE_D * np_ + nm * A.SMM_DENSE_D)
+    load().orc_gen_dense(seed, np_, nm, A.dptr(out))
+    return out

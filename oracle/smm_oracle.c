@@ -39,6 +39,8 @@
 #define ORC_OBJ_NORM 0
 #define ORC_OBJ_BANANA 1
 #define ORC_OBJ_NORM_FAILBOX 2
+#define ORC_OBJ_DENSE 3
+#define ORC_DENSE_D 256
 
 #define ORC_REDUCE_LANES 512 /* numerical contract, see include/smmhip.h */
 
@@ -295,6 +297,52 @@ static void objfunc_banana(int np, int nm, const double* theta, const double* mo
     *status = 1;
 }
 
+/* synthetic dense simulation (BASELINE config 5; no reference counterpart, PARITY UNPINNED; the
+ * spec is frozen in include/smmhip.h): x = B*theta, h = tanh(x), y = A*h, simM = y,
+ * value = mean(((simM-mom)/w)^2) as in objfunc_norm (ObjExamples.jl:90-101). */
+static void objfunc_dense(int np, int nm, const double* theta, const double* Bm /*[D][np]*/, const double* Am /*[nm][D]*/,
+                          const double* mom, const double* w, double* simM, double* value, int8_t* status) {
+    double h[ORC_DENSE_D];
+    for (int d = 0; d < ORC_DENSE_D; ++d) {
+        double acc = 0.0;
+        for (int p = 0; p < np; ++p) acc = fma(Bm[(size_t)d * np + p], theta[p], acc);
+        h[d] = tanh(acc);
+    }
+    double vsum = 0.0;
+    for (int k = 0; k < nm; ++k) {
+        double tot = 0.0;
+        for (int wv = 0; wv < 8; ++wv) {
+            double acc = 0.0;
+            for (int d = 32 * wv; d < 32 * wv + 32; ++d) acc = fma(Am[(size_t)k * ORC_DENSE_D + d], h[d], acc);
+            tot = (wv == 0) ? acc : tot + acc;
+        }
+        simM[k] = tot;
+        double dd = tot - mom[k];
+        if (!isnan(w[k])) dd = dd / w[k];
+        double v = dd * dd;
+        vsum = (k == 0) ? v : vsum + v;
+    }
+    *value = vsum / (double)nm;
+    *status = 1;
+}
+
+/* default matrices of the dense objective: N(0,1)/sqrt(fan-in) from the counter RNG (stream 5) */
+void orc_gen_dense(uint64_t seed, int np, int nm, double* out /* [D*np + nm*D] */) {
+    uint32_t key[2];
+    stream_key(seed, 5, key);
+    const size_t nB = (size_t)ORC_DENSE_D * np, nA = (size_t)nm * ORC_DENSE_D;
+    for (size_t i = 0; i < nB + nA; i += 2) {
+        uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)((i >> 1) >> 32), 0, 0}, x[4];
+        double z[2];
+        philox4x32_10(ctr, key, x);
+        box_muller(x, z);
+        for (int e = 0; e < 2 && i + e < nB + nA; ++e) {
+            const size_t idx = i + e;
+            out[idx] = z[e] / sqrt(idx < nB ? (double)np : (double)ORC_DENSE_D);
+        }
+    }
+}
+
 typedef struct {
     orc_problem_t prob;
     orc_opts_t opts;
@@ -327,6 +375,10 @@ static void evaluate_objective(const orc_t* o, const double* theta, double* simM
         break;
     case ORC_OBJ_BANANA:
         objfunc_banana(p->np, p->nm, theta, o->mom, simM, value, status);
+        break;
+    case ORC_OBJ_DENSE:
+        objfunc_dense(p->np, p->nm, theta, o->obj_params, o->obj_params + (size_t)ORC_DENSE_D * p->np, o->mom, o->w, simM,
+                      value, status);
         break;
     case ORC_OBJ_NORM_FAILBOX:
         if (o->obj_params && theta[0] >= o->obj_params[0] && theta[0] <= o->obj_params[1]) {
@@ -379,6 +431,10 @@ int orc_ctx_create(const orc_problem_t* prob, const orc_opts_t* opts, const orc_
     o->init = dupd(prob->init, np); o->lb = dupd(prob->lb, np); o->ub = dupd(prob->ub, np);
     o->mom = dupd(prob->mom, nm); o->w = dupd(prob->w, nm);
     o->obj_params = prob->n_obj_params > 0 ? dupd(prob->obj_params, prob->n_obj_params) : NULL;
+    if (prob->objective_id == ORC_OBJ_DENSE && !o->obj_params) {
+        o->obj_params = (double*)malloc(((size_t)ORC_DENSE_D * np + (size_t)nm * ORC_DENSE_D) * sizeof(double));
+        orc_gen_dense(opts->seed, np, nm, o->obj_params);
+    }
     o->acc_tuner = dupd(opts->acc_tuner, Ng); o->min_improve = dupd(opts->min_improve, Ng);
     o->sigma = dupd(opts->sigma + opts->chain_offset, N);
     size_t TN = (size_t)T * N;

@@ -31,6 +31,8 @@ SMM_ERR_STATE = -8
 SMM_OBJ_NORM = 0
 SMM_OBJ_BANANA = 1
 SMM_OBJ_NORM_FAILBOX = 2
+SMM_OBJ_DENSE = 3
+SMM_DENSE_D = 256
 
 SMM_REDUCE_LANES = 512
 

@@ -74,6 +74,10 @@ struct KParams {
     double sigma_adjust_by;
     uint64_t seed;
     const double* min_improve_g;  // [Ng]
+    // dense objective (SMM_OBJ_DENSE): B and A in MFMA fragment order
+    const double* dense_Bf;  // [D/16][ceil(np/4)][64]
+    const double* dense_Af;  // [nOt][D/16][4][64]
+    int dense_nOt;           // ceil(nm/16)
     // block widths (doubles, even)
     int RW, HW, RBW;
     int rb_tries;  // proposal tries held in a randomness block
@@ -231,6 +235,60 @@ __device__ inline void simulate_tile(const KParams& P, const double* s_theta, do
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Dense objective (SMM_OBJ_DENSE, BASELINE config 5): the simulation is a dense contraction, so it
+// runs on the FP64 matrix cores.  A tile is 16 chains = the N dimension of v_mfma_f64_16x16x4; wave w
+// of the 8 owns the hidden units d in [32w, 32w+32):
+//   x tile [16 d x 16 chains]  = B[16 d x np] * theta[np x 16]        (ceil(np/4) MFMAs)
+//   h = tanh(x): the accumulator layout (row = (lane>>4) + 4r, col = lane&15) IS the B-operand layout
+//   of the next product (k = 4s + (lane>>4)), so h feeds the second GEMM from registers;
+//   y tile [16 k x 16 chains] += A[16 k x 16 d] * h[16 d x 16]        (4 MFMAs per output tile)
+// B and A are stored in fragment order (one coalesced 8-byte load per lane per MFMA).  The wave's
+// partial y goes to LDS [w][k][chain]; the 8 partials are added left to right by the chain lane.
+// ------------------------------------------------------------------------------------------
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int DENSE_D = SMM_DENSE_D;
+
+template <int CT>
+__device__ inline void dense_tile(const KParams& P, const double* s_theta, double* s_part, int tid) {
+    static_assert(CT == 16, "the dense objective tiles 16 chains (MFMA N dimension)");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int np = P.np, nPs = (np + 3) / 4, nOt = P.dense_nOt, nmp = nOt * 16;
+    d4_t yacc[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) yacc[o] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int T = 2 * wave + tt;
+        d4_t xacc = d4_t{0.0, 0.0, 0.0, 0.0};
+        const double* __restrict__ bf = P.dense_Bf + (size_t)T * nPs * 64 + lane;
+        for (int s = 0; s < nPs; ++s) {
+            const int p = 4 * s + lk;
+            const double b = (p < np) ? s_theta[li * np + p] : 0.0;
+            xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[(size_t)s * 64], b, xacc, 0, 0, 0);
+        }
+        double h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = tanh(xacc[r]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < nOt) {
+                const double* __restrict__ af = P.dense_Af + ((size_t)(o * (DENSE_D / 16) + T) * 4) * 64 + lane;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4 * 64], h[s4], yacc[o], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (o < nOt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_part[((size_t)wave * nmp + 16 * o + lk + 4 * r) * 16 + li] = yacc[o][r];
+        }
+    }
+}
+
 // value / simulated moments / status for one chain from its reduced sums
 // (ObjExamples.jl:79-110; banana :251-265; "exception" -> status -2, mprob.jl:183-186).
 // s_mom / s_w: data moments and weights staged in LDS.
@@ -259,11 +317,14 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
         return;
     }
     double vsum = 0.0;
+    const bool dense = P.obj == SMM_OBJ_DENSE;
+    const int nmp = P.dense_nOt * 16;
     for (int k = 0; k < P.nm; ++k) {
-        double tot = s_part[(0 * CT + ci) * P.nm + k];
+        double tot = dense ? s_part[((size_t)0 * nmp + k) * 16 + ci] : s_part[(0 * CT + ci) * P.nm + k];
 #pragma unroll
-        for (int wv = 1; wv < WG / 64; ++wv) tot = tot + s_part[(wv * CT + ci) * P.nm + k];
-        const double m = tot / (double)P.ns;
+        for (int wv = 1; wv < WG / 64; ++wv)
+            tot = tot + (dense ? s_part[((size_t)wv * nmp + k) * 16 + ci] : s_part[(wv * CT + ci) * P.nm + k]);
+        const double m = dense ? tot : tot / (double)P.ns;
         simM[k] = m;
         double d = m - s_mom[k];
         const double wk = s_w[k];
@@ -297,8 +358,9 @@ struct TileSmem {
         (void)sim;
     }
 };
-__host__ __device__ inline size_t tile_smem_doubles(int CT, int np, int nm, int RW, int HW, int RBW, bool sim) {
-    return (size_t)CT * (CSW + RBW + 2 * RW + 2 * HW + np) + 3 * np + 2 * nm + (sim ? (size_t)(WG / 64) * CT * nm : 0) + 2;
+__host__ __device__ inline size_t tile_smem_doubles(int CT, int np, int nm, int RW, int HW, int RBW, int kind) {
+    const size_t part = kind == 1 ? (size_t)(WG / 64) * CT * nm : kind == 2 ? (size_t)(WG / 64) * (((nm + 15) / 16) * 16) * 16 : 0;
+    return (size_t)CT * (CSW + RBW + 2 * RW + 2 * HW + np) + 3 * np + 2 * nm + part + 2;
 }
 
 // lanes (cl, r) of the control wave move chain cl's block of W doubles (W even) in 16-byte pieces
@@ -342,14 +404,14 @@ __device__ inline void make_swapped_history(const KParams& P, double* hrec /*[HW
 // record the chain continues from), evaluates the proposal tries side by side, and after the
 // simulation lanes r == 0 run the accept step and the wave stores the result blocks.
 // ------------------------------------------------------------------------------------------
-template <bool SIM, int CT>
+template <int KIND, int CT>
 __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
                                                       double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NR = 64 / CT;
     const int np = P.np, nm = P.nm, N = P.N, RW = P.RW, HW = P.HW, RBW = P.RBW;
     TileSmem S;
-    S.carve(smem, CT, np, nm, RW, HW, RBW, SIM);
+    S.carve(smem, CT, np, nm, RW, HW, RBW, KIND != 0);
     const int tid = threadIdx.x;
     const int cl = tid % CT, r = (tid % 64) / CT;
     const int c = blockIdx.x * CT + cl;       // chain served by this lane (control wave only)
@@ -361,7 +423,7 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
 
     // ---- global reads, all issued before anything waits ----
     double za[ZU];
-    if constexpr (SIM) sim_load_chunk(P.Z, 0, tid, za, P.dbg);
+    if constexpr (KIND == 1) sim_load_chunk(P.Z, 0, tid, za, P.dbg);
     if (tid >= 64 && tid < 128) {  // wave 1: problem constants
         for (int k = tid - 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; S.init[k] = P.init[k]; }
         for (int k = tid - 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
@@ -482,8 +544,11 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
     TS_MARK(2);
 
     // ---- simulation: all 512 lanes, ns draws x nm moments x CT chains ----
-    if constexpr (SIM) {
+    if constexpr (KIND == 1) {
         if (!(P.dbg & 2)) simulate_tile<CT>(P, S.theta, S.part, tid, za);
+        __syncthreads();
+    } else if constexpr (KIND == 2) {
+        dense_tile<CT>(P, S.theta, S.part, tid);
         __syncthreads();
     }
     TS_MARK(3);
@@ -597,25 +662,28 @@ __global__ void k_flush(const KParams P, const int t_next, const double* __restr
 }
 
 // batched evaluateObjective(m,p), mprob.jl:175-188: params [np][M] -> value, simM [nm][M], status
-template <bool SIM, int CT>
+template <int KIND, int CT>
 __global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const double* __restrict__ params, const int M,
                                                       double* __restrict__ value, double* __restrict__ simM,
                                                       int8_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     TileSmem S;
-    S.carve(smem, CT, P.np, P.nm, P.RW, P.HW, P.RBW, SIM);
+    S.carve(smem, CT, P.np, P.nm, P.RW, P.HW, P.RBW, KIND != 0);
     const int tid = threadIdx.x;
     const int i = blockIdx.x * CT + tid;
     const bool chain_lane = (tid < CT) && (i < M);
     double za[ZU];
-    if constexpr (SIM) sim_load_chunk(P.Z, 0, tid, za, P.dbg);
+    if constexpr (KIND == 1) sim_load_chunk(P.Z, 0, tid, za, P.dbg);
     if (tid >= 64 && tid < 128)
         for (int k = tid - 64; k < P.nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
     if (tid < CT)
         for (int k = 0; k < P.np; ++k) S.theta[tid * P.np + k] = chain_lane ? params[(size_t)k * M + i] : 0.0;
     __syncthreads();
-    if constexpr (SIM) {
+    if constexpr (KIND == 1) {
         simulate_tile<CT>(P, S.theta, S.part, tid, za);
+        __syncthreads();
+    } else if constexpr (KIND == 2) {
+        dense_tile<CT>(P, S.theta, S.part, tid);
         __syncthreads();
     }
     if (chain_lane) {
@@ -1198,23 +1266,40 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lvl_big(const KParams P, c
     }
     __syncthreads();
     uint32_t b = 0;
+    constexpr int BATCH = 8;  // pairs of one level are independent: their loads are issued together
     for (int l = 0; l < nlev; ++l) {
         const uint32_t e = g_off[l];
-        for (uint32_t pos = b + tid; pos < e; pos += XWG) {
-            const uint32_t pw = g_pairs[pos];
-            const double m = g_mi[pos];
-            const uint32_t i = pw & 0xffffu, j = pw >> 16;
-            const double vi = __hip_atomic_load(&val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double vj = __hip_atomic_load(&val[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (vi - vj > m) {                          // dist_fun = -, AlgoBGP.jl:688
-                __hip_atomic_store(&val[i], vj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // swap_ev_ij!, :739-744
-                __hip_atomic_store(&val[j], vi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int si = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int sj = __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&src[i], sj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&src[j], si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&partner[i], (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :747-748
-                __hip_atomic_store(&partner[j], (int)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t p0 = b + tid; p0 < e; p0 += XWG * BATCH) {
+            uint32_t pw[BATCH];
+            double m[BATCH], vi[BATCH], vj[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const uint32_t pos = p0 + u * XWG;
+                pw[u] = pos < e ? g_pairs[pos] : 0u;
+                m[u] = pos < e ? g_mi[pos] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const uint32_t pos = p0 + u * XWG;
+                if (pos < e) {
+                    vi[u] = __hip_atomic_load(&val[pw[u] & 0xffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vj[u] = __hip_atomic_load(&val[pw[u] >> 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else { vi[u] = 0.0; vj[u] = 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const uint32_t pos = p0 + u * XWG;
+                const uint32_t i = pw[u] & 0xffffu, j = pw[u] >> 16;
+                if (pos < e && vi[u] - vj[u] > m[u]) {          // dist_fun = -, AlgoBGP.jl:688
+                    __hip_atomic_store(&val[i], vj[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // swap_ev_ij!, :739-744
+                    __hip_atomic_store(&val[j], vi[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int si = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int sj = __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&src[i], sj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&src[j], si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&partner[i], (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :747-748
+                    __hip_atomic_store(&partner[j], (int)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         b = e;
@@ -1383,10 +1468,11 @@ T* dupload(Ctx* c, const T* h, size_t n) {
 }
 
 bool is_sim(int obj) { return obj == SMM_OBJ_NORM || obj == SMM_OBJ_NORM_FAILBOX; }
+int obj_kind(int obj) { return is_sim(obj) ? 1 : obj == SMM_OBJ_DENSE ? 2 : 0; }
 
 size_t tile_smem(const Ctx* c, int ct) {
     const KParams& P = c->P;
-    return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, is_sim(c->obj)) * sizeof(double);
+    return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, obj_kind(c->obj)) * sizeof(double);
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
@@ -1424,22 +1510,24 @@ void ensure_windows(Ctx* c, int t) {
     }
 }
 
-template <bool SIM, int CT>
+template <int KIND, int CT>
 void launch_chain_iter_ct(Ctx* c, int t, int flags) {
     const KParams& P = c->P;
-    hipLaunchKernelGGL((k_chain_iter<SIM, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, t,
+    hipLaunchKernelGGL((k_chain_iter<KIND, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, t,
                        (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
 }
 
 void launch_chain_iter(Ctx* c, int t, int flags) {
     if (is_sim(c->obj)) {
-        if (c->ct == 4) launch_chain_iter_ct<true, 4>(c, t, flags);
-        else if (c->ct == 16) launch_chain_iter_ct<true, 16>(c, t, flags);
-        else launch_chain_iter_ct<true, 8>(c, t, flags);
+        if (c->ct == 4) launch_chain_iter_ct<1, 4>(c, t, flags);
+        else if (c->ct == 16) launch_chain_iter_ct<1, 16>(c, t, flags);
+        else launch_chain_iter_ct<1, 8>(c, t, flags);
+    } else if (c->obj == SMM_OBJ_DENSE) {
+        launch_chain_iter_ct<2, 16>(c, t, flags);
     } else if (tile_smem(c, 64) <= (size_t)60 * 1024) {
-        launch_chain_iter_ct<false, 64>(c, t, flags);
+        launch_chain_iter_ct<0, 64>(c, t, flags);
     } else {
-        launch_chain_iter_ct<false, 8>(c, t, flags);
+        launch_chain_iter_ct<0, 8>(c, t, flags);
     }
     c->cur ^= 1;
 }
@@ -1536,7 +1624,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         return fail(nullptr, SMM_ERR_INVALID_ARG, "need 1 <= np,nm <= 64 and ns >= 1");
     if (N < 1 || T < 1 || Ng < N || opts->chain_offset < 0 || opts->chain_offset + N > Ng || (Ng % N) != 0)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "bad N / N_global / chain_offset / maxiter");
-    if (prob->objective_id < 0 || prob->objective_id > SMM_OBJ_NORM_FAILBOX)
+    if (prob->objective_id < 0 || prob->objective_id > SMM_OBJ_DENSE)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "unknown objective_id");
     if (is_sim(prob->objective_id) && np != nm)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "objfunc_norm needs one moment per parameter (ObjExamples.jl:66-78)");
@@ -1571,6 +1659,39 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.init = dupload(c, prob->init, np); P.lb = dupload(c, prob->lb, np); P.ub = dupload(c, prob->ub, np);
         P.mom = dupload(c, prob->mom, nm); P.w = dupload(c, prob->w, nm);
         P.objp = prob->n_obj_params > 0 ? dupload(c, prob->obj_params, prob->n_obj_params) : nullptr;
+        if (prob->objective_id == SMM_OBJ_DENSE) {
+            const size_t nB = (size_t)DENSE_D * np, nA = (size_t)nm * DENSE_D;
+            if (prob->n_obj_params != 0 && (size_t)prob->n_obj_params != nB + nA)
+                throw std::string("SMM_OBJ_DENSE: obj_params must hold B (256 x np) and A (nm x 256), or be empty");
+            std::vector<double> M(nB + nA);
+            if (prob->n_obj_params) memcpy(M.data(), prob->obj_params, M.size() * 8);
+            else {  // N(0,1)/sqrt(fan-in) from the counter RNG, stream 5
+                for (size_t i = 0; i < nB + nA; i += 2) {
+                    double z0, z1;
+                    box_muller(philox_stream(opts->seed, 5, (uint32_t)(i >> 1), (uint32_t)((i >> 1) >> 32), 0, 0), z0, z1);
+                    M[i] = z0 / sqrt(i < nB ? (double)np : (double)DENSE_D);
+                    if (i + 1 < nB + nA) M[i + 1] = z1 / sqrt(i + 1 < nB ? (double)np : (double)DENSE_D);
+                }
+            }
+            const int nPs = (np + 3) / 4, nOt = (nm + 15) / 16;
+            std::vector<double> Bf((size_t)(DENSE_D / 16) * nPs * 64, 0.0), Af((size_t)nOt * (DENSE_D / 16) * 4 * 64, 0.0);
+            for (int T = 0; T < DENSE_D / 16; ++T)
+                for (int s = 0; s < nPs; ++s)
+                    for (int l = 0; l < 64; ++l) {
+                        const int d = 16 * T + (l & 15), p = 4 * s + (l >> 4);
+                        if (p < np) Bf[((size_t)T * nPs + s) * 64 + l] = M[(size_t)d * np + p];
+                    }
+            for (int o = 0; o < nOt; ++o)
+                for (int T = 0; T < DENSE_D / 16; ++T)
+                    for (int s = 0; s < 4; ++s)
+                        for (int l = 0; l < 64; ++l) {
+                            const int k = 16 * o + (l & 15), d = 16 * T + 4 * s + (l >> 4);
+                            if (k < nm) Af[(((size_t)o * (DENSE_D / 16) + T) * 4 + s) * 64 + l] = M[nB + (size_t)k * DENSE_D + d];
+                        }
+            P.dense_Bf = dupload(c, Bf.data(), Bf.size());
+            P.dense_Af = dupload(c, Af.data(), Af.size());
+            P.dense_nOt = nOt;
+        }
         {
             const int rows = (ns + WG - 1) / WG;
             P.zstride = ((rows + ZU) / ZU) * ZU * WG;  // at least one chunk beyond the last full one
@@ -1680,13 +1801,16 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         }
         {   // tiles of problems with many parameters need more than the default 64 KiB of dynamic LDS
             const int lim = 160 * 1024;
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            if (tile_smem(c, is_sim(c->obj) ? c->ct : 8) > (size_t)lim) throw std::string("tile does not fit the 160 KiB LDS");
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            if (tile_smem(c, is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8)) > (size_t)lim)
+                throw std::string("tile does not fit the 160 KiB LDS");
         }
         HIPCHK(hipDeviceSynchronize());
     } catch (const std::string& m) {
@@ -1852,9 +1976,11 @@ int smm_eval_batch(void* ctx, const double* params, int32_t M, double* value, do
         HIPCHK(hipMemcpyAsync(dp, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
         constexpr int CT = 8;
         if (is_sim(c->obj))
-            hipLaunchKernelGGL((k_eval_batch<true, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp, M, dv, dm, ds);
+            hipLaunchKernelGGL((k_eval_batch<1, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp, M, dv, dm, ds);
+        else if (c->obj == SMM_OBJ_DENSE)
+            hipLaunchKernelGGL((k_eval_batch<2, 16>), dim3((M + 15) / 16), dim3(WG), tile_smem(c, 16), c->stream, P, dp, M, dv, dm, ds);
         else
-            hipLaunchKernelGGL((k_eval_batch<false, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp, M, dv, dm, ds);
+            hipLaunchKernelGGL((k_eval_batch<0, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp, M, dv, dm, ds);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(value, dv, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(sim_moments, dm, (size_t)P.nm * M * 8, hipMemcpyDeviceToHost, c->stream));

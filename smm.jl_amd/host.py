@@ -42,6 +42,7 @@ def _no_mprob():
 
 objfunc_norm = DeviceObjective("objfunc_norm", A.SMM_OBJ_NORM, needs_square=True)   # ObjExamples.jl:59-116
 banana = DeviceObjective("banana", A.SMM_OBJ_BANANA, ns=1)                           # ObjExamples.jl:251-265
+dense_sim = DeviceObjective("dense_sim", A.SMM_OBJ_DENSE, ns=1)                     # BASELINE config 5 (include/smmhip.h)
 
 
 class MProb:

@@ -64,7 +64,7 @@ INT_FIELDS = ("best_id", "exchanged", "accepted", "status")
 F64_FIELDS = ("value", "prob", "curr_val", "best_val", "params", "sim_moments")
 
 
-def assert_history_equal(ha, hb, rtol=1e-9, exact_floats=False):
+def assert_history_equal(ha, hb, rtol=1e-9, exact_floats=False, atol=0.0):
     """bit-exact on bookkeeping (accepted / exchanged / best_id / status); floats within rtol
     (BASELINE.json north_star: 1e-6 relative on the objective; we hold 1e-9)."""
     for f in INT_FIELDS:
@@ -77,12 +77,12 @@ def assert_history_equal(ha, hb, rtol=1e-9, exact_floats=False):
         if exact_floats:
             assert np.array_equal(a, b, equal_nan=True), f
         else:
-            np.testing.assert_allclose(a, b, rtol=rtol, atol=0, equal_nan=True, err_msg=f)
+            np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True, err_msg=f)
 
 
-def assert_state_equal(sa, sb, rtol=1e-9):
+def assert_state_equal(sa, sb, rtol=1e-9, atol=0.0):
     assert sa.iter == sb.iter
     for f in ("la_status", "n_noex", "n_acc_noex", "best_id"):
         assert np.array_equal(getattr(sa, f), getattr(sb, f)), f
     for f in ("sigma", "accept_rate", "la_value", "la_prob", "la_params", "la_sim_moments", "best_val"):
-        np.testing.assert_allclose(getattr(sa, f), getattr(sb, f), rtol=rtol, atol=0, equal_nan=True, err_msg=f)
+        np.testing.assert_allclose(getattr(sa, f), getattr(sb, f), rtol=rtol, atol=atol, equal_nan=True, err_msg=f)

@@ -319,3 +319,69 @@ def test_window_boundaries(S, O):
     h, o = run_both(S, O, prob, opts, None)
     cm.assert_history_equal(h.history(), o.history())
     cm.assert_state_equal(h.state(), o.state())
+
+
+def dense_problem(S, O, npar, nm, N, T, seed=3, explicit=True, **kw):
+    from smm_jl_amd import Problem, BGPOpts
+    rng = np.random.default_rng(seed)
+    objp = None
+    if explicit:
+        objp = np.concatenate([rng.standard_normal(A.SMM_DENSE_D * npar) / np.sqrt(npar),
+                               rng.standard_normal(nm * A.SMM_DENSE_D) / np.sqrt(A.SMM_DENSE_D)])
+    prob = Problem(init=rng.uniform(-0.3, 0.3, npar), lb=-np.ones(npar), ub=np.ones(npar),
+                   mom=rng.uniform(-0.5, 0.5, nm), w=rng.uniform(0.5, 2.0, nm), ns=1,
+                   objective_id=A.SMM_OBJ_DENSE, obj_params=objp)
+    opts = BGPOpts(N=kw.pop("N_local", N), maxiter=T, sigma=0.02 * cm.temps(N, 4), acc_tuner=np.geomspace(20, 1, N) if N > 1 else [2.0],
+                   min_improve=np.zeros(N), N_global=N, seed=seed, **kw)
+    return prob, opts
+
+
+@pytest.mark.parametrize("npar,nm", [(1, 1), (3, 2), (6, 5), (17, 33), (50, 50), (64, 64)])
+def test_dense_objective_eval_batch(S, O, npar, nm):
+    # FP64 MFMA path against the oracle's fma chains (same summation order by contract)
+    prob, opts = dense_problem(S, O, npar, nm, N=4, T=2)
+    h, o = make_pair(S, O, prob, opts)
+    rng = np.random.default_rng(1)
+    for M in (1, 15, 16, 17, 200):
+        p = rng.uniform(-1, 1, (npar, M))
+        vh, mh, sh = h.eval_batch(p); vo, mo, so = o.eval_batch(p)
+        np.testing.assert_allclose(mh, mo, rtol=1e-11, atol=1e-13)   # tanh: ocml vs libm
+        np.testing.assert_allclose(vh, vo, rtol=1e-10)
+        assert np.array_equal(sh, so)
+
+
+def test_dense_generated_matrices_match_oracle(S, O):
+    prob, opts = dense_problem(S, O, 7, 9, N=4, T=2, explicit=False)
+    h, o = make_pair(S, O, prob, opts)
+    p = np.random.default_rng(2).uniform(-1, 1, (7, 40))
+    np.testing.assert_allclose(h.eval_batch(p)[1], o.eval_batch(p)[1], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("N", [1, 5, 16, 100])
+def test_dense_bgp_small(S, O, N):
+    prob, opts = dense_problem(S, O, 6, 5, N=N, T=30)
+    h, o = run_both(S, O, prob, opts, None)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+
+
+def test_c5_dense_4096_chains(S, O):
+    # BASELINE config 5 shape: 50 params, 256-wide dense simulation, 4096 chains
+    prob, opts = dense_problem(S, O, 50, 50, N=4096, T=20)
+    h, o = make_pair(S, O, prob, opts, threads=16)
+    h.step(20); o.step(20)
+    # simulated moments cross zero: tanh (ocml vs libm, <= 1 ulp) shows up as an absolute 1e-16 error
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+
+
+def test_c5_dense_sharded_8(S, O):
+    # ... sharded 8 ways (512 chains per shard), against the single-shard run
+    prob, opts = dense_problem(S, O, 50, 50, N=4096, T=8)
+    single = S.hip_context(prob, opts); single.step(8)
+    ctxs = sharded_run(S, prob, opts, 8, 8)
+    hs = single.history()
+    for r, c in enumerate(ctxs):
+        hr = c.history()
+        for f in A.HistoryBuffers.FIELDS:
+            assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * 512:(r + 1) * 512], equal_nan=True), (f, r)
