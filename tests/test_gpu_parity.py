@@ -272,6 +272,22 @@ def test_n_global_above_8192(S, O):
     assert (h.history().exchanged != 0).sum() > 0
 
 
+def test_c3_population_8_temperature_levels(S, O):
+    # BASELINE config 3 shape on one GPU: 32768 chains = 8 temperature levels x 4096 replicas
+    # (sigma = 0.05 * linspace(1,5,8)[level], acc_tuner log-spaced 20 -> 1 per level)
+    from smm_jl_amd import BGPOpts
+    L, R_, T = 8, 4096, 4
+    prob, _ = cm.serial_normal(N=3, T=T, ns=32)
+    opts = BGPOpts(N=L * R_, maxiter=T, sigma=np.repeat(0.05 * np.linspace(1, 5, L), R_),
+                   acc_tuner=np.repeat(np.geomspace(20, 1, L), R_), min_improve=np.zeros(L * R_))
+    h, o = make_pair(S, O, prob, opts, threads=8)
+    h.step(T); o.step(T)
+    hh = h.history()
+    cm.assert_history_equal(hh, o.history())
+    lev = (np.nonzero(hh.exchanged)[1] // R_, (hh.exchanged[hh.exchanged != 0] - 1) // R_)
+    assert (lev[0] != lev[1]).any()  # exchanges between temperature levels happened
+
+
 def test_exchange_worst_case_star_pairs(S, O):
     # injected pair list in which every pair touches chain 0: dependency depth == number of pairs
     N, T = 40, 6
