@@ -65,11 +65,12 @@ __host__ __device__ inline void box_muller(const U4& x, double& z0, double& z1) 
     const double u1 = u53_open0(x.x, x.y);
     const double u2 = u53(x.z, x.w);
     const double r = sqrt(-2.0 * log(u1));
-    const double a = 6.283185307179586476925286766559 * u2;
     double s, c;
 #if defined(__HIP_DEVICE_COMPILE__)
-    sincos(a, &s, &c);
+    // angle 2*pi*u2 in units of pi: exact argument reduction, no large-argument (Payne-Hanek) code in the kernel
+    sincospi(2.0 * u2, &s, &c);
 #else
+    const double a = 6.283185307179586476925286766559 * u2;
     s = sin(a);
     c = cos(a);
 #endif
