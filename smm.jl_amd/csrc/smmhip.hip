@@ -119,6 +119,15 @@ __device__ inline void report_error(const KParams& P, int kind, int t, int gchai
 
 __host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
 
+// The in-kernel generator behind mysample's rare late tries, out of line: its ~40 live registers
+// (Philox rounds, log, sincospi) then weigh only on the path that needs them.
+__device__ __attribute__((noinline)) double2 rng_prop_normal2_outofline(uint64_t seed, uint32_t chain, uint32_t iter,
+                                                                        uint32_t tr, uint32_t q) {
+    double z0, z1;
+    rng_prop_normal2(seed, chain, iter, tr, q, z0, z1);
+    return make_double2(z0, z1);
+}
+
 // ------------------------------------------------------------------------------------------
 // Transposed wave reduction: every lane holds CT partial sums a[0..CT); on return lane l holds the
 // 64-lane total of accumulator acc_index<CT>(l), combined by the canonical halving tree (offsets
@@ -518,7 +527,8 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
                             } else {
                                 if ((k >> 1) != zq) {
                                     zq = k >> 1;
-                                    rng_prop_normal2(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)rr, (uint32_t)zq, zc0, zc1);
+                                    const double2 zz2 = rng_prop_normal2_outofline(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)rr, (uint32_t)zq);
+                                    zc0 = zz2.x; zc1 = zz2.y;
                                 }
                                 z = (k & 1) ? zc1 : zc0;
                             }
