@@ -100,6 +100,8 @@ struct KParams {
     // state
     double* cs;                // [N][CSW]
     unsigned long long* xres;  // [Ng]
+    double* vals;              // [N] value of every chain's last accepted record after the accept step, contiguous
+                               //     (what the single-shard exchange resolution reads: 8 B per chain instead of a record)
     // scratch of the any-size exchange kernel
     int32_t *xsrc, *xpartner, *xnext, *xpairs;
     double* xval;
@@ -619,6 +621,7 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
         } else {
             for (int f = 0; f < RW; ++f) ro[f] = rc[f];
         }
+        P.vals[c] = acc ? value : old;
     }
     // ---- the control wave stores the tile's result blocks ----
     if (valid) {
@@ -990,8 +993,10 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
         pws[m] = (qq < K) ? plan[qq] : 0ull;
         mis[m] = (qq < K) ? plan_mi[qq] : 0.0;
     }
+    const double* __restrict__ vsrc = gathered ? gathered : P.vals;  // single shard: the compact value array
+    const int vstride = gathered ? RW : 1;
     for (int g = tid; g < Ng; g += XWG) {
-        val[g] = gathered[(size_t)g * RW];
+        val[g] = vsrc[(size_t)g * vstride];
         ticket[g] = 0;
         src[g] = (uint16_t)g;
         partner[g] = 0;
@@ -1070,8 +1075,10 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const
     // one level of global loads: values, plan, level offsets (the first 1024 unconditionally)
     const uint32_t nlev_w = g_off[K + 1];
     if (tid < K) loff[tid] = g_off[tid];
+    const double* __restrict__ vsrc = gathered ? gathered : P.vals;  // single shard: the compact value array
+    const int vstride = gathered ? RW : 1;
     for (int g = tid; g < Ng; g += LWG) {
-        val[g] = gathered[(size_t)g * RW];
+        val[g] = vsrc[(size_t)g * vstride];
         src[g] = (uint16_t)g;
         partner[g] = 0;
     }
@@ -1777,6 +1784,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             for (int b = 0; b < 2; ++b) c->rec[b] = dupload(c, rec.data(), rec.size());
         }
         P.xres = dalloc<unsigned long long>(c, Ng);
+        P.vals = dalloc<double>(c, N);
         if (!c->lds_exchange) {
             const int Kmax = std::max(K, 1);
             P.xval = dalloc<double>(c, Ng); P.xnext = dalloc<int32_t>(c, Ng); P.xpairs = dalloc<int32_t>(c, (size_t)Kmax * 2);
@@ -1888,7 +1896,7 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
             c->prev_open = true;
             c->pending = false;
             if (exchange_active(c, t)) {
-                launch_resolve(c, t, c->rec[c->cur]);
+                launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange) ? nullptr : c->rec[c->cur]);
                 c->pending = true;
             }
             if (c->profiling) HIPCHK(hipEventRecord(c->pev[3 * it + 2], c->stream));
