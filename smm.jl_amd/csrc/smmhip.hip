@@ -1055,65 +1055,73 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
 // disjoint chains, so a level is one parallel step and the walk needs (number of levels ~ log N)
 // barriers.  Plan, values and thresholds are staged in LDS with coalesced loads up front.
 constexpr int XLVL_MAX = 4096;
+struct __attribute__((aligned(16))) XSlot {  // one chain during the walk: 16 bytes, moved with one ds_read/write_b128
+    double val;
+    uint32_t src, partner;
+};
 template <int LWG>
 __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const int t, const double* __restrict__ gathered) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     const int tid = threadIdx.x;
     const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
     const int w = t - P.plan_t0;
-    double* val = (double*)xsm;                 // [Ng]
-    double* mi = val + Ng;                      // [K]
+    XSlot* slot = (XSlot*)xsm;                  // [Ng]
+    double* mi = (double*)(slot + Ng);          // [K]
     uint32_t* pairs = (uint32_t*)(mi + K);      // [K]
-    uint32_t* loff = pairs + K;                 // [K+2]
-    uint16_t* src = (uint16_t*)(loff + K + 2);  // [Ng]
-    uint16_t* partner = src + Ng;               // [Ng]
-    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);   // level ends: wave-uniform scalar loads
     const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
     const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
     XTS(0);
     const unsigned long long cyc0 = clock64();
-    // one level of global loads: values, plan, level offsets (the first 1024 unconditionally)
-    const uint32_t nlev_w = g_off[K + 1];
-    if (tid < K) loff[tid] = g_off[tid];
+    // one level of global loads: values, plan
+    const int nlev = (int)g_off[K + 1];
     const double* __restrict__ vsrc = gathered ? gathered : P.vals;  // single shard: the compact value array
     const int vstride = gathered ? RW : 1;
     for (int g = tid; g < Ng; g += LWG) {
-        val[g] = vsrc[(size_t)g * vstride];
-        src[g] = (uint16_t)g;
-        partner[g] = 0;
+        XSlot s_;
+        s_.val = vsrc[(size_t)g * vstride];
+        s_.src = (uint32_t)g;
+        s_.partner = 0;
+        slot[g] = s_;
     }
     for (int q = tid; q < K; q += LWG) { pairs[q] = g_pairs[q]; mi[q] = g_mi[q]; }
-    const int nlev = (int)nlev_w;
-    for (int l = tid + LWG; l < nlev; l += LWG) loff[l] = g_off[l];  // only for very deep lists
+    // the first XLV_REG level ends are read with one wide scalar load and live in SGPRs (no per-level load)
+    constexpr int XLV_REG = 16;
+    uint32_t ends[XLV_REG];
+#pragma unroll
+    for (int l = 0; l < XLV_REG; ++l) ends[l] = g_off[min(l, K)];
     __syncthreads();
     XTS(1);
     uint32_t b = 0;
-    uint32_t e = nlev > 0 ? loff[0] : 0u;
+    uint32_t e = nlev > 0 ? ends[0] : 0u;
     uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
     double m = (b + tid < e) ? mi[b + tid] : 0.0;
-    for (int l = 0; l < nlev; ++l) {
-        // fetch the next level's first pair of this thread while this level is processed
-        const uint32_t e2 = (l + 1 < nlev) ? loff[l + 1] : e;
+    auto run_level = [&](uint32_t e2) {
+        // this thread's first pair of the next level (LDS) is fetched while this level runs
         const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
         const double m2 = (e + tid < e2) ? mi[e + tid] : 0.0;
-        for (uint32_t pos = b + tid; pos < e; pos += LWG) {
+        for (uint32_t pos = b + tid; pos < e && !(P.dbg & 32); pos += LWG) {
             if (pos != b + tid) { pw = pairs[pos]; m = mi[pos]; }
             const uint32_t i = pw & 0xffffu, j = pw >> 16;
-            const double vi = val[i], vj = val[j];
-            if (vi - vj > m) {                          // dist_fun = -, AlgoBGP.jl:688
-                val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744
-                const uint16_t si = src[i];
-                src[i] = src[j]; src[j] = si;
-                partner[i] = (uint16_t)(j + 1); partner[j] = (uint16_t)(i + 1);  // set_exchanged!, :747-748
+            const XSlot si = slot[i], sj = slot[j];
+            if (si.val - sj.val > m) {                  // dist_fun = -, AlgoBGP.jl:688
+                XSlot ni, nj;                           // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                slot[i] = ni;
+                slot[j] = nj;
             }
         }
         b = e; e = e2; pw = pw2; m = m2;
-        if (P.ts && tid == 0 && l < 40) P.ts[(size_t)8 * 60000 + 16 + l] = clock64() - cyc0;
-        __syncthreads();
-        if (P.ts && tid == 0 && l < 40) P.ts[(size_t)8 * 60000 + 56 + l] = clock64() - cyc0;
+        if (!(P.dbg & 64)) __syncthreads();
+    };
+#pragma unroll
+    for (int l = 0; l < XLV_REG; ++l) {
+        if (l < nlev) run_level((l + 1 < nlev) ? ((l + 1 < XLV_REG) ? ends[(l + 1) % XLV_REG] : g_off[l + 1]) : e);
     }
+    for (int l = XLV_REG; l < nlev; ++l) run_level((l + 1 < nlev) ? g_off[l + 1] : e);  // very deep lists
     XTS(3);
-    for (int g = tid; g < Ng; g += LWG) P.xres[g] = (unsigned long long)src[g] | ((unsigned long long)partner[g] << 32);
+    for (int g = tid; g < Ng; g += LWG) P.xres[g] = (unsigned long long)slot[g].src | ((unsigned long long)slot[g].partner << 32);
     XTS(4);
     if (P.ts && tid == 0) { P.ts[(size_t)8 * 60000 + 6] = clock64() - cyc0; P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev; }
 }
@@ -1493,7 +1501,7 @@ size_t tile_smem(const Ctx* c, int ct) {
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
-size_t resolve_lvl_bytes(int Ng, int K) { return (size_t)Ng * 12 + (size_t)K * 16 + 64; }
+size_t resolve_lvl_bytes(int Ng, int K) { return (size_t)Ng * 16 + (size_t)K * 12 + 64; }
 
 int exchange_K(const Ctx* c) { return c->P.pairtab ? c->P.n_pairs_tab : n_exchange_pairs(c->P.Ng); }
 bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P.Ng > 1; }  // AlgoBGP.jl:637
