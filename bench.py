@@ -135,15 +135,19 @@ def main():
         ctx.step(ITERS_PER_STEP)
         tm = ctx.timing()
         ctx.set_profiling(False)
-        k_us = tm.iter_kernel_ms * 1e3 / ITERS_PER_STEP
-        x_us = tm.exch_kernel_ms * 1e3 / ITERS_PER_STEP
+        # every hipEvent bracket contains a fixed overhead (measured by brackets around nothing in the same
+        # stream): subtract it, so that the figure agrees with rocprofv3's per-kernel duration
+        null_us = tm.null_bracket_ms * 1e3 / ITERS_PER_STEP
+        k_us = tm.iter_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
+        x_us = tm.exch_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
         flops = n_loc * FLOP_PER_EVAL
         byts = n_loc * BYTES_PER_EVAL
         ach = flops / (k_us * 1e-6) / 1e12
         hbm = byts / (k_us * 1e-6) / 1e9
         roof = {"bound": "valu_fp64", "kernel": "k_chain_iter", "achieved": ach, "peak": PEAK_FP64_ADD_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP64_ADD_TFLOPS, "traffic": None,
-                "avg_kernel_us": k_us, "avg_exchange_us": x_us, "profiled_step_ms": tm.step_ms,
+                "avg_kernel_us": k_us, "avg_exchange_us": x_us, "event_bracket_overhead_us": null_us,
+                "profiled_step_ms": tm.step_ms,
                 "note": "2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes "
                         "x 2.4GHz adds/s (FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)",
                 "hbm": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",

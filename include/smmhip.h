@@ -160,6 +160,8 @@ typedef struct {
     int64_t chain_evals;  /* chain evaluations performed by the last smm_bgp_step      */
     int32_t iters;
     int32_t reserved;
+    double null_bracket_ms;/* summed device time of event pairs that bracket nothing: the per-bracket
+                              overhead contained in iter_kernel_ms / exch_kernel_ms            */
 } smm_timing_t;
 
 int  smm_abi_version(void);

@@ -89,6 +89,7 @@ class smm_timing_t(C.Structure):
     _fields_ = [
         ("step_ms", C.c_double), ("iter_kernel_ms", C.c_double), ("exch_kernel_ms", C.c_double),
         ("chain_evals", C.c_int64), ("iters", C.c_int32), ("reserved", C.c_int32),
+        ("null_bracket_ms", C.c_double),
     ]
 
 

@@ -1444,7 +1444,7 @@ struct Ctx {
     bool pending_timing = false;
     bool profiling = false;
     bool force_any_exchange = false;
-    std::vector<hipEvent_t> pev;  // profiling events: 3 per iteration
+    std::vector<hipEvent_t> pev;  // profiling events: 4 per iteration (the last two bracket nothing: the event overhead)
     int pev_iters = 0;
     // double-buffered last-accepted records [N][RW]
     double* rec[2] = {nullptr, nullptr};
@@ -1863,12 +1863,15 @@ int smm_sync(void* ctx) {
             c->pending_timing = false;
             c->timing.iter_kernel_ms = 0.0;
             c->timing.exch_kernel_ms = 0.0;
+            c->timing.null_bracket_ms = 0.0;
             for (int i = 0; i < c->pev_iters; ++i) {
-                float a = 0.f, b = 0.f;
-                HIPCHK(hipEventElapsedTime(&a, c->pev[3 * i], c->pev[3 * i + 1]));
-                HIPCHK(hipEventElapsedTime(&b, c->pev[3 * i + 1], c->pev[3 * i + 2]));
+                float a = 0.f, b = 0.f, n = 0.f;
+                HIPCHK(hipEventElapsedTime(&a, c->pev[4 * i], c->pev[4 * i + 1]));
+                HIPCHK(hipEventElapsedTime(&b, c->pev[4 * i + 1], c->pev[4 * i + 2]));
+                HIPCHK(hipEventElapsedTime(&n, c->pev[4 * i + 2], c->pev[4 * i + 3]));
                 c->timing.iter_kernel_ms += a;
                 c->timing.exch_kernel_ms += b;
+                c->timing.null_bracket_ms += n;
             }
             c->pev_iters = 0;
         }
@@ -1886,7 +1889,7 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
     try {
         HIPCHK(hipSetDevice(c->device));
         if (c->profiling) {
-            while ((int)c->pev.size() < 3 * n_iters) {
+            while ((int)c->pev.size() < 4 * n_iters) {
                 hipEvent_t e;
                 HIPCHK(hipEventCreate(&e));
                 c->pev.push_back(e);
@@ -1898,16 +1901,16 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
             const int t = c->iter + 1;
             ensure_windows(c, t);
             const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
-            if (c->profiling) HIPCHK(hipEventRecord(c->pev[3 * it], c->stream));
+            if (c->profiling) HIPCHK(hipEventRecord(c->pev[4 * it], c->stream));
             launch_chain_iter(c, t, flags);
-            if (c->profiling) HIPCHK(hipEventRecord(c->pev[3 * it + 1], c->stream));
+            if (c->profiling) HIPCHK(hipEventRecord(c->pev[4 * it + 1], c->stream));
             c->prev_open = true;
             c->pending = false;
             if (exchange_active(c, t)) {
                 launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange) ? nullptr : c->rec[c->cur]);
                 c->pending = true;
             }
-            if (c->profiling) HIPCHK(hipEventRecord(c->pev[3 * it + 2], c->stream));
+            if (c->profiling) { HIPCHK(hipEventRecord(c->pev[4 * it + 2], c->stream)); HIPCHK(hipEventRecord(c->pev[4 * it + 3], c->stream)); }
             c->iter = t;
         }
         HIPCHK(hipEventRecord(c->ev1, c->stream));
