@@ -29,6 +29,28 @@ PEAK_FP64_ADD_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3: 256 CU x 4 SIMD x 16
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic():
+    """HBM bytes per k_chain_iter launch from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
+    WRITE_SIZE are KB per launch; gfx950's FETCH_SIZE tallies wide coalesced reads at half their size
+    (MI355X_MICROARCH.md, HBM) so it is doubled.  None when no profile is committed."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+    if not files:
+        return None, None
+    fetch = write = None
+    for line in open(files[-1]):
+        if "k_chain_iter<1, 8>" in line or "k_chain_iter<1," in line:
+            m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+launches=\s*\d+\s+mean_per_launch=\s*([0-9.]+)", line)
+            if m and m.group(1) == "FETCH_SIZE":
+                fetch = float(m.group(2))
+            elif m:
+                write = float(m.group(2))
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT)
+
+
 def host_cores():
     """cores this process may really use: affinity mask and cgroup quota, not the machine total"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -144,14 +166,17 @@ def main():
         byts = n_loc * BYTES_PER_EVAL
         ach = flops / (k_us * 1e-6) / 1e12
         hbm = byts / (k_us * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic()
         roof = {"bound": "valu_fp64", "kernel": "k_chain_iter", "achieved": ach, "peak": PEAK_FP64_ADD_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_FP64_ADD_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": ach / PEAK_FP64_ADD_TFLOPS, "traffic": traffic,
+                "traffic_note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from %s; algorithmic: %d B"
+                                % (traffic_src, byts),
                 "avg_kernel_us": k_us, "avg_exchange_us": x_us, "event_bracket_overhead_us": null_us,
                 "profiled_step_ms": tm.step_ms,
                 "note": "2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes "
                         "x 2.4GHz adds/s (FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)",
                 "hbm": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": hbm / PEAK_HBM_GBS, "traffic": None,
+                        "frac": hbm / PEAK_HBM_GBS, "traffic": traffic,
                         "note": "algorithmic 128 B per chain-eval; small by construction"}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
