@@ -1073,30 +1073,67 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const
     const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
     XTS(0);
     const unsigned long long cyc0 = clock64();
-    // one level of global loads: values, plan
-    const int nlev = (int)g_off[K + 1];
+    // ONE round trip of global loads: values, plan and level ends are all requested before the first wait
+    // (the values were written by other XCDs a moment ago and come from memory-side cache, ~1 us away;
+    // a load-store loop would pay that latency once per trip).
+    constexpr int PT = XLVL_MAX / LWG;
     const double* __restrict__ vsrc = gathered ? gathered : P.vals;  // single shard: the compact value array
     const int vstride = gathered ? RW : 1;
-    for (int g = tid; g < Ng; g += LWG) {
-        XSlot s_;
-        s_.val = vsrc[(size_t)g * vstride];
-        s_.src = (uint32_t)g;
-        s_.partner = 0;
-        slot[g] = s_;
-    }
-    for (int q = tid; q < K; q += LWG) { pairs[q] = g_pairs[q]; mi[q] = g_mi[q]; }
-    // the first XLV_REG level ends are read with one wide scalar load and live in SGPRs (no per-level load)
-    constexpr int XLV_REG = 16;
-    uint32_t ends[XLV_REG];
+    const int lane = tid & 63;
+    double v_[PT], mq_[PT];
+    uint32_t pq_[PT];
 #pragma unroll
-    for (int l = 0; l < XLV_REG; ++l) ends[l] = g_off[min(l, K)];
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * LWG;
+        v_[r] = g < Ng ? vsrc[(size_t)g * vstride] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * LWG;
+        pq_[r] = q < K ? g_pairs[q] : 0u;
+        mq_[r] = q < K ? g_mi[q] : 0.0;
+    }
+    const uint32_t ev = g_off[min(lane, K)];   // lane l: end of level l (entries past the last level are unused)
+    const int nlev = (int)g_off[K + 1];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * LWG;
+        if (g < Ng) {
+            XSlot s_;
+            s_.val = v_[r];
+            s_.src = (uint32_t)g;
+            s_.partner = 0;
+            slot[g] = s_;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * LWG;
+        if (q < K) { pairs[q] = pq_[r]; mi[q] = mq_[r]; }
+    }
+    for (int q = tid + PT * LWG; q < K; q += LWG) { pairs[q] = g_pairs[q]; mi[q] = g_mi[q]; }  // K > XLVL_MAX: injected long pair lists
+    // Level ends: lane l of every wave holds the end of level l (one coalesced load, read back with
+    // v_readlane).  The level loop stays ROLLED on purpose: the kernel runs once per iteration on a CU whose
+    // instruction cache has been flushed by the chain kernel in between, so every byte of straight-line code
+    // is an instruction-fetch miss.
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
+    const int ltail = nlev;
     __syncthreads();
     XTS(1);
     uint32_t b = 0;
-    uint32_t e = nlev > 0 ? ends[0] : 0u;
+    int lvc = 0;
+    unsigned long long* lts = (unsigned long long*)(pairs + K + (K & 1));   // [64] level stamps (debug)
+    if (P.ts && tid == 0) lts[63] = clock64() - cyc0;
+    uint32_t e = nlev > 0 ? level_end(0) : 0u;
+    uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
     uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
     double m = (b + tid < e) ? mi[b + tid] : 0.0;
-    auto run_level = [&](uint32_t e2) {
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < ltail; ++l) {
+        const uint32_t e3 = level_end(l + 2);
         // this thread's first pair of the next level (LDS) is fetched while this level runs
         const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
         const double m2 = (e + tid < e2) ? mi[e + tid] : 0.0;
@@ -1112,14 +1149,15 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const
                 slot[j] = nj;
             }
         }
-        b = e; e = e2; pw = pw2; m = m2;
+        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
         if (!(P.dbg & 64)) __syncthreads();
-    };
-#pragma unroll
-    for (int l = 0; l < XLV_REG; ++l) {
-        if (l < nlev) run_level((l + 1 < nlev) ? ((l + 1 < XLV_REG) ? ends[(l + 1) % XLV_REG] : g_off[l + 1]) : e);
+        if (P.ts && tid == 0) { lts[lvc & 31] = clock64() - cyc0; ++lvc; }
     }
-    for (int l = XLV_REG; l < nlev; ++l) run_level((l + 1 < nlev) ? g_off[l + 1] : e);  // very deep lists
+    if (P.ts && tid == 0) {
+        P.ts[(size_t)8 * 60000 + 15] = lts[63];
+        for (int l = 0; l < min(lvc, 32); ++l) P.ts[(size_t)8 * 60000 + 16 + l] = lts[l];
+        P.ts[(size_t)8 * 60000 + 14] = (unsigned long long)ltail;
+    }
     XTS(3);
     for (int g = tid; g < Ng; g += LWG) P.xres[g] = (unsigned long long)slot[g].src | ((unsigned long long)slot[g].partner << 32);
     XTS(4);
@@ -1501,7 +1539,7 @@ size_t tile_smem(const Ctx* c, int ct) {
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
-size_t resolve_lvl_bytes(int Ng, int K) { return (size_t)Ng * 16 + (size_t)K * 12 + 64; }
+size_t resolve_lvl_bytes(int Ng, int K) { return (size_t)Ng * 16 + (size_t)K * 12 + 64 * 8 + 64; }
 
 int exchange_K(const Ctx* c) { return c->P.pairtab ? c->P.n_pairs_tab : n_exchange_pairs(c->P.Ng); }
 bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P.Ng > 1; }  // AlgoBGP.jl:637

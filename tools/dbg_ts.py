@@ -36,3 +36,7 @@ lib.smm_debug_ts(ctx._ctx, x.ctypes.data_as(C.c_void_p), -1)
 xs = x.astype(np.float64) / 100.0
 print("resolve kernel (thread 0): loads+init %.2f  levels %.2f  store %.2f us" % (xs[1]-xs[0], xs[3]-xs[1], xs[4]-xs[3]))
 print("resolve: %d levels, %d shader cycles over %.2f us -> %.0f MHz" % (int(x[7]), int(x[6]), xs[4]-xs[0], x[6]/(xs[4]-xs[0])))
+
+print("cycles at level ends (thread 0, shader clock):", [int(v) for v in x[15:15+int(x[7])+1]])
+print("ltail", int(x[14]))
+print("per level:", np.diff(x[15:15+int(x[7])+1].astype(np.int64)).tolist())
