@@ -383,6 +383,30 @@ __device__ inline void coop_load(double* lds_blk, const double* __restrict__ g, 
 #pragma unroll 2
     for (int i = r; i < W / 2; i += NR) ld[i] = gs[i];
 }
+// the same in two halves, so that the loads of several blocks are in flight together: coop_fetch requests
+// the first NI pieces per lane into registers, coop_put writes them to LDS (and moves what is left of a long block)
+template <int CT, int NI>
+__device__ inline void coop_fetch(double2 (&v)[NI], const double* __restrict__ g, int W, int r) {
+    constexpr int NR = 64 / CT;
+    const double2* __restrict__ gs = (const double2*)g;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = r + k * NR;
+        v[k] = i < W / 2 ? gs[i] : make_double2(0.0, 0.0);
+    }
+}
+template <int CT, int NI>
+__device__ inline void coop_put(double* lds_blk, const double2 (&v)[NI], const double* __restrict__ g, int W, int r) {
+    constexpr int NR = 64 / CT;
+    const double2* __restrict__ gs = (const double2*)g;
+    double2* ld = (double2*)lds_blk;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = r + k * NR;
+        if (i < W / 2) ld[i] = v[k];
+    }
+    for (int i = r + NI * NR; i < W / 2; i += NR) ld[i] = gs[i];
+}
 template <int CT>
 __device__ inline void coop_store(double* __restrict__ g, const double* lds_blk, int W, int r) {
     constexpr int NR = 64 / CT;
@@ -444,12 +468,22 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
         // level 1: exchange result, chain state block, this iteration's randomness block
         unsigned long long xr = (unsigned long long)(unsigned)gc;
         if (flags & F_HAS_PENDING) xr = P.xres[gc];
-        coop_load<CT>(S.cs + cl * CSW, P.cs + (size_t)c * CSW, CSW, r);
-        if (t > 1) coop_load<CT>(S.rb + cl * RBW, P.rb + ((size_t)(t - P.rb_t0) * N + c) * RBW, RBW, r);
-        // level 2: the record the chain continues from (its own, or the donor's)
+        constexpr int NI_CS = (CSW / 2 + NR - 1) / NR, NI_RB = (12 + NR - 1) / NR, NI_REC = (8 + NR - 1) / NR;
+        double2 v_cs[NI_CS], v_rb[NI_RB], v_rec[NI_REC];
+        const double* g_cs = P.cs + (size_t)c * CSW;
+        const double* g_rb = P.rb + ((size_t)(t > 1 ? t - P.rb_t0 : 0) * N + c) * RBW;
+        const int rbw = t > 1 ? RBW : 0;
+        coop_fetch<CT, NI_CS>(v_cs, g_cs, CSW, r);
+        coop_fetch<CT, NI_RB>(v_rb, g_rb, rbw, r);
+        // level 2: the record the chain continues from (its own, or the donor's); requested as soon as the
+        // exchange result is here, while the level-1 blocks are still in flight
         const int s = (int)(unsigned)(xr & 0xffffffffu) - P.offset;
         partner = (int)(xr >> 32);
-        coop_load<CT>(S.rec + cl * RW, rec_in + (size_t)s * RW, RW, r);
+        const double* g_rec = rec_in + (size_t)s * RW;
+        coop_fetch<CT, NI_REC>(v_rec, g_rec, RW, r);
+        coop_put<CT, NI_CS>(S.cs + cl * CSW, v_cs, g_cs, CSW, r);
+        coop_put<CT, NI_RB>(S.rb + cl * RBW, v_rb, g_rb, rbw, r);
+        coop_put<CT, NI_REC>(S.rec + cl * RW, v_rec, g_rec, RW, r);
     }
     TS_MARK(1);
     __syncthreads();
