@@ -174,22 +174,38 @@ __device__ inline bool acc_writer(int lane) {
 // chunk is added up.  Chunk 0 of moment 0 is loaded by the caller before its serial prologue.
 constexpr int ZU = 8;
 
-__device__ inline void sim_load_chunk(const double* __restrict__ Zk, int ch, int tid, double (&z)[ZU], int dbg) {
-    // uniform row base + lane offset: no per-load address arithmetic (the padding makes every row loadable)
-    const double* __restrict__ base = Zk + (size_t)((dbg & 8) ? 0 : ch) * (ZU * WG) + tid;  // dbg 8: timing experiment
+// The shock matrix is read through a buffer descriptor: row = scalar byte offset (SALU), lane = one constant
+// 32-bit vector offset, so a chunk load is ZU buffer_load instructions and no vector address arithmetic.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+struct ZBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lane_off;  // tid * 8
+    __device__ inline void init(const KParams& P, int tid) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.Z, 0, (int)((size_t)P.nm * P.zstride * sizeof(double)), 0x00020000);
+        lane_off = tid * (int)sizeof(double);
+    }
+};
+// chunk ch of moment k
+__device__ inline void sim_load_chunk(const ZBuf& zb, const KParams& P, int k, int ch, double (&z)[ZU]) {
+    const int row0 = (k * P.zstride + ((P.dbg & 8) ? 0 : ch) * (ZU * WG)) * (int)sizeof(double);  // dbg 8: timing experiment
 #pragma unroll
-    for (int u = 0; u < ZU; ++u) z[u] = base[u * WG];
+    for (int u = 0; u < ZU; ++u)
+        z[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zb.rsrc, zb.lane_off, row0 + u * WG * (int)sizeof(double), 0));
 }
 
 // zc: chunk 0 of moment 0 (already loaded).  s_theta [CT][np], s_part [WG/64][CT][nm] in LDS.
 // Moments are reduced in groups of G = 16/CT: one transposed reduction of G*CT accumulators has the
 // same number of dependent shuffle steps as one of CT, so grouping halves that latency for CT = 8.
+// A moment is nch chunks; the last one may be ragged (rows masked per lane).  Two chunks per trip, the
+// two register buffers trade places; the chunk after a moment's last is chunk 0 of the next moment.
 template <int CT>
-__device__ inline void simulate_tile(const KParams& P, const double* s_theta, double* s_part, int tid, double (&zc)[ZU]) {
+__device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const double* s_theta, double* s_part, int tid, double (&zc)[ZU]) {
     constexpr int G = (CT >= 16) ? 1 : 16 / CT;
     const int lane = tid & 63, wave = tid >> 6;
     const int ns = P.ns, nm = P.nm;
-    const int nfull = ns / (ZU * WG);  // chunks in which every lane has all ZU draws (uniform)
+    const int nch = (ns + ZU * WG - 1) / (ZU * WG);
+    const int last_draws = ns - (nch - 1) * (ZU * WG);   // draws of the last chunk, 1 .. ZU*WG
+    const bool ragged = last_draws < ZU * WG;
     for (int k0 = 0; k0 < nm; k0 += G) {
         double acc[G * CT];
 #pragma unroll
@@ -198,43 +214,48 @@ __device__ inline void simulate_tile(const KParams& P, const double* s_theta, do
         for (int kk = 0; kk < G; ++kk) {
             const int k = k0 + kk;
             if (k < nm) {
-                const double* __restrict__ Zk = P.Z + (size_t)k * P.zstride;
-                double mu[CT], zt[ZU];
-                // the ragged rest (< ZU rows): loaded now, used after the full chunks
-                sim_load_chunk(Zk, nfull, tid, zt, P.dbg);
+                double mu[CT];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) mu[c] = s_theta[c * P.np + k];
-                for (int ch = 0; ch < nfull; ++ch) {
-                    double zn[ZU];
-                    // next chunk of this moment, or chunk 0 of the next moment (last moment: harmless reload)
-                    const bool last = (ch + 1 == nfull);
-                    const double* __restrict__ Zn = (last && k + 1 < nm) ? Zk + P.zstride : Zk;
-                    sim_load_chunk(Zn, last ? 0 : ch + 1, tid, zn, P.dbg);
+                auto add_full = [&](const double (&z)[ZU]) {
 #pragma unroll
                     for (int u = 0; u < ZU; ++u) {
 #pragma unroll
                         for (int c = 0; c < CT; ++c) {
-                            const double x = zc[u] + mu[c];
+                            const double x = z[u] + mu[c];
                             acc[kk * CT + c] = acc[kk * CT + c] + x;
                         }
                     }
-#pragma unroll
-                    for (int u = 0; u < ZU; ++u) zc[u] = zn[u];
-                }
-                {
-                    const int s0 = nfull * ZU * WG + tid;
+                };
+                auto add_last = [&](const double (&z)[ZU]) {
+                    if (!ragged) { add_full(z); return; }
 #pragma unroll
                     for (int u = 0; u < ZU; ++u) {
-                        if (s0 + u * WG < ns) {
+                        if (tid + u * WG < last_draws) {
 #pragma unroll
                             for (int c = 0; c < CT; ++c) {
-                                const double x = zt[u] + mu[c];
+                                const double x = z[u] + mu[c];
                                 acc[kk * CT + c] = acc[kk * CT + c] + x;
                             }
                         }
                     }
+                };
+                const int knext = (k + 1 < nm) ? k + 1 : k;   // last moment: a harmless reload
+                double zn[ZU];
+                int ch = 0;
+                for (; ch + 2 <= nch; ch += 2) {
+                    sim_load_chunk(zb, P, k, ch + 1, zn);
+                    add_full(zc);
+                    const bool last = (ch + 2 == nch);
+                    sim_load_chunk(zb, P, last ? knext : k, last ? 0 : ch + 2, zc);
+                    if (last) add_last(zn); else add_full(zn);
                 }
-                if (nfull == 0 && k + 1 < nm) sim_load_chunk(Zk + P.zstride, 0, tid, zc, P.dbg);  // keeps zc defined (unused)
+                if (ch < nch) {  // odd count: the last chunk is in zc; afterwards the buffers are swapped by copy
+                    sim_load_chunk(zb, P, knext, 0, zn);
+                    add_last(zc);
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u) zc[u] = zn[u];
+                }
             }
         }
         const double tot = wave_reduce_transposed<G * CT>(acc, lane);
@@ -458,7 +479,24 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
 
     // ---- global reads, all issued before anything waits ----
     double za[ZU];
-    if constexpr (KIND == 1) sim_load_chunk(P.Z, 0, tid, za, P.dbg);
+    ZBuf zb;
+    if constexpr (KIND == 1) { zb.init(P, tid); sim_load_chunk(zb, P, 0, 0, za); }
+    if constexpr (KIND == 1) {
+        // Wave 2 warms the L2: the launch boundary invalidated it, and the first tile of an XCD to stream a chunk
+        // of the shock matrix would pay the memory latency chunk by chunk (measured: 11 us of simulation in
+        // those tiles against 6 us in the ones that follow them).  Workgroups are dealt round-robin to the 8
+        // XCDs, so the 64 tiles (blockIdx>>3) of an XCD each touch 1/64 of the matrix, all at once, while the
+        // serial prologue runs.  A hint only: nothing depends on which tiles share an L2.
+        if (tid >= 128 && tid < 192) {
+            const size_t nlines = ((size_t)nm * P.zstride * sizeof(double) + 127) / 128;
+            const size_t per = (nlines + 63) / 64;
+            const size_t first = (size_t)((blockIdx.x >> 3) & 63) * per;
+            unsigned touched = 0;
+            for (size_t l = tid - 128; l < per; l += 64)
+                if (first + l < nlines) touched |= ((const unsigned*)P.Z)[(first + l) * 32];
+            asm volatile("" ::"v"(touched));
+        }
+    }
     if (tid >= 64 && tid < 128) {  // wave 1: problem constants
         for (int k = tid - 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; S.init[k] = P.init[k]; }
         for (int k = tid - 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
@@ -489,14 +527,13 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
     __syncthreads();
 
     // ---- settle iteration t-1 (chain lanes; registers + LDS only) ----
-    double sig = 0.0, bp = INFINITY, bpid = -1.0, atun = 0.0, u = 0.0;
-    int nn = 0, na = 0;
+    // (its results go back to the LDS block and are read again after the simulation: nothing of the serial
+    // bookkeeping stays in registers across the register-hungry simulation loop)
     if (chain_lane) {
-        const double* csb = S.cs + cl * CSW;
-        sig = csb[CS_SIGMA]; nn = (int)csb[CS_NNOEX]; na = (int)csb[CS_NACC];
-        bp = csb[CS_BEST]; bpid = csb[CS_BESTID]; atun = csb[CS_ATUN];
+        double* csb = S.cs + cl * CSW;
+        int nn = (int)csb[CS_NNOEX], na = (int)csb[CS_NACC];
+        double bp = csb[CS_BEST], bpid = csb[CS_BESTID];
         if (t > 1) {
-            u = S.rb[cl * RBW];  // probs_acc[iter], :85
             bool exch_prev = false;
             if (partner != 0) {  // swap_ev_ij!, :734-749: iteration t-1's record becomes the donor's
                 exch_prev = true;
@@ -506,7 +543,8 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
             }
             if ((flags & F_CLOSE_PREV) && !exch_prev) { nn += 1; na += (int)csb[CS_LACC]; }  // set_acceptRate!, :253-257
         }
-        S.cs[cl * CSW + CS_PARTNER] = (double)partner;
+        csb[CS_NNOEX] = (double)nn; csb[CS_NACC] = (double)na; csb[CS_BEST] = bp; csb[CS_BESTID] = bpid;
+        csb[CS_PARTNER] = (double)partner;
     }
     TS_MARK(5);
     // ---- proposal(c), AlgoBGP.jl:424-471: lane (cl, r) evaluates try r of chain cl ----
@@ -591,7 +629,7 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
 
     // ---- simulation: all 512 lanes, ns draws x nm moments x CT chains ----
     if constexpr (KIND == 1) {
-        if (!(P.dbg & 2)) simulate_tile<CT>(P, S.theta, S.part, tid, za);
+        if (!(P.dbg & 2)) simulate_tile<CT>(P, zb, S.theta, S.part, tid, za);
         __syncthreads();
     } else if constexpr (KIND == 2) {
         dense_tile<CT>(P, S.theta, S.part, tid);
@@ -611,6 +649,9 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
         double value;
         int status;
         finish_objective<CT>(P, th, S.part, S.mom, S.w, cl, sm, value, status);
+        const double sig = csb[CS_SIGMA], bp = csb[CS_BEST], bpid = csb[CS_BESTID], atun = csb[CS_ATUN];
+        const int nn = (int)csb[CS_NNOEX], na = (int)csb[CS_NACC];
+        const double u = t > 1 ? S.rb[cl * RBW] : 0.0;  // probs_acc[iter], :85
 
         const double old = rc[0];
         double prob;
@@ -720,14 +761,15 @@ __global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const dou
     const int i = blockIdx.x * CT + tid;
     const bool chain_lane = (tid < CT) && (i < M);
     double za[ZU];
-    if constexpr (KIND == 1) sim_load_chunk(P.Z, 0, tid, za, P.dbg);
+    ZBuf zb;
+    if constexpr (KIND == 1) { zb.init(P, tid); sim_load_chunk(zb, P, 0, 0, za); }
     if (tid >= 64 && tid < 128)
         for (int k = tid - 64; k < P.nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
     if (tid < CT)
         for (int k = 0; k < P.np; ++k) S.theta[tid * P.np + k] = chain_lane ? params[(size_t)k * M + i] : 0.0;
     __syncthreads();
     if constexpr (KIND == 1) {
-        simulate_tile<CT>(P, S.theta, S.part, tid, za);
+        simulate_tile<CT>(P, zb, S.theta, S.part, tid, za);
         __syncthreads();
     } else if constexpr (KIND == 2) {
         dense_tile<CT>(P, S.theta, S.part, tid);
