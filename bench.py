@@ -114,7 +114,7 @@ def main():
     n_loc = args.chains
     n_glob = n_loc * world
     K, W = args.steps, args.warmup
-    T = ITERS_PER_STEP * (K + W + 1)
+    T = ITERS_PER_STEP * (K + W + 2)   # + the two profiled steps
     prob, opts = cm.serial_normal(N=n_glob, T=T, N_local=n_loc, chain_offset=rank * n_loc, device=local_rank)
     ctx = S.hip_context(prob, opts)
 
@@ -153,15 +153,22 @@ def main():
     # roofline of the dominant kernel (k_chain_iter), HIP events on the library's stream
     roof = None
     if world == 1 and not force_sharded:
-        ctx.set_profiling(True)
+        # (a) the kernels' own start/stop events (hipExtLaunchKernelGGL on the library's stream): dispatch begin to
+        #     end as the command processor stamps it -- the same quantity rocprofv3 --kernel-trace reports
+        ctx.set_profiling(2)
         ctx.step(ITERS_PER_STEP)
         tm = ctx.timing()
-        ctx.set_profiling(False)
-        # every hipEvent bracket contains a fixed overhead (measured by brackets around nothing in the same
-        # stream): subtract it, so that the figure agrees with rocprofv3's per-kernel duration
-        null_us = tm.null_bracket_ms * 1e3 / ITERS_PER_STEP
-        k_us = tm.iter_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
-        x_us = tm.exch_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
+        k_us = tm.iter_kernel_ms * 1e3 / ITERS_PER_STEP
+        x_us = tm.exch_kernel_ms * 1e3 / ITERS_PER_STEP   # the chains are past iteration 1: every iteration exchanges
+        # (b) event brackets around the kernels minus the measured empty-bracket overhead: the kernels' net cost on
+        #     the stream (excludes the part of dispatch/drain that overlaps with the neighbours)
+        ctx.set_profiling(1)
+        ctx.step(ITERS_PER_STEP)
+        tb = ctx.timing()
+        ctx.set_profiling(0)
+        null_us = tb.null_bracket_ms * 1e3 / ITERS_PER_STEP
+        k_net_us = tb.iter_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
+        x_net_us = tb.exch_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
         flops = n_loc * FLOP_PER_EVAL
         byts = n_loc * BYTES_PER_EVAL
         ach = flops / (k_us * 1e-6) / 1e12
@@ -171,7 +178,10 @@ def main():
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP64_ADD_TFLOPS, "traffic": traffic,
                 "traffic_note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from %s; algorithmic: %d B"
                                 % (traffic_src, byts),
-                "avg_kernel_us": k_us, "avg_exchange_us": x_us, "event_bracket_overhead_us": null_us,
+                "avg_kernel_us": k_us, "avg_exchange_us": x_us,
+                "net_kernel_us": k_net_us, "net_exchange_us": x_net_us, "event_bracket_overhead_us": null_us,
+                "timing_note": "avg_*: per-kernel start/stop events (dispatch duration, what rocprofv3 reports; used for "
+                               "'achieved'); net_*: event brackets minus the empty-bracket overhead",
                 "profiled_step_ms": tm.step_ms,
                 "note": "2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes "
                         "x 2.4GHz adds/s (FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)",

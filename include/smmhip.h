@@ -205,8 +205,12 @@ int  smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out);
 int  smm_get_state(void* ctx, smm_state_t* out);
 int  smm_set_state(void* ctx, const smm_state_t* in, const smm_history_t* hist /* iterations 0..iter-1 */);
 int  smm_get_timing(void* ctx, smm_timing_t* out);
-/* on != 0: bracket every kernel of smm_bgp_step with hipEvents on the ctx stream so that
- * smm_get_timing reports iter_kernel_ms / exch_kernel_ms (sums over the last step). */
+/* on = 1: bracket every kernel of smm_bgp_step with hipEvents on the ctx stream so that
+ * smm_get_timing reports iter_kernel_ms / exch_kernel_ms (sums over the last step; each bracket
+ * contains the event overhead reported as null_bracket_ms).
+ * on = 2: the kernels carry their own start/stop events (hipExtLaunchKernelGGL): the sums are the
+ * dispatch-begin to dispatch-end durations the command processor stamps, i.e. what rocprofv3
+ * --kernel-trace reports; null_bracket_ms = 0.   on = 0: off. */
 int  smm_set_profiling(void* ctx, int32_t on);
 /* copy of the shock matrix actually used, [nm][ns] */
 int  smm_get_Z(void* ctx, double* Z);

@@ -177,7 +177,8 @@ class BGPContext:
         return t
 
     def set_profiling(self, on=True):
-        self._check(self._fn("set_profiling")(self._ctx, int(bool(on))))
+        """0/False off; 1/True event brackets; 2 per-kernel begin/end timestamps (see include/smmhip.h)"""
+        self._check(self._fn("set_profiling")(self._ctx, int(on)))
 
     def Z(self):
         z = np.empty((self.nm, self.problem.ns))

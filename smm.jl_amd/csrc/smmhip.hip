@@ -28,6 +28,7 @@
 //                         params[np], simM[nm]   (transposed to the ABI's SoA on download)
 //   xres [Ng]             exchange result: src | partner<<32
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1556,7 +1557,9 @@ struct Ctx {
     std::string err;
     smm_timing_t timing{};
     bool pending_timing = false;
-    bool profiling = false;
+    int profiling = 0;   // 1: event brackets around the kernels; 2: the kernels' own begin/end timestamps (hipExtLaunchKernelGGL)
+    hipEvent_t kev0 = nullptr, kev1 = nullptr;   // mode 2: start/stop events of the next launch
+    std::vector<char> pev_exch;
     bool force_any_exchange = false;
     std::vector<hipEvent_t> pev;  // profiling events: 4 per iteration (the last two bracket nothing: the event overhead)
     int pev_iters = 0;
@@ -1652,8 +1655,12 @@ void ensure_windows(Ctx* c, int t) {
 template <int KIND, int CT>
 void launch_chain_iter_ct(Ctx* c, int t, int flags) {
     const KParams& P = c->P;
-    hipLaunchKernelGGL((k_chain_iter<KIND, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, t,
-                       (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
+    if (c->kev0)   // profiling mode 2: begin/end of this dispatch as the command processor stamps them
+        hipExtLaunchKernelGGL((k_chain_iter<KIND, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, c->kev0,
+                              c->kev1, 0, P, t, (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
+    else
+        hipLaunchKernelGGL((k_chain_iter<KIND, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, t,
+                           (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
 }
 
 void launch_chain_iter(Ctx* c, int t, int flags) {
@@ -1679,7 +1686,11 @@ void launch_resolve(Ctx* c, int t, const double* gathered) {
         else if (c->lvl_wg == 512)
             hipLaunchKernelGGL(k_exch_resolve_lvl<512>, dim3(1), dim3(512), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
         else
-            hipLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+            if (c->kev0)
+                hipExtLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, c->kev0,
+                                      c->kev1, 0, P, t, gathered);
+            else
+                hipLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
     else if (c->lds_exchange)
         hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), resolve_lds_bytes(P.Ng), c->stream, P, t, gathered);
     else if (c->big_exchange)
@@ -1981,8 +1992,12 @@ int smm_sync(void* ctx) {
             for (int i = 0; i < c->pev_iters; ++i) {
                 float a = 0.f, b = 0.f, n = 0.f;
                 HIPCHK(hipEventElapsedTime(&a, c->pev[4 * i], c->pev[4 * i + 1]));
-                HIPCHK(hipEventElapsedTime(&b, c->pev[4 * i + 1], c->pev[4 * i + 2]));
-                HIPCHK(hipEventElapsedTime(&n, c->pev[4 * i + 2], c->pev[4 * i + 3]));
+                if (c->profiling == 2) {
+                    if (c->pev_exch[i]) HIPCHK(hipEventElapsedTime(&b, c->pev[4 * i + 2], c->pev[4 * i + 3]));
+                } else {
+                    HIPCHK(hipEventElapsedTime(&b, c->pev[4 * i + 1], c->pev[4 * i + 2]));
+                    HIPCHK(hipEventElapsedTime(&n, c->pev[4 * i + 2], c->pev[4 * i + 3]));
+                }
                 c->timing.iter_kernel_ms += a;
                 c->timing.exch_kernel_ms += b;
                 c->timing.null_bracket_ms += n;
@@ -2008,6 +2023,7 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
                 HIPCHK(hipEventCreate(&e));
                 c->pev.push_back(e);
             }
+            c->pev_exch.assign((size_t)n_iters, 0);
         }
         c->pev_iters = 0;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
@@ -2015,16 +2031,22 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
             const int t = c->iter + 1;
             ensure_windows(c, t);
             const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
-            if (c->profiling) HIPCHK(hipEventRecord(c->pev[4 * it], c->stream));
+            const bool kscoped = c->profiling == 2 && c->lvl_exchange && c->lvl_wg == 1024;
+            if (c->profiling && !kscoped) HIPCHK(hipEventRecord(c->pev[4 * it], c->stream));
+            if (kscoped) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
             launch_chain_iter(c, t, flags);
-            if (c->profiling) HIPCHK(hipEventRecord(c->pev[4 * it + 1], c->stream));
+            c->kev0 = c->kev1 = nullptr;
+            if (c->profiling && !kscoped) HIPCHK(hipEventRecord(c->pev[4 * it + 1], c->stream));
             c->prev_open = true;
             c->pending = false;
+            if (c->profiling) c->pev_exch[it] = 0;
             if (exchange_active(c, t)) {
+                if (kscoped) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
                 launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange) ? nullptr : c->rec[c->cur]);
+                c->kev0 = c->kev1 = nullptr;
                 c->pending = true;
             }
-            if (c->profiling) { HIPCHK(hipEventRecord(c->pev[4 * it + 2], c->stream)); HIPCHK(hipEventRecord(c->pev[4 * it + 3], c->stream)); }
+            if (c->profiling && !kscoped) { HIPCHK(hipEventRecord(c->pev[4 * it + 2], c->stream)); HIPCHK(hipEventRecord(c->pev[4 * it + 3], c->stream)); }
             c->iter = t;
         }
         HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -2274,7 +2296,7 @@ int smm_get_timing(void* ctx, smm_timing_t* out) {
 int smm_set_profiling(void* ctx, int32_t on) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return SMM_ERR_INVALID_ARG;
-    c->profiling = on != 0;
+    c->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
     return SMM_OK;
 }
 
