@@ -61,7 +61,7 @@ enum : int { H_VALUE = 0, H_PROB, H_CURR, H_BEST, H_BESTID, H_EXCH, H_ACC, H_STA
 // error word: min over (iter<<34 | chain<<2 | kind); 1 negative objective, 2 no draw, 3 internal
 constexpr unsigned long long ERR_NONE = ~0ull;
 
-enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2 };
+enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2, F_WALK_INLINE = 4 };
 
 struct KParams {
     // problem
@@ -75,6 +75,9 @@ struct KParams {
     double sigma_adjust_by;
     uint64_t seed;
     const double* min_improve_g;  // [Ng]
+    int mi_uniform;               // all thresholds equal (the usual case): mi_value
+    int tile_off;                 // doubles in front of the tile's LDS blocks (the inline walk's chain slots)
+    double mi_value;
     // dense objective (SMM_OBJ_DENSE): B and A in MFMA fragment order
     const double* dense_Bf;  // [D/16][ceil(np/4)][64]
     const double* dense_Af;  // [nOt][D/16][4][64]
@@ -453,6 +456,134 @@ __device__ inline void make_swapped_history(const KParams& P, double* hrec /*[HW
 }
 
 // ------------------------------------------------------------------------------------------
+// exchangeMoves! inside the chain kernel (single shard, N_global <= XLVL_MAX).
+// The level walk of k_exch_resolve_lvl (below) costs ~7 us as a kernel of one workgroup plus a ~2.5 us
+// kernel boundary.  Executed redundantly by EVERY tile in the prologue of the next k_chain_iter it costs
+// the walk's ~4 us inside a kernel that is latency-structured anyway, and the boundary and the xres round
+// trip disappear.  Same plan (k_exch_plan: pairs grouped by dependency level), same arithmetic, same result;
+// the working set is 16 bytes per chain + 4 bytes per pair of LDS, the pair list overlaid by the tile's own
+// blocks once the walk is over: 80 KB at N = 4096, so two tiles still share a CU.  Thresholds: one scalar when min_improve is uniform, else read from the plan (L2).
+// ------------------------------------------------------------------------------------------
+constexpr int XLVL_MAX = 4096;
+struct __attribute__((aligned(16))) XSlot {  // one chain during the walk: 16 bytes, moved with one ds_read/write_b128
+    double val;
+    uint32_t src, partner;
+};
+// LDS of a tile with the inline walk: [XSlot slot[Ng]] [pairs[K] u32, later overlaid by the tile's own blocks]
+__host__ __device__ inline size_t walk_slot_bytes(int Ng) { return (size_t)Ng * sizeof(XSlot); }
+
+template <int NT>
+__device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsigned char* lds, const int tid) {
+    const int Ng = P.Ng, K = P.plan_K;
+    const int w = tx - P.plan_t0;
+    XSlot* slot = (XSlot*)lds;                              // [Ng]
+    uint32_t* pairs = (uint32_t*)(lds + walk_slot_bytes(Ng));   // [K]
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    const bool mi_u = P.mi_uniform != 0;
+    const double mi_v = P.mi_value;
+    // one round trip of global loads
+    constexpr int PT = XLVL_MAX / NT;
+    const int lane = tid & 63;
+    double v_[PT];
+    uint32_t pq_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        v_[r] = g < Ng ? P.vals[g] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * NT;
+        pq_[r] = q < K ? g_pairs[q] : 0u;
+    }
+    const uint32_t ev = g_off[min(lane, K)];   // lane l: end of level l
+    const int nlev = (int)g_off[K + 1];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        if (g < Ng) {
+            XSlot s_;
+            s_.val = v_[r]; s_.src = (uint32_t)g; s_.partner = 0;
+            slot[g] = s_;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * NT;
+        if (q < K) pairs[q] = pq_[r];
+    }
+    for (int q = tid + PT * NT; q < K; q += NT) pairs[q] = g_pairs[q];   // injected pair lists longer than XLVL_MAX
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
+    // The level sizes fall off geometrically.  The narrow tail (every remaining level <= 64 pairs) is walked by
+    // wave 0 alone: LDS operations of one wave complete in order, so its levels need no workgroup barrier and
+    // cost one LDS round trip each (a barrier level of a tile costs ~0.45 us next to a second walking tile).
+    int ltail = nlev;
+    if (nlev > 0 && nlev <= 64 && !(P.dbg & 128)) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)ev, 1, 64);
+        const unsigned long long wide = __ballot(lane < nlev && ev - (lane > 0 ? lo : 0u) > 64u);
+        ltail = wide ? 64 - __builtin_clzll(wide) : 0;
+    }
+    __syncthreads();
+    uint32_t b = 0;
+    uint32_t e = nlev > 0 ? level_end(0) : 0u;
+    uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
+    uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
+    double m = mi_u ? mi_v : ((b + tid < e) ? g_mi[b + tid] : 0.0);
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < ltail; ++l) {
+        const uint32_t e3 = level_end(l + 2);
+        // this thread's first pair of the next level is fetched while this level runs
+        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+        const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+        for (uint32_t pos = b + tid; pos < e; pos += NT) {
+            if (pos != b + tid) { pw = pairs[pos]; m = mi_u ? mi_v : g_mi[pos]; }
+            const uint32_t i = pw & 0xffffu, j = pw >> 16;
+            const XSlot si = slot[i], sj = slot[j];
+            if (si.val - sj.val > m) {                  // dist_fun = -, AlgoBGP.jl:688
+                XSlot ni, nj;                           // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                slot[i] = ni;
+                slot[j] = nj;
+            }
+        }
+        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+        __syncthreads();
+    }
+    if (ltail < nlev) {
+        if (tid < 64) {   // (pw, m) already hold this lane's pair of level ltail, e its end, e2 the next end
+            constexpr uint32_t NOPAIR = 0xffffffffu;   // i == j == 0xffff never occurs (chain ids < XLVL_MAX)
+            uint32_t cpw = (b + tid < e) ? pw : NOPAIR;
+#pragma clang loop unroll(disable)
+            for (int l = ltail; l < nlev; ++l) {
+                const uint32_t e3 = level_end(l + 2);
+                const uint32_t npw = (e + tid < e2) ? pairs[e + tid] : NOPAIR;
+                const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+                if (cpw != NOPAIR) {
+                    const uint32_t i = cpw & 0xffffu, j = cpw >> 16;
+                    const XSlot si = slot[i], sj = slot[j];
+                    if (si.val - sj.val > m) {
+                        XSlot ni, nj;
+                        ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                        nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                        slot[i] = ni;
+                        slot[j] = nj;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                cpw = npw; m = m2; e = e2; e2 = e3;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_chain_iter: one next_eval (AlgoBGP.jl:272-294) for every local chain, iteration t (1-based).
 // rec_in : last accepted records after iteration t-1's accept step   [N][RW]
 // rec_out: the same after iteration t's accept step (input of exchangeMoves!)
@@ -468,7 +599,7 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
     constexpr int NR = 64 / CT;
     const int np = P.np, nm = P.nm, N = P.N, RW = P.RW, HW = P.HW, RBW = P.RBW;
     TileSmem S;
-    S.carve(smem, CT, np, nm, RW, HW, RBW, KIND != 0);
+    S.carve(smem + P.tile_off, CT, np, nm, RW, HW, RBW, KIND != 0);
     const int tid = threadIdx.x;
     const int cl = tid % CT, r = (tid % 64) / CT;
     const int c = blockIdx.x * CT + cl;       // chain served by this lane (control wave only)
@@ -498,31 +629,57 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
             asm volatile("" ::"v"(touched));
         }
     }
-    if (tid >= 64 && tid < 128) {  // wave 1: problem constants
-        for (int k = tid - 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; S.init[k] = P.init[k]; }
-        for (int k = tid - 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
-    }
     int partner = 0;
-    if (valid) {
+    // wave 1: problem constants, requested now and written to LDS after the walk
+    const bool wave1 = tid >= 64 && tid < 128;
+    const int k1 = tid - 64;
+    double c_lb = 0.0, c_ub = 0.0, c_init = 0.0, c_mom = 0.0, c_w = 0.0;
+    if (wave1) {
+        if (k1 < np) { c_lb = P.lb[k1]; c_ub = P.ub[k1]; c_init = P.init[k1]; }
+        if (k1 < nm) { c_mom = P.mom[k1]; c_w = P.w[k1]; }
+    }
+    {
         // level 1: exchange result, chain state block, this iteration's randomness block
-        unsigned long long xr = (unsigned long long)(unsigned)gc;
-        if (flags & F_HAS_PENDING) xr = P.xres[gc];
-        constexpr int NI_CS = (CSW / 2 + NR - 1) / NR, NI_RB = (12 + NR - 1) / NR, NI_REC = (8 + NR - 1) / NR;
+        constexpr int NI_MAX = 4;   // pieces per lane held in registers; longer blocks finish with a load-store loop
+        constexpr int NI_CS = (CSW / 2 + NR - 1) / NR < NI_MAX ? (CSW / 2 + NR - 1) / NR : NI_MAX;
+        constexpr int NI_RB = (12 + NR - 1) / NR < NI_MAX ? (12 + NR - 1) / NR : NI_MAX;
+        constexpr int NI_REC = (8 + NR - 1) / NR < NI_MAX ? (8 + NR - 1) / NR : NI_MAX;
         double2 v_cs[NI_CS], v_rb[NI_RB], v_rec[NI_REC];
-        const double* g_cs = P.cs + (size_t)c * CSW;
-        const double* g_rb = P.rb + ((size_t)(t > 1 ? t - P.rb_t0 : 0) * N + c) * RBW;
+        const int cc = valid ? c : 0;
+        const double* g_cs = P.cs + (size_t)cc * CSW;
+        const double* g_rb = P.rb + ((size_t)(t > 1 ? t - P.rb_t0 : 0) * N + cc) * RBW;
         const int rbw = t > 1 ? RBW : 0;
-        coop_fetch<CT, NI_CS>(v_cs, g_cs, CSW, r);
-        coop_fetch<CT, NI_RB>(v_rb, g_rb, rbw, r);
-        // level 2: the record the chain continues from (its own, or the donor's); requested as soon as the
-        // exchange result is here, while the level-1 blocks are still in flight
-        const int s = (int)(unsigned)(xr & 0xffffffffu) - P.offset;
-        partner = (int)(xr >> 32);
-        const double* g_rec = rec_in + (size_t)s * RW;
-        coop_fetch<CT, NI_REC>(v_rec, g_rec, RW, r);
-        coop_put<CT, NI_CS>(S.cs + cl * CSW, v_cs, g_cs, CSW, r);
-        coop_put<CT, NI_RB>(S.rb + cl * RBW, v_rb, g_rb, rbw, r);
-        coop_put<CT, NI_REC>(S.rec + cl * RW, v_rec, g_rec, RW, r);
+        unsigned long long xr = (unsigned long long)(unsigned)gc;
+        if (valid) {
+            if ((flags & F_HAS_PENDING) && !(flags & F_WALK_INLINE)) xr = P.xres[gc];
+            coop_fetch<CT, NI_CS>(v_cs, g_cs, CSW, r);
+            coop_fetch<CT, NI_RB>(v_rb, g_rb, rbw, r);
+        }
+        if (flags & F_WALK_INLINE) {
+            // exchangeMoves! of iteration t-1, by all lanes of the tile, while the level-1 blocks are in flight
+            // (the tile's own LDS blocks overlay the walk's pair list: nothing of the tile is written before this returns)
+            exchange_walk_tile<WG>(P, t - 1, (unsigned char*)smem, tid);
+            if (valid) {
+                const XSlot sv = ((const XSlot*)smem)[gc];
+                xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
+            }
+        }
+        if (wave1) {  // problem constants into the tile's LDS (which the walk's pair list occupied until now)
+            if (k1 < np) { S.lb[k1] = c_lb; S.ub[k1] = c_ub; S.init[k1] = c_init; }
+            if (k1 < nm) { S.mom[k1] = c_mom; S.w[k1] = c_w; }
+            for (int k = k1 + 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; S.init[k] = P.init[k]; }
+            for (int k = k1 + 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
+        }
+        if (valid) {
+            // level 2: the record the chain continues from (its own, or the donor's)
+            const int s = (int)(unsigned)(xr & 0xffffffffu) - P.offset;
+            partner = (int)(xr >> 32);
+            const double* g_rec = rec_in + (size_t)s * RW;
+            coop_fetch<CT, NI_REC>(v_rec, g_rec, RW, r);
+            coop_put<CT, NI_CS>(S.cs + cl * CSW, v_cs, g_cs, CSW, r);
+            coop_put<CT, NI_RB>(S.rb + cl * RBW, v_rb, g_rb, rbw, r);
+            coop_put<CT, NI_REC>(S.rec + cl * RW, v_rec, g_rec, RW, r);
+        }
     }
     TS_MARK(1);
     __syncthreads();
@@ -1131,11 +1288,6 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
 // groups the pair list by dependency level (k_exch_plan); the pairs of one level touch pairwise
 // disjoint chains, so a level is one parallel step and the walk needs (number of levels ~ log N)
 // barriers.  Plan, values and thresholds are staged in LDS with coalesced loads up front.
-constexpr int XLVL_MAX = 4096;
-struct __attribute__((aligned(16))) XSlot {  // one chain during the walk: 16 bytes, moved with one ds_read/write_b128
-    double val;
-    uint32_t src, partner;
-};
 template <int LWG>
 __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const int t, const double* __restrict__ gathered) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
@@ -1576,6 +1728,8 @@ struct Ctx {
     uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr;
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
+    bool inline_walk = false;   // the exchange walk runs in the prologue of the next k_chain_iter (SMMHIP_INLINE_WALK=0: off)
+    bool unresolved = false;    // exchangeMoves! of iteration `iter` is still to be resolved (inline, or by resolve_now)
     bool big_exchange = false;   // 8192 < N_global <= 65535: level plan and walk in global memory
     uint32_t* big_scratch = nullptr;
     int lvl_wg = 1024;
@@ -1612,9 +1766,13 @@ T* dupload(Ctx* c, const T* h, size_t n) {
 bool is_sim(int obj) { return obj == SMM_OBJ_NORM || obj == SMM_OBJ_NORM_FAILBOX; }
 int obj_kind(int obj) { return is_sim(obj) ? 1 : obj == SMM_OBJ_DENSE ? 2 : 0; }
 
-size_t tile_smem(const Ctx* c, int ct) {
+size_t tile_smem_base(const Ctx* c, int ct) {
     const KParams& P = c->P;
     return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, obj_kind(c->obj)) * sizeof(double);
+}
+size_t tile_smem(const Ctx* c, int ct) {   // dynamic LDS of k_chain_iter: the tile; with the inline exchange walk its chain
+    const size_t base = tile_smem_base(c, ct);   // slots in front and its pair list under the tile
+    return c->inline_walk ? walk_slot_bytes(c->P.Ng) + std::max(base, (size_t)c->P.plan_K * 4) : base;
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
@@ -1670,7 +1828,7 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
         else launch_chain_iter_ct<1, 8>(c, t, flags);
     } else if (c->obj == SMM_OBJ_DENSE) {
         launch_chain_iter_ct<2, 16>(c, t, flags);
-    } else if (tile_smem(c, 64) <= (size_t)60 * 1024) {
+    } else if (tile_smem_base(c, 64) <= (size_t)60 * 1024 && !c->inline_walk) {
         launch_chain_iter_ct<0, 64>(c, t, flags);
     } else {
         launch_chain_iter_ct<0, 8>(c, t, flags);
@@ -1700,8 +1858,16 @@ void launch_resolve(Ctx* c, int t, const double* gathered) {
 }
 
 // settle the open end of the last iteration (no-op when nothing is open)
+// the exchange of iteration c->iter has been left to the next chain kernel, but something else needs it now
+void resolve_now(Ctx* c) {
+    if (!c->unresolved) return;
+    launch_resolve(c, c->iter, nullptr);
+    c->unresolved = false;
+}
+
 void flush(Ctx* c) {
     if (!c->pending && !c->prev_open) return;
+    resolve_now(c);
     const KParams& P = c->P;
     const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
     hipLaunchKernelGGL(k_flush, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter + 1, (const double*)c->rec[c->cur],
@@ -1855,6 +2021,9 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.sigma_update_steps = opts->sigma_update_steps; P.smpl_iters = opts->smpl_iters;
         P.batch_size = opts->batch_size; P.sigma_adjust_by = opts->sigma_adjust_by; P.seed = opts->seed;
         P.min_improve_g = dupload(c, opts->min_improve, Ng);
+        P.mi_uniform = 1; P.mi_value = opts->min_improve[0];
+        for (int i = 1; i < Ng; ++i)
+            if (!(opts->min_improve[i] == P.mi_value)) P.mi_uniform = 0;
         const size_t TN = (size_t)T * N;
         if (tab && tab->probs_acc) P.user_utab = dupload(c, tab->probs_acc, TN);
         if (tab && tab->prop_normals && tab->prop_tries > 0) {
@@ -1882,6 +2051,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const bool force_big = be && be[0] == '1';
             c->big_exchange = Ng > 1 && Ng <= 65535 && K >= 1 && K <= Ng && !c->force_any_exchange && (force_big || !c->lds_exchange);
             if (c->big_exchange) { c->lds_exchange = false; c->lvl_exchange = false; }
+            // inline exchange walk: single shard, level plan available, and two tiles must still share a CU's 160 KB LDS
+            const char* iw = getenv("SMMHIP_INLINE_WALK");
+            const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
+            c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng &&
+                             walk_slot_bytes(Ng) + std::max(tile_smem_base(c, tile_ct), (size_t)K * 4) <= (size_t)80 * 1024;
+            P.tile_off = c->inline_walk ? (int)(walk_slot_bytes(Ng) / sizeof(double)) : 0;
         }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
             const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 : 0);
@@ -2029,8 +2204,10 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         for (int it = 0; it < n_iters; ++it) {
             const int t = c->iter + 1;
+            // an exchange left to this chain kernel needs its plan: resolve it now if the plan window is about to move on
+            if (c->unresolved && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) resolve_now(c);
             ensure_windows(c, t);
-            const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
+            const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0) | (c->unresolved ? F_WALK_INLINE : 0);
             const bool kscoped = c->profiling == 2 && c->lvl_exchange && c->lvl_wg == 1024;
             if (c->profiling && !kscoped) HIPCHK(hipEventRecord(c->pev[4 * it], c->stream));
             if (kscoped) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
@@ -2040,10 +2217,15 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
             c->prev_open = true;
             c->pending = false;
             if (c->profiling) c->pev_exch[it] = 0;
+            c->unresolved = false;
             if (exchange_active(c, t)) {
-                if (kscoped) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
-                launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange) ? nullptr : c->rec[c->cur]);
-                c->kev0 = c->kev1 = nullptr;
+                if (c->inline_walk) {
+                    c->unresolved = true;   // resolved in the prologue of the next chain kernel (or by resolve_now)
+                } else {
+                    if (kscoped) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
+                    launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange) ? nullptr : c->rec[c->cur]);
+                    c->kev0 = c->kev1 = nullptr;
+                }
                 c->pending = true;
             }
             if (c->profiling && !kscoped) { HIPCHK(hipEventRecord(c->pev[4 * it + 2], c->stream)); HIPCHK(hipEventRecord(c->pev[4 * it + 3], c->stream)); }
@@ -2278,6 +2460,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
             HIPCHK(hipMemcpy(P.hrec + (size_t)t * N * HW, row.data(), row.size() * 8, hipMemcpyHostToDevice));
         }
         c->iter = s->iter;
+        c->unresolved = false;
         c->pending = false;
         c->prev_open = false;
     } catch (const std::string& m) {
