@@ -240,6 +240,34 @@ def test_any_size_exchange_kernel_matches(S, O, N, monkeypatch):
 
 
 @pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096])
+def test_inline_walk_equals_resolve_kernel(S, O, N, monkeypatch):
+    # default single-shard path: the exchange walk runs in the prologue of the next chain kernel (every tile,
+    # redundantly); against the stand-alone k_exch_resolve_lvl kernel and the oracle.  Non-uniform thresholds
+    # (the plan's per-pair column instead of one scalar) and stepping in uneven pieces (an unresolved exchange
+    # crosses smm_bgp_step calls; history reads in between force the stand-alone resolution).
+    rng = np.random.default_rng(N)
+    for uniform in (True, False):
+        mi = 0.0 if uniform else rng.uniform(-0.2, 0.4, N)
+        prob, opts = cm.serial_normal(N=N, T=24, ns=64, min_improve=mi)
+        a, o = make_pair(S, O, prob, opts, None)
+        for n in (1, 1, 2, 3, 5, 12):
+            a.step(n)
+            if n == 3:
+                a.history()       # flush: resolves the open exchange with the stand-alone kernel
+        o.step(24)
+        monkeypatch.setenv("SMMHIP_INLINE_WALK", "0")
+        b = S.hip_context(prob, opts)
+        monkeypatch.delenv("SMMHIP_INLINE_WALK")
+        b.step(24)
+        ha = a.history()
+        cm.assert_history_equal(ha, b.history(), exact_floats=True)
+        cm.assert_history_equal(ha, o.history())
+        cm.assert_state_equal(a.state(), o.state())
+        if N > 3:
+            assert (ha.exchanged != 0).any()
+
+
+@pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096])
 def test_dataflow_exchange_kernel_matches(S, O, N, monkeypatch):
     # the ticket (data-flow) resolution kernel (4096 < N_global <= 8192) against the level-synchronous one
     prob, opts = cm.serial_normal(N=N, T=12, ns=64)
