@@ -169,6 +169,27 @@ def main():
         null_us = tb.null_bracket_ms * 1e3 / ITERS_PER_STEP
         k_net_us = tb.iter_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
         x_net_us = tb.exch_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
+        # the same chain kernel without the exchange walk in its prologue (a second context with the stand-alone
+        # resolve kernel): shows what the fused launch consists of
+        unfused = None
+        if os.environ.get("SMMHIP_INLINE_WALK") != "0":
+            os.environ["SMMHIP_INLINE_WALK"] = "0"
+            try:
+                prob2, opts2 = cm.serial_normal(N=n_glob, T=2 * ITERS_PER_STEP, device=local_rank)
+                c2 = S.hip_context(prob2, opts2)
+            finally:
+                del os.environ["SMMHIP_INLINE_WALK"]
+            c2.step(ITERS_PER_STEP)
+            c2.set_profiling(2)
+            c2.step(ITERS_PER_STEP)
+            t2 = c2.timing()
+            c2.set_profiling(0)
+            ku = t2.iter_kernel_ms * 1e3 / ITERS_PER_STEP
+            unfused = {"chain_kernel_us": ku, "resolve_kernel_us": t2.exch_kernel_ms * 1e3 / ITERS_PER_STEP,
+                       "chain_kernel_frac": n_loc * FLOP_PER_EVAL / (ku * 1e-6) / 1e12 / PEAK_FP64_ADD_TFLOPS,
+                       "note": "SMMHIP_INLINE_WALK=0: k_chain_iter without the exchange walk + k_exch_resolve_lvl as its own "
+                               "launch (the configuration of the earlier round-1 profiles)"}
+            del c2
         flops = n_loc * FLOP_PER_EVAL
         byts = n_loc * BYTES_PER_EVAL
         ach = flops / (k_us * 1e-6) / 1e12
@@ -182,6 +203,9 @@ def main():
                 "net_kernel_us": k_net_us, "net_exchange_us": x_net_us, "event_bracket_overhead_us": null_us,
                 "timing_note": "avg_*: per-kernel start/stop events (dispatch duration, what rocprofv3 reports; used for "
                                "'achieved'); net_*: event brackets minus the empty-bracket overhead",
+                "kernel_contents": "one launch per iteration: exchangeMoves! of the previous iteration (level walk, every "
+                                   "tile, LDS/latency bound, no flops) + next_eval of 4096 chains",
+                "unfused": unfused,
                 "profiled_step_ms": tm.step_ms,
                 "note": "2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes "
                         "x 2.4GHz adds/s (FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)",
