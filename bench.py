@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unfused", action="store_true", help="skip the reference timing of the unfused kernels (profiling runs)")
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU)
     args = ap.parse_args()
 
@@ -172,7 +173,7 @@ def main():
         # the same chain kernel without the exchange walk in its prologue (a second context with the stand-alone
         # resolve kernel): shows what the fused launch consists of
         unfused = None
-        if os.environ.get("SMMHIP_INLINE_WALK") != "0":
+        if os.environ.get("SMMHIP_INLINE_WALK") != "0" and not args.no_unfused:
             os.environ["SMMHIP_INLINE_WALK"] = "0"
             try:
                 prob2, opts2 = cm.serial_normal(N=n_glob, T=2 * ITERS_PER_STEP, device=local_rank)
