@@ -116,7 +116,7 @@ struct KParams {
     unsigned long long* ts;  // SMMHIP_TS=1: per-workgroup phase timestamps of k_chain_iter (tools/)
 };
 
-#define TS_MARK(i) do { if (P.ts && threadIdx.x == 0) P.ts[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define TS_MARK(i) do { if (P.ts && tid == 0) P.ts[(size_t)tile * 8 + (i)] = wall_clock64(); } while (0)
 
 __device__ inline void report_error(const KParams& P, int kind, int t, int gchain) {
     const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)gchain << 2) | (unsigned)kind;
@@ -377,6 +377,7 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
 // ------------------------------------------------------------------------------------------
 struct TileSmem {
     double *cs, *rb, *rec, *rout, *h, *hp, *theta, *lb, *ub, *init, *mom, *w, *part;
+    unsigned* arrived;
     __device__ inline void carve(double* base, int CT, int np, int nm, int RW, int HW, int RBW, bool sim) {
         cs = base;                  // [CT][CSW]
         rb = cs + CT * CSW;         // [CT][RBW]
@@ -391,6 +392,7 @@ struct TileSmem {
         mom = init + np;            // [nm]
         w = mom + nm;
         part = w + nm;              // [WG/64][CT][nm]
+        arrived = (unsigned*)(part + (size_t)(WG / 64) * CT * nm);   // simulation kind: waves whose partial sums are in LDS
         (void)sim;
     }
 };
@@ -592,17 +594,23 @@ __device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsign
 // record the chain continues from), evaluates the proposal tries side by side, and after the
 // simulation lanes r == 0 run the accept step and the wave stores the result blocks.
 // ------------------------------------------------------------------------------------------
-template <int KIND, int CT>
-__global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
-                                                      double* __restrict__ rec_out, const int flags) {
+// TPW tiles per workgroup (TPW = 2 with the inline exchange walk: the two tiles that would share a CU anyway
+// become one workgroup of 1024 lanes, so the CU runs ONE walk with twice the lanes instead of two copies
+// contending for its LDS; everything else is per tile, on the tile-local lane id).
+template <int KIND, int CT, int TPW = 1>
+__global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                            double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NR = 64 / CT;
     const int np = P.np, nm = P.nm, N = P.N, RW = P.RW, HW = P.HW, RBW = P.RBW;
+    const int st = (TPW > 1) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / WG) : 0;   // tile of this workgroup (wave-uniform: scalar)
+    const int tid = (int)threadIdx.x - st * WG;             // lane of the tile
+    const int tile = (int)blockIdx.x * TPW + st;
     TileSmem S;
-    S.carve(smem + P.tile_off, CT, np, nm, RW, HW, RBW, KIND != 0);
-    const int tid = threadIdx.x;
+    S.carve(smem + P.tile_off + (size_t)st * ((tile_smem_doubles(CT, np, nm, RW, HW, RBW, KIND) + 1) & ~(size_t)1), CT, np, nm, RW, HW,
+            RBW, KIND != 0);
     const int cl = tid % CT, r = (tid % 64) / CT;
-    const int c = blockIdx.x * CT + cl;       // chain served by this lane (control wave only)
+    const int c = tile * CT + cl;             // chain served by this lane (control wave only)
     const bool ctl = tid < 64;
     const bool valid = ctl && (c < N);
     const bool chain_lane = valid && r == 0;
@@ -613,22 +621,6 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
     double za[ZU];
     ZBuf zb;
     if constexpr (KIND == 1) { zb.init(P, tid); sim_load_chunk(zb, P, 0, 0, za); }
-    if constexpr (KIND == 1) {
-        // Wave 2 warms the L2: the launch boundary invalidated it, and the first tile of an XCD to stream a chunk
-        // of the shock matrix would pay the memory latency chunk by chunk (measured: 11 us of simulation in
-        // those tiles against 6 us in the ones that follow them).  Workgroups are dealt round-robin to the 8
-        // XCDs, so the 64 tiles (blockIdx>>3) of an XCD each touch 1/64 of the matrix, all at once, while the
-        // serial prologue runs.  A hint only: nothing depends on which tiles share an L2.
-        if (tid >= 128 && tid < 192) {
-            const size_t nlines = ((size_t)nm * P.zstride * sizeof(double) + 127) / 128;
-            const size_t per = (nlines + 63) / 64;
-            const size_t first = (size_t)((blockIdx.x >> 3) & 63) * per;
-            unsigned touched = 0;
-            for (size_t l = tid - 128; l < per; l += 64)
-                if (first + l < nlines) touched |= ((const unsigned*)P.Z)[(first + l) * 32];
-            asm volatile("" ::"v"(touched));
-        }
-    }
     int partner = 0;
     // wave 1: problem constants, requested now and written to LDS after the walk
     const bool wave1 = tid >= 64 && tid < 128;
@@ -658,12 +650,13 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
         if (flags & F_WALK_INLINE) {
             // exchangeMoves! of iteration t-1, by all lanes of the tile, while the level-1 blocks are in flight
             // (the tile's own LDS blocks overlay the walk's pair list: nothing of the tile is written before this returns)
-            exchange_walk_tile<WG>(P, t - 1, (unsigned char*)smem, tid);
+            exchange_walk_tile<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x);
             if (valid) {
                 const XSlot sv = ((const XSlot*)smem)[gc];
                 xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
             }
         }
+        if (KIND == 1 && tid == 64) *S.arrived = 0u;
         if (wave1) {  // problem constants into the tile's LDS (which the walk's pair list occupied until now)
             if (k1 < np) { S.lb[k1] = c_lb; S.ub[k1] = c_ub; S.init[k1] = c_init; }
             if (k1 < nm) { S.mom[k1] = c_mom; S.w[k1] = c_w; }
@@ -788,7 +781,15 @@ __global__ __launch_bounds__(WG, 4) void k_chain_iter(const KParams P, const int
     // ---- simulation: all 512 lanes, ns draws x nm moments x CT chains ----
     if constexpr (KIND == 1) {
         if (!(P.dbg & 2)) simulate_tile<CT>(P, zb, S.theta, S.part, tid, za);
-        __syncthreads();
+        // No workgroup barrier here: only the tile's control wave consumes the partial sums.  Every wave announces
+        // its partials with one LDS add and is done; the control wave waits for the tile's 8 announcements.  (With
+        // two tiles per workgroup a barrier would also make the faster tile wait for the slower one.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((tid & 63) == 0) __hip_atomic_fetch_add(S.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!ctl) return;
+        while (__hip_atomic_load(S.arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(WG / 64))
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     } else if constexpr (KIND == 2) {
         dense_tile<CT>(P, S.theta, S.part, tid);
         __syncthreads();
@@ -1728,6 +1729,7 @@ struct Ctx {
     uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr;
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
+    int tpw = 1;                // tiles per workgroup of k_chain_iter (2 with the inline walk: one walk per CU)
     bool inline_walk = false;   // the exchange walk runs in the prologue of the next k_chain_iter (SMMHIP_INLINE_WALK=0: off)
     bool unresolved = false;    // exchangeMoves! of iteration `iter` is still to be resolved (inline, or by resolve_now)
     bool big_exchange = false;   // 8192 < N_global <= 65535: level plan and walk in global memory
@@ -1770,9 +1772,10 @@ size_t tile_smem_base(const Ctx* c, int ct) {
     const KParams& P = c->P;
     return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, obj_kind(c->obj)) * sizeof(double);
 }
-size_t tile_smem(const Ctx* c, int ct) {   // dynamic LDS of k_chain_iter: the tile; with the inline exchange walk its chain
-    const size_t base = tile_smem_base(c, ct);   // slots in front and its pair list under the tile
-    return c->inline_walk ? walk_slot_bytes(c->P.Ng) + std::max(base, (size_t)c->P.plan_K * 4) : base;
+size_t tile_smem(const Ctx* c, int ct, int tpw = 1) {   // dynamic LDS of k_chain_iter: tpw tiles; with the inline exchange
+    const size_t base = tile_smem_base(c, ct);           // walk its chain slots in front and its pair list under the tiles
+    const size_t tiles = (size_t)tpw * ((base + 15) & ~(size_t)15);
+    return c->inline_walk ? walk_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)c->P.plan_K * 4) : tiles;
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
@@ -1810,14 +1813,16 @@ void ensure_windows(Ctx* c, int t) {
     }
 }
 
-template <int KIND, int CT>
+template <int KIND, int CT, int TPW = 1>
 void launch_chain_iter_ct(Ctx* c, int t, int flags) {
     const KParams& P = c->P;
+    const int tiles = (P.N + CT - 1) / CT;
+    const dim3 grid((tiles + TPW - 1) / TPW), block(WG * TPW);
     if (c->kev0)   // profiling mode 2: begin/end of this dispatch as the command processor stamps them
-        hipExtLaunchKernelGGL((k_chain_iter<KIND, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, c->kev0,
-                              c->kev1, 0, P, t, (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
+        hipExtLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, c->kev0, c->kev1, 0, P, t,
+                              (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
     else
-        hipLaunchKernelGGL((k_chain_iter<KIND, CT>), dim3((P.N + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, t,
+        hipLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, P, t,
                            (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
 }
 
@@ -1825,6 +1830,7 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
     if (is_sim(c->obj)) {
         if (c->ct == 4) launch_chain_iter_ct<1, 4>(c, t, flags);
         else if (c->ct == 16) launch_chain_iter_ct<1, 16>(c, t, flags);
+        else if (c->tpw == 2) launch_chain_iter_ct<1, 8, 2>(c, t, flags);
         else launch_chain_iter_ct<1, 8>(c, t, flags);
     } else if (c->obj == SMM_OBJ_DENSE) {
         launch_chain_iter_ct<2, 16>(c, t, flags);
@@ -2054,9 +2060,14 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             // inline exchange walk: single shard, level plan available, and two tiles must still share a CU's 160 KB LDS
             const char* iw = getenv("SMMHIP_INLINE_WALK");
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
+            const size_t tile_b = (tile_smem_base(c, tile_ct) + 15) & ~(size_t)15;
             c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng &&
-                             walk_slot_bytes(Ng) + std::max(tile_smem_base(c, tile_ct), (size_t)K * 4) <= (size_t)80 * 1024;
+                             walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024;
             P.tile_off = c->inline_walk ? (int)(walk_slot_bytes(Ng) / sizeof(double)) : 0;
+            // two tiles per workgroup share one walk (the 2p/2m-style simulation tile of 8 chains only)
+            const char* tp = getenv("SMMHIP_TPW");
+            c->tpw = (c->inline_walk && is_sim(c->obj) && c->ct == 8 && N > 8 && !(tp && tp[0] == '1') &&
+                      walk_slot_bytes(Ng) + std::max(2 * tile_b, (size_t)K * 4) <= (size_t)160 * 1024) ? 2 : 1;
         }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
             const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 : 0);
@@ -2129,6 +2140,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const int lim = 160 * 1024;
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
