@@ -1394,6 +1394,85 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const
     if (P.ts && tid == 0) { P.ts[(size_t)8 * 60000 + 6] = clock64() - cyc0; P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev; }
 }
 
+// k_exch_resolve_lvl_soa: the level walk for XLVL_MAX < N_global <= XLDS_MAX (e.g. 2 GPUs x 4096 chains).  Same plan,
+// same arithmetic; the chain slots are split (8-byte value, 4-byte src | partner << 16) so that 8192 chains and
+// their pair list take 128 KB of LDS.  Thresholds: one scalar when min_improve is uniform, else from the plan.
+template <int LWG>
+__global__ __launch_bounds__(LWG) void k_exch_resolve_lvl_soa(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
+    const int w = t - P.plan_t0;
+    double* val = (double*)xsm;                 // [Ng]
+    uint32_t* sp = (uint32_t*)(val + Ng);       // [Ng]
+    uint32_t* pairs = sp + Ng;                  // [K]
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    const bool mi_u = P.mi_uniform != 0;
+    const double mi_v = P.mi_value;
+    const double* __restrict__ vsrc = gathered ? gathered : P.vals;
+    const int vstride = gathered ? RW : 1;
+    constexpr int PT = XLDS_MAX / LWG;
+    double v_[PT];
+    uint32_t pq_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * LWG;
+        v_[r] = g < Ng ? vsrc[(size_t)g * vstride] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * LWG;
+        pq_[r] = q < K ? g_pairs[q] : 0u;
+    }
+    const uint32_t ev = g_off[min(lane, K)];
+    const int nlev = (int)g_off[K + 1];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * LWG;
+        if (g < Ng) { val[g] = v_[r]; sp[g] = (uint32_t)g; }
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * LWG;
+        if (q < K) pairs[q] = pq_[r];
+    }
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
+    __syncthreads();
+    uint32_t b = 0;
+    uint32_t e = nlev > 0 ? level_end(0) : 0u;
+    uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
+    uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
+    double m = mi_u ? mi_v : ((b + tid < e) ? g_mi[b + tid] : 0.0);
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < nlev; ++l) {
+        const uint32_t e3 = level_end(l + 2);
+        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+        const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+        for (uint32_t pos = b + tid; pos < e; pos += LWG) {
+            if (pos != b + tid) { pw = pairs[pos]; m = mi_u ? mi_v : g_mi[pos]; }
+            const uint32_t i = pw & 0xffffu, j = pw >> 16;
+            const double vi = val[i], vj = val[j];
+            const uint32_t si = sp[i], sj = sp[j];
+            if (vi - vj > m) {                          // dist_fun = -, AlgoBGP.jl:688
+                val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                sp[i] = (sj & 0xffffu) | ((j + 1) << 16);
+                sp[j] = (si & 0xffffu) | ((i + 1) << 16);
+            }
+        }
+        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+        __syncthreads();
+    }
+    for (int g = tid; g < Ng; g += LWG) {
+        const uint32_t s_ = sp[g];
+        P.xres[g] = (unsigned long long)(s_ & 0xffffu) | ((unsigned long long)(s_ >> 16) << 32);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Large populations (8192 < N_global <= 65535, e.g. 8 GPUs x 4096 chains): the same level plan and
 // level-synchronous walk with their working sets in global memory (the LDS of one CU is too small).
@@ -1729,6 +1808,7 @@ struct Ctx {
     uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr;
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
+    bool lvl_soa_exchange = false;   // XLVL_MAX < N_global <= XLDS_MAX: level walk on split chain slots
     int tpw = 1;                // tiles per workgroup of k_chain_iter (2 with the inline walk: one walk per CU)
     bool inline_walk = false;   // the exchange walk runs in the prologue of the next k_chain_iter (SMMHIP_INLINE_WALK=0: off)
     bool unresolved = false;    // exchangeMoves! of iteration `iter` is still to be resolved (inline, or by resolve_now)
@@ -1779,6 +1859,7 @@ size_t tile_smem(const Ctx* c, int ct, int tpw = 1) {   // dynamic LDS of k_chai
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
+size_t resolve_lvl_soa_bytes(int Ng, int K) { return (size_t)Ng * 12 + (size_t)K * 4 + 16; }
 size_t resolve_lvl_bytes(int Ng, int K) { return (size_t)Ng * 16 + (size_t)K * 12 + 64 * 8 + 64; }
 
 int exchange_K(const Ctx* c) { return c->P.pairtab ? c->P.n_pairs_tab : n_exchange_pairs(c->P.Ng); }
@@ -1855,6 +1936,8 @@ void launch_resolve(Ctx* c, int t, const double* gathered) {
                                       c->kev1, 0, P, t, gathered);
             else
                 hipLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+    else if (c->lvl_soa_exchange)
+        hipLaunchKernelGGL(k_exch_resolve_lvl_soa<1024>, dim3(1), dim3(1024), resolve_lvl_soa_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
     else if (c->lds_exchange)
         hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), resolve_lds_bytes(P.Ng), c->stream, P, t, gathered);
     else if (c->big_exchange)
@@ -2051,12 +2134,13 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         {
             const char* e = getenv("SMMHIP_DATAFLOW_EXCHANGE");  // test hook: force the ticket (data-flow) resolution kernel
             c->lvl_exchange = c->lds_exchange && Ng <= XLVL_MAX && !(e && e[0] == '1');
+            c->lvl_soa_exchange = c->lds_exchange && !c->lvl_exchange && !(e && e[0] == '1');
             const char* lw = getenv("SMMHIP_LVL_WG");  // tuning hook
             if (lw) c->lvl_wg = atoi(lw);
             const char* be = getenv("SMMHIP_BIG_EXCHANGE");  // test hook: force the global-memory level kernels
             const bool force_big = be && be[0] == '1';
             c->big_exchange = Ng > 1 && Ng <= 65535 && K >= 1 && K <= Ng && !c->force_any_exchange && (force_big || !c->lds_exchange);
-            if (c->big_exchange) { c->lds_exchange = false; c->lvl_exchange = false; }
+            if (c->big_exchange) { c->lds_exchange = false; c->lvl_exchange = false; c->lvl_soa_exchange = false; }
             // inline exchange walk: single shard, level plan available, and two tiles must still share a CU's 160 KB LDS
             const char* iw = getenv("SMMHIP_INLINE_WALK");
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
@@ -2133,6 +2217,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<512>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl_soa<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_lvl_soa_bytes(XLDS_MAX, XLDS_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
         }

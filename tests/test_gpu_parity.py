@@ -267,9 +267,10 @@ def test_inline_walk_equals_resolve_kernel(S, O, N, monkeypatch):
             assert (ha.exchanged != 0).any()
 
 
-@pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096])
+@pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096, 6000])
 def test_dataflow_exchange_kernel_matches(S, O, N, monkeypatch):
-    # the ticket (data-flow) resolution kernel (4096 < N_global <= 8192) against the level-synchronous one
+    # the ticket (data-flow) resolution kernel against the level-synchronous ones (16-byte chain slots up to
+    # N_global = 4096, split slots up to 8192: N = 6000)
     prob, opts = cm.serial_normal(N=N, T=12, ns=64)
     a, o = run_both(S, O, prob, opts, None)
     monkeypatch.setenv("SMMHIP_DATAFLOW_EXCHANGE", "1")
