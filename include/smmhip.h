@@ -192,6 +192,18 @@ int  smm_bgp_local_step(void* ctx);
 int  smm_bgp_record_doubles(void* ctx);
 int  smm_bgp_export_records_dev(void* ctx, void* rec_dev);
 int  smm_bgp_exchange_dev(void* ctx, const void* gathered_dev);
+/* The same iteration in two enqueues instead of five.  Both buffers are [N_global][RW] in global chain order:
+ *   smm_bgp_sharded_step(ctx, gathered_prev, gathered_next): resolves exchangeMoves! of the previous iteration
+ *        from gathered_prev (the all-gathered records after that iteration's accept step; may be NULL before
+ *        the first sharded step), runs next_eval for the local chains — every chain continues from its own or
+ *        its donor's record taken straight from gathered_prev — and writes the new last-accepted records into
+ *        THIS shard's slice of gathered_next (rows chain_offset .. chain_offset+N).  The caller then all-gathers
+ *        gathered_next in place (RCCL: ncclAllGather with sendbuff = recvbuff + rank*N*RW) and passes it as
+ *        gathered_prev of the next call; two buffers alternate.
+ *   smm_bgp_sharded_finish(ctx, gathered): settles the last sharded step (its exchange, history, counters) into
+ *        the context; required before smm_get_history / smm_get_state / the three-phase calls. */
+int  smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathered_next_dev);
+int  smm_bgp_sharded_finish(void* ctx, const void* gathered_dev);
 /* the HIP stream all of the ctx's work is enqueued on (hipStream_t as void*) */
 void* smm_stream(void* ctx);
 

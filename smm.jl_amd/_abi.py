@@ -108,6 +108,8 @@ SYMBOLS = [
     ("smm_bgp_record_doubles", C.c_int, [C.c_void_p]),
     ("smm_bgp_export_records_dev", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smm_bgp_exchange_dev", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("smm_bgp_sharded_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("smm_bgp_sharded_finish", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smm_stream", C.c_void_p, [C.c_void_p]),
     ("smm_eval_batch", C.c_int, [C.c_void_p, c_double_p, C.c_int32, c_double_p, c_double_p, c_int8_p]),
     ("smm_get_history", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(smm_history_t)]),

@@ -140,6 +140,13 @@ class BGPContext:
     def exchange_dev(self, ptr):
         self._check(self._fn("bgp_exchange_dev")(self._ctx, C.c_void_p(ptr)))
 
+    def sharded_step(self, prev_ptr, next_ptr):
+        """fused sharded iteration (include/smmhip.h): prev/next are device pointers of [N_global][RW] buffers"""
+        self._check(self._fn("bgp_sharded_step")(self._ctx, C.c_void_p(prev_ptr or 0), C.c_void_p(next_ptr)))
+
+    def sharded_finish(self, ptr):
+        self._check(self._fn("bgp_sharded_finish")(self._ctx, C.c_void_p(ptr or 0)))
+
     def stream(self):
         return self._fn("stream")(self._ctx)
 

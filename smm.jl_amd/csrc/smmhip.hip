@@ -61,7 +61,7 @@ enum : int { H_VALUE = 0, H_PROB, H_CURR, H_BEST, H_BESTID, H_EXCH, H_ACC, H_STA
 // error word: min over (iter<<34 | chain<<2 | kind); 1 negative objective, 2 no draw, 3 internal
 constexpr unsigned long long ERR_NONE = ~0ull;
 
-enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2, F_WALK_INLINE = 4 };
+enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2, F_WALK_INLINE = 4, F_GLOBAL_REC = 8 };  // F_GLOBAL_REC: rec_in is the all-gathered buffer (global chain ids)
 
 struct KParams {
     // problem
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         }
         if (valid) {
             // level 2: the record the chain continues from (its own, or the donor's)
-            const int s = (int)(unsigned)(xr & 0xffffffffu) - P.offset;
+            const int s = (int)(unsigned)(xr & 0xffffffffu) - ((flags & F_GLOBAL_REC) ? 0 : P.offset);
             partner = (int)(xr >> 32);
             const double* g_rec = rec_in + (size_t)s * RW;
             coop_fetch<CT, NI_REC>(v_rec, g_rec, RW, r);
@@ -877,14 +877,15 @@ __global__ void k_flush(const KParams P, const int t_next, const double* __restr
     if (c >= P.N) return;
     const int RW = P.RW, HW = P.HW, N = P.N;
     double* csb = P.cs + (size_t)c * CSW;
-    int s = c;
+    const int goff = (flags & F_GLOBAL_REC) ? 0 : P.offset;   // rec_in indexed by global chain id (all-gathered buffer)?
+    int s = P.offset + c - goff;
     bool exch = false;
     if (flags & F_HAS_PENDING) {
         const unsigned long long xr = P.xres[P.offset + c];
         const int partner = (int)(xr >> 32);
         if (partner != 0) {
             exch = true;
-            s = (int)(unsigned)(xr & 0xffffffffu) - P.offset;
+            s = (int)(unsigned)(xr & 0xffffffffu) - goff;
             const int tp = t_next - 1;
             const double* donor = rec_in + (size_t)s * RW;
             double* hrec = P.hrec + ((size_t)(tp - 1) * N + c) * HW;
@@ -1811,6 +1812,10 @@ struct Ctx {
     bool lvl_soa_exchange = false;   // XLVL_MAX < N_global <= XLDS_MAX: level walk on split chain slots
     int tpw = 1;                // tiles per workgroup of k_chain_iter (2 with the inline walk: one walk per CU)
     bool inline_walk = false;   // the exchange walk runs in the prologue of the next k_chain_iter (SMMHIP_INLINE_WALK=0: off)
+    const double* ext_rec_in = nullptr;   // sharded_step: donor records come from / results go to the caller's gather buffers
+    double* ext_rec_out = nullptr;
+    bool pending_ext = false;   // sharded_step: the exchange of iteration `iter` is still to be resolved from the gathered records
+    bool rec_external = false;  // the records after the last accept step were written to the caller's gather buffer (sharded_step)
     bool unresolved = false;    // exchangeMoves! of iteration `iter` is still to be resolved (inline, or by resolve_now)
     bool big_exchange = false;   // 8192 < N_global <= 65535: level plan and walk in global memory
     uint32_t* big_scratch = nullptr;
@@ -1899,12 +1904,13 @@ void launch_chain_iter_ct(Ctx* c, int t, int flags) {
     const KParams& P = c->P;
     const int tiles = (P.N + CT - 1) / CT;
     const dim3 grid((tiles + TPW - 1) / TPW), block(WG * TPW);
+    const double* rin = c->ext_rec_in ? c->ext_rec_in : (const double*)c->rec[c->cur];
+    double* rout = c->ext_rec_out ? c->ext_rec_out : c->rec[c->cur ^ 1];
     if (c->kev0)   // profiling mode 2: begin/end of this dispatch as the command processor stamps them
         hipExtLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, c->kev0, c->kev1, 0, P, t,
-                              (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
+                              rin, rout, flags);
     else
-        hipLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, P, t,
-                           (const double*)c->rec[c->cur], c->rec[c->cur ^ 1], flags);
+        hipLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, P, t, rin, rout, flags);
 }
 
 void launch_chain_iter(Ctx* c, int t, int flags) {
@@ -1920,7 +1926,7 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
     } else {
         launch_chain_iter_ct<0, 8>(c, t, flags);
     }
-    c->cur ^= 1;
+    if (!c->ext_rec_out) c->cur ^= 1;
 }
 
 void launch_resolve(Ctx* c, int t, const double* gathered) {
@@ -1955,6 +1961,7 @@ void resolve_now(Ctx* c) {
 }
 
 void flush(Ctx* c) {
+    if (c->rec_external) throw std::string("records are in the gather buffer: call smm_bgp_sharded_finish first");
     if (!c->pending && !c->prev_open) return;
     resolve_now(c);
     const KParams& P = c->P;
@@ -2350,6 +2357,7 @@ int smm_bgp_step(void* ctx, int32_t n_iters) {
 int smm_bgp_local_step(void* ctx) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return SMM_ERR_INVALID_ARG;
+    if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
     if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     try {
         HIPCHK(hipSetDevice(c->device));
@@ -2361,6 +2369,72 @@ int smm_bgp_local_step(void* ctx) {
         c->prev_open = true;
         c->pending = false;
         c->iter = t;
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
+// Sharded iteration in two enqueues (instead of local_step / export / exchange = five): the exchange of the previous
+// iteration is resolved from gathered_prev, the chain kernel takes every chain's continuation record (its own or the
+// donor's) straight from gathered_prev and writes the new records into this shard's slice of gathered_next.
+int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathered_next_dev) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !gathered_next_dev) return SMM_ERR_INVALID_ARG;
+    if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
+    if (c->rec_external && !gathered_prev_dev) return fail(c, SMM_ERR_INVALID_ARG, "gathered_prev required: the last records live there");
+    if (c->unresolved) return fail(c, SMM_ERR_STATE, "mixing smm_bgp_step and smm_bgp_sharded_step without a flush");
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        const int t = c->iter + 1;
+        const KParams& P = c->P;
+        int flags = (c->prev_open ? F_CLOSE_PREV : 0);
+        if (c->rec_external) {
+            if (c->pending_ext) {   // exchangeMoves! of iteration t-1 over the gathered records (before its plan window can move on)
+                launch_resolve(c, t - 1, (const double*)gathered_prev_dev);
+                flags |= F_HAS_PENDING;
+            }
+            flags |= F_GLOBAL_REC;
+            c->ext_rec_in = (const double*)gathered_prev_dev;
+        } else if (c->pending) {
+            flags |= F_HAS_PENDING;   // resolved earlier through the three-phase calls
+        }
+        ensure_windows(c, t);
+        c->ext_rec_out = (double*)gathered_next_dev + (size_t)P.offset * P.RW;
+        launch_chain_iter(c, t, flags);
+        c->ext_rec_in = nullptr; c->ext_rec_out = nullptr;
+        HIPCHK(hipGetLastError());
+        c->prev_open = true;
+        c->pending = false;
+        c->rec_external = true;
+        c->pending_ext = exchange_active(c, t);
+        c->iter = t;
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
+// settle the last sharded_step: resolve its exchange from the gathered records and bring records, history and
+// counters into the context (afterwards history/state can be read, or stepping continues in either form)
+int smm_bgp_sharded_finish(void* ctx, const void* gathered_dev) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return SMM_ERR_INVALID_ARG;
+    if (!c->rec_external) return SMM_OK;
+    if (!gathered_dev) return SMM_ERR_INVALID_ARG;
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        const KParams& P = c->P;
+        int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
+        if (c->pending_ext) {
+            launch_resolve(c, c->iter, (const double*)gathered_dev);
+            flags |= F_HAS_PENDING;
+        }
+        hipLaunchKernelGGL(k_flush, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter + 1, (const double*)gathered_dev,
+                           c->rec[c->cur ^ 1], flags);
+        HIPCHK(hipGetLastError());
+        c->cur ^= 1;
+        c->pending = false; c->prev_open = false; c->rec_external = false; c->pending_ext = false;
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }

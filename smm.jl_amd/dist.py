@@ -33,6 +33,13 @@ class HipShardEngine:
     def exchange(self, gathered):
         self.ctx.exchange_dev(gathered.data_ptr())
 
+    # fused form (two enqueues per iteration, see include/smmhip.h): used by ShardedBGP when the engine offers it
+    def fused_step(self, prev, nxt):
+        self.ctx.sharded_step(prev.data_ptr() if prev is not None else 0, nxt.data_ptr())
+
+    def fused_finish(self, gathered):
+        self.ctx.sharded_finish(gathered.data_ptr() if gathered is not None else 0)
+
     def sync(self):
         self.ctx.sync()
 
@@ -50,10 +57,22 @@ class ShardedBGP:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.local = engine.new_tensor((engine.N, engine.R))
         self.gathered = engine.new_tensor((self.world, engine.N, engine.R))  # == [N_global][R] in global chain order
+        self.fused = hasattr(engine, "fused_step")
+        if self.fused:   # two gather buffers alternate: iteration t reads donors from one, writes its records to the other
+            self.gbuf = [self.gathered, engine.new_tensor((self.world, engine.N, engine.R))]
+            self.gcur = None   # index of the buffer holding the gathered records of the last iteration
 
     def step(self, n_iters=1):
         e = self.e
         with e.stream_ctx():
+            if self.fused:
+                for _ in range(n_iters):
+                    nxt = 0 if self.gcur is None else self.gcur ^ 1
+                    e.fused_step(self.gbuf[self.gcur] if self.gcur is not None else None, self.gbuf[nxt])
+                    if self.world > 1:   # in place: this rank's slice is already where the collective wants it
+                        dist.all_gather_into_tensor(self.gbuf[nxt].view(-1), self.gbuf[nxt][self.rank].view(-1), group=self.group)
+                    self.gcur = nxt
+                return
             for _ in range(n_iters):
                 e.local_step()
                 if self.world == 1:
@@ -64,4 +83,9 @@ class ShardedBGP:
                 e.exchange(self.gathered)
 
     def sync(self):
+        """settle the last iteration into the context (history/state readable afterwards) and wait for the device"""
+        if self.fused and self.gcur is not None:
+            with self.e.stream_ctx():
+                self.e.fused_finish(self.gbuf[self.gcur])
+            self.gcur = None
         self.e.sync()

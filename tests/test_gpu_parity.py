@@ -195,6 +195,64 @@ def sharded_run(S, prob, opts_full, G, T):
     return ctxs
 
 
+def sharded_run_fused(S, prob, opts_full, G, T, finish_every=None):
+    """the two-enqueue form (smm_bgp_sharded_step): all shards write their slices of the same gather buffer, which
+    stands in for the in-place all-gather; two buffers alternate"""
+    import torch
+    from smm_jl_amd import BGPOpts
+    N = opts_full.N_global // G
+    ctxs = []
+    for r in range(G):
+        o = BGPOpts(N=N, maxiter=opts_full.maxiter, sigma=opts_full.sigma, acc_tuner=opts_full.acc_tuner,
+                    min_improve=opts_full.min_improve, sigma_update_steps=opts_full.sigma_update_steps,
+                    sigma_adjust_by=opts_full.sigma_adjust_by, smpl_iters=opts_full.smpl_iters,
+                    batch_size=opts_full.batch_size, seed=opts_full.seed, chain_offset=r * N,
+                    N_global=opts_full.N_global)
+        ctxs.append(S.hip_context(prob, o))
+    R = ctxs[0].record_doubles()
+    bufs = [torch.zeros((G, N, R), dtype=torch.float64, device="cuda") for _ in range(2)]
+    cur = None
+    for it in range(T):
+        nxt = 0 if cur is None else cur ^ 1
+        for c in ctxs:
+            c.sharded_step(bufs[cur].data_ptr() if cur is not None else 0, bufs[nxt].data_ptr())
+        for c in ctxs:
+            c.sync()
+        cur = nxt
+        if finish_every and (it + 1) % finish_every == 0 and it + 1 < T:
+            for c in ctxs:
+                c.sharded_finish(bufs[cur].data_ptr())
+                c.sync()
+            cur = None
+    for c in ctxs:
+        c.sharded_finish(bufs[cur].data_ptr() if cur is not None else 0)
+        c.sync()
+    return ctxs
+
+
+@pytest.mark.parametrize("G,N,T,fe", [(2, 32, 25, None), (4, 32, 25, 7), (2, 9000, 6, None), (4, 600, 300, 97)])
+def test_fused_sharded_equals_single(S, O, G, N, T, fe):
+    # 9000: above the LDS kernels (global-memory level walk); 600 x 300: crosses a look-ahead window with an open exchange
+    N -= N % G
+    prob, opts = cm.serial_normal(N=N, T=T, ns=64 if N > 100 else 300)
+    single = S.hip_context(prob, opts)
+    single.step(T)
+    ctxs = sharded_run_fused(S, prob, opts, G, T, finish_every=fe)
+    hs = single.history()
+    n = N // G
+    for r, c in enumerate(ctxs):
+        hr = c.history()
+        for f in A.HistoryBuffers.FIELDS:
+            assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+        st, ss = c.state(), single.state()
+        assert np.array_equal(st.sigma, ss.sigma[r * n:(r + 1) * n]) and np.array_equal(st.accept_rate, ss.accept_rate[r * n:(r + 1) * n])
+    assert (hs.exchanged != 0).any()
+    if N <= 100:
+        o = O.OracleContext(prob, opts, S.Tables(Z=single.Z()))
+        o.step(T)
+        cm.assert_history_equal(hs, o.history())
+
+
 @pytest.mark.parametrize("G", [2, 4])
 def test_sharded_equals_single(S, O, G):
     prob, opts = cm.serial_normal(N=32, T=25, ns=300)
