@@ -43,7 +43,29 @@ class OracleShardEngine:
         return contextlib.nullcontext()
 
 
-def _worker(rank, world, port, N, T, q):
+class OracleFusedEngine(OracleShardEngine):
+    """the two-enqueue protocol of ShardedBGP (fused_step / fused_finish: alternating gather buffers, in-place
+    all-gather of this rank's slice) on top of the oracle's three phases"""
+
+    def __init__(self, ctx, rank):
+        super().__init__(ctx)
+        self.rank = rank
+        self.open = False
+
+    def fused_step(self, prev, nxt):
+        if self.open:
+            self.ctx.exchange(prev.reshape(-1, self.R).numpy())
+        self.ctx.local_step()
+        nxt[self.rank].copy_(torch.from_numpy(self.ctx.export_records()))
+        self.open = True
+
+    def fused_finish(self, gathered):
+        if self.open:
+            self.ctx.exchange(gathered.reshape(-1, self.R).numpy())
+        self.open = False
+
+
+def _worker(rank, world, port, N, T, q, fused=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import common as cm
     from oracle import oracle as O
@@ -54,9 +76,11 @@ def _worker(rank, world, port, N, T, q):
     try:
         n = N // world
         prob, opts = cm.serial_normal(N=N, T=T, ns=100, N_local=n, chain_offset=rank * n)
-        sh = ShardedBGP(OracleShardEngine(O.OracleContext(prob, opts)))
-        assert sh.world == world and sh.rank == rank
-        sh.step(T)
+        octx = O.OracleContext(prob, opts)
+        sh = ShardedBGP(OracleFusedEngine(octx, rank) if fused else OracleShardEngine(octx))
+        assert sh.world == world and sh.rank == rank and sh.fused == fused
+        sh.step(T // 2); sh.step(T - T // 2)
+        sh.sync()
         hs = sh.e.ctx.history()
         # single-process reference of the whole population
         prob1, opts1 = cm.serial_normal(N=N, T=T, ns=100)
@@ -76,13 +100,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_gloo_equals_single_process(world):
+@pytest.mark.parametrize("world,fused", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_gloo_equals_single_process(world, fused):
     N, T = 12 * world, 30
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, T, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, T, q, fused)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
