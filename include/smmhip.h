@@ -67,6 +67,21 @@ typedef enum {
 } smm_objective_t;
 #define SMM_DENSE_D 256
 
+/* User objectives — the reference's "bring your own objfunc" (MProb.objfunc, mprob.jl:159,182) on the device.
+ * objective_id >= SMM_OBJ_USER_BASE is a handle returned by smm_register_user_objective.  The source is HIP/C++
+ * text defining ONE function with this exact signature (SMM_USER_OBJECTIVE expands to the required linkage):
+ *
+ *   SMM_USER_OBJECTIVE(const double* theta, int np, const double* mom, const double* w, int nm,
+ *                      const double* udata, int n_udata, double* sim_moments, double* value, int* status)
+ *
+ * It must fill sim_moments[0..nm), *value (>= 0, AlgoBGP.jl:341) and *status (1 = ok; < 0 = failed, the record is
+ * rejected like an objective that threw, mprob.jl:183-186).  It must be a deterministic function of its inputs
+ * (a simulation seeds its own generator, as objfunc_norm does with Random.seed!(1234)); udata = obj_params.
+ * It is compiled at registration (hiprtc, -ffp-contract=off) and evaluated for all chains of an iteration by one
+ * kernel launch, one thread per chain, between the proposal and the accept step. */
+#define SMM_OBJ_USER_BASE 1000
+#define SMM_OBJ_USER 4   /* internal kind of every user objective */
+
 /* MProb (mprob.jl:29-53) flattened: parameters to sample with bounds and start
  * values (addSampledParam!, mprob.jl:81-98), data moments and weights
  * (addMoment!, mprob.jl:123-155). */
@@ -165,6 +180,8 @@ typedef struct {
 } smm_timing_t;
 
 int  smm_abi_version(void);
+/* compile a user objective; errors (with the compiler log) through smm_last_error(NULL) */
+int  smm_register_user_objective(const char* hip_source, int32_t* objective_id_out);
 int  smm_device_count(void);
 
 /* MAlgoBGP(m,opts) constructor, AlgoBGP.jl:505-537 + BGPChain ctor :78-109 */

@@ -40,6 +40,11 @@
 #define ORC_OBJ_BANANA 1
 #define ORC_OBJ_NORM_FAILBOX 2
 #define ORC_OBJ_DENSE 3
+#define ORC_OBJ_USER_BASE 1000
+#define ORC_MAX_USER 64
+typedef void (*orc_user_fn)(const double* theta, int np, const double* mom, const double* w, int nm, const double* udata,
+                            int n_udata, double* sim_moments, double* value, int* status);
+static orc_user_fn g_user_fn[ORC_MAX_USER];
 #define ORC_DENSE_D 256
 
 #define ORC_REDUCE_LANES 512 /* numerical contract, see include/smmhip.h */
@@ -390,10 +395,27 @@ static void evaluate_objective(const orc_t* o, const double* theta, double* simM
         }
         break;
     default:
+        if (p->objective_id >= ORC_OBJ_USER_BASE && p->objective_id - ORC_OBJ_USER_BASE < ORC_MAX_USER &&
+            g_user_fn[p->objective_id - ORC_OBJ_USER_BASE]) {
+            /* user objective (include/smmhip.h, SMM_USER_OBJECTIVE): the same source text the device compiles,
+             * built for the host by the test and registered under the same handle */
+            int st = 1;
+            double v = 0.0;
+            g_user_fn[p->objective_id - ORC_OBJ_USER_BASE](theta, p->np, o->mom, o->w, p->nm, o->obj_params, p->n_obj_params, simM,
+                                                           &v, &st);
+            *value = v;
+            *status = (int8_t)st;
+            break;
+        }
         for (int k = 0; k < p->nm; ++k) simM[k] = NAN;
         *value = -1.0;
         *status = -2;
     }
+}
+
+void orc_set_user_objective(int objective_id, orc_user_fn fn) {
+    if (objective_id >= ORC_OBJ_USER_BASE && objective_id - ORC_OBJ_USER_BASE < ORC_MAX_USER)
+        g_user_fn[objective_id - ORC_OBJ_USER_BASE] = fn;
 }
 
 static double* dupd(const double* s, size_t n) {

@@ -7,11 +7,11 @@ The compute path is libsmmhip.so (hand-written HIP, csrc/); there is no CPU fall
 """
 from . import _abi
 from ._abi import SMMHipError
-from .backend import BGPContext, BGPOpts, Problem, Tables, hip_context
+from .backend import BGPContext, BGPOpts, Problem, Tables, hip_context, register_user_objective
 from .host import (CI, BGPChain, Eval, MAlgoBGP, MProb, addEvalFunc, addMoment, addParam, addSampledParam, allAccepted,
                    banana, best, computeNextIteration, dataMoment, dataMomentd, dataMomentW, dataMomentWd,
                    evaluateObjective, fill, dense_sim, history, mean, median, ms_names, objfunc_norm, param, paramd, params,
                    ps2s_names, ps_names, readMalgo, restart, run, save, serialNormal, setMoments, setValue, snorm_impl,
-                   summary)
+                   summary, user_objective)
 
 __all__ = [n for n in dir() if not n.startswith("_")] + ["_abi"]

@@ -32,6 +32,7 @@ SMM_OBJ_NORM = 0
 SMM_OBJ_BANANA = 1
 SMM_OBJ_NORM_FAILBOX = 2
 SMM_OBJ_DENSE = 3
+SMM_OBJ_USER_BASE = 1000   # objective ids >= this are handles of smm_register_user_objective
 SMM_DENSE_D = 256
 
 SMM_REDUCE_LANES = 512
@@ -96,6 +97,7 @@ class smm_timing_t(C.Structure):
 # every symbol declared in include/smmhip.h: (name, restype, argtypes)
 SYMBOLS = [
     ("smm_abi_version", C.c_int, []),
+    ("smm_register_user_objective", C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     ("smm_device_count", C.c_int, []),
     ("smm_ctx_create", C.c_int, [C.POINTER(smm_problem_t), C.POINTER(smm_bgp_opts_t), C.POINTER(smm_tables_t),
                                  C.POINTER(C.c_void_p)]),

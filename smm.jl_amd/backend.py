@@ -193,6 +193,17 @@ class BGPContext:
         return z
 
 
+def register_user_objective(source):
+    """Compile a user objective (HIP/C++ text defining SMM_USER_OBJECTIVE(...), see include/smmhip.h) for the device
+    and return its objective_id handle.  Raises with the compiler log if it does not compile."""
+    lib = A.load()
+    oid = C.c_int32(0)
+    rc = lib.smm_register_user_objective(source.encode(), C.byref(oid))
+    if rc != 0:
+        raise RuntimeError("smm_register_user_objective failed (%d): %s" % (rc, lib.smm_last_error(None).decode()))
+    return int(oid.value)
+
+
 def hip_context(problem, opts, tables=None):
     """The product constructor: a BGPContext on libsmmhip.so. Raises if the library is missing."""
     return BGPContext(A.load(), "smm_", problem, opts, tables)

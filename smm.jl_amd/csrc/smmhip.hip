@@ -29,6 +29,9 @@
 //   xres [Ng]             exchange result: src | partner<<32
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -61,7 +64,7 @@ enum : int { H_VALUE = 0, H_PROB, H_CURR, H_BEST, H_BESTID, H_EXCH, H_ACC, H_STA
 // error word: min over (iter<<34 | chain<<2 | kind); 1 negative objective, 2 no draw, 3 internal
 constexpr unsigned long long ERR_NONE = ~0ull;
 
-enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2, F_WALK_INLINE = 4, F_GLOBAL_REC = 8 };  // F_GLOBAL_REC: rec_in is the all-gathered buffer (global chain ids)
+enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2, F_WALK_INLINE = 4, F_GLOBAL_REC = 8, F_PROPOSE_ONLY = 16 };  // F_GLOBAL_REC: rec_in is the all-gathered buffer (global chain ids)
 
 struct KParams {
     // problem
@@ -75,6 +78,8 @@ struct KParams {
     double sigma_adjust_by;
     uint64_t seed;
     const double* min_improve_g;  // [Ng]
+    // user objective (objective_id >= SMM_OBJ_USER_BASE): proposals out, results in, [N][np] / [N][nm] / [N]
+    double* u_theta; double* u_simM; double* u_value; int* u_status;
     int mi_uniform;               // all thresholds equal (the usual case): mi_value
     int tile_off;                 // doubles in front of the tile's LDS blocks (the inline walk's chain slots)
     double mi_value;
@@ -331,7 +336,13 @@ __device__ inline void dense_tile(const KParams& P, const double* s_theta, doubl
 template <int CT>
 __device__ inline void finish_objective(const KParams& P, const double* theta /*LDS [np]*/, const double* s_part,
                                         const double* s_mom, const double* s_w, int ci, double* simM /*[nm] out, LDS*/,
-                                        double& value, int& status) {
+                                        double& value, int& status, int c_local = 0) {
+    if (P.obj == SMM_OBJ_USER) {  // evaluated by the user's kernel between the proposal and the accept launch
+        for (int k = 0; k < P.nm; ++k) simM[k] = P.u_simM[(size_t)c_local * P.nm + k];
+        value = P.u_value[c_local];
+        status = P.u_status[c_local];
+        return;
+    }
     if (P.obj == SMM_OBJ_BANANA) {
         double v = 0.0;
         for (int i = 0; i + 1 < P.np; ++i) {
@@ -777,6 +788,11 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     TS_MARK(6);
     __syncthreads();
     TS_MARK(2);
+    if (flags & F_PROPOSE_ONLY) {  // user objective: hand the proposals to the user's kernel; nothing has been stored yet, the
+        if (valid)                 // accept launch repeats this (deterministic) prologue
+            for (int k = r; k < np; k += NR) P.u_theta[(size_t)c * np + k] = S.theta[cl * np + k];
+        return;
+    }
 
     // ---- simulation: all 512 lanes, ns draws x nm moments x CT chains ----
     if constexpr (KIND == 1) {
@@ -807,7 +823,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         double* sm = hr + H_PARAMS + np;
         double value;
         int status;
-        finish_objective<CT>(P, th, S.part, S.mom, S.w, cl, sm, value, status);
+        finish_objective<CT>(P, th, S.part, S.mom, S.w, cl, sm, value, status, c);
         const double sig = csb[CS_SIGMA], bp = csb[CS_BEST], bpid = csb[CS_BESTID], atun = csb[CS_ATUN];
         const int nn = (int)csb[CS_NNOEX], na = (int)csb[CS_NACC];
         const double u = t > 1 ? S.rb[cl * RBW] : 0.0;  // probs_acc[iter], :85
@@ -1780,6 +1796,51 @@ __global__ void k_exch_apply(const KParams P, const int t, const double* __restr
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_create_err;
 
+// ------------------------------------------------------------------------------------------
+// user objectives: compiled with hiprtc (loaded lazily, the library does not link against it)
+// ------------------------------------------------------------------------------------------
+struct UserObjective { std::vector<char> code; };
+std::vector<UserObjective> g_user_objectives;
+std::mutex g_user_mutex;
+
+const char* USER_PRELUDE =
+    "#define SMM_USER_OBJECTIVE extern \"C\" __device__ void smm_user_objective\n"
+    "extern \"C\" __device__ void smm_user_objective(const double* theta, int np, const double* mom, const double* w, int nm,\n"
+    "                                              const double* udata, int n_udata, double* sim_moments, double* value, int* status);\n";
+const char* USER_KERNEL =
+    "\nextern \"C\" __global__ void smm_user_eval_kernel(const double* theta, int N, int np, const double* mom, const double* w, int nm,\n"
+    "        const double* udata, int n_udata, double* simM, double* value, int* status) {\n"
+    "    const int c = blockIdx.x * blockDim.x + threadIdx.x;\n"
+    "    if (c >= N) return;\n"
+    "    int st = 1; double v = 0.0;\n"
+    "    smm_user_objective(theta + (size_t)c * np, np, mom, w, nm, udata, n_udata, simM + (size_t)c * nm, &v, &st);\n"
+    "    value[c] = v; status[c] = st;\n"
+    "}\n";
+
+struct Hiprtc {
+    void* lib = nullptr;
+    decltype(&hiprtcCreateProgram) create = nullptr;
+    decltype(&hiprtcCompileProgram) compile = nullptr;
+    decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+    decltype(&hiprtcGetProgramLog) log = nullptr;
+    decltype(&hiprtcGetCodeSize) code_size = nullptr;
+    decltype(&hiprtcGetCode) code = nullptr;
+    decltype(&hiprtcDestroyProgram) destroy = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        lib = dlopen("libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { err = std::string("cannot load libhiprtc.so: ") + dlerror(); return false; }
+#define RTC_SYM(f, name) f = (decltype(f))dlsym(lib, name); if (!f) { err = std::string("libhiprtc.so lacks ") + name; return false; }
+        RTC_SYM(create, "hiprtcCreateProgram") RTC_SYM(compile, "hiprtcCompileProgram") RTC_SYM(log_size, "hiprtcGetProgramLogSize")
+        RTC_SYM(log, "hiprtcGetProgramLog") RTC_SYM(code_size, "hiprtcGetCodeSize") RTC_SYM(code, "hiprtcGetCode")
+        RTC_SYM(destroy, "hiprtcDestroyProgram")
+#undef RTC_SYM
+        return true;
+    }
+};
+Hiprtc g_rtc;
+
 struct Ctx {
     KParams P{};
     int obj = 0, device = 0, exchange_from = 2;
@@ -1815,6 +1876,9 @@ struct Ctx {
     const double* ext_rec_in = nullptr;   // sharded_step: donor records come from / results go to the caller's gather buffers
     double* ext_rec_out = nullptr;
     bool pending_ext = false;   // sharded_step: the exchange of iteration `iter` is still to be resolved from the gathered records
+    int n_objp = 0;                 // doubles in P.objp
+    hipModule_t umod = nullptr;     // user objective: this context's module and kernel
+    hipFunction_t ufn = nullptr;
     bool rec_external = false;  // the records after the last accept step were written to the caller's gather buffer (sharded_step)
     bool unresolved = false;    // exchangeMoves! of iteration `iter` is still to be resolved (inline, or by resolve_now)
     bool big_exchange = false;   // 8192 < N_global <= 65535: level plan and walk in global memory
@@ -1913,7 +1977,28 @@ void launch_chain_iter_ct(Ctx* c, int t, int flags) {
         hipLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, P, t, rin, rout, flags);
 }
 
+// one thread per evaluation: theta [n][np] -> simM [n][nm], value [n], status [n]
+void launch_user_kernel(Ctx* c, const double* theta, int n, double* simM, double* value, int* status) {
+    const KParams& P = c->P;
+    int np = P.np, nm = P.nm, nud = c->n_objp;
+    const double *mom = P.mom, *w = P.w, *ud = P.objp;
+    void* args[] = {(void*)&theta, (void*)&n, (void*)&np, (void*)&mom, (void*)&w, (void*)&nm, (void*)&ud, (void*)&nud,
+                    (void*)&simM, (void*)&value, (void*)&status};
+    HIPCHK(hipModuleLaunchKernel(c->ufn, (unsigned)((n + 127) / 128), 1, 1, 128, 1, 1, 0, c->stream, args, nullptr));
+}
+
 void launch_chain_iter(Ctx* c, int t, int flags) {
+    if (c->obj == SMM_OBJ_USER) {
+        // proposal launch (stores nothing but the proposals) -> the user's kernel -> accept launch (repeats the
+        // deterministic prologue, takes value / moments / status from the user's kernel)
+        const KParams& P = c->P;
+        const bool big = tile_smem_base(c, 64) <= (size_t)60 * 1024;
+        if (big) launch_chain_iter_ct<0, 64>(c, t, flags | F_PROPOSE_ONLY); else launch_chain_iter_ct<0, 8>(c, t, flags | F_PROPOSE_ONLY);
+        launch_user_kernel(c, P.u_theta, P.N, P.u_simM, P.u_value, P.u_status);
+        if (big) launch_chain_iter_ct<0, 64>(c, t, flags); else launch_chain_iter_ct<0, 8>(c, t, flags);
+        if (!c->ext_rec_out) c->cur ^= 1;
+        return;
+    }
     if (is_sim(c->obj)) {
         if (c->ct == 4) launch_chain_iter_ct<1, 4>(c, t, flags);
         else if (c->ct == 16) launch_chain_iter_ct<1, 16>(c, t, flags);
@@ -2008,6 +2093,39 @@ extern "C" {
 
 int smm_abi_version(void) { return SMMHIP_ABI_VERSION; }
 
+int smm_register_user_objective(const char* hip_source, int32_t* objective_id_out) {
+    if (!hip_source || !objective_id_out) { g_create_err = "smm_register_user_objective: null argument"; return SMM_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lock(g_user_mutex);
+    std::string err;
+    if (!g_rtc.load(err)) { g_create_err = err; return SMM_ERR_HIP; }
+    const std::string src = std::string(USER_PRELUDE) + hip_source + USER_KERNEL;
+    hiprtcProgram prog = nullptr;
+    if (g_rtc.create(&prog, src.c_str(), "smm_user_objective.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        g_create_err = "hiprtcCreateProgram failed";
+        return SMM_ERR_HIP;
+    }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
+    const hiprtcResult rc = g_rtc.compile(prog, 4, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        g_rtc.log_size(prog, &n);
+        std::string log(n, ' ');
+        if (n) g_rtc.log(prog, &log[0]);
+        g_create_err = "user objective does not compile:\n" + log;
+        g_rtc.destroy(&prog);
+        return SMM_ERR_INVALID_ARG;
+    }
+    size_t cs = 0;
+    g_rtc.code_size(prog, &cs);
+    UserObjective u;
+    u.code.resize(cs);
+    g_rtc.code(prog, u.code.data());
+    g_rtc.destroy(&prog);
+    g_user_objectives.push_back(std::move(u));
+    *objective_id_out = SMM_OBJ_USER_BASE + (int32_t)g_user_objectives.size() - 1;
+    return SMM_OK;
+}
+
 int smm_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -2022,6 +2140,7 @@ void smm_ctx_destroy(void* ctx) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
+    if (c->umod) (void)hipModuleUnload(c->umod);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->pev) (void)hipEventDestroy(e);
@@ -2036,7 +2155,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         return fail(nullptr, SMM_ERR_INVALID_ARG, "need 1 <= np,nm <= 64 and ns >= 1");
     if (N < 1 || T < 1 || Ng < N || opts->chain_offset < 0 || opts->chain_offset + N > Ng || (Ng % N) != 0)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "bad N / N_global / chain_offset / maxiter");
-    if (prob->objective_id < 0 || prob->objective_id > SMM_OBJ_DENSE)
+    const bool user_obj = prob->objective_id >= SMM_OBJ_USER_BASE;
+    if (user_obj) {
+        std::lock_guard<std::mutex> lock(g_user_mutex);
+        if (prob->objective_id - SMM_OBJ_USER_BASE >= (int)g_user_objectives.size())
+            return fail(nullptr, SMM_ERR_INVALID_ARG, "unknown user objective handle");
+    } else if (prob->objective_id < 0 || prob->objective_id > SMM_OBJ_DENSE)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "unknown objective_id");
     if (is_sim(prob->objective_id) && np != nm)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "objfunc_norm needs one moment per parameter (ObjExamples.jl:66-78)");
@@ -2055,7 +2179,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         HIPCHK(hipEventCreate(&c->ev0));
         HIPCHK(hipEventCreate(&c->ev1));
         KParams& P = c->P;
-        c->obj = prob->objective_id;
+        c->obj = user_obj ? SMM_OBJ_USER : prob->objective_id;
         c->exchange_from = opts->exchange_from_iter;
         {
             const char* e = getenv("SMMHIP_ANY_EXCHANGE");  // test hook: force the any-size resolution kernel
@@ -2067,10 +2191,23 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* ct = getenv("SMMHIP_CT");  // tuning hook: chains per tile (4, 8, 16); numerics unaffected
             c->ct = ct ? atoi(ct) : 8;
         }
-        P.np = np; P.nm = nm; P.ns = ns; P.obj = prob->objective_id;
+        P.np = np; P.nm = nm; P.ns = ns; P.obj = c->obj;
         P.init = dupload(c, prob->init, np); P.lb = dupload(c, prob->lb, np); P.ub = dupload(c, prob->ub, np);
         P.mom = dupload(c, prob->mom, nm); P.w = dupload(c, prob->w, nm);
         P.objp = prob->n_obj_params > 0 ? dupload(c, prob->obj_params, prob->n_obj_params) : nullptr;
+        c->n_objp = prob->n_obj_params > 0 ? prob->n_obj_params : 0;
+        if (user_obj) {
+            {
+                std::lock_guard<std::mutex> lock(g_user_mutex);
+                const UserObjective& u = g_user_objectives[prob->objective_id - SMM_OBJ_USER_BASE];
+                HIPCHK(hipModuleLoadData(&c->umod, u.code.data()));
+            }
+            HIPCHK(hipModuleGetFunction(&c->ufn, c->umod, "smm_user_eval_kernel"));
+            P.u_theta = dalloc<double>(c, (size_t)N * np);
+            P.u_simM = dalloc<double>(c, (size_t)N * nm);
+            P.u_value = dalloc<double>(c, N);
+            P.u_status = dalloc<int>(c, N);
+        }
         if (prob->objective_id == SMM_OBJ_DENSE) {
             const size_t nB = (size_t)DENSE_D * np, nA = (size_t)nm * DENSE_D;
             if (prob->n_obj_params != 0 && (size_t)prob->n_obj_params != nB + nA)
@@ -2152,7 +2289,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* iw = getenv("SMMHIP_INLINE_WALK");
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
             const size_t tile_b = (tile_smem_base(c, tile_ct) + 15) & ~(size_t)15;
-            c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng &&
+            c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng && c->obj != SMM_OBJ_USER &&
                              walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024;
             P.tile_off = c->inline_walk ? (int)(walk_slot_bytes(Ng) / sizeof(double)) : 0;
             // two tiles per workgroup share one walk (the 2p/2m-style simulation tile of 8 chains only)
@@ -2492,6 +2629,26 @@ int smm_eval_batch(void* ctx, const double* params, int32_t M, double* value, do
         HIPCHK(hipMalloc((void**)&dv, (size_t)M * 8));
         HIPCHK(hipMalloc((void**)&dm, (size_t)P.nm * M * 8));
         HIPCHK(hipMalloc((void**)&ds, (size_t)M));
+        if (c->obj == SMM_OBJ_USER) {   // the user's kernel wants [M][np] / [M][nm]: transpose on the host
+            std::vector<double> tp((size_t)M * P.np), tm((size_t)M * P.nm);
+            std::vector<int> ts((size_t)M);
+            for (int i = 0; i < M; ++i)
+                for (int k = 0; k < P.np; ++k) tp[(size_t)i * P.np + k] = params[(size_t)k * M + i];
+            int* dsi = nullptr;
+            HIPCHK(hipMalloc((void**)&dsi, (size_t)M * sizeof(int)));
+            HIPCHK(hipMemcpyAsync(dp, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream));
+            launch_user_kernel(c, dp, M, dm, dv, dsi);
+            HIPCHK(hipMemcpyAsync(value, dv, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(tm.data(), dm, tm.size() * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(ts.data(), dsi, ts.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            for (int i = 0; i < M; ++i) {
+                status[i] = (int8_t)ts[i];
+                for (int k = 0; k < P.nm; ++k) sim_moments[(size_t)k * M + i] = tm[(size_t)i * P.nm + k];
+            }
+            (void)hipFree(dp); (void)hipFree(dv); (void)hipFree(dm); (void)hipFree(ds); (void)hipFree(dsi);
+            return SMM_OK;
+        }
         HIPCHK(hipMemcpyAsync(dp, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
         constexpr int CT = 8;
         if (is_sim(c->obj))

@@ -40,6 +40,14 @@ def _no_mprob():
     raise ValueError("a device objective needs an Eval built from an MProb (Eval(mprob, p))")
 
 
+def user_objective(source, name="user_objective", obj_params=None):
+    """A user-written device objective (MProb.objfunc of the reference, mprob.jl:159): `source` is HIP/C++ text that
+    defines SMM_USER_OBJECTIVE(theta, np, mom, w, nm, udata, n_udata, sim_moments, value, status) — see
+    include/smmhip.h.  addEvalFunc(m, user_objective(src)); addEvalFuncOpts(m, {"obj_params": [...]}) passes udata."""
+    from .backend import register_user_objective
+    return DeviceObjective(name, register_user_objective(source), ns=1)
+
+
 objfunc_norm = DeviceObjective("objfunc_norm", A.SMM_OBJ_NORM, needs_square=True)   # ObjExamples.jl:59-116
 banana = DeviceObjective("banana", A.SMM_OBJ_BANANA, ns=1)                           # ObjExamples.jl:251-265
 dense_sim = DeviceObjective("dense_sim", A.SMM_OBJ_DENSE, ns=1)                     # BASELINE config 5 (include/smmhip.h)
@@ -120,15 +128,16 @@ def ms_names(m):
 
 def _flat_problem(m):
     if not isinstance(m.objfunc, DeviceObjective):
-        raise TypeError("MProb.objfunc must be a device objective (objfunc_norm, banana): arbitrary host closures "
-                        "cannot run inside the GPU iteration")
+        raise TypeError("MProb.objfunc must be a device objective (objfunc_norm, banana, dense_sim, or user_objective(src) "
+                        "for your own): arbitrary host closures cannot run inside the GPU iteration")
     names = ps2s_names(m)
     init = [m.initial_value[k] for k in names]
     lb = [m.params_to_sample[k]["lb"] for k in names]
     ub = [m.params_to_sample[k]["ub"] for k in names]
     mom = [m.moments[k]["value"] for k in ms_names(m)]
     w = [np.nan if m.moments[k]["weight"] is None else m.moments[k]["weight"] for k in ms_names(m)]
-    return Problem(init, lb, ub, mom, w, ns=m.objfunc_opts.get("ns", m.objfunc.ns), objective_id=m.objfunc.objective_id)
+    return Problem(init, lb, ub, mom, w, ns=m.objfunc_opts.get("ns", m.objfunc.ns), objective_id=m.objfunc.objective_id,
+                   obj_params=m.objfunc_opts.get("obj_params"))
 
 
 class Eval:

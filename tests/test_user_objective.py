@@ -1,0 +1,93 @@
+"""User-defined device objectives (include/smmhip.h SMM_USER_OBJECTIVE)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import common as cm  # noqa: E402
+from user_objective_src import AR1_SOURCE, ar1_numpy  # noqa: E402
+
+
+def ar1_problem(S, oid, N, T, fail_above=None, seed=5):
+    udata = [400.0] + ([fail_above] if fail_above is not None else [])
+    prob = S.Problem(init=[0.3, 1.0], lb=[-0.95, 0.1], ub=[0.95, 3.0], mom=[0.0, 0.12, 0.06], w=[0.05, 0.05, 0.05], ns=1,
+                     objective_id=oid, obj_params=udata)
+    opts = S.BGPOpts(N=N, maxiter=T, sigma=0.05 * cm.temps(N, 4.0), acc_tuner=np.geomspace(3.0, 0.5, N) if N > 1 else [2.0],
+                     min_improve=np.zeros(N), seed=seed, N_global=N)
+    return prob, opts
+
+
+def test_oracle_user_objective_hook(O, S):
+    # CPU only: the oracle calls the gcc build of the objective source; against an independent numpy restatement
+    oid = 1000 + 63
+    O.register_user_objective(AR1_SOURCE, oid)
+    prob, opts = ar1_problem(S, oid, N=1, T=1, fail_above=0.5)
+    o = O.OracleContext(prob, opts)
+    rng = np.random.default_rng(0)
+    th = np.stack([rng.uniform(-0.9, 0.9, 12), rng.uniform(0.2, 2.5, 12)])
+    v, sm, st = o.eval_batch(th)
+    for i in range(12):
+        smr, vr, sr = ar1_numpy(th[:, i], prob.mom, prob.w, prob.obj_params)
+        assert st[i] == sr and np.allclose(sm[:, i], smr, rtol=1e-13, atol=1e-15)
+        assert (v[i] == -1.0) if sr < 0 else np.isclose(v[i], vr, rtol=1e-12)
+    assert (st < 0).any() and (st > 0).any()
+
+
+@pytest.mark.gpu
+def test_user_objective_eval_batch_and_run(S, O):
+    oid = S.register_user_objective(AR1_SOURCE)
+    assert oid >= 1000
+    O.register_user_objective(AR1_SOURCE, oid)
+    prob, opts = ar1_problem(S, oid, N=24, T=40, fail_above=0.8)
+    h = S.hip_context(prob, opts)
+    o = O.OracleContext(prob, opts)
+    rng = np.random.default_rng(1)
+    th = np.stack([rng.uniform(-0.9, 0.9, 300), rng.uniform(0.2, 2.5, 300)])
+    vh, smh, sth = h.eval_batch(th)
+    vo, smo, sto = o.eval_batch(th)
+    assert np.array_equal(sth, sto) and np.array_equal(smh, smo) and np.array_equal(vh, vo)   # pure arithmetic: bit-exact
+    assert (sth < 0).any()
+    h.step(40); o.step(40)
+    hh = h.history()
+    cm.assert_history_equal(hh, o.history())
+    cm.assert_state_equal(h.state(), o.state())
+    assert (hh.exchanged != 0).any() and (hh.status == -2).any() and hh.accepted[1:].any()
+
+
+@pytest.mark.gpu
+def test_user_objective_sharded_equals_single(S, O):
+    from test_gpu_parity import sharded_run_fused
+    from smm_jl_amd import _abi as A
+    oid = S.register_user_objective(AR1_SOURCE)
+    prob, opts = ar1_problem(S, oid, N=32, T=20)
+    single = S.hip_context(prob, opts)
+    single.step(20)
+    ctxs = sharded_run_fused(S, prob, opts, 2, 20)
+    hs = single.history()
+    for r, c in enumerate(ctxs):
+        hr = c.history()
+        for f in A.HistoryBuffers.FIELDS:
+            assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * 16:(r + 1) * 16], equal_nan=True), (f, r)
+
+
+@pytest.mark.gpu
+def test_user_objective_through_the_host_api(S):
+    m = S.MProb()
+    S.addSampledParam(m, {"rho": [0.3, -0.95, 0.95], "sigma": [1.0, 0.1, 3.0]})
+    S.addMoment(m, {"name": ["m1", "m2", "m3"], "value": [0.0, 0.12, 0.06], "weight": [0.05, 0.05, 0.05]})
+    S.addEvalFunc(m, S.user_objective(AR1_SOURCE, name="ar1"))
+    m.objfunc_opts["obj_params"] = [400.0]
+    MA = S.MAlgoBGP(m, {"N": 6, "maxiter": 60, "maxtemp": 3, "smpl_iters": 1000, "min_improve": [0.0] * 6,
+                        "acc_tuners": [3.0, 2.0, 1.5, 1.0, 0.7, 0.5]})
+    S.run(MA)
+    h = S.history(MA.chains[0])
+    assert len(h["value"]) == 60 and np.isfinite(h["value"]).all() and min(h["best_val"]) < h["value"][0]
+
+
+@pytest.mark.gpu
+def test_user_objective_compile_error_is_reported(S):
+    with pytest.raises(RuntimeError) as e:
+        S.register_user_objective("SMM_USER_OBJECTIVE(const double* theta) { this is not C }")
+    assert "compile" in str(e.value)
