@@ -13,7 +13,7 @@ module SMMHip
 
 using Libdl
 
-export MAlgoBGPHip, hip_run!, hip_step!, hip_history, hip_state, hip_eval_batch
+export MAlgoBGPHip, hip_run!, hip_step!, hip_history, hip_state, hip_eval_batch, hip_register_objective
 
 const LIB = Ref{Ptr{Cvoid}}(C_NULL)
 
@@ -81,19 +81,21 @@ mutable struct MAlgoBGPHip
     pnames::Vector{Symbol}; mnames::Vector{Symbol}
 end
 
-function MAlgoBGPHip(pnames, init, lb, ub, mnames, mom, w, opts::Dict; objective::Symbol = :norm, ns::Integer = 10000)
+function MAlgoBGPHip(pnames, init, lb, ub, mnames, mom, w, opts::Dict; objective = :norm, ns::Integer = 10000,
+                     obj_params::Vector{Float64} = Float64[])
     N = Int(opts["N"])
     temps = N > 1 ? collect(range(1.0, stop = Float64(opts["maxtemp"]), length = N)) : [1.0]   # AlgoBGP.jl:508
     sigma = get(opts, "sigma", 0.05) .* temps                                                    # :518
     mi = Float64.(get(opts, "min_improve", fill(0.5, N)))                                        # :522
     acc = Float64.(get(opts, "acc_tuners", fill(2.0, N)))                                        # :523
     init = Float64.(init); lb = Float64.(lb); ub = Float64.(ub); mom = Float64.(mom); w = Float64.(w)
-    oid = objective == :norm ? OBJ_NORM : objective == :banana ? OBJ_BANANA : objective == :dense ? OBJ_DENSE :
+    oid = objective isa Integer ? Cint(objective) :      # handle of hip_register_objective
+          objective == :norm ? OBJ_NORM : objective == :banana ? OBJ_BANANA : objective == :dense ? OBJ_DENSE :
           error("unknown device objective $objective")
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve init lb ub mom w sigma mi acc begin
+    GC.@preserve init lb ub mom w sigma mi acc obj_params begin
         p = SmmProblem(length(init), length(mom), ns, oid, pointer(init), pointer(lb), pointer(ub),
-                       pointer(mom), pointer(w), C_NULL, 0, 0)
+                       pointer(mom), pointer(w), isempty(obj_params) ? C_NULL : pointer(obj_params), length(obj_params), 0)
         o = SmmBgpOpts(N, Int(opts["maxiter"]), pointer(sigma), pointer(acc), pointer(mi),
                        get(opts, "sigma_update_steps", 10), get(opts, "smpl_iters", 1000),
                        Float64(get(opts, "sigma_adjust_by", 0.01)),
@@ -172,6 +174,20 @@ function hip_eval_batch(a::MAlgoBGPHip, params::Matrix{Float64})
                            a.ctx, pointer(params), M, pointer(value), pointer(simm), pointer(st)))
     end
     return value, simm, st
+end
+
+"""
+    hip_register_objective(src) -> objective id
+
+Compile a user objective (HIP/C++ text defining `SMM_USER_OBJECTIVE(theta, np, mom, w, nm, udata, n_udata,
+sim_moments, value, status)`, see include/smmhip.h) for the device: the counterpart of `addEvalFunc!(m, f)`
+(mprob.jl:159).  Pass the returned id as `objective = id` to `MAlgoBGPHip`.
+"""
+function hip_register_objective(src::AbstractString)
+    id = Ref{Int32}(0)
+    rc = ccall(sym(:smm_register_user_objective), Cint, (Cstring, Ref{Int32}), src, id)
+    rc == 0 || error("smm_register_user_objective failed ($rc): $(last_error(C_NULL))")
+    return Int(id[])
 end
 
 # ---- glue for SMM.jl (only evaluated when SMM is loaded next to this module) ----------------
