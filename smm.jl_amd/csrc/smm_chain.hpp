@@ -1,0 +1,824 @@
+// the chain kernel: tile reduction, simulation, objectives, block moves, inline exchange walk, k_chain_iter, k_flush, k_eval_batch — part of libsmmhip (included by smmhip.hip inside its anonymous namespace; gfx950 device code).
+#pragma once
+// ------------------------------------------------------------------------------------------
+// Transposed wave reduction: every lane holds CT partial sums a[0..CT); on return lane l holds the
+// 64-lane total of accumulator acc_index<CT>(l), combined by the canonical halving tree (offsets
+// 32,16,8,4,2,1; IEEE addition is commutative so both partners compute the same bits).
+// ------------------------------------------------------------------------------------------
+template <int CT, int NN, int OFF>
+__device__ inline void wave_reduce_step(double (&a)[CT], int lane) {
+    if constexpr (NN > 1) {
+        const bool upper = (lane & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < NN / 2; ++i) {
+            const double mine = upper ? a[i + NN / 2] : a[i];
+            const double send = upper ? a[i] : a[i + NN / 2];
+            const double recv = __shfl_xor(send, OFF, 64);
+            a[i] = mine + recv;
+        }
+        wave_reduce_step<CT, NN / 2, OFF / 2>(a, lane);
+    } else if constexpr (OFF >= 1) {
+        a[0] = a[0] + __shfl_xor(a[0], OFF, 64);
+        wave_reduce_step<CT, 1, OFF / 2>(a, lane);
+    }
+}
+template <int CT>
+__device__ inline double wave_reduce_transposed(double (&a)[CT], int lane) {
+    wave_reduce_step<CT, CT, 32>(a, lane);
+    return a[0];
+}
+template <int CT>
+__device__ inline int acc_index(int lane) {  // the log2(CT) top lane bits
+    constexpr int LG = (CT == 1) ? 0 : (CT == 2) ? 1 : (CT == 4) ? 2 : (CT == 8) ? 3 : (CT == 16) ? 4 : (CT == 32) ? 5 : 6;
+    return LG == 0 ? 0 : (lane >> (6 - LG));
+}
+template <int CT>
+__device__ inline bool acc_writer(int lane) {
+    return (lane & ((64 / CT) - 1)) == 0;
+}
+
+// The simulation of objfunc_norm (ObjExamples.jl:76-79) for a tile of CT chains:
+// X[k,s] = theta_c[k] + z[k,s]; lane `tid` of the 512 sums its draws tid, tid+512, ... of moment k
+// in that order (numerical contract).  Rows are processed in chunks of ZU; the shocks of the next
+// chunk (of this or of the next moment) are loaded from the L2-resident matrix while the current
+// chunk is added up.  Chunk 0 of moment 0 is loaded by the caller before its serial prologue.
+constexpr int ZU = 8;
+
+// The shock matrix is read through a buffer descriptor: row = scalar byte offset (SALU), lane = one constant
+// 32-bit vector offset, so a chunk load is ZU buffer_load instructions and no vector address arithmetic.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+struct ZBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lane_off;  // tid * 8
+    __device__ inline void init(const KParams& P, int tid) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.Z, 0, (int)((size_t)P.nm * P.zstride * sizeof(double)), 0x00020000);
+        lane_off = tid * (int)sizeof(double);
+    }
+};
+// chunk ch of moment k
+__device__ inline void sim_load_chunk(const ZBuf& zb, const KParams& P, int k, int ch, double (&z)[ZU]) {
+    const int row0 = (k * P.zstride + ((P.dbg & 8) ? 0 : ch) * (ZU * WG)) * (int)sizeof(double);  // dbg 8: timing experiment
+#pragma unroll
+    for (int u = 0; u < ZU; ++u)
+        z[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zb.rsrc, zb.lane_off, row0 + u * WG * (int)sizeof(double), 0));
+}
+
+// zc: chunk 0 of moment 0 (already loaded).  s_theta [CT][np], s_part [WG/64][CT][nm] in LDS.
+// Moments are reduced in groups of G = 16/CT: one transposed reduction of G*CT accumulators has the
+// same number of dependent shuffle steps as one of CT, so grouping halves that latency for CT = 8.
+// A moment is nch chunks; the last one may be ragged (rows masked per lane).  Two chunks per trip, the
+// two register buffers trade places; the chunk after a moment's last is chunk 0 of the next moment.
+template <int CT>
+__device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const double* s_theta, double* s_part, int tid, double (&zc)[ZU]) {
+    constexpr int G = (CT >= 16) ? 1 : 16 / CT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ns = P.ns, nm = P.nm;
+    const int nch = (ns + ZU * WG - 1) / (ZU * WG);
+    const int last_draws = ns - (nch - 1) * (ZU * WG);   // draws of the last chunk, 1 .. ZU*WG
+    const bool ragged = last_draws < ZU * WG;
+    for (int k0 = 0; k0 < nm; k0 += G) {
+        double acc[G * CT];
+#pragma unroll
+        for (int i = 0; i < G * CT; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+            const int k = k0 + kk;
+            if (k < nm) {
+                double mu[CT];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) mu[c] = s_theta[c * P.np + k];
+                auto add_full = [&](const double (&z)[ZU]) {
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u) {
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            const double x = z[u] + mu[c];
+                            acc[kk * CT + c] = acc[kk * CT + c] + x;
+                        }
+                    }
+                };
+                auto add_last = [&](const double (&z)[ZU]) {
+                    if (!ragged) { add_full(z); return; }
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u) {
+                        if (tid + u * WG < last_draws) {
+#pragma unroll
+                            for (int c = 0; c < CT; ++c) {
+                                const double x = z[u] + mu[c];
+                                acc[kk * CT + c] = acc[kk * CT + c] + x;
+                            }
+                        }
+                    }
+                };
+                const int knext = (k + 1 < nm) ? k + 1 : k;   // last moment: a harmless reload
+                double zn[ZU];
+                int ch = 0;
+                for (; ch + 2 <= nch; ch += 2) {
+                    sim_load_chunk(zb, P, k, ch + 1, zn);
+                    add_full(zc);
+                    const bool last = (ch + 2 == nch);
+                    sim_load_chunk(zb, P, last ? knext : k, last ? 0 : ch + 2, zc);
+                    if (last) add_last(zn); else add_full(zn);
+                }
+                if (ch < nch) {  // odd count: the last chunk is in zc; afterwards the buffers are swapped by copy
+                    sim_load_chunk(zb, P, knext, 0, zn);
+                    add_last(zc);
+#pragma unroll
+                    for (int u = 0; u < ZU; ++u) zc[u] = zn[u];
+                }
+            }
+        }
+        const double tot = wave_reduce_transposed<G * CT>(acc, lane);
+        if (acc_writer<G * CT>(lane)) {
+            const int a = acc_index<G * CT>(lane);
+            const int kk = a / CT, c = a - kk * CT;
+            if (k0 + kk < nm) s_part[(wave * CT + c) * nm + k0 + kk] = tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense objective (SMM_OBJ_DENSE, BASELINE config 5): the simulation is a dense contraction, so it
+// runs on the FP64 matrix cores.  A tile is 16 chains = the N dimension of v_mfma_f64_16x16x4; wave w
+// of the 8 owns the hidden units d in [32w, 32w+32):
+//   x tile [16 d x 16 chains]  = B[16 d x np] * theta[np x 16]        (ceil(np/4) MFMAs)
+//   h = tanh(x): the accumulator layout (row = (lane>>4) + 4r, col = lane&15) IS the B-operand layout
+//   of the next product (k = 4s + (lane>>4)), so h feeds the second GEMM from registers;
+//   y tile [16 k x 16 chains] += A[16 k x 16 d] * h[16 d x 16]        (4 MFMAs per output tile)
+// B and A are stored in fragment order (one coalesced 8-byte load per lane per MFMA).  The wave's
+// partial y goes to LDS [w][k][chain]; the 8 partials are added left to right by the chain lane.
+// ------------------------------------------------------------------------------------------
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int DENSE_D = SMM_DENSE_D;
+
+template <int CT>
+__device__ inline void dense_tile(const KParams& P, const double* s_theta, double* s_part, int tid) {
+    static_assert(CT == 16, "the dense objective tiles 16 chains (MFMA N dimension)");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int np = P.np, nPs = (np + 3) / 4, nOt = P.dense_nOt, nmp = nOt * 16;
+    d4_t yacc[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) yacc[o] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int T = 2 * wave + tt;
+        d4_t xacc = d4_t{0.0, 0.0, 0.0, 0.0};
+        const double* __restrict__ bf = P.dense_Bf + (size_t)T * nPs * 64 + lane;
+        for (int s = 0; s < nPs; ++s) {
+            const int p = 4 * s + lk;
+            const double b = (p < np) ? s_theta[li * np + p] : 0.0;
+            xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[(size_t)s * 64], b, xacc, 0, 0, 0);
+        }
+        double h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = tanh(xacc[r]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < nOt) {
+                const double* __restrict__ af = P.dense_Af + ((size_t)(o * (DENSE_D / 16) + T) * 4) * 64 + lane;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4 * 64], h[s4], yacc[o], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (o < nOt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_part[((size_t)wave * nmp + 16 * o + lk + 4 * r) * 16 + li] = yacc[o][r];
+        }
+    }
+}
+
+// value / simulated moments / status for one chain from its reduced sums
+// (ObjExamples.jl:79-110; banana :251-265; "exception" -> status -2, mprob.jl:183-186).
+// s_mom / s_w: data moments and weights staged in LDS.
+template <int CT>
+__device__ inline void finish_objective(const KParams& P, const double* theta /*LDS [np]*/, const double* s_part,
+                                        const double* s_mom, const double* s_w, int ci, double* simM /*[nm] out, LDS*/,
+                                        double& value, int& status, int c_local = 0) {
+    if (P.obj == SMM_OBJ_USER) {  // evaluated by the user's kernel between the proposal and the accept launch
+        for (int k = 0; k < P.nm; ++k) simM[k] = P.u_simM[(size_t)c_local * P.nm + k];
+        value = P.u_value[c_local];
+        status = P.u_status[c_local];
+        return;
+    }
+    if (P.obj == SMM_OBJ_BANANA) {
+        double v = 0.0;
+        for (int i = 0; i + 1 < P.np; ++i) {
+            const double a = theta[i], b = theta[i + 1];
+            const double t1 = b - a * a;
+            const double t2 = 1.0 - a;
+            const double term = 100.0 * (t1 * t1) + t2 * t2;
+            v = (i == 0) ? term : v + term;
+        }
+        for (int k = 0; k < P.nm; ++k) simM[k] = s_mom[k] + 2.2;
+        value = v;
+        status = 1;
+        return;
+    }
+    if (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp && theta[0] >= P.objp[0] && theta[0] <= P.objp[1]) {
+        for (int k = 0; k < P.nm; ++k) simM[k] = NAN;
+        value = -1.0;  // Eval() default, Eval.jl:84
+        status = -2;
+        return;
+    }
+    double vsum = 0.0;
+    const bool dense = P.obj == SMM_OBJ_DENSE;
+    const int nmp = P.dense_nOt * 16;
+    for (int k = 0; k < P.nm; ++k) {
+        double tot = dense ? s_part[((size_t)0 * nmp + k) * 16 + ci] : s_part[(0 * CT + ci) * P.nm + k];
+#pragma unroll
+        for (int wv = 1; wv < WG / 64; ++wv)
+            tot = tot + (dense ? s_part[((size_t)wv * nmp + k) * 16 + ci] : s_part[(wv * CT + ci) * P.nm + k]);
+        const double m = dense ? tot : tot / (double)P.ns;
+        simM[k] = m;
+        double d = m - s_mom[k];
+        const double wk = s_w[k];
+        if (!isnan(wk)) d = d / wk;
+        const double v = d * d;
+        vsum = (k == 0) ? v : vsum + v;
+    }
+    value = vsum / (double)P.nm;
+    status = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tile shared memory and wave-cooperative block moves
+// ------------------------------------------------------------------------------------------
+struct TileSmem {
+    double *cs, *rb, *rec, *rout, *h, *hp, *theta, *lb, *ub, *init, *mom, *w, *part;
+    unsigned* arrived;
+    __device__ inline void carve(double* base, int CT, int np, int nm, int RW, int HW, int RBW, bool sim) {
+        cs = base;                  // [CT][CSW]
+        rb = cs + CT * CSW;         // [CT][RBW]
+        rec = rb + CT * RBW;        // [CT][RW]   record the chain continues from
+        rout = rec + CT * RW;       // [CT][RW]   record after this iteration's accept step
+        h = rout + CT * RW;         // [CT][HW]   history record of iteration t
+        hp = h + CT * HW;           // [CT][HW]   rewritten history record of iteration t-1 (exchanged chains)
+        theta = hp + CT * HW;       // [CT][np]
+        lb = theta + CT * np;       // [np] ...
+        ub = lb + np;
+        init = ub + np;
+        mom = init + np;            // [nm]
+        w = mom + nm;
+        part = w + nm;              // [WG/64][CT][nm]
+        arrived = (unsigned*)(part + (size_t)(WG / 64) * CT * nm);   // simulation kind: waves whose partial sums are in LDS
+        (void)sim;
+    }
+};
+__host__ __device__ inline size_t tile_smem_doubles(int CT, int np, int nm, int RW, int HW, int RBW, int kind) {
+    const size_t part = kind == 1 ? (size_t)(WG / 64) * CT * nm : kind == 2 ? (size_t)(WG / 64) * (((nm + 15) / 16) * 16) * 16 : 0;
+    return (size_t)CT * (CSW + RBW + 2 * RW + 2 * HW + np) + 3 * np + 2 * nm + part + 2;
+}
+
+// lanes (cl, r) of the control wave move chain cl's block of W doubles (W even) in 16-byte pieces
+template <int CT>
+__device__ inline void coop_load(double* lds_blk, const double* __restrict__ g, int W, int r) {
+    constexpr int NR = 64 / CT;
+    const double2* __restrict__ gs = (const double2*)g;
+    double2* ld = (double2*)lds_blk;
+#pragma unroll 2
+    for (int i = r; i < W / 2; i += NR) ld[i] = gs[i];
+}
+// the same in two halves, so that the loads of several blocks are in flight together: coop_fetch requests
+// the first NI pieces per lane into registers, coop_put writes them to LDS (and moves what is left of a long block)
+template <int CT, int NI>
+__device__ inline void coop_fetch(double2 (&v)[NI], const double* __restrict__ g, int W, int r) {
+    constexpr int NR = 64 / CT;
+    const double2* __restrict__ gs = (const double2*)g;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = r + k * NR;
+        v[k] = i < W / 2 ? gs[i] : make_double2(0.0, 0.0);
+    }
+}
+template <int CT, int NI>
+__device__ inline void coop_put(double* lds_blk, const double2 (&v)[NI], const double* __restrict__ g, int W, int r) {
+    constexpr int NR = 64 / CT;
+    const double2* __restrict__ gs = (const double2*)g;
+    double2* ld = (double2*)lds_blk;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = r + k * NR;
+        if (i < W / 2) ld[i] = v[k];
+    }
+    for (int i = r + NI * NR; i < W / 2; i += NR) ld[i] = gs[i];
+}
+template <int CT>
+__device__ inline void coop_store(double* __restrict__ g, const double* lds_blk, int W, int r) {
+    constexpr int NR = 64 / CT;
+    double2* __restrict__ gd = (double2*)g;
+    const double2* ld = (const double2*)lds_blk;
+#pragma unroll 2
+    for (int i = r; i < W / 2; i += NR) gd[i] = ld[i];
+}
+
+// set_eval!(ci, ej) of swap_ev_ij! (AlgoBGP.jl:734-749) as a history record: the chain's record of
+// the exchanged iteration tp is the donor's last accepted one (accepted = true, the donor's
+// prob/status), curr = donor value, best recomputed against iteration tp-1 (:231-243).
+__device__ inline void make_swapped_history(const KParams& P, double* hrec /*[HW]*/, const double* donor /*[RW]*/, int tp,
+                                            int partner, double bpp, double bppid, double& bestv, double& bestid) {
+    const double value = donor[0];
+    if (value < bpp) { bestv = value; bestid = (double)tp; }
+    else { bestv = bpp; bestid = bppid; }
+    hrec[H_VALUE] = value; hrec[H_PROB] = donor[1]; hrec[H_CURR] = value; hrec[H_BEST] = bestv;
+    hrec[H_BESTID] = bestid; hrec[H_EXCH] = (double)partner; hrec[H_ACC] = 1.0; hrec[H_STATUS] = donor[2];
+    const int nv = P.np + P.nm;
+    for (int k = 0; k < nv; ++k) hrec[H_PARAMS + k] = donor[3 + k];
+}
+
+// ------------------------------------------------------------------------------------------
+// exchangeMoves! inside the chain kernel (single shard, N_global <= XLVL_MAX).
+// The level walk of k_exch_resolve_lvl (below) costs ~7 us as a kernel of one workgroup plus a ~2.5 us
+// kernel boundary.  Executed redundantly by EVERY tile in the prologue of the next k_chain_iter it costs
+// the walk's ~4 us inside a kernel that is latency-structured anyway, and the boundary and the xres round
+// trip disappear.  Same plan (k_exch_plan: pairs grouped by dependency level), same arithmetic, same result;
+// the working set is 16 bytes per chain + 4 bytes per pair of LDS, the pair list overlaid by the tile's own
+// blocks once the walk is over: 80 KB at N = 4096, so two tiles still share a CU.  Thresholds: one scalar when min_improve is uniform, else read from the plan (L2).
+// ------------------------------------------------------------------------------------------
+constexpr int XLVL_MAX = 4096;
+struct __attribute__((aligned(16))) XSlot {  // one chain during the walk: 16 bytes, moved with one ds_read/write_b128
+    double val;
+    uint32_t src, partner;
+};
+// LDS of a tile with the inline walk: [XSlot slot[Ng]] [pairs[K] u32, later overlaid by the tile's own blocks]
+__host__ __device__ inline size_t walk_slot_bytes(int Ng) { return (size_t)Ng * sizeof(XSlot); }
+
+template <int NT>
+__device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsigned char* lds, const int tid) {
+    const int Ng = P.Ng, K = P.plan_K;
+    const int w = tx - P.plan_t0;
+    XSlot* slot = (XSlot*)lds;                              // [Ng]
+    uint32_t* pairs = (uint32_t*)(lds + walk_slot_bytes(Ng));   // [K]
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    const bool mi_u = P.mi_uniform != 0;
+    const double mi_v = P.mi_value;
+    // one round trip of global loads
+    constexpr int PT = XLVL_MAX / NT;
+    const int lane = tid & 63;
+    double v_[PT];
+    uint32_t pq_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        v_[r] = g < Ng ? P.vals[g] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * NT;
+        pq_[r] = q < K ? g_pairs[q] : 0u;
+    }
+    const uint32_t ev = g_off[min(lane, K)];   // lane l: end of level l
+    const int nlev = (int)g_off[K + 1];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        if (g < Ng) {
+            XSlot s_;
+            s_.val = v_[r]; s_.src = (uint32_t)g; s_.partner = 0;
+            slot[g] = s_;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * NT;
+        if (q < K) pairs[q] = pq_[r];
+    }
+    for (int q = tid + PT * NT; q < K; q += NT) pairs[q] = g_pairs[q];   // injected pair lists longer than XLVL_MAX
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
+    // The level sizes fall off geometrically.  The narrow tail (every remaining level <= 64 pairs) is walked by
+    // wave 0 alone: LDS operations of one wave complete in order, so its levels need no workgroup barrier and
+    // cost one LDS round trip each (a barrier level of a tile costs ~0.45 us next to a second walking tile).
+    int ltail = nlev;
+    if (nlev > 0 && nlev <= 64 && !(P.dbg & 128)) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)ev, 1, 64);
+        const unsigned long long wide = __ballot(lane < nlev && ev - (lane > 0 ? lo : 0u) > 64u);
+        ltail = wide ? 64 - __builtin_clzll(wide) : 0;
+    }
+    __syncthreads();
+    uint32_t b = 0;
+    uint32_t e = nlev > 0 ? level_end(0) : 0u;
+    uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
+    uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
+    double m = mi_u ? mi_v : ((b + tid < e) ? g_mi[b + tid] : 0.0);
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < ltail; ++l) {
+        const uint32_t e3 = level_end(l + 2);
+        // this thread's first pair of the next level is fetched while this level runs
+        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+        const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+        for (uint32_t pos = b + tid; pos < e; pos += NT) {
+            if (pos != b + tid) { pw = pairs[pos]; m = mi_u ? mi_v : g_mi[pos]; }
+            const uint32_t i = pw & 0xffffu, j = pw >> 16;
+            const XSlot si = slot[i], sj = slot[j];
+            if (si.val - sj.val > m) {                  // dist_fun = -, AlgoBGP.jl:688
+                XSlot ni, nj;                           // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                slot[i] = ni;
+                slot[j] = nj;
+            }
+        }
+        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+        __syncthreads();
+    }
+    if (ltail < nlev) {
+        if (tid < 64) {   // (pw, m) already hold this lane's pair of level ltail, e its end, e2 the next end
+            constexpr uint32_t NOPAIR = 0xffffffffu;   // i == j == 0xffff never occurs (chain ids < XLVL_MAX)
+            uint32_t cpw = (b + tid < e) ? pw : NOPAIR;
+#pragma clang loop unroll(disable)
+            for (int l = ltail; l < nlev; ++l) {
+                const uint32_t e3 = level_end(l + 2);
+                const uint32_t npw = (e + tid < e2) ? pairs[e + tid] : NOPAIR;
+                const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+                if (cpw != NOPAIR) {
+                    const uint32_t i = cpw & 0xffffu, j = cpw >> 16;
+                    const XSlot si = slot[i], sj = slot[j];
+                    if (si.val - sj.val > m) {
+                        XSlot ni, nj;
+                        ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                        nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                        slot[i] = ni;
+                        slot[j] = nj;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                cpw = npw; m = m2; e = e2; e2 = e3;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_chain_iter: one next_eval (AlgoBGP.jl:272-294) for every local chain, iteration t (1-based).
+// rec_in : last accepted records after iteration t-1's accept step   [N][RW]
+// rec_out: the same after iteration t's accept step (input of exchangeMoves!)
+// Wave 0 is the tile's control wave: lane = r*CT + cl works for chain cl.  It moves the per-chain
+// blocks with 16-byte pieces (two dependent levels: state/randomness/exchange result, then the
+// record the chain continues from), evaluates the proposal tries side by side, and after the
+// simulation lanes r == 0 run the accept step and the wave stores the result blocks.
+// ------------------------------------------------------------------------------------------
+// TPW tiles per workgroup (TPW = 2 with the inline exchange walk: the two tiles that would share a CU anyway
+// become one workgroup of 1024 lanes, so the CU runs ONE walk with twice the lanes instead of two copies
+// contending for its LDS; everything else is per tile, on the tile-local lane id).
+template <int KIND, int CT, int TPW = 1>
+__global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                            double* __restrict__ rec_out, const int flags) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NR = 64 / CT;
+    const int np = P.np, nm = P.nm, N = P.N, RW = P.RW, HW = P.HW, RBW = P.RBW;
+    const int st = (TPW > 1) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / WG) : 0;   // tile of this workgroup (wave-uniform: scalar)
+    const int tid = (int)threadIdx.x - st * WG;             // lane of the tile
+    const int tile = (int)blockIdx.x * TPW + st;
+    TileSmem S;
+    S.carve(smem + P.tile_off + (size_t)st * ((tile_smem_doubles(CT, np, nm, RW, HW, RBW, KIND) + 1) & ~(size_t)1), CT, np, nm, RW, HW,
+            RBW, KIND != 0);
+    const int cl = tid % CT, r = (tid % 64) / CT;
+    const int c = tile * CT + cl;             // chain served by this lane (control wave only)
+    const bool ctl = tid < 64;
+    const bool valid = ctl && (c < N);
+    const bool chain_lane = valid && r == 0;
+    const int gc = P.offset + c;
+    TS_MARK(0);
+
+    // ---- global reads, all issued before anything waits ----
+    double za[ZU];
+    ZBuf zb;
+    if constexpr (KIND == 1) { zb.init(P, tid); sim_load_chunk(zb, P, 0, 0, za); }
+    int partner = 0;
+    // wave 1: problem constants, requested now and written to LDS after the walk
+    const bool wave1 = tid >= 64 && tid < 128;
+    const int k1 = tid - 64;
+    double c_lb = 0.0, c_ub = 0.0, c_init = 0.0, c_mom = 0.0, c_w = 0.0;
+    if (wave1) {
+        if (k1 < np) { c_lb = P.lb[k1]; c_ub = P.ub[k1]; c_init = P.init[k1]; }
+        if (k1 < nm) { c_mom = P.mom[k1]; c_w = P.w[k1]; }
+    }
+    {
+        // level 1: exchange result, chain state block, this iteration's randomness block
+        constexpr int NI_MAX = 4;   // pieces per lane held in registers; longer blocks finish with a load-store loop
+        constexpr int NI_CS = (CSW / 2 + NR - 1) / NR < NI_MAX ? (CSW / 2 + NR - 1) / NR : NI_MAX;
+        constexpr int NI_RB = (12 + NR - 1) / NR < NI_MAX ? (12 + NR - 1) / NR : NI_MAX;
+        constexpr int NI_REC = (8 + NR - 1) / NR < NI_MAX ? (8 + NR - 1) / NR : NI_MAX;
+        double2 v_cs[NI_CS], v_rb[NI_RB], v_rec[NI_REC];
+        const int cc = valid ? c : 0;
+        const double* g_cs = P.cs + (size_t)cc * CSW;
+        const double* g_rb = P.rb + ((size_t)(t > 1 ? t - P.rb_t0 : 0) * N + cc) * RBW;
+        const int rbw = t > 1 ? RBW : 0;
+        unsigned long long xr = (unsigned long long)(unsigned)gc;
+        if (valid) {
+            if ((flags & F_HAS_PENDING) && !(flags & F_WALK_INLINE)) xr = P.xres[gc];
+            coop_fetch<CT, NI_CS>(v_cs, g_cs, CSW, r);
+            coop_fetch<CT, NI_RB>(v_rb, g_rb, rbw, r);
+        }
+        if (flags & F_WALK_INLINE) {
+            // exchangeMoves! of iteration t-1, by all lanes of the tile, while the level-1 blocks are in flight
+            // (the tile's own LDS blocks overlay the walk's pair list: nothing of the tile is written before this returns)
+            exchange_walk_tile<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x);
+            if (valid) {
+                const XSlot sv = ((const XSlot*)smem)[gc];
+                xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
+            }
+        }
+        if (KIND == 1 && tid == 64) *S.arrived = 0u;
+        if (wave1) {  // problem constants into the tile's LDS (which the walk's pair list occupied until now)
+            if (k1 < np) { S.lb[k1] = c_lb; S.ub[k1] = c_ub; S.init[k1] = c_init; }
+            if (k1 < nm) { S.mom[k1] = c_mom; S.w[k1] = c_w; }
+            for (int k = k1 + 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; S.init[k] = P.init[k]; }
+            for (int k = k1 + 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
+        }
+        if (valid) {
+            // level 2: the record the chain continues from (its own, or the donor's)
+            const int s = (int)(unsigned)(xr & 0xffffffffu) - ((flags & F_GLOBAL_REC) ? 0 : P.offset);
+            partner = (int)(xr >> 32);
+            const double* g_rec = rec_in + (size_t)s * RW;
+            coop_fetch<CT, NI_REC>(v_rec, g_rec, RW, r);
+            coop_put<CT, NI_CS>(S.cs + cl * CSW, v_cs, g_cs, CSW, r);
+            coop_put<CT, NI_RB>(S.rb + cl * RBW, v_rb, g_rb, rbw, r);
+            coop_put<CT, NI_REC>(S.rec + cl * RW, v_rec, g_rec, RW, r);
+        }
+    }
+    TS_MARK(1);
+    __syncthreads();
+
+    // ---- settle iteration t-1 (chain lanes; registers + LDS only) ----
+    // (its results go back to the LDS block and are read again after the simulation: nothing of the serial
+    // bookkeeping stays in registers across the register-hungry simulation loop)
+    if (chain_lane) {
+        double* csb = S.cs + cl * CSW;
+        int nn = (int)csb[CS_NNOEX], na = (int)csb[CS_NACC];
+        double bp = csb[CS_BEST], bpid = csb[CS_BESTID];
+        if (t > 1) {
+            bool exch_prev = false;
+            if (partner != 0) {  // swap_ev_ij!, :734-749: iteration t-1's record becomes the donor's
+                exch_prev = true;
+                make_swapped_history(P, S.hp + cl * HW, S.rec + cl * RW, t - 1, partner, csb[CS_BESTP], csb[CS_BESTPID], bp, bpid);
+            } else if (csb[CS_WASX] != 0.0) {  // sharded path: k_exch_apply already rewrote record and history
+                exch_prev = true;
+            }
+            if ((flags & F_CLOSE_PREV) && !exch_prev) { nn += 1; na += (int)csb[CS_LACC]; }  // set_acceptRate!, :253-257
+        }
+        csb[CS_NNOEX] = (double)nn; csb[CS_NACC] = (double)na; csb[CS_BEST] = bp; csb[CS_BESTID] = bpid;
+        csb[CS_PARTNER] = (double)partner;
+    }
+    TS_MARK(5);
+    // ---- proposal(c), AlgoBGP.jl:424-471: lane (cl, r) evaluates try r of chain cl ----
+    if (ctl) {
+        double* th = S.theta + cl * np;
+        const double* rc = S.rec + cl * RW;
+        if (t == 1 || !valid || (P.dbg & 1)) {
+            if (r == 0)
+                for (int k = 0; k < np; ++k) th[k] = !valid ? 0.0 : (t == 1 ? S.init[k] : rc[3 + k]);  // :426-427
+        } else {
+            const int bs = P.batch_size;
+            const int max_tries = P.user_n ? min(P.rb_tries, P.smpl_iters) : P.smpl_iters;
+            const int npar = min(min(NR, P.rb_tries), max_tries);  // tries evaluated side by side
+            const double sg = S.cs[cl * CSW + CS_SIGMA];
+            const double* zz = S.rb + cl * RBW + 1;  // [tries][np]
+            for (int b0 = 0; b0 < np; b0 += bs) {
+                bool ok = r < npar;
+                if (ok) {
+                    for (int k = b0; k < b0 + bs; ++k) {  // mysample, :400-410, try r
+                        const double lbk = S.lb[k];
+                        const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);  // mapto_01, mprob.jl:248
+                        const double step = sg * zz[r * np + k];  // MvNormal(mu01, sigma): x = mu + sigma*z
+                        const double x = mu01 + step;
+                        if (!(x >= 0.0 && x <= 1.0)) ok = false;  // inclusive bounds, :405
+                    }
+                }
+                const unsigned long long m = __ballot(ok);  // first successful try of every chain
+                unsigned long long pat = 0;
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) pat |= ((m >> (rr * CT + cl)) & 1ull) << rr;
+                const int rwin = pat ? (__ffsll((long long)pat) - 1) : -1;
+                if (rwin == r) {
+                    for (int k = b0; k < b0 + bs; ++k) {
+                        const double lbk = S.lb[k];
+                        const double span = S.ub[k] - lbk;
+                        const double mu01 = (rc[3 + k] - lbk) / span;
+                        const double step = sg * zz[r * np + k];
+                        const double x = mu01 + step;
+                        const double sc = x * span;
+                        th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
+                    }
+                } else if (rwin < 0 && r == 0) {  // rare: one try at a time (block, then the in-kernel generator)
+                    bool ok2 = false;
+                    for (int rr = npar; rr < max_tries && !ok2; ++rr) {
+                        ok2 = true;
+                        double zc0 = 0.0, zc1 = 0.0;
+                        int zq = -1;
+                        for (int k = b0; k < b0 + bs; ++k) {
+                            const double lbk = S.lb[k];
+                            const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);
+                            double z;
+                            if (rr < P.rb_tries) {
+                                z = zz[rr * np + k];
+                            } else {
+                                if ((k >> 1) != zq) {
+                                    zq = k >> 1;
+                                    const double2 zz2 = rng_prop_normal2_outofline(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)rr, (uint32_t)zq);
+                                    zc0 = zz2.x; zc1 = zz2.y;
+                                }
+                                z = (k & 1) ? zc1 : zc0;
+                            }
+                            const double step = sg * z;
+                            const double x = mu01 + step;
+                            th[k] = x;
+                            if (!(x >= 0.0 && x <= 1.0)) ok2 = false;
+                        }
+                    }
+                    if (!ok2) report_error(P, 2, t, gc);  // :409
+                    for (int k = b0; k < b0 + bs; ++k) {
+                        const double lbk = S.lb[k];
+                        const double span = S.ub[k] - lbk;
+                        const double sc = th[k] * span;
+                        th[k] = sc + lbk;
+                    }
+                }
+            }
+        }
+    }
+    TS_MARK(6);
+    __syncthreads();
+    TS_MARK(2);
+    if (flags & F_PROPOSE_ONLY) {  // user objective: hand the proposals to the user's kernel; nothing has been stored yet, the
+        if (valid)                 // accept launch repeats this (deterministic) prologue
+            for (int k = r; k < np; k += NR) P.u_theta[(size_t)c * np + k] = S.theta[cl * np + k];
+        return;
+    }
+
+    // ---- simulation: all 512 lanes, ns draws x nm moments x CT chains ----
+    if constexpr (KIND == 1) {
+        if (!(P.dbg & 2)) simulate_tile<CT>(P, zb, S.theta, S.part, tid, za);
+        // No workgroup barrier here: only the tile's control wave consumes the partial sums.  Every wave announces
+        // its partials with one LDS add and is done; the control wave waits for the tile's 8 announcements.  (With
+        // two tiles per workgroup a barrier would also make the faster tile wait for the slower one.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((tid & 63) == 0) __hip_atomic_fetch_add(S.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!ctl) return;
+        while (__hip_atomic_load(S.arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(WG / 64))
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else if constexpr (KIND == 2) {
+        dense_tile<CT>(P, S.theta, S.part, tid);
+        __syncthreads();
+    }
+    TS_MARK(3);
+    if (P.dbg & 4) return;
+
+    // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245): chain lanes ----
+    if (chain_lane) {
+        const double* th = S.theta + cl * np;
+        const double* rc = S.rec + cl * RW;
+        double* hr = S.h + cl * HW;
+        double* ro = S.rout + cl * RW;
+        double* csb = S.cs + cl * CSW;
+        double* sm = hr + H_PARAMS + np;
+        double value;
+        int status;
+        finish_objective<CT>(P, th, S.part, S.mom, S.w, cl, sm, value, status, c);
+        const double sig = csb[CS_SIGMA], bp = csb[CS_BEST], bpid = csb[CS_BESTID], atun = csb[CS_ATUN];
+        const int nn = (int)csb[CS_NNOEX], na = (int)csb[CS_NACC];
+        const double u = t > 1 ? S.rb[cl * RBW] : 0.0;  // probs_acc[iter], :85
+
+        const double old = rc[0];
+        double prob;
+        bool acc;
+        if (t == 1) {  // :326-332
+            prob = 1.0; acc = true; status = 1;
+        } else if (status < 0) {  // :336-338
+            prob = 0.0; acc = false;
+        } else {
+            if (!(value >= 0.0)) report_error(P, 1, t, gc);  // :341
+            const double e = exp(atun * (old - value));
+            prob = (e != e) ? e : (e < 1.0 ? e : 1.0);  // minimum([1.0,e]), NaN propagates (:344)
+            if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }  // :350-353
+            else if (!isfinite(old)) { prob = 1.0; acc = true; }            // :355-359
+            else { status = 1; acc = prob > u; }                            // strict >, :362-367
+        }
+        TS_MARK(7);
+        // set_acceptRate!, :253-257 (iteration t has exchanged==0 at this point)
+        const double rate = (double)(na + (acc ? 1 : 0)) / (double)(nn + 1);
+        double nsig = sig;
+        if (t > 1 && (t % P.sigma_update_steps) == 0)  // :381-390
+            nsig = (rate > 0.234) ? sig * (1.0 + P.sigma_adjust_by) : sig * (1.0 - P.sigma_adjust_by);
+        // set_eval!, :220-245
+        double bestv, currv, bestid;
+        if (t == 1) { bestv = value; currv = value; bestid = 1.0; }
+        else {
+            currv = acc ? value : old;  // curr_val[t-1] == value of the last accepted record
+            if (value < bp) { bestv = value; bestid = (double)t; }
+            else { bestv = bp; bestid = bpid; }
+        }
+        csb[CS_SIGMA] = nsig; csb[CS_RATE] = rate; csb[CS_NNOEX] = (double)nn; csb[CS_NACC] = (double)na;
+        csb[CS_LACC] = acc ? 1.0 : 0.0; csb[CS_WASX] = 0.0; csb[CS_BEST] = bestv; csb[CS_BESTID] = bestid;
+        csb[CS_BESTP] = bp; csb[CS_BESTPID] = bpid;  // best after t-1: needed if iteration t gets exchanged
+        hr[H_VALUE] = value; hr[H_PROB] = prob; hr[H_CURR] = currv; hr[H_BEST] = bestv; hr[H_BESTID] = bestid;
+        hr[H_EXCH] = 0.0; hr[H_ACC] = acc ? 1.0 : 0.0; hr[H_STATUS] = (double)status;
+        for (int k = 0; k < np; ++k) hr[H_PARAMS + k] = th[k];
+        // the chain's last accepted record (lastAccepted :209-215) = input of the exchange step
+        if (acc) {
+            ro[0] = value; ro[1] = prob; ro[2] = (double)status;
+            for (int k = 0; k < np; ++k) ro[3 + k] = th[k];
+            for (int k = 0; k < nm; ++k) ro[3 + np + k] = sm[k];
+        } else {
+            for (int f = 0; f < RW; ++f) ro[f] = rc[f];
+        }
+        P.vals[c] = acc ? value : old;
+    }
+    // ---- the control wave stores the tile's result blocks ----
+    if (valid) {
+        __builtin_amdgcn_wave_barrier();
+        coop_store<CT>(P.cs + (size_t)c * CSW, S.cs + cl * CSW, CSW, r);
+        coop_store<CT>(rec_out + (size_t)c * RW, S.rout + cl * RW, RW, r);
+        coop_store<CT>(P.hrec + ((size_t)(t - 1) * N + c) * HW, S.h + cl * HW, HW, r);
+        if (t > 1 && S.cs[cl * CSW + CS_PARTNER] != 0.0)
+            coop_store<CT>(P.hrec + ((size_t)(t - 2) * N + c) * HW, S.hp + cl * HW, HW, r);
+    }
+    TS_MARK(4);
+}
+
+// k_flush: settle the last iteration (pending exchange + accept-rate counters) without starting a
+// new one, so that state/history can be read back or saved (save/readMalgo, AlgoAbstract.jl:83-102).
+__global__ void k_flush(const KParams P, const int t_next, const double* __restrict__ rec_in, double* __restrict__ rec_out,
+                        const int flags) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.N) return;
+    const int RW = P.RW, HW = P.HW, N = P.N;
+    double* csb = P.cs + (size_t)c * CSW;
+    const int goff = (flags & F_GLOBAL_REC) ? 0 : P.offset;   // rec_in indexed by global chain id (all-gathered buffer)?
+    int s = P.offset + c - goff;
+    bool exch = false;
+    if (flags & F_HAS_PENDING) {
+        const unsigned long long xr = P.xres[P.offset + c];
+        const int partner = (int)(xr >> 32);
+        if (partner != 0) {
+            exch = true;
+            s = (int)(unsigned)(xr & 0xffffffffu) - goff;
+            const int tp = t_next - 1;
+            const double* donor = rec_in + (size_t)s * RW;
+            double* hrec = P.hrec + ((size_t)(tp - 1) * N + c) * HW;
+            const double value = donor[0];
+            double bestv, bestid;
+            if (value < csb[CS_BESTP]) { bestv = value; bestid = (double)tp; }
+            else { bestv = csb[CS_BESTP]; bestid = csb[CS_BESTPID]; }
+            hrec[H_VALUE] = value; hrec[H_PROB] = donor[1]; hrec[H_CURR] = value; hrec[H_BEST] = bestv;
+            hrec[H_BESTID] = bestid; hrec[H_EXCH] = (double)partner; hrec[H_ACC] = 1.0; hrec[H_STATUS] = donor[2];
+            for (int k = 0; k < P.np + P.nm; ++k) hrec[H_PARAMS + k] = donor[3 + k];
+            csb[CS_BEST] = bestv; csb[CS_BESTID] = bestid;
+        }
+    } else if (csb[CS_WASX] != 0.0) {
+        exch = true;
+        csb[CS_WASX] = 0.0;
+    }
+    if ((flags & F_CLOSE_PREV) && !exch) {
+        csb[CS_NNOEX] += 1.0;
+        csb[CS_NACC] += csb[CS_LACC];
+    }
+    for (int f = 0; f < RW; ++f) rec_out[(size_t)c * RW + f] = rec_in[(size_t)s * RW + f];
+}
+
+// batched evaluateObjective(m,p), mprob.jl:175-188: params [np][M] -> value, simM [nm][M], status
+template <int KIND, int CT>
+__global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const double* __restrict__ params, const int M,
+                                                      double* __restrict__ value, double* __restrict__ simM,
+                                                      int8_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    TileSmem S;
+    S.carve(smem, CT, P.np, P.nm, P.RW, P.HW, P.RBW, KIND != 0);
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * CT + tid;
+    const bool chain_lane = (tid < CT) && (i < M);
+    double za[ZU];
+    ZBuf zb;
+    if constexpr (KIND == 1) { zb.init(P, tid); sim_load_chunk(zb, P, 0, 0, za); }
+    if (tid >= 64 && tid < 128)
+        for (int k = tid - 64; k < P.nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
+    if (tid < CT)
+        for (int k = 0; k < P.np; ++k) S.theta[tid * P.np + k] = chain_lane ? params[(size_t)k * M + i] : 0.0;
+    __syncthreads();
+    if constexpr (KIND == 1) {
+        simulate_tile<CT>(P, zb, S.theta, S.part, tid, za);
+        __syncthreads();
+    } else if constexpr (KIND == 2) {
+        dense_tile<CT>(P, S.theta, S.part, tid);
+        __syncthreads();
+    }
+    if (chain_lane) {
+        double v;
+        int st;
+        double* sm = S.h + tid * P.HW;
+        finish_objective<CT>(P, S.theta + tid * P.np, S.part, S.mom, S.w, tid, sm, v, st);
+        value[i] = v;
+        status[i] = (int8_t)st;
+        for (int k = 0; k < P.nm; ++k) simM[(size_t)k * M + i] = sm[k];
+    }
+}

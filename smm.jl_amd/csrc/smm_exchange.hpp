@@ -1,0 +1,582 @@
+// stand-alone exchangeMoves! kernels: k_exch_resolve_lds / _lvl / _lvl_soa / _lvl_big / _any, k_exch_plan_big, k_exch_apply — part of libsmmhip (included by smmhip.hip inside its anonymous namespace; gfx950 device code).
+#pragma once
+// ------------------------------------------------------------------------------------------
+// k_exch_resolve_lds: exchangeMoves! (AlgoBGP.jl:647-716) for N_global <= XLDS_MAX, one workgroup,
+// all state in LDS.  The reference walks the K sampled pairs in order and swaps the two chains'
+// last accepted records when value_i - value_j > min_improve_i (:688).  Pairs that share no chain
+// commute, so the list is executed as a data-flow graph: ticket[c] counts the executed pairs of
+// chain c and pair q = (i,j) runs exactly when ticket[i]==r_i && ticket[j]==r_j (all of its
+// predecessors on both chains ran, none of its successors did); then it publishes ticket+1 on both
+// chains (release/acquire at workgroup scope).  Critical path = longest dependency chain of the
+// list (~log N) x one LDS round trip.  Output xres[g] = src | partner<<32: whose record chain g
+// ends up with, and its last exchange partner (1-based, 0 = none).
+// gathered: last accepted records of all chains, [Ng][RW].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
+    double* val = (double*)xsm;               // [Ng]
+    uint32_t* ticket = (uint32_t*)(val + Ng);  // [Ng]
+    uint16_t* src = (uint16_t*)(ticket + Ng);  // [Ng]
+    uint16_t* partner = src + Ng;              // [Ng]
+    const unsigned long long* __restrict__ plan = P.plan + (size_t)(t - P.plan_t0) * K;
+    const double* __restrict__ plan_mi = P.plan_mi + (size_t)(t - P.plan_t0) * K;
+
+#define XTS(i) do { if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + (i)] = wall_clock64(); } while (0)
+    XTS(0);
+    // this thread's pairs (list positions tid, tid+1024, ...): plan words and thresholds up front
+    constexpr int MAXPP = XLDS_MAX / XWG;
+    unsigned long long pws[MAXPP];
+    double mis[MAXPP];
+#pragma unroll
+    for (int m = 0; m < MAXPP; ++m) {
+        const int qq = tid + m * XWG;
+        pws[m] = (qq < K) ? plan[qq] : 0ull;
+        mis[m] = (qq < K) ? plan_mi[qq] : 0.0;
+    }
+    const double* __restrict__ vsrc = gathered ? gathered : P.vals;  // single shard: the compact value array
+    const int vstride = gathered ? RW : 1;
+    for (int g = tid; g < Ng; g += XWG) {
+        val[g] = vsrc[(size_t)g * vstride];
+        ticket[g] = 0;
+        src[g] = (uint16_t)g;
+        partner[g] = 0;
+    }
+    __syncthreads();
+    XTS(1);
+    int q = tid, m = 0;
+    unsigned long long pw = pws[0];
+    double mi = mis[0];
+    unsigned spins = 0;
+    while (true) {
+        bool progressed = false;
+        if (q < K) {
+            const uint32_t i = (uint32_t)(pw & 0xffff), j = (uint32_t)((pw >> 16) & 0xffff);
+            const uint32_t ri = (uint32_t)((pw >> 32) & 0xffff), rj = (uint32_t)(pw >> 48);
+            const uint32_t ti = __hip_atomic_load(&ticket[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t tj = __hip_atomic_load(&ticket[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ti == ri && tj == rj) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const double vi = val[i], vj = val[j];
+                if (vi - vj > mi) {                         // dist_fun = -, :688
+                    val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744
+                    const uint16_t si = src[i];
+                    src[i] = src[j]; src[j] = si;
+                    partner[i] = (uint16_t)(j + 1); partner[j] = (uint16_t)(i + 1);  // set_exchanged!, :747-748
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&ticket[i], ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&ticket[j], tj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                q += XWG;
+                ++m;
+#pragma unroll
+                for (int k = 1; k < MAXPP; ++k)
+                    if (m == k) { pw = pws[k]; mi = mis[k]; }
+                progressed = true;
+            }
+        }
+        if (__all(q >= K)) break;
+        if (!__any(progressed)) {
+            if (++spins > XSPIN_LIMIT) {  // cannot happen: the smallest pending list position is always runnable
+                if (lane == 0) report_error(P, 3, t, 0);
+                break;
+            }
+            if (!(P.dbg & 16)) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    XTS(2);
+    __syncthreads();
+    XTS(3);
+    for (int g = tid; g < Ng; g += XWG) P.xres[g] = (unsigned long long)src[g] | ((unsigned long long)partner[g] << 32);
+    XTS(4);
+}
+
+// k_exch_resolve_lvl: the same result for N_global <= XLVL_MAX, executed level by level: the plan
+// groups the pair list by dependency level (k_exch_plan); the pairs of one level touch pairwise
+// disjoint chains, so a level is one parallel step and the walk needs (number of levels ~ log N)
+// barriers.  Plan, values and thresholds are staged in LDS with coalesced loads up front.
+template <int LWG>
+__global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x;
+    const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
+    const int w = t - P.plan_t0;
+    XSlot* slot = (XSlot*)xsm;                  // [Ng]
+    double* mi = (double*)(slot + Ng);          // [K]
+    uint32_t* pairs = (uint32_t*)(mi + K);      // [K]
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);   // level ends: wave-uniform scalar loads
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    XTS(0);
+    const unsigned long long cyc0 = clock64();
+    // ONE round trip of global loads: values, plan and level ends are all requested before the first wait
+    // (the values were written by other XCDs a moment ago and come from memory-side cache, ~1 us away;
+    // a load-store loop would pay that latency once per trip).
+    constexpr int PT = XLVL_MAX / LWG;
+    const double* __restrict__ vsrc = gathered ? gathered : P.vals;  // single shard: the compact value array
+    const int vstride = gathered ? RW : 1;
+    const int lane = tid & 63;
+    double v_[PT], mq_[PT];
+    uint32_t pq_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * LWG;
+        v_[r] = g < Ng ? vsrc[(size_t)g * vstride] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * LWG;
+        pq_[r] = q < K ? g_pairs[q] : 0u;
+        mq_[r] = q < K ? g_mi[q] : 0.0;
+    }
+    const uint32_t ev = g_off[min(lane, K)];   // lane l: end of level l (entries past the last level are unused)
+    const int nlev = (int)g_off[K + 1];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * LWG;
+        if (g < Ng) {
+            XSlot s_;
+            s_.val = v_[r];
+            s_.src = (uint32_t)g;
+            s_.partner = 0;
+            slot[g] = s_;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * LWG;
+        if (q < K) { pairs[q] = pq_[r]; mi[q] = mq_[r]; }
+    }
+    for (int q = tid + PT * LWG; q < K; q += LWG) { pairs[q] = g_pairs[q]; mi[q] = g_mi[q]; }  // K > XLVL_MAX: injected long pair lists
+    // Level ends: lane l of every wave holds the end of level l (one coalesced load, read back with
+    // v_readlane).  The level loop stays ROLLED on purpose: the kernel runs once per iteration on a CU whose
+    // instruction cache has been flushed by the chain kernel in between, so every byte of straight-line code
+    // is an instruction-fetch miss.
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
+    const int ltail = nlev;
+    __syncthreads();
+    XTS(1);
+    uint32_t b = 0;
+    int lvc = 0;
+    unsigned long long* lts = (unsigned long long*)(pairs + K + (K & 1));   // [64] level stamps (debug)
+    if (P.ts && tid == 0) lts[63] = clock64() - cyc0;
+    uint32_t e = nlev > 0 ? level_end(0) : 0u;
+    uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
+    uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
+    double m = (b + tid < e) ? mi[b + tid] : 0.0;
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < ltail; ++l) {
+        const uint32_t e3 = level_end(l + 2);
+        // this thread's first pair of the next level (LDS) is fetched while this level runs
+        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+        const double m2 = (e + tid < e2) ? mi[e + tid] : 0.0;
+        for (uint32_t pos = b + tid; pos < e && !(P.dbg & 32); pos += LWG) {
+            if (pos != b + tid) { pw = pairs[pos]; m = mi[pos]; }
+            const uint32_t i = pw & 0xffffu, j = pw >> 16;
+            const XSlot si = slot[i], sj = slot[j];
+            if (si.val - sj.val > m) {                  // dist_fun = -, AlgoBGP.jl:688
+                XSlot ni, nj;                           // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                slot[i] = ni;
+                slot[j] = nj;
+            }
+        }
+        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+        if (!(P.dbg & 64)) __syncthreads();
+        if (P.ts && tid == 0) { lts[lvc & 31] = clock64() - cyc0; ++lvc; }
+    }
+    if (P.ts && tid == 0) {
+        P.ts[(size_t)8 * 60000 + 15] = lts[63];
+        for (int l = 0; l < min(lvc, 32); ++l) P.ts[(size_t)8 * 60000 + 16 + l] = lts[l];
+        P.ts[(size_t)8 * 60000 + 14] = (unsigned long long)ltail;
+    }
+    XTS(3);
+    for (int g = tid; g < Ng; g += LWG) P.xres[g] = (unsigned long long)slot[g].src | ((unsigned long long)slot[g].partner << 32);
+    XTS(4);
+    if (P.ts && tid == 0) { P.ts[(size_t)8 * 60000 + 6] = clock64() - cyc0; P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev; }
+}
+
+// k_exch_resolve_lvl_soa: the level walk for XLVL_MAX < N_global <= XLDS_MAX (e.g. 2 GPUs x 4096 chains).  Same plan,
+// same arithmetic; the chain slots are split (8-byte value, 4-byte src | partner << 16) so that 8192 chains and
+// their pair list take 128 KB of LDS.  Thresholds: one scalar when min_improve is uniform, else from the plan.
+template <int LWG>
+__global__ __launch_bounds__(LWG) void k_exch_resolve_lvl_soa(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
+    const int w = t - P.plan_t0;
+    double* val = (double*)xsm;                 // [Ng]
+    uint32_t* sp = (uint32_t*)(val + Ng);       // [Ng]
+    uint32_t* pairs = sp + Ng;                  // [K]
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    const bool mi_u = P.mi_uniform != 0;
+    const double mi_v = P.mi_value;
+    const double* __restrict__ vsrc = gathered ? gathered : P.vals;
+    const int vstride = gathered ? RW : 1;
+    constexpr int PT = XLDS_MAX / LWG;
+    double v_[PT];
+    uint32_t pq_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * LWG;
+        v_[r] = g < Ng ? vsrc[(size_t)g * vstride] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * LWG;
+        pq_[r] = q < K ? g_pairs[q] : 0u;
+    }
+    const uint32_t ev = g_off[min(lane, K)];
+    const int nlev = (int)g_off[K + 1];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * LWG;
+        if (g < Ng) { val[g] = v_[r]; sp[g] = (uint32_t)g; }
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * LWG;
+        if (q < K) pairs[q] = pq_[r];
+    }
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
+    __syncthreads();
+    uint32_t b = 0;
+    uint32_t e = nlev > 0 ? level_end(0) : 0u;
+    uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
+    uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
+    double m = mi_u ? mi_v : ((b + tid < e) ? g_mi[b + tid] : 0.0);
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < nlev; ++l) {
+        const uint32_t e3 = level_end(l + 2);
+        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+        const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+        for (uint32_t pos = b + tid; pos < e; pos += LWG) {
+            if (pos != b + tid) { pw = pairs[pos]; m = mi_u ? mi_v : g_mi[pos]; }
+            const uint32_t i = pw & 0xffffu, j = pw >> 16;
+            const double vi = val[i], vj = val[j];
+            const uint32_t si = sp[i], sj = sp[j];
+            if (vi - vj > m) {                          // dist_fun = -, AlgoBGP.jl:688
+                val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                sp[i] = (sj & 0xffffu) | ((j + 1) << 16);
+                sp[j] = (si & 0xffffu) | ((i + 1) << 16);
+            }
+        }
+        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+        __syncthreads();
+    }
+    for (int g = tid; g < Ng; g += LWG) {
+        const uint32_t s_ = sp[g];
+        P.xres[g] = (unsigned long long)(s_ & 0xffffu) | ((unsigned long long)(s_ >> 16) << 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Large populations (8192 < N_global <= 65535, e.g. 8 GPUs x 4096 chains): the same level plan and
+// level-synchronous walk with their working sets in global memory (the LDS of one CU is too small).
+// k_exch_plan_big: one workgroup per iteration, scratch [blockIdx] in global memory; speed is not
+// critical (runs ahead of the dependent loop, one window at a time).
+// ------------------------------------------------------------------------------------------
+struct BigPlanScratch {  // per workgroup
+    uint32_t *cnt, *ep, *pi, *pj, *ri, *rj, *prei, *prej, *lvl, *nl;
+    __host__ __device__ static size_t words(int Ng, int K) { return (size_t)(Ng + 4) + (size_t)K * 10; }
+    __device__ void carve(uint32_t* base, int Ng, int K) {
+        cnt = base; ep = cnt + Ng + 4; pi = ep + 2 * K; pj = pi + K; ri = pj + K; rj = ri + K;
+        prei = rj + K; prej = prei + K; lvl = prej + K; nl = lvl + K;
+    }
+};
+
+__device__ inline uint32_t block_excl_scan_step(uint32_t v, uint32_t* wsum, int tid, uint32_t& total) {
+    // exclusive scan of one value per thread over the 1024-thread block
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    total = 0;
+    for (int w = 0; w < XWG / 64; ++w) total += wsum[w];
+    return base + incl - v;
+}
+
+// in-place exclusive scan of a[0..n) (n arbitrary), returns nothing; all threads must call
+__device__ inline void block_excl_scan(uint32_t* a, int n, uint32_t* wsum, int tid) {
+    uint32_t carry = 0;
+    for (int b = 0; b < n; b += XWG) {
+        const int i = b + tid;
+        const uint32_t v = i < n ? a[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan_step(v, wsum, tid, total);
+        if (i < n) a[i] = carry + ex;
+        carry += total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(XWG) void k_exch_plan_big(const KParams P, const int t0, uint32_t* __restrict__ scratch,
+                                                       uint32_t* __restrict__ lv_pairs, double* __restrict__ lv_mi,
+                                                       uint32_t* __restrict__ lv_off) {
+    __shared__ uint32_t wsum[XWG / 64];
+    __shared__ uint32_t s_nlev;
+    const int tid = threadIdx.x;
+    const int t = t0 + blockIdx.x;
+    const int Ng = P.Ng, K = P.plan_K;
+    BigPlanScratch S;
+    S.carve(scratch + (size_t)blockIdx.x * BigPlanScratch::words(Ng, K), Ng, K);
+    for (int c = tid; c < Ng + 4; c += XWG) S.cnt[c] = 0;
+    if (P.pairtab) {
+        for (int q = tid; q < K; q += XWG) {
+            S.pi[q] = (uint32_t)P.pairtab[((size_t)(t - 1) * K + q) * 2];
+            S.pj[q] = (uint32_t)P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
+        }
+    } else {
+        PairPerm pp;
+        pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
+        for (int q = tid; q < K; q += XWG) {
+            int32_t i, j;
+            pair_unrank(pp.eval((uint64_t)q), i, j);
+            S.pi[q] = (uint32_t)i;
+            S.pj[q] = (uint32_t)j;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) { atomicAdd(&S.cnt[S.pi[q]], 1u); atomicAdd(&S.cnt[S.pj[q]], 1u); }
+    __syncthreads();
+    block_excl_scan(S.cnt, Ng, wsum, tid);  // bucket starts
+    for (int q = tid; q < K; q += XWG) {   // scatter (arbitrary order inside a bucket)
+        S.ep[atomicAdd(&S.cnt[S.pi[q]], 1u)] = (uint32_t)q;
+        S.ep[atomicAdd(&S.cnt[S.pj[q]], 1u)] = (uint32_t)q;
+    }
+    __syncthreads();  // cnt[c] == end of bucket c
+    for (int q = tid; q < K; q += XWG) {   // ranks
+        const uint32_t i = S.pi[q], j = S.pj[q];
+        uint32_t b = i ? S.cnt[i - 1] : 0u, e = S.cnt[i], ri = 0, rj = 0;
+        for (uint32_t x = b; x < e; ++x) ri += (S.ep[x] < (uint32_t)q) ? 1u : 0u;
+        b = j ? S.cnt[j - 1] : 0u; e = S.cnt[j];
+        for (uint32_t x = b; x < e; ++x) rj += (S.ep[x] < (uint32_t)q) ? 1u : 0u;
+        S.ri[q] = ri; S.rj[q] = rj;
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) {   // buckets in rank order
+        const uint32_t i = S.pi[q], j = S.pj[q];
+        S.ep[(i ? S.cnt[i - 1] : 0u) + S.ri[q]] = (uint32_t)q;
+        S.ep[(j ? S.cnt[j - 1] : 0u) + S.rj[q]] = (uint32_t)q;
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) {   // predecessors
+        const uint32_t i = S.pi[q], j = S.pj[q];
+        S.prei[q] = S.ri[q] ? S.ep[(i ? S.cnt[i - 1] : 0u) + S.ri[q] - 1] : 0xffffffffu;
+        S.prej[q] = S.rj[q] ? S.ep[(j ? S.cnt[j - 1] : 0u) + S.rj[q] - 1] : 0xffffffffu;
+        S.lvl[q] = 0;
+    }
+    __syncthreads();
+    int changed = 1;
+    while (changed) {  // Jacobi sweeps
+        for (int q = tid; q < K; q += XWG) {
+            const uint32_t pa = S.prei[q], pb = S.prej[q];
+            const uint32_t a = pa != 0xffffffffu ? S.lvl[pa] : 0u, b = pb != 0xffffffffu ? S.lvl[pb] : 0u;
+            const bool known = (pa == 0xffffffffu || a) && (pb == 0xffffffffu || b);
+            S.nl[q] = known ? 1u + (a > b ? a : b) : 0u;
+        }
+        __syncthreads();
+        int mine = 0;
+        for (int q = tid; q < K; q += XWG)
+            if (S.nl[q] != S.lvl[q]) { S.lvl[q] = S.nl[q]; mine = 1; }
+        changed = __syncthreads_or(mine);
+    }
+    // counting sort by level (cnt is free now)
+    for (int c = tid; c < Ng + 4; c += XWG) S.cnt[c] = 0;
+    if (tid == 0) s_nlev = 0;
+    __syncthreads();
+    {
+        uint32_t mx = 0;
+        for (int q = tid; q < K; q += XWG) { atomicAdd(&S.cnt[S.lvl[q]], 1u); mx = S.lvl[q] > mx ? S.lvl[q] : mx; }
+        atomicMax(&s_nlev, mx);
+    }
+    __syncthreads();
+    const int nlev = (int)s_nlev;
+    block_excl_scan(S.cnt, nlev + 1, wsum, tid);  // cnt[l] = pairs in levels < l (1-based l)
+    uint32_t* o_off = lv_off + (size_t)blockIdx.x * (K + 2);
+    for (int l = tid; l < nlev; l += XWG) o_off[l] = (l + 2 <= nlev) ? S.cnt[l + 2] : (uint32_t)K;
+    if (tid == 0) o_off[K + 1] = (uint32_t)nlev;
+    __syncthreads();
+    uint32_t* o_pairs = lv_pairs + (size_t)blockIdx.x * K;
+    double* o_mi = lv_mi + (size_t)blockIdx.x * K;
+    for (int q = tid; q < K; q += XWG) {
+        const uint32_t pos = atomicAdd(&S.cnt[S.lvl[q]], 1u);
+        const uint32_t i = S.pi[q], j = S.pj[q];
+        o_pairs[pos] = i | (j << 16);
+        o_mi[pos] = P.min_improve_g[i];
+    }
+}
+
+// k_exch_resolve_lvl_big: level-synchronous walk with values / sources / partners in global memory
+// (agent-scope relaxed atomics: the lines are shared between the waves of the workgroup through L2).
+__global__ __launch_bounds__(XWG) void k_exch_resolve_lvl_big(const KParams P, const int t, const double* __restrict__ gathered) {
+    const int tid = threadIdx.x;
+    const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
+    const int w = t - P.plan_t0;
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    double* val = P.xval;
+    int32_t* src = P.xsrc;
+    int32_t* partner = P.xpartner;
+    const int nlev = (int)g_off[K + 1];
+    for (int g = tid; g < Ng; g += XWG) {
+        __hip_atomic_store(&val[g], gathered[(size_t)g * RW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&src[g], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&partner[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    uint32_t b = 0;
+    constexpr int BATCH = 8;  // pairs of one level are independent: their loads are issued together
+    for (int l = 0; l < nlev; ++l) {
+        const uint32_t e = g_off[l];
+        for (uint32_t p0 = b + tid; p0 < e; p0 += XWG * BATCH) {
+            uint32_t pw[BATCH];
+            double m[BATCH], vi[BATCH], vj[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const uint32_t pos = p0 + u * XWG;
+                pw[u] = pos < e ? g_pairs[pos] : 0u;
+                m[u] = pos < e ? g_mi[pos] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const uint32_t pos = p0 + u * XWG;
+                if (pos < e) {
+                    vi[u] = __hip_atomic_load(&val[pw[u] & 0xffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vj[u] = __hip_atomic_load(&val[pw[u] >> 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else { vi[u] = 0.0; vj[u] = 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const uint32_t pos = p0 + u * XWG;
+                const uint32_t i = pw[u] & 0xffffu, j = pw[u] >> 16;
+                if (pos < e && vi[u] - vj[u] > m[u]) {          // dist_fun = -, AlgoBGP.jl:688
+                    __hip_atomic_store(&val[i], vj[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // swap_ev_ij!, :739-744
+                    __hip_atomic_store(&val[j], vi[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int si = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int sj = __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&src[i], sj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&src[j], si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&partner[i], (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :747-748
+                    __hip_atomic_store(&partner[j], (int)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        b = e;
+        __syncthreads();
+    }
+    for (int g = tid; g < Ng; g += XWG) {
+        const unsigned s_ = (unsigned)__hip_atomic_load(&src[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned p_ = (unsigned)__hip_atomic_load(&partner[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        P.xres[g] = (unsigned long long)s_ | ((unsigned long long)p_ << 32);
+    }
+}
+
+// k_exch_resolve_any: the same result for any N_global, state in global memory, executed in
+// barrier-separated dependency rounds: every pending pair bids (atomicMin of its list position) on
+// both of its chains; a pair that wins both bids has no pending predecessor and is executed.
+__global__ __launch_bounds__(XWG) void k_exch_resolve_any(const KParams P, const int t, const double* __restrict__ gathered) {
+    const int tid = threadIdx.x;
+    const int Ng = P.Ng, RW = P.RW;
+    const int K = P.pairtab ? P.n_pairs_tab : n_exchange_pairs(Ng);
+    for (int g = tid; g < Ng; g += XWG) {
+        P.xval[g] = gathered[(size_t)g * RW];
+        P.xsrc[g] = g;
+        P.xpartner[g] = 0;
+        P.xnext[g] = 0x7fffffff;
+    }
+    if (P.pairtab) {
+        for (int q = tid; q < K; q += XWG) {
+            P.xpairs[2 * q] = P.pairtab[((size_t)(t - 1) * K + q) * 2];
+            P.xpairs[2 * q + 1] = P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
+        }
+    } else {
+        PairPerm pp;
+        pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
+        for (int q = tid; q < K; q += XWG) {
+            int32_t i, j;
+            pair_unrank(pp.eval((uint64_t)q), i, j);
+            P.xpairs[2 * q] = i;
+            P.xpairs[2 * q + 1] = j;
+        }
+    }
+    __syncthreads();
+    int remaining = 1;
+    while (remaining) {
+        for (int q = tid; q < K; q += XWG) {
+            const int i = P.xpairs[2 * q];
+            if (i < 0) continue;  // executed
+            const int j = P.xpairs[2 * q + 1];
+            atomicMin(&P.xnext[i], q);
+            atomicMin(&P.xnext[j], q);
+        }
+        __syncthreads();
+        int mine = 0;
+        for (int q = tid; q < K; q += XWG) {
+            const int i = P.xpairs[2 * q];
+            if (i < 0) continue;
+            const int j = P.xpairs[2 * q + 1];
+            if (__hip_atomic_load(&P.xnext[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == q &&
+                __hip_atomic_load(&P.xnext[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == q) {
+                const double vi = P.xval[i], vj = P.xval[j];
+                if (vi - vj > P.min_improve_g[i]) {  // dist_fun = -, :688
+                    P.xval[i] = vj; P.xval[j] = vi;   // swap_ev_ij!, :739-744
+                    const int si = P.xsrc[i];
+                    P.xsrc[i] = P.xsrc[j]; P.xsrc[j] = si;
+                    P.xpartner[i] = j + 1; P.xpartner[j] = i + 1;  // set_exchanged!, :747-748
+                }
+                P.xnext[i] = 0x7fffffff; P.xnext[j] = 0x7fffffff;
+                P.xpairs[2 * q] = -1 - i;  // mark executed
+            } else {
+                mine = 1;
+            }
+        }
+        remaining = __syncthreads_or(mine);
+    }
+    for (int g = tid; g < Ng; g += XWG)
+        P.xres[g] = (unsigned long long)(unsigned)P.xsrc[g] | ((unsigned long long)(unsigned)P.xpartner[g] << 32);
+}
+
+// k_exch_apply (sharded path): set_eval!(ci, ej) + set_exchanged! of swap_ev_ij! (AlgoBGP.jl:734-749)
+// for the local chains, reading the donor records from the all-gathered buffer [Ng][RW];
+// rec = this shard's own post-accept records [N][RW], updated in place.
+__global__ void k_exch_apply(const KParams P, const int t, const double* __restrict__ gathered, double* __restrict__ rec) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.N) return;
+    const int N = P.N, RW = P.RW, HW = P.HW;
+    const unsigned long long xr = P.xres[P.offset + c];
+    const int partner = (int)(xr >> 32);
+    if (partner == 0) return;
+    const int s = (int)(unsigned)(xr & 0xffffffffu);
+    const double* __restrict__ donor = gathered + (size_t)s * RW;
+    double* csb = P.cs + (size_t)c * CSW;
+    double* hrec = P.hrec + ((size_t)(t - 1) * N + c) * HW;
+    const double value = donor[0];
+    double bestv, bestid;
+    if (value < csb[CS_BESTP]) { bestv = value; bestid = (double)t; }
+    else { bestv = csb[CS_BESTP]; bestid = csb[CS_BESTPID]; }
+    csb[CS_BEST] = bestv; csb[CS_BESTID] = bestid; csb[CS_WASX] = 1.0;
+    hrec[H_VALUE] = value; hrec[H_PROB] = donor[1]; hrec[H_CURR] = value; hrec[H_BEST] = bestv;
+    hrec[H_BESTID] = bestid; hrec[H_EXCH] = (double)partner; hrec[H_ACC] = 1.0; hrec[H_STATUS] = donor[2];
+    for (int k = 0; k < P.np + P.nm; ++k) hrec[H_PARAMS + k] = donor[3 + k];
+    for (int f = 0; f < RW; ++f) rec[(size_t)c * RW + f] = donor[f];
+}

@@ -1,0 +1,249 @@
+// look-ahead kernels: k_pregen_rng (randomness blocks) and k_exch_plan (pair list, ranks, dependency levels) — part of libsmmhip (included by smmhip.hip inside its anonymous namespace; gfx950 device code).
+#pragma once
+// ------------------------------------------------------------------------------------------
+// k_pregen_rng: the state-independent randomness of iterations t0 .. t0+W-1 as per-chain blocks
+//   rb[w][c] = { u, z[try][k] }:  u = the MH uniform (probs_acc = rand(n), AlgoBGP.jl:85),
+//   z = standard normals of mysample's first tries (rand(RAND,d), :404) — injected or generated.
+// one thread per (iteration, try, parameter pair, chain).
+// ------------------------------------------------------------------------------------------
+__global__ void k_pregen_rng(const KParams P, const int t0, const int W, double* __restrict__ rb) {
+    const int N = P.N, np = P.np, TR = P.rb_tries;
+    const int Q = (np + 1) / 2;
+    const size_t total = (size_t)W * TR * Q * N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i % Q);
+    size_t rest = i / Q;
+    const int r = (int)(rest % TR); rest /= TR;
+    const int c = (int)(rest % N);
+    const int w = (int)(rest / N);
+    const int t = t0 + w;
+    const uint32_t gc = (uint32_t)(P.offset + c);
+    double* blk = rb + ((size_t)w * N + c) * P.RBW;
+    if (t > 1) {  // iteration 1 proposes the initial value (:426-427)
+        double z0, z1 = 0.0;
+        if (P.user_ntab) {
+            const size_t base = (((size_t)(t - 1) * TR + r) * np) * N + c;
+            z0 = P.user_ntab[base + (size_t)(2 * q) * N];
+            if (2 * q + 1 < np) z1 = P.user_ntab[base + (size_t)(2 * q + 1) * N];
+        } else {
+            rng_prop_normal2(P.seed, gc, (uint32_t)t, (uint32_t)r, (uint32_t)q, z0, z1);
+        }
+        blk[1 + r * np + 2 * q] = z0;
+        if (2 * q + 1 < np) blk[1 + r * np + 2 * q + 1] = z1;
+    }
+    if (r == 0 && q == 0) blk[0] = P.user_utab ? P.user_utab[(size_t)(t - 1) * N + c] : rng_u(P.seed, gc, (uint32_t)t);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_exch_plan: one workgroup per iteration t = t0 + blockIdx.x.  Samples the exchange pair list
+// (sample(props, K, replace=false), AlgoBGP.jl:653-656) and derives the dependency structure of
+// the ordered walk (:662-691): for pair q = (i,j), r_i / r_j = number of earlier pairs touching
+// chain i / chain j (counting sort of the 2K endpoints by chain: LDS atomics + block scan).
+// plan[t-t0][q] = i | j<<16 | r_i<<32 | r_j<<48, plan_mi[t-t0][q] = min_improve[i].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0, unsigned long long* __restrict__ plan,
+                                                   double* __restrict__ plan_mi, uint32_t* __restrict__ lv_pairs,
+                                                   double* __restrict__ lv_mi, uint32_t* __restrict__ lv_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = t0 + blockIdx.x;
+    const int Ng = P.Ng, K = P.plan_K;
+    uint32_t* cnt = (uint32_t*)xsm;          // [Ng+2]  histogram -> cursor (later: level histogram)
+    uint32_t* ep = cnt + Ng + 2;             // [2K]  list positions bucketed by chain (later: levels)
+    uint16_t* pi = (uint16_t*)(ep + 2 * K);  // [K]
+    uint16_t* pj = pi + K;                   // [K]
+    uint32_t* wsum = (uint32_t*)(pj + K);    // [32] (pi,pj: 4K bytes from a 4-byte aligned base)
+    unsigned long long* out = plan + (size_t)blockIdx.x * K;
+    double* out_mi = plan_mi + (size_t)blockIdx.x * K;
+
+    for (int c = tid; c < Ng; c += XWG) cnt[c] = 0;
+    if (P.pairtab) {
+        for (int q = tid; q < K; q += XWG) {
+            pi[q] = (uint16_t)P.pairtab[((size_t)(t - 1) * K + q) * 2];
+            pj[q] = (uint16_t)P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
+        }
+    } else {
+        PairPerm pp;
+        pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
+        for (int q = tid; q < K; q += XWG) {
+            int32_t i, j;
+            pair_unrank(pp.eval((uint64_t)q), i, j);
+            pi[q] = (uint16_t)i;
+            pj[q] = (uint16_t)j;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) {  // histogram of endpoints
+        atomicAdd(&cnt[pi[q]], 1u);
+        atomicAdd(&cnt[pj[q]], 1u);
+    }
+    __syncthreads();
+    {   // exclusive scan of cnt[0..Ng) -> bucket start
+        constexpr int PER = XLDS_MAX / XWG;
+        const int per = (Ng + XWG - 1) / XWG;
+        const int c0 = tid * per;
+        uint32_t loc[PER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u;
+            const uint32_t v = (u < per && c < Ng) ? cnt[c] : 0u;
+            loc[u] = sum;
+            sum += v;
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const uint32_t excl = base + incl - sum;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u;
+            if (u < per && c < Ng) cnt[c] = excl + loc[u];
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) {  // scatter (order inside a bucket is arbitrary)
+        ep[atomicAdd(&cnt[pi[q]], 1u)] = (uint32_t)q;
+        ep[atomicAdd(&cnt[pj[q]], 1u)] = (uint32_t)q;
+    }
+    __syncthreads();  // now cnt[c] == end of chain c's bucket
+    // rank = number of smaller list positions in the bucket; kept in registers for the level pass
+    constexpr int MAXPP = XLDS_MAX / XWG;
+    uint16_t rri[MAXPP], rrj[MAXPP];
+#pragma unroll
+    for (int m = 0; m < MAXPP; ++m) {
+        const int q = tid + m * XWG;
+        rri[m] = 0; rrj[m] = 0;
+        if (q < K) {
+            const uint32_t i = pi[q], j = pj[q];
+            uint32_t b = i ? cnt[i - 1] : 0u, e = cnt[i], ri = 0, rj = 0;
+            for (uint32_t x = b; x < e; ++x) ri += (ep[x] < (uint32_t)q) ? 1u : 0u;
+            b = j ? cnt[j - 1] : 0u; e = cnt[j];
+            for (uint32_t x = b; x < e; ++x) rj += (ep[x] < (uint32_t)q) ? 1u : 0u;
+            out[q] = (unsigned long long)i | ((unsigned long long)j << 16) | ((unsigned long long)ri << 32) |
+                     ((unsigned long long)rj << 48);
+            out_mi[q] = P.min_improve_g[i];  // the threshold of the pair's colder chain, AlgoBGP.jl:688
+            rri[m] = (uint16_t)ri; rrj[m] = (uint16_t)rj;
+        }
+    }
+    __syncthreads();
+    // ---- dependency levels: level(q) = 1 + max(level of q's predecessor on chain i, on chain j) ----
+    // buckets re-written in rank order, so that the predecessor of rank r is the entry of rank r-1
+#pragma unroll
+    for (int m = 0; m < MAXPP; ++m) {
+        const int q = tid + m * XWG;
+        if (q < K) {
+            const uint32_t i = pi[q], j = pj[q];
+            ep[(i ? cnt[i - 1] : 0u) + rri[m]] = (uint32_t)q;
+            ep[(j ? cnt[j - 1] : 0u) + rrj[m]] = (uint32_t)q;
+        }
+    }
+    __syncthreads();
+    int prei[MAXPP], prej[MAXPP];
+#pragma unroll
+    for (int m = 0; m < MAXPP; ++m) {
+        const int q = tid + m * XWG;
+        prei[m] = -1; prej[m] = -1;
+        if (q < K) {
+            const uint32_t i = pi[q], j = pj[q];
+            if (rri[m]) prei[m] = (int)ep[(i ? cnt[i - 1] : 0u) + rri[m] - 1];
+            if (rrj[m]) prej[m] = (int)ep[(j ? cnt[j - 1] : 0u) + rrj[m] - 1];
+        }
+    }
+    __syncthreads();  // cnt / ep are free from here on
+    uint16_t* lvl = (uint16_t*)ep;          // [K]
+    uint32_t* lhist = cnt;                   // [nlev+1] <= Ng+2 entries
+    for (int q = tid; q < K; q += XWG) lvl[q] = 0;
+    __syncthreads();
+    int changed = 1;
+    while (changed) {  // Jacobi sweeps: converges after (number of levels) sweeps
+        int mine = 0;
+        uint16_t nl[MAXPP];
+#pragma unroll
+        for (int m = 0; m < MAXPP; ++m) {
+            const int q = tid + m * XWG;
+            nl[m] = 0;
+            if (q < K) {
+                const uint32_t a = prei[m] >= 0 ? lvl[prei[m]] : 0u, b = prej[m] >= 0 ? lvl[prej[m]] : 0u;
+                const bool known = (prei[m] < 0 || a) && (prej[m] < 0 || b);
+                nl[m] = known ? (uint16_t)(1u + (a > b ? a : b)) : (uint16_t)0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MAXPP; ++m) {
+            const int q = tid + m * XWG;
+            if (q < K && nl[m] != lvl[q]) { lvl[q] = nl[m]; mine = 1; }
+        }
+        changed = __syncthreads_or(mine);
+    }
+    // counting sort of the pairs by level
+    for (int c = tid; c < Ng + 2; c += XWG) lhist[c] = 0;
+    __syncthreads();
+    for (int q = tid; q < K; q += XWG) atomicAdd(&lhist[lvl[q]], 1u);  // lhist[l] = size of level l (1-based), lhist[0] = 0
+    __syncthreads();
+    uint32_t* wsum2 = wsum + 16;
+    __shared__ uint32_t s_nlev;
+    if (tid == 0) s_nlev = 0;
+    __syncthreads();
+    {
+        uint32_t mx = 0;
+        for (int q = tid; q < K; q += XWG) mx = lvl[q] > mx ? lvl[q] : mx;
+        atomicMax(&s_nlev, mx);
+    }
+    __syncthreads();
+    const int nlev = (int)s_nlev;
+    {   // exclusive scan of lhist[0..nlev] -> first position of level l (stored at lhist[l-1] after the shift below)
+        constexpr int PER = XLDS_MAX / XWG + 1;
+        const int n = nlev + 1;
+        const int per = (n + XWG - 1) / XWG;
+        const int c0 = tid * per;
+        uint32_t loc[PER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u;
+            const uint32_t v = (u < per && c < n) ? lhist[c] : 0u;
+            loc[u] = sum;
+            sum += v;
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum2[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wsum2[w];
+        const uint32_t excl = base + incl - sum;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u;
+            if (u < per && c < n) lhist[c] = excl + loc[u];  // = number of pairs in levels < c  (level c starts here)
+        }
+    }
+    __syncthreads();
+    uint32_t* o_off = lv_off + (size_t)blockIdx.x * (K + 2);
+    // o_off[l] = end of the l-th level (0-based) = start of 1-based level l+2
+    for (int l = tid; l < nlev; l += XWG) o_off[l] = (l + 2 <= nlev) ? lhist[l + 2] : (uint32_t)K;
+    if (tid == 0) o_off[K + 1] = (uint32_t)nlev;
+    __syncthreads();
+    uint32_t* o_pairs = lv_pairs + (size_t)blockIdx.x * K;
+    double* o_mi = lv_mi + (size_t)blockIdx.x * K;
+    for (int q = tid; q < K; q += XWG) {
+        const uint32_t pos = atomicAdd(&lhist[lvl[q]], 1u);
+        const uint32_t i = pi[q], j = pj[q];
+        o_pairs[pos] = i | (j << 16);
+        o_mi[pos] = P.min_improve_g[i];
+    }
+}

@@ -1,0 +1,93 @@
+// constants, kernel parameter block, block layouts, error word — part of libsmmhip (included by smmhip.hip inside its anonymous namespace; gfx950 device code).
+#pragma once
+
+constexpr int WG = SMM_REDUCE_LANES;  // 512 lanes own one chain tile (numerical contract)
+constexpr int MAX_DIM = 64;           // np, nm <= 64
+constexpr int XWG = 1024;             // exchange workgroup
+constexpr int XLDS_MAX = 8192;        // largest N_global resolved in LDS (16 B per chain)
+constexpr unsigned XSPIN_LIMIT = 1u << 22;
+
+// chain state block
+constexpr int CSW = 16;
+enum : int { CS_SIGMA = 0, CS_RATE, CS_NNOEX, CS_NACC, CS_LACC, CS_WASX, CS_BEST, CS_BESTID, CS_BESTP, CS_BESTPID, CS_ATUN,
+             CS_PARTNER /* LDS only */ };
+// history record
+enum : int { H_VALUE = 0, H_PROB, H_CURR, H_BEST, H_BESTID, H_EXCH, H_ACC, H_STATUS, H_PARAMS };
+
+// error word: min over (iter<<34 | chain<<2 | kind); 1 negative objective, 2 no draw, 3 internal
+constexpr unsigned long long ERR_NONE = ~0ull;
+
+enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2, F_WALK_INLINE = 4, F_GLOBAL_REC = 8, F_PROPOSE_ONLY = 16 };  // F_GLOBAL_REC: rec_in is the all-gathered buffer (global chain ids)
+
+struct KParams {
+    // problem
+    int np, nm, ns, obj;
+    const double *init, *lb, *ub, *mom, *w, *objp;
+    const double* Z;  // [nm][zstride]: the shock matrix, every moment padded to whole chunks of ZU rows x 512 lanes
+    int zstride;
+    // opts
+    int N, Ng, offset, T;
+    int sigma_update_steps, smpl_iters, batch_size;
+    double sigma_adjust_by;
+    uint64_t seed;
+    const double* min_improve_g;  // [Ng]
+    // user objective (objective_id >= SMM_OBJ_USER_BASE): proposals out, results in, [N][np] / [N][nm] / [N]
+    double* u_theta; double* u_simM; double* u_value; int* u_status;
+    int mi_uniform;               // all thresholds equal (the usual case): mi_value
+    int tile_off;                 // doubles in front of the tile's LDS blocks (the inline walk's chain slots)
+    double mi_value;
+    // dense objective (SMM_OBJ_DENSE): B and A in MFMA fragment order
+    const double* dense_Bf;  // [D/16][ceil(np/4)][64]
+    const double* dense_Af;  // [nOt][D/16][4][64]
+    int dense_nOt;           // ceil(nm/16)
+    // block widths (doubles, even)
+    int RW, HW, RBW;
+    int rb_tries;  // proposal tries held in a randomness block
+    int user_n;    // normals are injected: tries beyond rb_tries are an error, not the generator's
+    const double* rb;  // [W][N][RBW] window of randomness blocks
+    int rb_t0;
+    // injected tables in the ABI's layout (device copies), consumed by k_pregen_rng / k_exch_plan
+    const double* user_utab;  // [T][N]
+    const double* user_ntab;  // [T][K][np][N]
+    const int32_t* pairtab;   // [T][n_pairs][2]
+    int n_pairs_tab;
+    // exchange plan window
+    const unsigned long long* plan;  // [W][K]: pi | pj<<16 | ri<<32 | rj<<48
+    const double* plan_mi;           // [W][K]: min_improve of chain pi
+    // the same list grouped by dependency level (pairs of one level touch disjoint chains)
+    const uint32_t* lv_pairs;        // [W][K]: pi | pj<<16, level by level
+    const double* lv_mi;             // [W][K]: min_improve of chain pi, same order
+    const uint32_t* lv_off;          // [W][K+2]: lv_off[l] = first position of level l; entry K+1 = number of levels
+    int plan_t0, plan_K;
+    // state
+    double* cs;                // [N][CSW]
+    unsigned long long* xres;  // [Ng]
+    double* vals;              // [N] value of every chain's last accepted record after the accept step, contiguous
+                               //     (what the single-shard exchange resolution reads: 8 B per chain instead of a record)
+    // scratch of the any-size exchange kernel
+    int32_t *xsrc, *xpartner, *xnext, *xpairs;
+    double* xval;
+    // history
+    double* hrec;  // [T][N][HW]
+    unsigned long long* err;
+    int dbg;                 // SMMHIP_DBG timing experiments (results invalid when != 0)
+    unsigned long long* ts;  // SMMHIP_TS=1: per-workgroup phase timestamps of k_chain_iter (tools/)
+};
+
+#define TS_MARK(i) do { if (P.ts && tid == 0) P.ts[(size_t)tile * 8 + (i)] = wall_clock64(); } while (0)
+
+__device__ inline void report_error(const KParams& P, int kind, int t, int gchain) {
+    const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)gchain << 2) | (unsigned)kind;
+    atomicMin(P.err, key);
+}
+
+__host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
+
+// The in-kernel generator behind mysample's rare late tries, out of line: its ~40 live registers
+// (Philox rounds, log, sincospi) then weigh only on the path that needs them.
+__device__ __attribute__((noinline)) double2 rng_prop_normal2_outofline(uint64_t seed, uint32_t chain, uint32_t iter,
+                                                                        uint32_t tr, uint32_t q) {
+    double z0, z1;
+    rng_prop_normal2(seed, chain, iter, tr, q, z0, z1);
+    return make_double2(z0, z1);
+}
