@@ -696,6 +696,7 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
     if (!c || n_iters < 0) return SMM_ERR_INVALID_ARG;
     if (c->P.N != c->P.Ng) return fail(c, SMM_ERR_STATE, "smm_bgp_step needs a single shard (N == N_global); use the sharded calls");
     if (c->iter + n_iters > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
+    if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
     try {
         HIPCHK(hipSetDevice(c->device));
         if (c->profiling) {
@@ -1053,7 +1054,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
             HIPCHK(hipMemcpy(P.hrec + (size_t)t * N * HW, row.data(), row.size() * 8, hipMemcpyHostToDevice));
         }
         c->iter = s->iter;
-        c->unresolved = false;
+        c->rec_external = false; c->pending_ext = false; c->unresolved = false;
         c->pending = false;
         c->prev_open = false;
     } catch (const std::string& m) {
