@@ -58,6 +58,7 @@ class ShardedBGP:
         self.local = engine.new_tensor((engine.N, engine.R))
         self.gathered = engine.new_tensor((self.world, engine.N, engine.R))  # == [N_global][R] in global chain order
         self.fused = hasattr(engine, "fused_step")
+        self.inplace_ok = True
         if self.fused:   # two gather buffers alternate: iteration t reads donors from one, writes its records to the other
             self.gbuf = [self.gathered, engine.new_tensor((self.world, engine.N, engine.R))]
             self.gcur = None   # index of the buffer holding the gathered records of the last iteration
@@ -69,8 +70,8 @@ class ShardedBGP:
                 for _ in range(n_iters):
                     nxt = 0 if self.gcur is None else self.gcur ^ 1
                     e.fused_step(self.gbuf[self.gcur] if self.gcur is not None else None, self.gbuf[nxt])
-                    if self.world > 1:   # in place: this rank's slice is already where the collective wants it
-                        dist.all_gather_into_tensor(self.gbuf[nxt].view(-1), self.gbuf[nxt][self.rank].view(-1), group=self.group)
+                    if self.world > 1:
+                        self._all_gather(self.gbuf[nxt])
                     self.gcur = nxt
                 return
             for _ in range(n_iters):
@@ -81,6 +82,18 @@ class ShardedBGP:
                     e.export_records(self.local)
                     dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
                 e.exchange(self.gathered)
+
+    def _all_gather(self, buf):
+        """in place: this rank's slice is already where the collective wants it (ncclAllGather with
+        sendbuff == recvbuff + rank * count).  A backend that refuses aliased buffers gets a staged copy instead."""
+        if self.inplace_ok:
+            try:
+                dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].view(-1), group=self.group)
+                return
+            except RuntimeError:
+                self.inplace_ok = False
+        self.local.copy_(buf[self.rank])
+        dist.all_gather_into_tensor(buf.view(-1), self.local.view(-1), group=self.group)
 
     def sync(self):
         """settle the last iteration into the context (history/state readable afterwards) and wait for the device"""
