@@ -425,59 +425,63 @@ __global__ __launch_bounds__(XWG) void k_exch_plan_big(const KParams P, const in
     }
 }
 
-// k_exch_resolve_lvl_big: level-synchronous walk with values / sources / partners in global memory
-// (agent-scope relaxed atomics: the lines are shared between the waves of the workgroup through L2).
+// k_exch_resolve_lvl_big: level-synchronous walk with the 16-byte chain slots {value, src, partner} in global memory
+// (one 16-byte load or store per chain access: a single CU's address path is what bounds this kernel).  The slots
+// are shared by the waves of ONE workgroup only: plain loads and stores with the workgroup barrier between levels
+// are coherent (all waves of a workgroup sit on one CU and share its write-through L1), so a level costs L1/L2
+// round trips, not the memory round trips of agent-scope accesses (those made a level ~12 us).
 __global__ __launch_bounds__(XWG) void k_exch_resolve_lvl_big(const KParams P, const int t, const double* __restrict__ gathered) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
     const int w = t - P.plan_t0;
     const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
     const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
     const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
-    double* val = P.xval;
-    int32_t* src = P.xsrc;
-    int32_t* partner = P.xpartner;
+    XSlot* slot = (XSlot*)P.xslot;
+    const bool mi_u = P.mi_uniform != 0;
+    const double mi_v = P.mi_value;
+    const uint32_t ev = g_off[min(lane, K)];   // lane l: end of level l
     const int nlev = (int)g_off[K + 1];
     for (int g = tid; g < Ng; g += XWG) {
-        __hip_atomic_store(&val[g], gathered[(size_t)g * RW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&src[g], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&partner[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        XSlot s_;
+        s_.val = gathered[(size_t)g * RW]; s_.src = (uint32_t)g; s_.partner = 0;
+        slot[g] = s_;
     }
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
     __syncthreads();
     uint32_t b = 0;
     constexpr int BATCH = 8;  // pairs of one level are independent: their loads are issued together
+#pragma clang loop unroll(disable)
     for (int l = 0; l < nlev; ++l) {
-        const uint32_t e = g_off[l];
+        const uint32_t e = level_end(l);
         for (uint32_t p0 = b + tid; p0 < e; p0 += XWG * BATCH) {
             uint32_t pw[BATCH];
-            double m[BATCH], vi[BATCH], vj[BATCH];
+            double m[BATCH];
+            XSlot si[BATCH], sj[BATCH];
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const uint32_t pos = p0 + u * XWG;
                 pw[u] = pos < e ? g_pairs[pos] : 0u;
-                m[u] = pos < e ? g_mi[pos] : 0.0;
+                m[u] = mi_u ? mi_v : (pos < e ? g_mi[pos] : 0.0);
             }
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const uint32_t pos = p0 + u * XWG;
-                if (pos < e) {
-                    vi[u] = __hip_atomic_load(&val[pw[u] & 0xffffu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vj[u] = __hip_atomic_load(&val[pw[u] >> 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else { vi[u] = 0.0; vj[u] = 0.0; }
+            for (int u = 0; u < BATCH; ++u) {   // (pair word 0 = chains (0,0): never swaps, see the guard below)
+                si[u] = slot[pw[u] & 0xffffu];
+                sj[u] = slot[pw[u] >> 16];
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const uint32_t pos = p0 + u * XWG;
                 const uint32_t i = pw[u] & 0xffffu, j = pw[u] >> 16;
-                if (pos < e && vi[u] - vj[u] > m[u]) {          // dist_fun = -, AlgoBGP.jl:688
-                    __hip_atomic_store(&val[i], vj[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // swap_ev_ij!, :739-744
-                    __hip_atomic_store(&val[j], vi[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int si = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int sj = __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&src[i], sj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&src[j], si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&partner[i], (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // :747-748
-                    __hip_atomic_store(&partner[j], (int)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pos < e && si[u].val - sj[u].val > m[u]) {  // dist_fun = -, AlgoBGP.jl:688
+                    XSlot ni, nj;                               // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                    ni.val = sj[u].val; ni.src = sj[u].src; ni.partner = j + 1;
+                    nj.val = si[u].val; nj.src = si[u].src; nj.partner = i + 1;
+                    slot[i] = ni;
+                    slot[j] = nj;
                 }
             }
         }
@@ -485,9 +489,8 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lvl_big(const KParams P, c
         __syncthreads();
     }
     for (int g = tid; g < Ng; g += XWG) {
-        const unsigned s_ = (unsigned)__hip_atomic_load(&src[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned p_ = (unsigned)__hip_atomic_load(&partner[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        P.xres[g] = (unsigned long long)s_ | ((unsigned long long)p_ << 32);
+        const XSlot s_ = slot[g];
+        P.xres[g] = (unsigned long long)s_.src | ((unsigned long long)s_.partner << 32);
     }
 }
 

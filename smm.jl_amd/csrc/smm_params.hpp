@@ -67,6 +67,7 @@ struct KParams {
     // scratch of the any-size exchange kernel
     int32_t *xsrc, *xpartner, *xnext, *xpairs;
     double* xval;
+    void* xslot;   // [Ng] 16-byte chain slots {value, src, partner} of k_exch_resolve_lvl_big
     // history
     double* hrec;  // [T][N][HW]
     unsigned long long* err;

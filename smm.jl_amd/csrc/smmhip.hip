@@ -600,6 +600,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const int Kmax = std::max(K, 1);
             P.xval = dalloc<double>(c, Ng); P.xnext = dalloc<int32_t>(c, Ng); P.xpairs = dalloc<int32_t>(c, (size_t)Kmax * 2);
             P.xsrc = dalloc<int32_t>(c, Ng); P.xpartner = dalloc<int32_t>(c, Ng);
+            P.xslot = dalloc<double>(c, (size_t)Ng * 2);
         }
         {   // history: NaN values, curr/best = Inf, best_id = -1, exchanged = accepted = status = 0
             std::vector<double> row((size_t)N * P.HW, NAN);

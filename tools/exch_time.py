@@ -1,0 +1,15 @@
+"""device time of the stand-alone exchange resolution kernel by population size (event brackets, net of the empty bracket)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["SMMHIP_INLINE_WALK"] = "0"
+import smm_jl_amd as S, common as cm
+for N in (4096, 8192, 16384, 32768, 65000):
+    prob, opts = cm.serial_normal(N=N, T=60, ns=64)
+    c = S.hip_context(prob, opts)
+    c.step(10)
+    c.set_profiling(1)
+    c.step(40)
+    tm = c.timing()
+    print("N=%6d  exchange %.1f us  chain kernel %.1f us" % (N, (tm.exch_kernel_ms - tm.null_bracket_ms) * 1e3 / 40,
+                                                           (tm.iter_kernel_ms - tm.null_bracket_ms) * 1e3 / 40))
