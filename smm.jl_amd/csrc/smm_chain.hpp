@@ -574,17 +574,20 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     if (ctl) {
         double* th = S.theta + cl * np;
         const double* rc = S.rec + cl * RW;
-        if (t == 1 || !valid || (P.dbg & 1)) {
+        const bool draws = (t > 1) && !(P.dbg & 1);   // uniform: iteration 1 proposes the initial value (:426-427)
+        if (!draws || !valid) {
             if (r == 0)
-                for (int k = 0; k < np; ++k) th[k] = !valid ? 0.0 : (t == 1 ? S.init[k] : rc[3 + k]);  // :426-427
-        } else {
+                for (int k = 0; k < np; ++k) th[k] = !valid ? 0.0 : (t == 1 ? S.init[k] : rc[3 + k]);
+        }
+        if (draws) {   // all 64 lanes walk the batches together; lanes of absent chains take no part in the tries
             const int bs = P.batch_size;
             const int max_tries = P.user_n ? min(P.rb_tries, P.smpl_iters) : P.smpl_iters;
             const int npar = min(min(NR, P.rb_tries), max_tries);  // tries evaluated side by side
             const double sg = S.cs[cl * CSW + CS_SIGMA];
             const double* zz = S.rb + cl * RBW + 1;  // [tries][np]
+            const int lane = tid & 63;
             for (int b0 = 0; b0 < np; b0 += bs) {
-                bool ok = r < npar;
+                bool ok = valid && r < npar;
                 if (ok) {
                     for (int k = b0; k < b0 + bs; ++k) {  // mysample, :400-410, try r
                         const double lbk = S.lb[k];
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
 #pragma unroll
                 for (int rr = 0; rr < NR; ++rr) pat |= ((m >> (rr * CT + cl)) & 1ull) << rr;
                 const int rwin = pat ? (__ffsll((long long)pat) - 1) : -1;
-                if (rwin == r) {
+                if (valid && rwin == r) {
                     for (int k = b0; k < b0 + bs; ++k) {
                         const double lbk = S.lb[k];
                         const double span = S.ub[k] - lbk;
@@ -609,7 +612,13 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                         const double sc = x * span;
                         th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
                     }
-                } else if (rwin < 0 && r == 0) {  // rare: one try at a time (block, then the in-kernel generator)
+                }
+                // Chains whose side-by-side tries all left the unit box redraw one try at a time.  Many components: with the
+                // whole wave on one chain — lane l draws and tests component b0+l (+64, ...), so a try costs one
+                // generator call instead of one per component pair in sequence (the redraw loop of mysample is what a
+                // 50-parameter problem spends its time in).  Same tries, same order, same winner as the serial form.
+                const bool coop = bs >= 16;   // few components: every failing chain's own lane redraws (chains in parallel)
+                if (!coop && valid && r == 0 && rwin < 0) {
                     bool ok2 = false;
                     for (int rr = npar; rr < max_tries && !ok2; ++rr) {
                         ok2 = true;
@@ -617,7 +626,8 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                         int zq = -1;
                         for (int k = b0; k < b0 + bs; ++k) {
                             const double lbk = S.lb[k];
-                            const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);
+                            const double span = S.ub[k] - lbk;
+                            const double mu01 = (rc[3 + k] - lbk) / span;
                             double z;
                             if (rr < P.rb_tries) {
                                 z = zz[rr * np + k];
@@ -631,17 +641,45 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                             }
                             const double step = sg * z;
                             const double x = mu01 + step;
-                            th[k] = x;
                             if (!(x >= 0.0 && x <= 1.0)) ok2 = false;
+                            const double sc = x * span;
+                            th[k] = sc + lbk;
                         }
                     }
                     if (!ok2) report_error(P, 2, t, gc);  // :409
-                    for (int k = b0; k < b0 + bs; ++k) {
-                        const double lbk = S.lb[k];
-                        const double span = S.ub[k] - lbk;
-                        const double sc = th[k] * span;
-                        th[k] = sc + lbk;
+                }
+                unsigned long long fm = coop ? __ballot(valid && r == 0 && rwin < 0) : 0ull;   // lane index of (cl, r = 0) is cl
+                while (fm) {
+                    const int cf = __ffsll((long long)fm) - 1;
+                    fm &= fm - 1;
+                    const double* rcf = S.rec + cf * RW;
+                    const double sgf = S.cs[cf * CSW + CS_SIGMA];
+                    const double* zzf = S.rb + cf * RBW + 1;
+                    double* thf = S.theta + cf * np;
+                    const int gcf = P.offset + tile * CT + cf;
+                    bool done = false;
+                    for (int rr = npar; rr < max_tries && !done; ++rr) {
+                        bool okl = true;
+                        for (int k = b0 + lane; k < b0 + bs; k += 64) {
+                            double z;
+                            if (rr < P.rb_tries) {
+                                z = zzf[rr * np + k];
+                            } else {
+                                const double2 zz2 = rng_prop_normal2_outofline(P.seed, (uint32_t)gcf, (uint32_t)t, (uint32_t)rr, (uint32_t)(k >> 1));
+                                z = (k & 1) ? zz2.y : zz2.x;
+                            }
+                            const double lbk = S.lb[k];
+                            const double span = S.ub[k] - lbk;
+                            const double mu01 = (rcf[3 + k] - lbk) / span;
+                            const double step = sgf * z;
+                            const double x = mu01 + step;
+                            if (!(x >= 0.0 && x <= 1.0)) okl = false;
+                            const double sc = x * span;
+                            thf[k] = sc + lbk;   // kept if this try wins (or is the last one)
+                        }
+                        done = __all(okl);
                     }
+                    if (!done && lane == 0) report_error(P, 2, t, gcf);  // :409
                 }
             }
         }
