@@ -264,9 +264,7 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
         return;
     }
     if (is_sim(c->obj)) {
-        if (c->ct == 4) launch_chain_iter_ct<1, 4>(c, t, flags);
-        else if (c->ct == 16) launch_chain_iter_ct<1, 16>(c, t, flags);
-        else if (c->tpw == 2) launch_chain_iter_ct<1, 8, 2>(c, t, flags);
+        if (c->tpw == 2) launch_chain_iter_ct<1, 8, 2>(c, t, flags);
         else launch_chain_iter_ct<1, 8>(c, t, flags);
     } else if (c->obj == SMM_OBJ_DENSE) {
         launch_chain_iter_ct<2, 16>(c, t, flags);
@@ -452,8 +450,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             P.dbg = d ? atoi(d) : 0;
             const char* tsv = getenv("SMMHIP_TS");
             if (tsv && tsv[0] == '1') P.ts = dalloc<unsigned long long>(c, (size_t)8 * 65536);
-            const char* ct = getenv("SMMHIP_CT");  // tuning hook: chains per tile (4, 8, 16); numerics unaffected
-            c->ct = ct ? atoi(ct) : 8;
+            c->ct = 8;   // chains per simulation tile (4 and 16 were measured and rejected: more shock traffic / spills)
         }
         P.np = np; P.nm = nm; P.ns = ns; P.obj = c->obj;
         P.init = dupload(c, prob->init, np); P.lb = dupload(c, prob->lb, np); P.ub = dupload(c, prob->ub, np);
@@ -633,10 +630,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         }
         {   // tiles of problems with many parameters need more than the default 64 KiB of dynamic LDS
             const int lim = 160 * 1024;
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
