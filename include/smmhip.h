@@ -78,7 +78,21 @@ typedef enum {
  * rejected like an objective that threw, mprob.jl:183-186).  It must be a deterministic function of its inputs
  * (a simulation seeds its own generator, as objfunc_norm does with Random.seed!(1234)); udata = obj_params.
  * It is compiled at registration (hiprtc, -ffp-contract=off) and evaluated for all chains of an iteration by one
- * kernel launch, one thread per chain, between the proposal and the accept step. */
+ * kernel launch, one thread per chain, between the proposal and the accept step.
+ *
+ * Map-reduce form for simulations that are sums over many independent units (agents, draws, paths) —
+ * smm_register_user_objective_lanes(source, n_sums, lanes, &id): `lanes` threads (a multiple of 64, <= 1024)
+ * evaluate one chain.  The source defines TWO functions:
+ *
+ *   SMM_USER_PARTIAL(const double* theta, int np, const double* udata, int n_udata, int lane, int n_lanes,
+ *                    double* partial)          lane's partial sums, partial[0..n_sums) (zero on entry);
+ *                                              by convention lane l works on units l, l + n_lanes, ...
+ *   SMM_USER_FINISH (const double* theta, int np, const double* totals, int n_sums, const double* mom,
+ *                    const double* w, int nm, const double* udata, int n_udata, double* sim_moments,
+ *                    double* value, int* status)   from the totals to moments, objective value, status.
+ *
+ * The library reduces the partials in a fixed order (numerical contract): inside each group of 64 lanes the
+ * halving tree (offsets 32,16,..,1), then the group totals left to right. */
 #define SMM_OBJ_USER_BASE 1000
 #define SMM_OBJ_USER 4   /* internal kind of every user objective */
 
@@ -182,6 +196,7 @@ typedef struct {
 int  smm_abi_version(void);
 /* compile a user objective; errors (with the compiler log) through smm_last_error(NULL) */
 int  smm_register_user_objective(const char* hip_source, int32_t* objective_id_out);
+int  smm_register_user_objective_lanes(const char* hip_source, int32_t n_sums, int32_t lanes, int32_t* objective_id_out);
 int  smm_device_count(void);
 
 /* MAlgoBGP(m,opts) constructor, AlgoBGP.jl:505-537 + BGPChain ctor :78-109 */

@@ -22,6 +22,7 @@ _ORC_ONLY = [
     ("orc_max_threads", C.c_int, []),
     ("orc_gen_dense", None, [C.c_uint64, C.c_int, C.c_int, A.c_double_p]),
     ("orc_set_user_objective", None, [C.c_int, C.c_void_p]),
+    ("orc_set_user_objective_lanes", None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
 ]
 _SHARED = ["smm_ctx_create", "smm_ctx_destroy", "smm_last_error", "smm_bgp_step", "smm_bgp_local_step",
            "smm_bgp_record_doubles", "smm_eval_batch", "smm_get_history", "smm_get_state", "smm_get_Z"]
@@ -97,18 +98,24 @@ def gen_dense(seed, np_, nm):
 _user_libs = []
 
 
-def register_user_objective(source, objective_id, workdir=None):
-    """Build the SAME objective source the device compiles (SMM_USER_OBJECTIVE(...), include/smmhip.h) for the host
-    with gcc (-ffp-contract=off like the device build) and hook it into the oracle under the device's handle."""
+def register_user_objective(source, objective_id, workdir=None, n_sums=None, lanes=256):
+    """Build the SAME objective source the device compiles (include/smmhip.h: SMM_USER_OBJECTIVE, or with n_sums the
+    map-reduce pair SMM_USER_PARTIAL / SMM_USER_FINISH) for the host with gcc (-ffp-contract=off like the device
+    build) and hook it into the oracle under the device's handle."""
     import tempfile
     d = workdir or tempfile.mkdtemp(prefix="smm_user_obj_")
     src = os.path.join(d, "user_objective_%d.c" % objective_id)
     so = os.path.join(d, "user_objective_%d.so" % objective_id)
     with open(src, "w") as f:
-        f.write("#include <math.h>\n#include <stddef.h>\n#define SMM_USER_OBJECTIVE void smm_user_objective\n" + source)
+        f.write("#include <math.h>\n#include <stddef.h>\n#define SMM_USER_OBJECTIVE void smm_user_objective\n"
+                "#define SMM_USER_PARTIAL void smm_user_partial\n#define SMM_USER_FINISH void smm_user_finish\n"
+                "#define SMM_NSUMS %d\n" % (n_sums or 1) + source)
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src, "-lm"])
     lib = C.CDLL(so)
     _user_libs.append(lib)
-    fn = C.cast(lib.smm_user_objective, C.c_void_p)
-    load().orc_set_user_objective(int(objective_id), fn)
+    if n_sums is None:
+        load().orc_set_user_objective(int(objective_id), C.cast(lib.smm_user_objective, C.c_void_p))
+    else:
+        load().orc_set_user_objective_lanes(int(objective_id), C.cast(lib.smm_user_partial, C.c_void_p),
+                                            C.cast(lib.smm_user_finish, C.c_void_p), int(n_sums), int(lanes))
     return so

@@ -45,6 +45,15 @@
 typedef void (*orc_user_fn)(const double* theta, int np, const double* mom, const double* w, int nm, const double* udata,
                             int n_udata, double* sim_moments, double* value, int* status);
 static orc_user_fn g_user_fn[ORC_MAX_USER];
+/* map-reduce form (SMM_USER_PARTIAL / SMM_USER_FINISH, include/smmhip.h) */
+typedef void (*orc_user_partial_fn)(const double* theta, int np, const double* udata, int n_udata, int lane, int n_lanes,
+                                    double* partial);
+typedef void (*orc_user_finish_fn)(const double* theta, int np, const double* totals, int n_sums, const double* mom,
+                                   const double* w, int nm, const double* udata, int n_udata, double* sim_moments,
+                                   double* value, int* status);
+static orc_user_partial_fn g_user_partial[ORC_MAX_USER];
+static orc_user_finish_fn g_user_finish[ORC_MAX_USER];
+static int g_user_nsums[ORC_MAX_USER], g_user_lanes[ORC_MAX_USER];
 #define ORC_DENSE_D 256
 
 #define ORC_REDUCE_LANES 512 /* numerical contract, see include/smmhip.h */
@@ -396,6 +405,31 @@ static void evaluate_objective(const orc_t* o, const double* theta, double* simM
         break;
     default:
         if (p->objective_id >= ORC_OBJ_USER_BASE && p->objective_id - ORC_OBJ_USER_BASE < ORC_MAX_USER &&
+            g_user_partial[p->objective_id - ORC_OBJ_USER_BASE]) {
+            /* map-reduce form: every lane's partial sums, then the library's reduction order — inside each group of 64
+             * lanes the halving tree (offsets 32..1; lane l takes l + off), the group totals left to right */
+            const int u = p->objective_id - ORC_OBJ_USER_BASE, ns = g_user_nsums[u], nl = g_user_lanes[u];
+            double* parts = (double*)calloc((size_t)nl * ns, sizeof(double));
+            double* tot = (double*)calloc((size_t)ns, sizeof(double));
+            for (int l = 0; l < nl; ++l) g_user_partial[u](theta, p->np, o->obj_params, p->n_obj_params, l, nl, parts + (size_t)l * ns);
+            for (int i = 0; i < ns; ++i) {
+                for (int g = 0; g < nl / 64; ++g) {
+                    double a[64];
+                    for (int l = 0; l < 64; ++l) a[l] = parts[(size_t)(g * 64 + l) * ns + i];
+                    for (int off = 32; off >= 1; off >>= 1)
+                        for (int l = 0; l < off; ++l) a[l] = a[l] + a[l + off];
+                    tot[i] = (g == 0) ? a[0] : tot[i] + a[0];
+                }
+            }
+            int st = 1;
+            double v = 0.0;
+            g_user_finish[u](theta, p->np, tot, ns, o->mom, o->w, p->nm, o->obj_params, p->n_obj_params, simM, &v, &st);
+            *value = v;
+            *status = (int8_t)st;
+            free(parts); free(tot);
+            break;
+        }
+        if (p->objective_id >= ORC_OBJ_USER_BASE && p->objective_id - ORC_OBJ_USER_BASE < ORC_MAX_USER &&
             g_user_fn[p->objective_id - ORC_OBJ_USER_BASE]) {
             /* user objective (include/smmhip.h, SMM_USER_OBJECTIVE): the same source text the device compiles,
              * built for the host by the test and registered under the same handle */
@@ -410,6 +444,13 @@ static void evaluate_objective(const orc_t* o, const double* theta, double* simM
         for (int k = 0; k < p->nm; ++k) simM[k] = NAN;
         *value = -1.0;
         *status = -2;
+    }
+}
+
+void orc_set_user_objective_lanes(int objective_id, orc_user_partial_fn pf, orc_user_finish_fn ff, int n_sums, int lanes) {
+    if (objective_id >= ORC_OBJ_USER_BASE && objective_id - ORC_OBJ_USER_BASE < ORC_MAX_USER) {
+        const int u = objective_id - ORC_OBJ_USER_BASE;
+        g_user_partial[u] = pf; g_user_finish[u] = ff; g_user_nsums[u] = n_sums; g_user_lanes[u] = lanes;
     }
 }
 

@@ -98,6 +98,7 @@ class smm_timing_t(C.Structure):
 SYMBOLS = [
     ("smm_abi_version", C.c_int, []),
     ("smm_register_user_objective", C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    ("smm_register_user_objective_lanes", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     ("smm_device_count", C.c_int, []),
     ("smm_ctx_create", C.c_int, [C.POINTER(smm_problem_t), C.POINTER(smm_bgp_opts_t), C.POINTER(smm_tables_t),
                                  C.POINTER(C.c_void_p)]),

@@ -193,12 +193,18 @@ class BGPContext:
         return z
 
 
-def register_user_objective(source):
-    """Compile a user objective (HIP/C++ text defining SMM_USER_OBJECTIVE(...), see include/smmhip.h) for the device
-    and return its objective_id handle.  Raises with the compiler log if it does not compile."""
+def register_user_objective(source, n_sums=None, lanes=256):
+    """Compile a user objective for the device and return its objective_id handle (include/smmhip.h).
+    n_sums=None: `source` defines SMM_USER_OBJECTIVE(...), evaluated by one thread per chain.
+    n_sums=k:    map-reduce form — `source` defines SMM_USER_PARTIAL(...) and SMM_USER_FINISH(...); `lanes` threads
+                 evaluate one chain and their k partial sums are reduced in a fixed order.
+    Raises with the compiler log if the source does not compile."""
     lib = A.load()
     oid = C.c_int32(0)
-    rc = lib.smm_register_user_objective(source.encode(), C.byref(oid))
+    if n_sums is None:
+        rc = lib.smm_register_user_objective(source.encode(), C.byref(oid))
+    else:
+        rc = lib.smm_register_user_objective_lanes(source.encode(), int(n_sums), int(lanes), C.byref(oid))
     if rc != 0:
         raise RuntimeError("smm_register_user_objective failed (%d): %s" % (rc, lib.smm_last_error(None).decode()))
     return int(oid.value)

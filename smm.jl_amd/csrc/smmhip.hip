@@ -63,7 +63,7 @@ thread_local std::string g_create_err;
 // ------------------------------------------------------------------------------------------
 // user objectives: compiled with hiprtc (loaded lazily, the library does not link against it)
 // ------------------------------------------------------------------------------------------
-struct UserObjective { std::vector<char> code; };
+struct UserObjective { std::vector<char> code; int lanes = 0; /* 0: one thread per chain; else lanes per chain (map-reduce form) */ };
 std::vector<UserObjective> g_user_objectives;
 std::mutex g_user_mutex;
 
@@ -79,6 +79,39 @@ const char* USER_KERNEL =
     "    int st = 1; double v = 0.0;\n"
     "    smm_user_objective(theta + (size_t)c * np, np, mom, w, nm, udata, n_udata, simM + (size_t)c * nm, &v, &st);\n"
     "    value[c] = v; status[c] = st;\n"
+    "}\n";
+
+const char* USER_PRELUDE_LANES =
+    "#define SMM_USER_PARTIAL extern \"C\" __device__ void smm_user_partial\n"
+    "#define SMM_USER_FINISH extern \"C\" __device__ void smm_user_finish\n"
+    "extern \"C\" __device__ void smm_user_partial(const double* theta, int np, const double* udata, int n_udata, int lane, int n_lanes,\n"
+    "                                            double* partial);\n"
+    "extern \"C\" __device__ void smm_user_finish(const double* theta, int np, const double* totals, int n_sums, const double* mom,\n"
+    "                                           const double* w, int nm, const double* udata, int n_udata, double* sim_moments,\n"
+    "                                           double* value, int* status);\n";
+// one workgroup of n_lanes threads per evaluation.  Numerical contract of the reduction: inside a
+// wave the 64 partials are combined by the halving tree (offsets 32,16,...,1), the wave totals are added left to right.
+const char* USER_KERNEL_LANES =
+    "\nextern \"C\" __global__ void smm_user_eval_kernel(const double* theta, int N, int np, const double* mom, const double* w, int nm,\n"
+    "        const double* udata, int n_udata, double* simM, double* value, int* status) {\n"
+    "    __shared__ double wsum[16][SMM_NSUMS];\n"
+    "    const int c = blockIdx.x, lane = threadIdx.x, nl = blockDim.x;\n"
+    "    double part[SMM_NSUMS];\n"
+    "    for (int i = 0; i < SMM_NSUMS; ++i) part[i] = 0.0;\n"
+    "    smm_user_partial(theta + (size_t)c * np, np, udata, n_udata, lane, nl, part);\n"
+    "    for (int i = 0; i < SMM_NSUMS; ++i) {\n"
+    "        double a = part[i];\n"
+    "        for (int off = 32; off >= 1; off >>= 1) a = a + __shfl_xor(a, off, 64);\n"
+    "        if ((lane & 63) == 0) wsum[lane >> 6][i] = a;\n"
+    "    }\n"
+    "    __syncthreads();\n"
+    "    if (lane == 0) {\n"
+    "        double tot[SMM_NSUMS];\n"
+    "        for (int i = 0; i < SMM_NSUMS; ++i) { double a = wsum[0][i]; for (int wv = 1; wv < nl / 64; ++wv) a = a + wsum[wv][i]; tot[i] = a; }\n"
+    "        int st = 1; double v = 0.0;\n"
+    "        smm_user_finish(theta + (size_t)c * np, np, tot, SMM_NSUMS, mom, w, nm, udata, n_udata, simM + (size_t)c * nm, &v, &st);\n"
+    "        value[c] = v; status[c] = st;\n"
+    "    }\n"
     "}\n";
 
 struct Hiprtc {
@@ -140,6 +173,7 @@ struct Ctx {
     const double* ext_rec_in = nullptr;   // sharded_step: donor records come from / results go to the caller's gather buffers
     double* ext_rec_out = nullptr;
     bool pending_ext = false;   // sharded_step: the exchange of iteration `iter` is still to be resolved from the gathered records
+    int u_lanes = 0;                // user objective: lanes per evaluation (0 = one thread per chain)
     int n_objp = 0;                 // doubles in P.objp
     hipModule_t umod = nullptr;     // user objective: this context's module and kernel
     hipFunction_t ufn = nullptr;
@@ -248,7 +282,10 @@ void launch_user_kernel(Ctx* c, const double* theta, int n, double* simM, double
     const double *mom = P.mom, *w = P.w, *ud = P.objp;
     void* args[] = {(void*)&theta, (void*)&n, (void*)&np, (void*)&mom, (void*)&w, (void*)&nm, (void*)&ud, (void*)&nud,
                     (void*)&simM, (void*)&value, (void*)&status};
-    HIPCHK(hipModuleLaunchKernel(c->ufn, (unsigned)((n + 127) / 128), 1, 1, 128, 1, 1, 0, c->stream, args, nullptr));
+    if (c->u_lanes > 0)   // map-reduce form: one workgroup of u_lanes threads per evaluation
+        HIPCHK(hipModuleLaunchKernel(c->ufn, (unsigned)n, 1, 1, (unsigned)c->u_lanes, 1, 1, 0, c->stream, args, nullptr));
+    else
+        HIPCHK(hipModuleLaunchKernel(c->ufn, (unsigned)((n + 127) / 128), 1, 1, 128, 1, 1, 0, c->stream, args, nullptr));
 }
 
 void launch_chain_iter(Ctx* c, int t, int flags) {
@@ -355,19 +392,18 @@ extern "C" {
 
 int smm_abi_version(void) { return SMMHIP_ABI_VERSION; }
 
-int smm_register_user_objective(const char* hip_source, int32_t* objective_id_out) {
-    if (!hip_source || !objective_id_out) { g_create_err = "smm_register_user_objective: null argument"; return SMM_ERR_INVALID_ARG; }
+static int register_user_source(const std::string& src, int n_sums, int lanes, int32_t* objective_id_out) {
     std::lock_guard<std::mutex> lock(g_user_mutex);
     std::string err;
     if (!g_rtc.load(err)) { g_create_err = err; return SMM_ERR_HIP; }
-    const std::string src = std::string(USER_PRELUDE) + hip_source + USER_KERNEL;
     hiprtcProgram prog = nullptr;
     if (g_rtc.create(&prog, src.c_str(), "smm_user_objective.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         g_create_err = "hiprtcCreateProgram failed";
         return SMM_ERR_HIP;
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
-    const hiprtcResult rc = g_rtc.compile(prog, 4, opts);
+    const std::string nsd = "-DSMM_NSUMS=" + std::to_string(n_sums > 0 ? n_sums : 1);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", nsd.c_str()};
+    const hiprtcResult rc = g_rtc.compile(prog, 5, opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0;
         g_rtc.log_size(prog, &n);
@@ -381,11 +417,26 @@ int smm_register_user_objective(const char* hip_source, int32_t* objective_id_ou
     g_rtc.code_size(prog, &cs);
     UserObjective u;
     u.code.resize(cs);
+    u.lanes = lanes;
     g_rtc.code(prog, u.code.data());
     g_rtc.destroy(&prog);
     g_user_objectives.push_back(std::move(u));
     *objective_id_out = SMM_OBJ_USER_BASE + (int32_t)g_user_objectives.size() - 1;
     return SMM_OK;
+}
+
+int smm_register_user_objective(const char* hip_source, int32_t* objective_id_out) {
+    if (!hip_source || !objective_id_out) { g_create_err = "smm_register_user_objective: null argument"; return SMM_ERR_INVALID_ARG; }
+    return register_user_source(std::string(USER_PRELUDE) + hip_source + USER_KERNEL, 1, 0, objective_id_out);
+}
+
+int smm_register_user_objective_lanes(const char* hip_source, int32_t n_sums, int32_t lanes, int32_t* objective_id_out) {
+    if (!hip_source || !objective_id_out) { g_create_err = "smm_register_user_objective_lanes: null argument"; return SMM_ERR_INVALID_ARG; }
+    if (n_sums < 1 || n_sums > 64 || lanes < 64 || lanes > 1024 || lanes % 64 != 0) {
+        g_create_err = "smm_register_user_objective_lanes: need 1 <= n_sums <= 64 and lanes a multiple of 64 in [64, 1024]";
+        return SMM_ERR_INVALID_ARG;
+    }
+    return register_user_source(std::string(USER_PRELUDE_LANES) + hip_source + USER_KERNEL_LANES, n_sums, lanes, objective_id_out);
 }
 
 int smm_device_count(void) {
@@ -462,6 +513,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 std::lock_guard<std::mutex> lock(g_user_mutex);
                 const UserObjective& u = g_user_objectives[prob->objective_id - SMM_OBJ_USER_BASE];
                 HIPCHK(hipModuleLoadData(&c->umod, u.code.data()));
+                c->u_lanes = u.lanes;
             }
             HIPCHK(hipModuleGetFunction(&c->ufn, c->umod, "smm_user_eval_kernel"));
             P.u_theta = dalloc<double>(c, (size_t)N * np);

@@ -40,12 +40,13 @@ def _no_mprob():
     raise ValueError("a device objective needs an Eval built from an MProb (Eval(mprob, p))")
 
 
-def user_objective(source, name="user_objective", obj_params=None):
-    """A user-written device objective (MProb.objfunc of the reference, mprob.jl:159): `source` is HIP/C++ text that
-    defines SMM_USER_OBJECTIVE(theta, np, mom, w, nm, udata, n_udata, sim_moments, value, status) — see
-    include/smmhip.h.  addEvalFunc(m, user_objective(src)); addEvalFuncOpts(m, {"obj_params": [...]}) passes udata."""
+def user_objective(source, name="user_objective", n_sums=None, lanes=256):
+    """A user-written device objective (MProb.objfunc of the reference, mprob.jl:159): HIP/C++ text that defines
+    SMM_USER_OBJECTIVE(...) — or, with n_sums=k, the map-reduce pair SMM_USER_PARTIAL / SMM_USER_FINISH evaluated by
+    `lanes` threads per chain — see include/smmhip.h.  addEvalFunc(m, user_objective(src));
+    m.objfunc_opts["obj_params"] = [...] passes udata."""
     from .backend import register_user_objective
-    return DeviceObjective(name, register_user_objective(source), ns=1)
+    return DeviceObjective(name, register_user_objective(source, n_sums, lanes), ns=1)
 
 
 objfunc_norm = DeviceObjective("objfunc_norm", A.SMM_OBJ_NORM, needs_square=True)   # ObjExamples.jl:59-116

@@ -7,7 +7,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import common as cm  # noqa: E402
-from user_objective_src import AR1_SOURCE, ar1_numpy  # noqa: E402
+from user_objective_src import AR1_SOURCE, PANEL_SOURCE, ar1_numpy  # noqa: E402
 
 
 def ar1_problem(S, oid, N, T, fail_above=None, seed=5):
@@ -91,3 +91,58 @@ def test_user_objective_compile_error_is_reported(S):
     with pytest.raises(RuntimeError) as e:
         S.register_user_objective("SMM_USER_OBJECTIVE(const double* theta) { this is not C }")
     assert "compile" in str(e.value)
+
+
+def panel_problem(S, oid, N, T, seed=9):
+    prob = S.Problem(init=[0.3, 1.0], lb=[-0.95, 0.1], ub=[0.95, 3.0], mom=[0.0, 0.12, 0.06], w=[0.05, 0.05, 0.05], ns=1,
+                     objective_id=oid, obj_params=[40.0, 1000.0, 0.85])   # 40 periods x 1000 agents; fails above rho = 0.85
+    opts = S.BGPOpts(N=N, maxiter=T, sigma=0.05 * cm.temps(N, 4.0), acc_tuner=np.geomspace(3.0, 0.5, N) if N > 1 else [2.0],
+                     min_improve=np.zeros(N), seed=seed, N_global=N)
+    return prob, opts
+
+
+def test_oracle_map_reduce_objective(O, S):
+    # CPU only: lanes form in the oracle; 1000 agents over 256 lanes == the same sums in a different order (close, not equal)
+    oid = 1000 + 62
+    O.register_user_objective(PANEL_SOURCE, oid, n_sums=3, lanes=256)
+    prob, opts = panel_problem(S, oid, N=1, T=1)
+    o = O.OracleContext(prob, opts)
+    th = np.array([[0.2, 0.7, 0.9], [1.0, 0.5, 2.0]])
+    v, sm, st = o.eval_batch(th)
+    assert list(st) == [1, 1, -2] and v[2] == -1.0
+    # independent check of moment 2 for theta 0: plain python over all agents
+    tot = 0.0
+    for a in range(1000):
+        s_ = 12345 + 7919 * a
+        y = 0.0
+        for _ in range(40):
+            s_ = (s_ * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+            y = 0.2 * y + 1.0 * (float(s_ >> 11) / 9007199254740992.0 - 0.5)
+            tot += y * y
+    assert np.isclose(sm[1, 0], tot / 40000.0, rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [64, 256, 1024])
+def test_map_reduce_user_objective(S, O, lanes):
+    oid = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=lanes)
+    O.register_user_objective(PANEL_SOURCE, oid, n_sums=3, lanes=lanes)
+    prob, opts = panel_problem(S, oid, N=16, T=25)
+    h = S.hip_context(prob, opts)
+    o = O.OracleContext(prob, opts)
+    rng = np.random.default_rng(2)
+    th = np.stack([rng.uniform(-0.9, 0.9, 100), rng.uniform(0.2, 2.5, 100)])
+    vh, smh, sth = h.eval_batch(th)
+    vo, smo, sto = o.eval_batch(th)
+    assert np.array_equal(sth, sto) and np.array_equal(smh, smo) and np.array_equal(vh, vo)   # same reduction order: bit-exact
+    h.step(25); o.step(25)
+    cm.assert_history_equal(h.history(), o.history())
+    cm.assert_state_equal(h.state(), o.state())
+
+
+@pytest.mark.gpu
+def test_map_reduce_registration_checks(S):
+    with pytest.raises(RuntimeError):
+        S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=100)     # not a multiple of 64
+    with pytest.raises(RuntimeError):
+        S.register_user_objective(PANEL_SOURCE, n_sums=0, lanes=64)

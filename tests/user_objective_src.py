@@ -48,3 +48,39 @@ def ar1_numpy(theta, mom, w, udata):
         return sm, -1.0, -2
     d = (sm - np.asarray(mom)) / np.asarray(w)
     return sm, float((d * d).sum() / len(mom)), 1
+
+
+# The map-reduce form: a panel of AR(1) agents; lane l simulates agents l, l + n_lanes, ...; three sums.
+PANEL_SOURCE = r"""
+SMM_USER_PARTIAL(const double* theta, int np, const double* udata, int n_udata, int lane, int n_lanes, double* partial)
+{
+    const double rho = theta[0], sig = theta[1];
+    const int T = (int)udata[0], A = (int)udata[1];
+    for (int a = lane; a < A; a += n_lanes) {
+        unsigned long long st = 12345ull + 7919ull * (unsigned long long)a;
+        double y = 0.0, yp = 0.0;
+        for (int t = 0; t < T; ++t) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            const double u = (double)(st >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+            yp = y;
+            y = rho * y + sig * u;
+            partial[0] += y; partial[1] += y * y; partial[2] += y * yp;
+        }
+    }
+}
+
+SMM_USER_FINISH(const double* theta, int np, const double* totals, int n_sums, const double* mom, const double* w, int nm,
+                const double* udata, int n_udata, double* sim_moments, double* value, int* status)
+{
+    const double n = udata[0] * udata[1];
+    double v = 0.0;
+    for (int k = 0; k < nm; ++k) {
+        sim_moments[k] = totals[k] / n;
+        const double d = (sim_moments[k] - mom[k]) / w[k];
+        v += d * d;
+    }
+    *value = v / nm;
+    *status = (n_udata > 2 && theta[0] > udata[2]) ? -2 : 1;
+    if (*status < 0) *value = -1.0;
+}
+"""

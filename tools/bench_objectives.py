@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import smm_jl_amd as S  # noqa: E402
 import common as cm  # noqa: E402
 from smm_jl_amd import _abi as A  # noqa: E402
-from user_objective_src import AR1_SOURCE  # noqa: E402
+from user_objective_src import AR1_SOURCE, PANEL_SOURCE  # noqa: E402
 
 
 def rate(ctx, N, iters=200, reps=3):
@@ -53,6 +53,11 @@ def main():
     opts = S.BGPOpts(N=N, maxiter=T, sigma=0.05 * cm.temps(N, 4.0), acc_tuner=np.geomspace(3.0, 0.5, N), min_improve=np.zeros(N),
                      seed=5, N_global=N)
     rows.append(("user objective AR(1) T=400, N=4096", rate(S.hip_context(prob, opts), N)))
+    # user objective, map-reduce form: a panel of 4096 AR(1) agents x 40 periods per evaluation, 256 lanes per chain
+    oid = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=256)
+    prob = S.Problem(init=[0.3, 1.0], lb=[-0.95, 0.1], ub=[0.95, 3.0], mom=[0.0, 0.12, 0.06], w=[0.05, 0.05, 0.05], ns=1,
+                     objective_id=oid, obj_params=[40.0, 4096.0])
+    rows.append(("user map-reduce panel 4096x40, N=4096", rate(S.hip_context(prob, opts), N, iters=100)))
     for name, r in rows:
         print("%-44s %8.1f M chain-evals/s  (%.1f us per iteration)" % (name, r / 1e6, 1e6 / (r / int(name.split("N=")[1]))))
 
