@@ -244,6 +244,11 @@ void* smm_stream(void* ctx);
  * the other callers of evaluateObjective (slices.jl:153, econometrics.jl:42). */
 int  smm_eval_batch(void* ctx, const double* params, int32_t M,
                     double* value, double* sim_moments, int8_t* status);
+/* the same for objfunc_norm with options[:noseed] = true (ObjExamples.jl:71-75): evaluation i draws its own
+ * shocks (generator keyed by base_seed + i) instead of the fixed seed-1234 matrix — the repetitions of
+ * getSigma (econometrics.jl:125-145). */
+int  smm_eval_batch_noseed(void* ctx, const double* params, int32_t M, uint64_t base_seed,
+                           double* value, double* sim_moments, int8_t* status);
 
 int  smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out);
 int  smm_get_state(void* ctx, smm_state_t* out);

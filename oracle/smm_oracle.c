@@ -774,6 +774,26 @@ int orc_bgp_step(void* v, int n_iters) {
     return rc;
 }
 
+/* objfunc_norm with options[:noseed] = true (ObjExamples.jl:71-75): every evaluation draws its own shocks — here the
+ * counter generator keyed by base_seed + i — as getSigma's repetitions do (econometrics.jl:125-145). */
+int orc_eval_batch_noseed(void* v, const double* params, int M, uint64_t base_seed, double* value, double* simM, int8_t* status) {
+    orc_t* o = (orc_t*)v;
+    const int np = o->prob.np, nm = o->prob.nm;
+    if (o->prob.objective_id != ORC_OBJ_NORM && o->prob.objective_id != ORC_OBJ_NORM_FAILBOX) return ORC_ERR_INVALID_ARG;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(o->threads) if (o->threads > 1)
+#endif
+    for (int i = 0; i < M; ++i) {
+        double* th = (double*)malloc((size_t)(np + nm) * sizeof(double));
+        double* sm = th + np;
+        for (int k = 0; k < np; ++k) th[k] = params[(size_t)k * M + i];
+        objfunc_norm(nm, o->prob.ns, th, NULL, 1, base_seed + (uint64_t)i, o->mom, o->w, sm, &value[i], &status[i]);
+        for (int k = 0; k < nm; ++k) simM[(size_t)k * M + i] = sm[k];
+        free(th);
+    }
+    return ORC_OK;
+}
+
 /* batched evaluateObjective: params [np][M] -> value[M], simM[nm][M], status[M] */
 int orc_eval_batch(void* v, const double* params, int M, double* value, double* simM, int8_t* status) {
     orc_t* o = (orc_t*)v;

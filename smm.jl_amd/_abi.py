@@ -115,6 +115,7 @@ SYMBOLS = [
     ("smm_bgp_sharded_finish", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smm_stream", C.c_void_p, [C.c_void_p]),
     ("smm_eval_batch", C.c_int, [C.c_void_p, c_double_p, C.c_int32, c_double_p, c_double_p, c_int8_p]),
+    ("smm_eval_batch_noseed", C.c_int, [C.c_void_p, c_double_p, C.c_int32, C.c_uint64, c_double_p, c_double_p, c_int8_p]),
     ("smm_get_history", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(smm_history_t)]),
     ("smm_get_state", C.c_int, [C.c_void_p, C.POINTER(smm_state_t)]),
     ("smm_set_state", C.c_int, [C.c_void_p, C.POINTER(smm_state_t), C.POINTER(smm_history_t)]),

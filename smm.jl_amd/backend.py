@@ -159,6 +159,16 @@ class BGPContext:
                                            status.ctypes.data_as(A.c_int8_p)))
         return value, simM, status
 
+    def eval_batch_noseed(self, params, base_seed):
+        """objfunc_norm with noseed=true (ObjExamples.jl:71-75): evaluation i draws its own shocks (base_seed + i)"""
+        params = A.f64(params)
+        assert params.shape[0] == self.np
+        M = params.shape[1]
+        value = np.empty(M); simM = np.empty((self.nm, M)); status = np.empty(M, np.int8)
+        self._check(self._fn("eval_batch_noseed")(self._ctx, A.dptr(params), M, C.c_uint64(int(base_seed)), A.dptr(value),
+                                                  A.dptr(simM), status.ctypes.data_as(A.c_int8_p)))
+        return value, simM, status
+
     # --- read back --------------------------------------------------------------------
     def history(self, t0=0, t1=None):
         t1 = self.state().iter if t1 is None else t1

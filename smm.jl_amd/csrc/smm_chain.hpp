@@ -860,3 +860,47 @@ __global__ __launch_bounds__(WG, 4) void k_eval_batch(const KParams P, const dou
         for (int k = 0; k < P.nm; ++k) simM[(size_t)k * M + i] = sm[k];
     }
 }
+
+// objfunc_norm with options[:noseed] = true (ObjExamples.jl:71-75): every evaluation draws its own shock matrix (the
+// counter generator keyed by base_seed + i) — getSigma's repetitions (econometrics.jl:125-145).  One workgroup per
+// evaluation; lane l generates and sums its draws l, l + 512, ... (the numerical contract of the seeded form).
+__global__ __launch_bounds__(WG) void k_eval_batch_noseed(const KParams P, const double* __restrict__ params, const int M,
+                                                          const uint64_t base_seed, double* __restrict__ value,
+                                                          double* __restrict__ simM, int8_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // [WG/64][nm] wave totals
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nm = P.nm, ns = P.ns;
+    const uint64_t seed = base_seed + (uint64_t)i;
+    for (int q = 0; 2 * q < nm; ++q) {   // one Philox block serves moments 2q and 2q+1
+        const int k0 = 2 * q, k1 = 2 * q + 1;
+        const double mu0 = params[(size_t)k0 * M + i], mu1 = k1 < nm ? params[(size_t)k1 * M + i] : 0.0;
+        double a0 = 0.0, a1 = 0.0;
+        for (int s = tid; s < ns; s += WG) {
+            double z0, z1;
+            box_muller(philox_stream(seed, STREAM_Z, (uint32_t)s, (uint32_t)q, 0, 0), z0, z1);
+            const double x0 = z0 + mu0, x1 = z1 + mu1;
+            a0 = a0 + x0;
+            a1 = a1 + x1;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a0 = a0 + __shfl_xor(a0, off, 64); a1 = a1 + __shfl_xor(a1, off, 64); }
+        if (lane == 0) { smem[wave * nm + k0] = a0; if (k1 < nm) smem[wave * nm + k1] = a1; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double vsum = 0.0;
+        for (int k = 0; k < nm; ++k) {
+            double tot = smem[k];
+            for (int wv = 1; wv < WG / 64; ++wv) tot = tot + smem[wv * nm + k];
+            const double m = tot / (double)ns;
+            simM[(size_t)k * M + i] = m;
+            double d = m - P.mom[k];
+            const double wk = P.w[k];
+            if (!isnan(wk)) d = d / wk;
+            const double v = d * d;
+            vsum = (k == 0) ? v : vsum + v;
+        }
+        value[i] = vsum / (double)nm;
+        status[i] = 1;
+    }
+}

@@ -982,6 +982,36 @@ int smm_eval_batch(void* ctx, const double* params, int32_t M, double* value, do
     return SMM_OK;
 }
 
+int smm_eval_batch_noseed(void* ctx, const double* params, int32_t M, uint64_t base_seed, double* value, double* sim_moments,
+                          int8_t* status) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !params || M < 0 || !value || !sim_moments || !status) return SMM_ERR_INVALID_ARG;
+    if (!is_sim(c->obj)) return fail(c, SMM_ERR_INVALID_ARG, "noseed evaluations exist for objfunc_norm only");
+    if (M == 0) return SMM_OK;
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        const KParams& P = c->P;
+        double *dp = nullptr, *dv = nullptr, *dm = nullptr;
+        int8_t* ds = nullptr;
+        HIPCHK(hipMalloc((void**)&dp, (size_t)P.np * M * 8));
+        HIPCHK(hipMalloc((void**)&dv, (size_t)M * 8));
+        HIPCHK(hipMalloc((void**)&dm, (size_t)P.nm * M * 8));
+        HIPCHK(hipMalloc((void**)&ds, (size_t)M));
+        HIPCHK(hipMemcpyAsync(dp, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_eval_batch_noseed, dim3(M), dim3(WG), (size_t)(WG / 64) * P.nm * 8, c->stream, P, (const double*)dp, M,
+                           (uint64_t)base_seed, dv, dm, ds);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(value, dv, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(sim_moments, dm, (size_t)P.nm * M * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(status, ds, (size_t)M, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(dp); (void)hipFree(dv); (void)hipFree(dm); (void)hipFree(ds);
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
 // history(c) (AlgoBGP.jl:138-160): download iterations t0..t1-1 and transpose the per-chain history
 // records into the ABI's structure-of-arrays buffers.
 int smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out) {

@@ -488,3 +488,20 @@ def test_c5_dense_sharded_8(S, O):
         hr = c.history()
         for f in A.HistoryBuffers.FIELDS:
             assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * 512:(r + 1) * 512], equal_nan=True), (f, r)
+
+
+@pytest.mark.gpu
+def test_noseed_eval_batch(S, O):
+    # objfunc_norm with noseed=true: every evaluation has its own shock matrix (getSigma's repetitions)
+    prob, opts = cm.serial_normal(N=3, T=2, ns=2000)
+    h, o = make_pair(S, O, prob, opts, None)
+    th = np.tile(np.array([[0.4], [-0.3]]), (1, 40))             # the same parameter vector 40 times
+    vh, smh, sth = h.eval_batch_noseed(th, 777)
+    vo, smo, sto = o.eval_batch_noseed(th, 777)
+    assert np.array_equal(sth, sto) and (sth == 1).all()
+    np.testing.assert_allclose(smh, smo, rtol=1e-12, atol=1e-14)   # device sincospi vs host sin/cos in Box-Muller
+    np.testing.assert_allclose(vh, vo, rtol=1e-10)
+    assert np.unique(np.round(smh[0], 12)).size == 40             # 40 different shock matrices ...
+    v2, sm2, _ = h.eval_batch_noseed(th[:, :5], 777 + 10)
+    assert np.array_equal(sm2, smh[:, 10:15])                      # ... keyed by base_seed + i
+    assert abs(smh[0].mean() - 0.4) < 0.02 and abs(smh[0].std() - 1 / np.sqrt(2000)) < 0.01   # mean of ns draws of N(theta, 1)
