@@ -148,11 +148,12 @@ def load():
     """dlopen libsmmhip.so (built by __graft_entry__.build() / csrc/Makefile). Fails loudly."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("SMMHIP_LIB", LIB_PATH)   # development hook: an alternative build of the same library
+        if not os.path.exists(path):
             raise ImportError(
                 "libsmmhip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-        _lib = bind(C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL))
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+        _lib = bind(C.CDLL(path, mode=C.RTLD_GLOBAL))
         if _lib.smm_abi_version() != 1:
             raise ImportError("libsmmhip.so ABI version mismatch")
     return _lib
