@@ -386,6 +386,16 @@ int fail(Ctx* c, int code, const std::string& m) {
     return code;
 }
 
+// temporary device buffer of one call (freed on every exit path)
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    explicit DevBuf(size_t n) { HIPCHK(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T))); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
 }  // namespace
 
 extern "C" {
@@ -936,46 +946,42 @@ int smm_eval_batch(void* ctx, const double* params, int32_t M, double* value, do
     try {
         HIPCHK(hipSetDevice(c->device));
         const KParams& P = c->P;
-        double *dp = nullptr, *dv = nullptr, *dm = nullptr;
-        int8_t* ds = nullptr;
-        HIPCHK(hipMalloc((void**)&dp, (size_t)P.np * M * 8));
-        HIPCHK(hipMalloc((void**)&dv, (size_t)M * 8));
-        HIPCHK(hipMalloc((void**)&dm, (size_t)P.nm * M * 8));
-        HIPCHK(hipMalloc((void**)&ds, (size_t)M));
+        DevBuf<double> dp((size_t)P.np * M), dv((size_t)M), dm((size_t)P.nm * M);
         if (c->obj == SMM_OBJ_USER) {   // the user's kernel wants [M][np] / [M][nm]: transpose on the host
             std::vector<double> tp((size_t)M * P.np), tm((size_t)M * P.nm);
             std::vector<int> ts((size_t)M);
             for (int i = 0; i < M; ++i)
                 for (int k = 0; k < P.np; ++k) tp[(size_t)i * P.np + k] = params[(size_t)k * M + i];
-            int* dsi = nullptr;
-            HIPCHK(hipMalloc((void**)&dsi, (size_t)M * sizeof(int)));
-            HIPCHK(hipMemcpyAsync(dp, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream));
-            launch_user_kernel(c, dp, M, dm, dv, dsi);
-            HIPCHK(hipMemcpyAsync(value, dv, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(tm.data(), dm, tm.size() * 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(ts.data(), dsi, ts.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            DevBuf<int> dsi((size_t)M);
+            HIPCHK(hipMemcpyAsync(dp.p, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream));
+            launch_user_kernel(c, dp.p, M, dm.p, dv.p, dsi.p);
+            HIPCHK(hipMemcpyAsync(value, dv.p, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(tm.data(), dm.p, tm.size() * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(ts.data(), dsi.p, ts.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             for (int i = 0; i < M; ++i) {
                 status[i] = (int8_t)ts[i];
                 for (int k = 0; k < P.nm; ++k) sim_moments[(size_t)k * M + i] = tm[(size_t)i * P.nm + k];
             }
-            (void)hipFree(dp); (void)hipFree(dv); (void)hipFree(dm); (void)hipFree(ds); (void)hipFree(dsi);
             return SMM_OK;
         }
-        HIPCHK(hipMemcpyAsync(dp, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
+        DevBuf<int8_t> ds((size_t)M);
+        HIPCHK(hipMemcpyAsync(dp.p, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
         constexpr int CT = 8;
         if (is_sim(c->obj))
-            hipLaunchKernelGGL((k_eval_batch<1, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp, M, dv, dm, ds);
+            hipLaunchKernelGGL((k_eval_batch<1, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp.p, M, dv.p,
+                               dm.p, ds.p);
         else if (c->obj == SMM_OBJ_DENSE)
-            hipLaunchKernelGGL((k_eval_batch<2, 16>), dim3((M + 15) / 16), dim3(WG), tile_smem(c, 16), c->stream, P, dp, M, dv, dm, ds);
+            hipLaunchKernelGGL((k_eval_batch<2, 16>), dim3((M + 15) / 16), dim3(WG), tile_smem(c, 16), c->stream, P, dp.p, M, dv.p, dm.p,
+                               ds.p);
         else
-            hipLaunchKernelGGL((k_eval_batch<0, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp, M, dv, dm, ds);
+            hipLaunchKernelGGL((k_eval_batch<0, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp.p, M, dv.p,
+                               dm.p, ds.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(value, dv, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(sim_moments, dm, (size_t)P.nm * M * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(status, ds, (size_t)M, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(value, dv.p, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(sim_moments, dm.p, (size_t)P.nm * M * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(status, ds.p, (size_t)M, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(dp); (void)hipFree(dv); (void)hipFree(dm); (void)hipFree(ds);
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
@@ -991,21 +997,16 @@ int smm_eval_batch_noseed(void* ctx, const double* params, int32_t M, uint64_t b
     try {
         HIPCHK(hipSetDevice(c->device));
         const KParams& P = c->P;
-        double *dp = nullptr, *dv = nullptr, *dm = nullptr;
-        int8_t* ds = nullptr;
-        HIPCHK(hipMalloc((void**)&dp, (size_t)P.np * M * 8));
-        HIPCHK(hipMalloc((void**)&dv, (size_t)M * 8));
-        HIPCHK(hipMalloc((void**)&dm, (size_t)P.nm * M * 8));
-        HIPCHK(hipMalloc((void**)&ds, (size_t)M));
-        HIPCHK(hipMemcpyAsync(dp, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_eval_batch_noseed, dim3(M), dim3(WG), (size_t)(WG / 64) * P.nm * 8, c->stream, P, (const double*)dp, M,
-                           (uint64_t)base_seed, dv, dm, ds);
+        DevBuf<double> dp((size_t)P.np * M), dv((size_t)M), dm((size_t)P.nm * M);
+        DevBuf<int8_t> ds((size_t)M);
+        HIPCHK(hipMemcpyAsync(dp.p, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_eval_batch_noseed, dim3(M), dim3(WG), (size_t)(WG / 64) * P.nm * 8, c->stream, P, (const double*)dp.p, M,
+                           (uint64_t)base_seed, dv.p, dm.p, ds.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(value, dv, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(sim_moments, dm, (size_t)P.nm * M * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(status, ds, (size_t)M, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(value, dv.p, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(sim_moments, dm.p, (size_t)P.nm * M * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(status, ds.p, (size_t)M, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(dp); (void)hipFree(dv); (void)hipFree(dm); (void)hipFree(ds);
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
