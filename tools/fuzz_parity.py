@@ -1,0 +1,67 @@
+"""Randomised parity sweep: libsmmhip (default path) against the oracle on random problem shapes.
+python tools/fuzz_parity.py [cases] [seed]   (GPU box; test infrastructure, not part of the product)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import smm_jl_amd as S  # noqa: E402
+import common as cm  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for it in range(cases):
+        npar = int(rng.choice([1, 2, 2, 3, 4, 6, 9, 18]))
+        N = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 40, 100, 255, 256, 257, 600, 1500, 4096, 4100, 8192, 9001]))
+        T = int(rng.integers(3, 50))
+        ns = int(rng.choice([1, 17, 64, 511, 512, 513, 1000, 4096, 4097, 10000]))
+        divs = [d for d in range(1, npar + 1) if npar % d == 0]
+        bs = int(rng.choice(divs))
+        half = rng.uniform(1.0, 5.0, npar)
+        init = rng.uniform(-0.5, 0.5, npar) * half
+        mom = rng.uniform(-0.5, 0.5, npar) * half
+        w = rng.uniform(0.5, 2.0, npar)
+        if rng.random() < 0.2:
+            w[rng.integers(npar)] = np.nan
+        prob = S.Problem(init=init, lb=-half, ub=half, mom=mom, w=w, ns=ns)
+        mi = float(rng.choice([0.0, 0.0, -0.1, 0.3])) if rng.random() < 0.6 else rng.uniform(-0.2, 0.5, N)
+        opts = S.BGPOpts(N=N, maxiter=T, sigma=float(rng.choice([0.02, 0.05, 0.3])) * cm.temps(N, float(rng.choice([1.5, 3.0, 8.0]))),
+                         acc_tuner=np.geomspace(10.0, 0.5, N) if N > 1 else np.array([2.0]),
+                         min_improve=np.broadcast_to(np.asarray(mi, float), (N,)).copy(), seed=int(rng.integers(1, 1 << 30)),
+                         batch_size=bs, sigma_update_steps=int(rng.choice([3, 10])), N_global=N)
+        desc = "case %d: np=%d N=%d T=%d ns=%d bs=%d" % (it, npar, N, T, ns, bs)
+        try:
+            h = S.hip_context(prob, opts)
+            o = O.OracleContext(prob, opts, S.Tables(Z=h.Z()))
+            split = int(rng.integers(1, T))
+            h.step(split); h.step(T - split)
+            o.step(T)
+            cm.assert_history_equal(h.history(), o.history(), rtol=1e-9, atol=1e-12)   # bookkeeping exact; floats 1e-9 / 1e-12
+            cm.assert_state_equal(h.state(), o.state(), rtol=1e-9, atol=1e-12)
+            print("ok  ", desc)
+        except Exception as e:  # noqa: BLE001
+            msg = " | ".join(x for x in str(e).splitlines() if x.strip())[:400]
+            both_fail = False
+            if "no draw in support" in msg or "non-negative" in msg:
+                try:
+                    o2 = O.OracleContext(prob, opts, S.Tables(Z=S.hip_context(prob, opts).Z()))
+                    o2.step(T)
+                except Exception as e2:  # noqa: BLE001
+                    both_fail = str(e2).splitlines()[0][:40] == msg[:40]
+            if both_fail:
+                print("ok  ", desc, "(both stop with:", msg[:70] + ")")
+            else:
+                bad += 1
+                print("FAIL", desc, "->", msg)
+    print("%d cases, %d failures" % (cases, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
