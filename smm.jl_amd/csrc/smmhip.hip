@@ -307,6 +307,8 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
         launch_chain_iter_ct<2, 16>(c, t, flags);
     } else if (tile_smem_base(c, 64) <= (size_t)60 * 1024 && !c->inline_walk) {
         launch_chain_iter_ct<0, 64>(c, t, flags);
+    } else if (c->tpw == 2) {
+        launch_chain_iter_ct<0, 8, 2>(c, t, flags);
     } else {
         launch_chain_iter_ct<0, 8>(c, t, flags);
     }
@@ -617,7 +619,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             P.tile_off = c->inline_walk ? (int)(walk_slot_bytes(Ng) / sizeof(double)) : 0;
             // two tiles per workgroup share one walk (the 2p/2m-style simulation tile of 8 chains only)
             const char* tp = getenv("SMMHIP_TPW");
-            c->tpw = (c->inline_walk && is_sim(c->obj) && c->ct == 8 && N > 8 && !(tp && tp[0] == '1') &&
+            int n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+            // ... worth it only when two tiles would share a CU anyway (more tiles than CUs)
+            const bool force2 = tp && tp[0] == '2';   // test hook: two tiles per workgroup at any size
+            c->tpw = (c->inline_walk && (is_sim(c->obj) ? c->ct == 8 : c->obj != SMM_OBJ_DENSE) && ((N + 7) / 8 > n_cu || force2) &&
+                      !(tp && tp[0] == '1') &&
                       walk_slot_bytes(Ng) + std::max(2 * tile_b, (size_t)K * 4) <= (size_t)160 * 1024) ? 2 : 1;
         }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
@@ -696,6 +703,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));

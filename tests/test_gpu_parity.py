@@ -325,6 +325,24 @@ def test_inline_walk_equals_resolve_kernel(S, O, N, monkeypatch):
             assert (ha.exchanged != 0).any()
 
 
+@pytest.mark.parametrize("N", [9, 24, 50, 1000])
+@pytest.mark.parametrize("banana", [False, True])
+def test_two_tiles_per_workgroup_forced(S, O, N, banana, monkeypatch):
+    # two tiles per workgroup (one inline exchange walk per CU) is chosen above 2048 chains; force it at small and odd tile counts
+    monkeypatch.setenv("SMMHIP_TPW", "2")
+    if banana:
+        prob = S.Problem(init=np.zeros(4), lb=-2 * np.ones(4), ub=2 * np.ones(4), mom=np.zeros(4), w=np.ones(4), ns=1,
+                         objective_id=A.SMM_OBJ_BANANA)
+        opts = S.BGPOpts(N=N, maxiter=30, sigma=0.05 * cm.temps(N, 4), acc_tuner=np.geomspace(2.0, 0.1, N), min_improve=np.zeros(N),
+                         N_global=N, seed=3)
+    else:
+        prob, opts = cm.serial_normal(N=N, T=30, ns=200)
+    h, o = run_both(S, O, prob, opts, None)
+    cm.assert_history_equal(h.history(), o.history())
+    cm.assert_state_equal(h.state(), o.state())
+    assert banana or (h.history().exchanged != 0).any()
+
+
 @pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096, 6000])
 def test_dataflow_exchange_kernel_matches(S, O, N, monkeypatch):
     # the ticket (data-flow) resolution kernel against the level-synchronous ones (16-byte chain slots up to
