@@ -494,6 +494,9 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     ZBuf zb;
     if constexpr (KIND == 1) { zb.init(P, tid); sim_load_chunk(zb, P, 0, 0, za); }
     int partner = 0;
+    // a hard error raised by an earlier iteration (AlgoBGP.jl:341,409 abort the run): later launches store nothing
+    unsigned long long err_word = ERR_NONE;
+    if (ctl) err_word = *(const volatile unsigned long long*)P.err;
     // wave 1: problem constants, requested now and written to LDS after the walk
     const bool wave1 = tid >= 64 && tid < 128;
     const int k1 = tid - 64;
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     __syncthreads();
     TS_MARK(2);
     if (flags & F_PROPOSE_ONLY) {  // user objective: hand the proposals to the user's kernel; nothing has been stored yet, the
-        if (valid)                 // accept launch repeats this (deterministic) prologue
+        if (valid && err_word == ERR_NONE)   // accept launch repeats this (deterministic) prologue
             for (int k = r; k < np; k += NR) P.u_theta[(size_t)c * np + k] = S.theta[cl * np + k];
         return;
     }
@@ -711,6 +714,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     }
     TS_MARK(3);
     if (P.dbg & 4) return;
+    if (err_word != ERR_NONE) return;
 
     // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245): chain lanes ----
     if (chain_lane) {
@@ -790,6 +794,7 @@ __global__ void k_flush(const KParams P, const int t_next, const double* __restr
                         const int flags) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.N) return;
+    if (*(const volatile unsigned long long*)P.err != ERR_NONE) return;   // the run stopped at the failing iteration
     const int RW = P.RW, HW = P.HW, N = P.N;
     double* csb = P.cs + (size_t)c * CSW;
     const int goff = (flags & F_GLOBAL_REC) ? 0 : P.offset;   // rec_in indexed by global chain id (all-gathered buffer)?

@@ -1,0 +1,461 @@
+// the chain kernel of the bundled objective (objfunc_norm, np == nm <= 2 — the kernel is written for <= 4, the larger two spill —, one proposal batch): k_chain_iter_norm — part of
+// libsmmhip (included by smmhip.hip inside its anonymous namespace; gfx950 device code).
+#pragma once
+// ------------------------------------------------------------------------------------------
+// k_chain_iter_norm<NP, WALK>: the same iteration as k_chain_iter<1, ...> (next_eval for every chain, AlgoBGP.jl:272-294,
+// with exchangeMoves! of the previous iteration in its prologue), arranged for the configuration the headline metric is
+// quoted on.  Results are bit-identical to the general kernel's (same numerical contract, same arithmetic).
+//
+//   * ONE tile of 16 chains per workgroup of 1024 lanes (one workgroup per CU at 4096 chains).  The two halves of the
+//     workgroup take the moments k = h, h+2, ...: every shock is loaded once per CU and used for 16 chains from a register
+//     (32 FP64 adds per 8-byte L2 read; the 8-chain tiles of the general kernel read the matrix twice per CU and the two
+//     tiles of a CU finish 4 us apart).  Measured in isolation (tools/sim_bench.hip): 7.0 us against 8.9 us per launch.
+//   * the serial bracket lives in registers: a chain is served by FOUR adjacent lanes of the control wave that hold
+//     identical state (same loads: the four requests merge), evaluate four proposal tries side by side and store different
+//     16-byte pieces of the result blocks straight from registers.  Nothing is staged in LDS except what has to survive
+//     the register-hungry simulation (one 16-double line per chain).
+// LDS: [exchange walk: chain slots | pair list] theta[16][NP] part[NP][8][16] park[16][PARKW] arrived.
+// ------------------------------------------------------------------------------------------
+constexpr int NORM_CT = 16;           // chains per tile
+constexpr int NORM_NR = 4;            // lanes per chain in the control wave
+constexpr int NORM_WG = 2 * WG;       // 1024 lanes
+constexpr int NORM_ZU = 4;            // shock rows per chunk: 16 accumulators + 16 means + two chunk buffers must stay under 128 VGPRs
+
+template <int ZK>
+__device__ inline void sim_load_chunk_n(const ZBuf& zb, const KParams& P, int k, int ch, double (&z)[ZK]) {
+    const int row0 = (k * P.zstride + ch * (ZK * WG)) * (int)sizeof(double);
+#pragma unroll
+    for (int u = 0; u < ZK; ++u)
+        z[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zb.rsrc, zb.lane_off, row0 + u * WG * (int)sizeof(double), 0));
+}
+
+template <int NP>
+struct NormLayout {
+    static constexpr int RW = (3 + 2 * NP + 1) & ~1;
+    static constexpr int HW = (H_PARAMS + 2 * NP + 1) & ~1;
+    static constexpr int PARKW = 8 + RW;   // sigma, acc_tuner, u, best, best_id, n_noex, n_acc, partner, record[RW]
+    static constexpr size_t doubles = (size_t)NORM_CT * NP + (size_t)NP * 8 * NORM_CT + (size_t)NORM_CT * PARKW + 2;
+};
+__host__ __device__ inline size_t norm_tile_doubles(int np) {
+    const int RW = (3 + 2 * np + 1) & ~1;
+    return (size_t)NORM_CT * np + (size_t)np * 8 * NORM_CT + (size_t)NORM_CT * (8 + RW) + 2;
+}
+
+// one of four values by the lane's position in its quad
+// (two levels of selects on the bits of r: a ternary chain over double2 becomes a table in scratch memory)
+__device__ inline double sel4d(int r, double a, double b, double c, double d) {
+    const double x = (r & 1) ? b : a, y = (r & 1) ? d : c;
+    return (r & 2) ? y : x;
+}
+__device__ inline double2 sel4(int r, const double2& a, const double2& b, const double2& c, const double2& d) {
+    return make_double2(sel4d(r, a.x, b.x, c.x, d.x), sel4d(r, a.y, b.y, c.y, d.y));
+}
+// value held by lane q of this lane's quad (DPP quad_perm broadcast, no LDS)
+template <int Q>
+__device__ inline double quad_bcast(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)u, Q * 0x55, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), Q * 0x55, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ inline double quad_bcast_dyn(double v, int lane, int q) {   // q: wave-varying source position
+    return __shfl(v, (lane & ~3) + q, 64);
+}
+
+// the simulation for a tile of 16 chains: half h (512 lanes, l = lane of the half) sums the draws of the moments
+// k = h, h+2, ...; lane l takes the draws l, l+512, ... in that order (numerical contract).  s_part [NP][8][16].
+template <int NP>
+__device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb, const double* s_theta, double* s_part, const int h, const int wih, const int l,
+                                       double (&zc)[NORM_ZU]) {
+    constexpr int ZU = NORM_ZU;
+    constexpr int CT = NORM_CT;
+    const int ns = P.ns;
+    const int nch = (ns + ZU * WG - 1) / (ZU * WG);
+    const int last_draws = ns - (nch - 1) * (ZU * WG);
+    const bool ragged = last_draws < ZU * WG;
+#pragma clang loop unroll(disable)
+    for (int k = h; k < NP; k += 2) {
+        double acc[CT], mu[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { acc[c] = 0.0; mu[c] = s_theta[c * NP + k]; }
+        auto add_full = [&](const double (&z)[ZU]) {
+#pragma unroll
+            for (int u = 0; u < ZU; ++u) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const double x = z[u] + mu[c];
+                    acc[c] = acc[c] + x;
+                }
+            }
+        };
+        auto add_last = [&](const double (&z)[ZU]) {
+            if (!ragged) { add_full(z); return; }
+            int ll = l;   // laundered: the row masks are computed here, not hoisted above the main loop where they cost registers
+            asm volatile("" : "+v"(ll));
+#pragma unroll
+            for (int u = 0; u < ZU; ++u) {
+                if (ll + u * WG < last_draws) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const double x = z[u] + mu[c];
+                        acc[c] = acc[c] + x;
+                    }
+                }
+            }
+        };
+        const int knext = (k + 2 < NP) ? k + 2 : k;   // last moment of the half: a harmless reload
+        double zn[ZU];
+        int ch = 0;
+#pragma clang loop unroll(disable)
+        for (; ch + 2 <= nch; ch += 2) {
+            sim_load_chunk_n<ZU>(zb, P, k, ch + 1, zn);
+            add_full(zc);
+            const bool last = (ch + 2 == nch);
+            sim_load_chunk_n<ZU>(zb, P, last ? knext : k, last ? 0 : ch + 2, zc);
+            if (last) add_last(zn); else add_full(zn);
+        }
+        if (ch < nch) {
+            sim_load_chunk_n<ZU>(zb, P, knext, 0, zn);
+            add_last(zc);
+#pragma unroll
+            for (int u = 0; u < ZU; ++u) zc[u] = zn[u];
+        }
+        // lane id derived anew (mbcnt needs no input register): the loop above has no register to spare for it
+        const int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const double tot = wave_reduce_transposed<CT>(acc, lane2);
+        if ((lane2 & 3) == 0) s_part[(k * 8 + wih) * CT + (lane2 >> 2)] = tot;
+    }
+}
+
+template <int NP>
+__device__ inline void epilogue_norm(const KParams& P, const int t, double* __restrict__ rec_out, const double* s_theta, const double* s_part,
+                                     const double* s_park, const int tile, const int tid);
+
+template <int NP, bool WALK>
+__global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                 double* __restrict__ rec_out, const int flags) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    using L = NormLayout<NP>;
+    constexpr int CT = NORM_CT, RW = L::RW, HW = L::HW, PARKW = L::PARKW;
+    constexpr int NPC = RW / 2, NPH = HW / 2;   // 16-byte pieces of a record / a history row
+    const int tid = (int)threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave of the workgroup (scalar)
+    const int h = wave >> 3;                                      // half of the workgroup
+    const int l = tid & (WG - 1), lane = tid & 63;
+    const int tile = (int)blockIdx.x;
+    const int N = P.N;
+    double* s_theta = smem + P.tile_off;                  // [CT][NP]
+    double* s_part = s_theta + CT * NP;                   // [NP][8][CT]
+    double* s_park = s_part + NP * 8 * CT;                // [CT][PARKW]
+    unsigned* s_arrived = (unsigned*)(s_park + CT * PARKW);   // + 1: the poisoned flag
+    const bool ctl = tid < 64;
+    const int cl = lane >> 2, r = lane & 3;               // control wave: chain of the tile, position in its quad
+    const int c = tile * CT + cl;
+    const bool valid = ctl && c < N;
+    const int gc = P.offset + c;
+    const int goff = (flags & F_GLOBAL_REC) ? 0 : P.offset;   // rec_in indexed by global chain id (all-gathered buffer)?
+    TS_MARK(0);
+
+    // ---- global reads that do not depend on the exchange, all issued before anything waits ----
+    double za[NORM_ZU];
+    ZBuf zb;
+    const bool simw = h < NP;   // NP == 1: the second half has no moment
+    if (simw) { zb.init(P, l); sim_load_chunk_n<NORM_ZU>(zb, P, h, 0, za); }
+    unsigned long long err_word = ERR_NONE;
+    double2 csq[6];             // the chain state block, fields 0..11
+    double u = 0.0, zA[NP], zB[NP];
+    unsigned long long xr = (unsigned long long)(unsigned)gc;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { zA[k] = 0.0; zB[k] = 0.0; }
+    if (ctl) err_word = *(const volatile unsigned long long*)P.err;
+    if (valid) {
+        const double2* g_cs = (const double2*)(P.cs + (size_t)c * CSW);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) csq[i] = g_cs[i];
+        if (t > 1) {
+            const double* g_rb = P.rb + ((size_t)(t - P.rb_t0) * N + c) * P.RBW;
+            u = g_rb[0];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (r < P.rb_tries) zA[k] = g_rb[1 + r * NP + k];
+                if (NORM_NR + r < P.rb_tries) zB[k] = g_rb[1 + (NORM_NR + r) * NP + k];
+            }
+        }
+        if (!WALK && (flags & F_HAS_PENDING)) xr = P.xres[gc];
+    }
+    if constexpr (WALK) {
+        // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
+        exchange_walk_tile<NORM_WG>(P, t - 1, (unsigned char*)smem, tid);
+        if (valid) {
+            const XSlot sv = ((const XSlot*)smem)[gc];
+            xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
+        }
+    }
+    if (tid == 64) *s_arrived = 0u;
+    TS_MARK(1);
+
+    // ---- control wave: the record the chain continues from, settle iteration t-1, propose (AlgoBGP.jl:424-471) ----
+    const bool poisoned = err_word != ERR_NONE;   // an earlier iteration raised a hard error: nothing is stored any more
+    if (ctl) {
+        if (tid == 0) s_park[CT * PARKW + 1] = poisoned ? 1.0 : 0.0;
+        const int partner = (int)(xr >> 32);
+        double mu01[NP], th[NP];
+        const double sigma = csq[0].x;
+        {
+            // its own record, or its donor's (swap_ev_ij!, :734-749): the one dependent memory level of the iteration
+            double rc[RW];
+            if (valid) {
+                const int s = (int)(unsigned)(xr & 0xffffffffu) - goff;
+                const double2* g_rec = (const double2*)(rec_in + (size_t)s * RW);
+#pragma unroll
+                for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc[2 * i] = q.x; rc[2 * i + 1] = q.y; }
+            } else {
+#pragma unroll
+                for (int f = 0; f < RW; ++f) rc[f] = 0.0;
+            }
+            int nn = (int)csq[1].x, na = (int)csq[1].y;
+            double bp = csq[3].x, bpid = csq[3].y;
+            if (valid && t > 1) {
+                bool exch_prev = false;
+                if (partner != 0) {
+                    // set_eval!(ci, ej) of swap_ev_ij! as a history record: the chain's record of iteration t-1 is the donor's last
+                    // accepted one (accepted = true, the donor's prob/status), curr = donor value, best against iteration t-2 (:231-243)
+                    exch_prev = true;
+                    const double value = rc[0];
+                    if (value < csq[4].x) { bp = value; bpid = (double)(t - 1); }
+                    else { bp = csq[4].x; bpid = csq[4].y; }
+                    if (!poisoned) {
+                        double hv[HW];
+                        hv[H_VALUE] = value; hv[H_PROB] = rc[1]; hv[H_CURR] = value; hv[H_BEST] = bp; hv[H_BESTID] = bpid;
+                        hv[H_EXCH] = (double)partner; hv[H_ACC] = 1.0; hv[H_STATUS] = rc[2];
+#pragma unroll
+                        for (int k = 0; k < 2 * NP; ++k) hv[H_PARAMS + k] = rc[3 + k];
+                        if (HW > H_PARAMS + 2 * NP) hv[HW - 1] = 0.0;
+                        double2* g_h = (double2*)(P.hrec + ((size_t)(t - 2) * N + c) * HW);
+#pragma unroll
+                        for (int j = 0; 4 * j < NPH; ++j) {
+                            const int i = 4 * j + r;
+                            const double2 v = sel4(r, make_double2(hv[8 * j], hv[8 * j + 1]),
+                                                   make_double2(hv[(8 * j + 2) % HW], hv[(8 * j + 3) % HW]),
+                                                   make_double2(hv[(8 * j + 4) % HW], hv[(8 * j + 5) % HW]),
+                                                   make_double2(hv[(8 * j + 6) % HW], hv[(8 * j + 7) % HW]));
+                            if (i < NPH) g_h[i] = v;
+                        }
+                    }
+                } else if (csq[2].y != 0.0) {   // sharded three-phase path: k_exch_apply already rewrote record and history
+                    exch_prev = true;
+                }
+                if ((flags & F_CLOSE_PREV) && !exch_prev) { nn += 1; na += (int)csq[2].x; }   // set_acceptRate!, :253-257
+            }
+            // park what the epilogue needs (one line per chain; nothing of it stays in registers across the simulation)
+            if (r == 0) {
+                double* pk = s_park + cl * PARKW;
+                pk[0] = sigma; pk[1] = csq[5].x; pk[2] = u; pk[3] = bp; pk[4] = bpid; pk[5] = (double)nn; pk[6] = (double)na;
+                pk[7] = (double)partner;
+#pragma unroll
+                for (int f = 0; f < RW; ++f) pk[8 + f] = rc[f];
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                th[k] = !valid ? 0.0 : (t == 1 ? P.init[k] : rc[3 + k]);
+                mu01[k] = (rc[3 + k] - P.lb[k]) / (P.ub[k] - P.lb[k]);   // mapto_01, mprob.jl:248
+            }
+        }
+        // proposal: lane r evaluates try j0 + r; the chain's first try inside the unit box wins (mysample, :400-410)
+        if (t > 1) {
+            const int max_tries = P.user_n ? min(P.rb_tries, P.smpl_iters) : P.smpl_iters;
+            bool found = !valid;
+            const double* g_rb = P.rb + ((size_t)(t - P.rb_t0) * N + (valid ? c : 0)) * P.RBW;
+            for (int j0 = 0; __any(!found) && j0 < max_tries; j0 += NORM_NR) {
+                const int j = j0 + r;
+                double x[NP], z[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) { x[k] = 0.0; z[k] = 0.0; }
+                bool ok = !found && j < max_tries;
+                if (ok) {
+                    if (j0 == 0) {
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) z[k] = zA[k];
+                    } else if (j0 == NORM_NR) {
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) z[k] = zB[k];
+                    } else if (j < P.rb_tries) {
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) z[k] = g_rb[1 + j * NP + k];
+                    }
+                    if (j >= P.rb_tries) {   // past the pre-generated tries: the in-kernel generator (never with injected normals)
+#pragma unroll
+                        for (int q = 0; 2 * q < NP; ++q) {
+                            const double2 zz2 = rng_prop_normal2_outofline(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)j, (uint32_t)q);
+                            z[2 * q] = zz2.x;
+                            if (2 * q + 1 < NP) z[2 * q + 1] = zz2.y;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const double step = sigma * z[k];   // MvNormal(mu01, sigma): x = mu + sigma*z
+                        x[k] = mu01[k] + step;
+                        if (!(x[k] >= 0.0 && x[k] <= 1.0)) ok = false;   // inclusive bounds, :405
+                    }
+                }
+                const unsigned long long m = __ballot(ok);
+                const unsigned quad = (unsigned)(m >> (lane & ~3)) & 0xfu;
+                if (!found && quad) {   // (found and quad are the same in the four lanes of a chain: its shuffles run with the whole quad active)
+                    const int rwin = __builtin_ctz(quad);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const double lbk = P.lb[k];
+                        const double sc = x[k] * (P.ub[k] - lbk);
+                        const double thk = sc + lbk;   // mapto_ab, mprob.jl:271
+                        th[k] = quad_bcast_dyn(thk, lane, rwin);
+                    }
+                    found = true;
+                }
+            }
+            if (!found && r == 0) report_error(P, 2, t, gc);   // :409
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) s_theta[cl * NP + k] = th[k];
+        }
+    }
+    TS_MARK(6);
+    __syncthreads();
+    TS_MARK(2);
+
+    // ---- simulation: every lane, ns draws x its half's moments x 16 chains ----
+    if (simw) simulate_tile16<NP>(P, zb, s_theta, s_part, h, wave & 7, l, za);
+    // No workgroup barrier: only the control wave consumes the partial sums.  Every wave announces its partials with one
+    // LDS add and is done; the control wave waits for the announcements of the waves that had a moment.
+    // (lane ids are derived anew from mbcnt and the scalar wave id: no register of the prologue stays live across the simulation)
+    const int tid2 = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (simw && (tid2 & 63) == 0) __hip_atomic_fetch_add(s_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (tid2 >= 64) return;
+    {
+        const unsigned want = (unsigned)(8 * (NP < 2 ? NP : 2));
+        while (__hip_atomic_load(s_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (P.ts && tid2 == 0) P.ts[(size_t)tile * 8 + 3] = wall_clock64();
+    // Epilogue by the control wave: everything it needs comes from LDS (parked by the prologue)
+    epilogue_norm<NP>(P, t, rec_out, s_theta, s_part, s_park, tile, tid2);
+}
+
+// objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks
+template <int NP>
+__device__ inline void epilogue_norm(const KParams& P, const int t, double* __restrict__ rec_out, const double* s_theta,
+                                     const double* s_part, const double* s_park, const int tile, const int tid) {
+    using L = NormLayout<NP>;
+    constexpr int CT = NORM_CT, RW = L::RW, HW = L::HW, PARKW = L::PARKW;
+    constexpr int NPC = RW / 2, NPH = HW / 2;
+    const int lane = tid & 63, cl = lane >> 2, r = lane & 3;
+    const int c = tile * CT + cl, N = P.N;
+    const int gc = P.offset + c;
+    if (c >= N) return;
+    const double* pk = s_park + cl * PARKW;
+    if (s_park[CT * PARKW + 1] != 0.0) return;   // poisoned (parked by the prologue)
+
+    const double sig = pk[0], atun = pk[1], uu = pk[2], bp = pk[3], bpid = pk[4];
+    const int nn = (int)pk[5], na = (int)pk[6];
+    double rc[RW], th[NP], sm[NP];
+#pragma unroll
+    for (int f = 0; f < RW; ++f) rc[f] = pk[8 + f];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) th[k] = s_theta[cl * NP + k];
+    double value;
+    int status;
+    if (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp && th[0] >= P.objp[0] && th[0] <= P.objp[1]) {   // "exception": mprob.jl:183-186
+#pragma unroll
+        for (int k = 0; k < NP; ++k) sm[k] = NAN;
+        value = -1.0;   // Eval() default, Eval.jl:84
+        status = -2;
+    } else {
+        // lane r finishes moment r: wave totals left to right, mean, weighted deviation; the squares are added in moment order
+        double mk = 0.0, vk = 0.0;
+        if (r < NP) {
+            double tot = s_part[(r * 8 + 0) * CT + cl];
+#pragma unroll
+            for (int wv = 1; wv < 8; ++wv) tot = tot + s_part[(r * 8 + wv) * CT + cl];
+            mk = tot / (double)P.ns;
+            double d = mk - P.mom[r];
+            const double wk = P.w[r];
+            if (!isnan(wk)) d = d / wk;
+            vk = d * d;
+        }
+        double vsum = 0.0;
+        {
+            const double m0 = quad_bcast<0>(mk), v0 = quad_bcast<0>(vk);
+            sm[0] = m0; vsum = v0;
+            if constexpr (NP > 1) { const double m1 = quad_bcast<1>(mk), v1 = quad_bcast<1>(vk); sm[1] = m1; vsum = vsum + v1; }
+            if constexpr (NP > 2) { const double m2 = quad_bcast<2>(mk), v2 = quad_bcast<2>(vk); sm[2] = m2; vsum = vsum + v2; }
+            if constexpr (NP > 3) { const double m3 = quad_bcast<3>(mk), v3 = quad_bcast<3>(vk); sm[3] = m3; vsum = vsum + v3; }
+        }
+        value = vsum / (double)NP;
+        status = 1;
+    }
+    const double old = rc[0];
+    double prob;
+    bool acc;
+    if (t == 1) {   // :326-332
+        prob = 1.0; acc = true; status = 1;
+    } else if (status < 0) {   // :336-338
+        prob = 0.0; acc = false;
+    } else {
+        if (!(value >= 0.0) && r == 0) report_error(P, 1, t, gc);   // :341
+        const double e = exp(atun * (old - value));
+        prob = (e != e) ? e : (e < 1.0 ? e : 1.0);   // minimum([1.0,e]), NaN propagates (:344)
+        if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }   // :350-353
+        else if (!isfinite(old)) { prob = 1.0; acc = true; }             // :355-359
+        else { status = 1; acc = prob > uu; }                            // strict >, :362-367
+    }
+    TS_MARK(7);
+    const double rate = (double)(na + (acc ? 1 : 0)) / (double)(nn + 1);   // set_acceptRate!, :253-257
+    double nsig = sig;
+    if (t > 1 && (t % P.sigma_update_steps) == 0)   // :381-390
+        nsig = (rate > 0.234) ? sig * (1.0 + P.sigma_adjust_by) : sig * (1.0 - P.sigma_adjust_by);
+    double bestv, currv, bestid;   // set_eval!, :220-245
+    if (t == 1) { bestv = value; currv = value; bestid = 1.0; }
+    else {
+        currv = acc ? value : old;
+        if (value < bp) { bestv = value; bestid = (double)t; }
+        else { bestv = bp; bestid = bpid; }
+    }
+    if (r == 0) P.vals[c] = acc ? value : old;
+    // ---- result blocks, straight from registers: lane r of the quad stores the 16-byte pieces r, r+4, ... ----
+    {
+        double2* g_cs = (double2*)(P.cs + (size_t)c * CSW);
+        const double accd = acc ? 1.0 : 0.0;
+        g_cs[r] = sel4(r, make_double2(nsig, rate), make_double2((double)nn, (double)na), make_double2(accd, 0.0), make_double2(bestv, bestid));
+        if (r < 2) g_cs[4 + r] = r == 0 ? make_double2(bp, bpid) : make_double2(atun, pk[7]);
+        // the chain's last accepted record (lastAccepted :209-215) = input of the exchange step
+        double nr[RW];
+        nr[0] = acc ? value : rc[0]; nr[1] = acc ? prob : rc[1]; nr[2] = acc ? (double)status : rc[2];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { nr[3 + k] = acc ? th[k] : rc[3 + k]; nr[3 + NP + k] = acc ? sm[k] : rc[3 + NP + k]; }
+        if (RW > 3 + 2 * NP) nr[RW - 1] = 0.0;
+        double2* g_ro = (double2*)(rec_out + (size_t)c * RW);
+#pragma unroll
+        for (int j = 0; 4 * j < NPC; ++j) {
+            const int i = 4 * j + r;
+            const double2 v = sel4(r, make_double2(nr[8 * j], nr[8 * j + 1]), make_double2(nr[(8 * j + 2) % RW], nr[(8 * j + 3) % RW]),
+                                   make_double2(nr[(8 * j + 4) % RW], nr[(8 * j + 5) % RW]), make_double2(nr[(8 * j + 6) % RW], nr[(8 * j + 7) % RW]));
+            if (i < NPC) g_ro[i] = v;
+        }
+        double hv[HW];
+        hv[H_VALUE] = value; hv[H_PROB] = prob; hv[H_CURR] = currv; hv[H_BEST] = bestv; hv[H_BESTID] = bestid;
+        hv[H_EXCH] = 0.0; hv[H_ACC] = accd; hv[H_STATUS] = (double)status;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { hv[H_PARAMS + k] = th[k]; hv[H_PARAMS + NP + k] = sm[k]; }
+        if (HW > H_PARAMS + 2 * NP) hv[HW - 1] = 0.0;
+        double2* g_h = (double2*)(P.hrec + ((size_t)(t - 1) * N + c) * HW);
+#pragma unroll
+        for (int j = 0; 4 * j < NPH; ++j) {
+            const int i = 4 * j + r;
+            const double2 v = sel4(r, make_double2(hv[8 * j], hv[8 * j + 1]), make_double2(hv[(8 * j + 2) % HW], hv[(8 * j + 3) % HW]),
+                                   make_double2(hv[(8 * j + 4) % HW], hv[(8 * j + 5) % HW]), make_double2(hv[(8 * j + 6) % HW], hv[(8 * j + 7) % HW]));
+            if (i < NPH) g_h[i] = v;
+        }
+    }
+    TS_MARK(4);
+}

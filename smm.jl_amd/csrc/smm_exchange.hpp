@@ -565,6 +565,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_any(const KParams P, const
 __global__ void k_exch_apply(const KParams P, const int t, const double* __restrict__ gathered, double* __restrict__ rec) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.N) return;
+    if (*(const volatile unsigned long long*)P.err != ERR_NONE) return;   // the run stopped at the failing iteration
     const int N = P.N, RW = P.RW, HW = P.HW;
     const unsigned long long xr = P.xres[P.offset + c];
     const int partner = (int)(xr >> 32);

@@ -52,6 +52,7 @@ using namespace smm;
 
 #include "smm_params.hpp"
 #include "smm_chain.hpp"
+#include "smm_chain_norm.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
 
@@ -186,6 +187,8 @@ struct Ctx {
     int plan_t0 = 0, plan_w = 0;
     bool lds_exchange = false;
     int ct = 8;
+    bool norm_fast = false;     // objfunc_norm with np == nm <= 2 and one proposal batch: k_chain_iter_norm (16-chain tiles)
+    int failed = 0;             // a hard device error (AlgoBGP.jl:341,409) stopped the run at iteration `iter`: sticky until smm_set_state
 };
 
 #define HIPCHK(call)                                                                                  \
@@ -219,7 +222,11 @@ size_t tile_smem_base(const Ctx* c, int ct) {
     const KParams& P = c->P;
     return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, obj_kind(c->obj)) * sizeof(double);
 }
+size_t norm_smem(const Ctx* c) {   // k_chain_iter_norm: [walk: chain slots | pair list] theta, partial sums, parked state
+    return (size_t)c->P.tile_off * sizeof(double) + norm_tile_doubles(c->P.np) * sizeof(double);
+}
 size_t tile_smem(const Ctx* c, int ct, int tpw = 1) {   // dynamic LDS of k_chain_iter: tpw tiles; with the inline exchange
+    if (c->norm_fast) return norm_smem(c);
     const size_t base = tile_smem_base(c, ct);           // walk its chain slots in front and its pair list under the tiles
     const size_t tiles = (size_t)tpw * ((base + 15) & ~(size_t)15);
     return c->inline_walk ? walk_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)c->P.plan_K * 4) : tiles;
@@ -275,6 +282,27 @@ void launch_chain_iter_ct(Ctx* c, int t, int flags) {
         hipLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, P, t, rin, rout, flags);
 }
 
+template <int NP, bool WALK>
+void launch_chain_iter_norm_t(Ctx* c, int t, int flags) {
+    const KParams& P = c->P;
+    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
+    const double* rin = c->ext_rec_in ? c->ext_rec_in : (const double*)c->rec[c->cur];
+    double* rout = c->ext_rec_out ? c->ext_rec_out : c->rec[c->cur ^ 1];
+    if (c->kev0)
+        hipExtLaunchKernelGGL((k_chain_iter_norm<NP, WALK>), grid, block, norm_smem(c), c->stream, c->kev0, c->kev1, 0, P, t, rin, rout, flags);
+    else
+        hipLaunchKernelGGL((k_chain_iter_norm<NP, WALK>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
+}
+void launch_chain_iter_norm(Ctx* c, int t, int flags) {
+    const bool walk = (flags & F_WALK_INLINE) != 0;
+    switch (c->P.np * 2 + (walk ? 1 : 0)) {
+        case 2: launch_chain_iter_norm_t<1, false>(c, t, flags); break;
+        case 3: launch_chain_iter_norm_t<1, true>(c, t, flags); break;
+        case 4: launch_chain_iter_norm_t<2, false>(c, t, flags); break;
+        default: launch_chain_iter_norm_t<2, true>(c, t, flags); break;
+    }
+}
+
 // one thread per evaluation: theta [n][np] -> simM [n][nm], value [n], status [n]
 void launch_user_kernel(Ctx* c, const double* theta, int n, double* simM, double* value, int* status) {
     const KParams& P = c->P;
@@ -300,7 +328,9 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
         if (!c->ext_rec_out) c->cur ^= 1;
         return;
     }
-    if (is_sim(c->obj)) {
+    if (c->norm_fast) {
+        launch_chain_iter_norm(c, t, flags);
+    } else if (is_sim(c->obj)) {
         if (c->tpw == 2) launch_chain_iter_ct<1, 8, 2>(c, t, flags);
         else launch_chain_iter_ct<1, 8>(c, t, flags);
     } else if (c->obj == SMM_OBJ_DENSE) {
@@ -360,26 +390,35 @@ void flush(Ctx* c) {
 }
 
 int check_device_error(Ctx* c) {
+    if (c->failed) return c->failed;   // err holds the message of the first failure
     unsigned long long e = ERR_NONE;
     HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
     if (e == ERR_NONE) return SMM_OK;
     const int kind = (int)(e & 3), chain = (int)((e >> 2) & 0xffffffffu), it = (int)(e >> 34);
     char b[256];
+    int rc;
     if (kind == 3) {
         snprintf(b, sizeof b, "internal error: exchange resolution did not converge (iteration %d)", it);
-        c->err = b;
-        return SMM_ERR_HIP;
-    }
-    if (kind == 1) {
+        rc = SMM_ERR_HIP;
+    } else if (kind == 1) {
         snprintf(b, sizeof b, "AlgoBGP assumes that your objective function returns a non-negative number "
                  "(chain %d, iteration %d)", chain + 1, it);
-        c->err = b;
-        return SMM_ERR_NEGATIVE_OBJECTIVE;
+        rc = SMM_ERR_NEGATIVE_OBJECTIVE;
+    } else {
+        snprintf(b, sizeof b, "no draw in support after %d trials (chain %d, iteration %d): increase smpl_iters",
+                 c->P.user_n ? std::min(c->P.rb_tries, c->P.smpl_iters) : c->P.smpl_iters, chain + 1, it);
+        rc = SMM_ERR_NO_DRAW_IN_SUPPORT;
     }
-    snprintf(b, sizeof b, "no draw in support after %d trials (chain %d, iteration %d): increase smpl_iters",
-             c->P.user_n ? std::min(c->P.rb_tries, c->P.smpl_iters) : c->P.smpl_iters, chain + 1, it);
     c->err = b;
-    return SMM_ERR_NO_DRAW_IN_SUPPORT;
+    // The reference aborts inside the failing iteration (AlgoBGP.jl:341,409).  Here that iteration completes for all chains
+    // and every later launch of the step sees the error word and stores nothing: the run stands at the failing iteration,
+    // its exchange is never applied, and the context refuses to go on until smm_set_state.
+    if (kind != 3 && it >= 1 && it <= c->iter) {
+        c->iter = it;
+        c->pending = false; c->prev_open = false; c->unresolved = false; c->pending_ext = false; c->rec_external = false;
+    }
+    c->failed = rc;
+    return rc;
 }
 
 int fail(Ctx* c, int code, const std::string& m) {
@@ -614,16 +653,20 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* iw = getenv("SMMHIP_INLINE_WALK");
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
             const size_t tile_b = (tile_smem_base(c, tile_ct) + 15) & ~(size_t)15;
+            const char* nf = getenv("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
+            c->norm_fast = is_sim(c->obj) && np == nm && np <= 2 && opts->batch_size == np && P.dbg == 0 && !(nf && nf[0] == '0');
+            const size_t walk_b = walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15);   // k_chain_iter_norm: pair list NOT overlaid
             c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng && c->obj != SMM_OBJ_USER &&
-                             walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024;
-            P.tile_off = c->inline_walk ? (int)(walk_slot_bytes(Ng) / sizeof(double)) : 0;
+                             (c->norm_fast ? walk_b + norm_tile_doubles(np) * 8 <= (size_t)160 * 1024
+                                           : walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024);
+            P.tile_off = c->inline_walk ? (int)((c->norm_fast ? walk_b : walk_slot_bytes(Ng)) / sizeof(double)) : 0;
             // two tiles per workgroup share one walk (the 2p/2m-style simulation tile of 8 chains only)
             const char* tp = getenv("SMMHIP_TPW");
             int n_cu = 256;
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
             // ... worth it only when two tiles would share a CU anyway (more tiles than CUs)
             const bool force2 = tp && tp[0] == '2';   // test hook: two tiles per workgroup at any size
-            c->tpw = (c->inline_walk && (is_sim(c->obj) ? c->ct == 8 : c->obj != SMM_OBJ_DENSE) && ((N + 7) / 8 > n_cu || force2) &&
+            c->tpw = (c->inline_walk && !c->norm_fast && (is_sim(c->obj) ? c->ct == 8 : c->obj != SMM_OBJ_DENSE) && ((N + 7) / 8 > n_cu || force2) &&
                       !(tp && tp[0] == '1') &&
                       walk_slot_bytes(Ng) + std::max(2 * tile_b, (size_t)K * 4) <= (size_t)160 * 1024) ? 2 : 1;
         }
@@ -704,6 +747,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -760,6 +807,7 @@ int smm_sync(void* ctx) {
 int smm_bgp_step_async(void* ctx, int32_t n_iters) {
     Ctx* c = (Ctx*)ctx;
     if (!c || n_iters < 0) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
     if (c->P.N != c->P.Ng) return fail(c, SMM_ERR_STATE, "smm_bgp_step needs a single shard (N == N_global); use the sharded calls");
     if (c->iter + n_iters > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
@@ -825,11 +873,15 @@ int smm_bgp_step(void* ctx, int32_t n_iters) {
 int smm_bgp_local_step(void* ctx) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
     if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
     if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     try {
         HIPCHK(hipSetDevice(c->device));
         const int t = c->iter + 1;
+        // smm_bgp_step leaves the exchange of its last iteration to the next chain kernel (inline walk): the three-phase
+        // form reads P.xres, so resolve it now (local_step after step read an unresolved xres)
+        resolve_now(c);
         ensure_windows(c, t);
         const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0);
         launch_chain_iter(c, t, flags);
@@ -849,6 +901,7 @@ int smm_bgp_local_step(void* ctx) {
 int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathered_next_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !gathered_next_dev) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
     if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     if (c->rec_external && !gathered_prev_dev) return fail(c, SMM_ERR_INVALID_ARG, "gathered_prev required: the last records live there");
     if (c->unresolved) return fail(c, SMM_ERR_STATE, "mixing smm_bgp_step and smm_bgp_sharded_step without a flush");
@@ -917,8 +970,13 @@ int smm_bgp_record_doubles(void* ctx) {
 int smm_bgp_export_records_dev(void* ctx, void* rec_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !rec_dev) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
+    if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
     try {
         HIPCHK(hipSetDevice(c->device));
+        // after smm_bgp_step the exchange of the last iteration is still pending (resolved or not): the exported records must
+        // be the ones AFTER that exchange, as the three-phase protocol defines them
+        if (c->pending || c->unresolved) flush(c);
         HIPCHK(hipMemcpyAsync(rec_dev, c->rec[c->cur], (size_t)c->P.RW * c->P.N * sizeof(double), hipMemcpyDeviceToDevice,
                               c->stream));
     } catch (const std::string& m) {
@@ -930,6 +988,7 @@ int smm_bgp_export_records_dev(void* ctx, void* rec_dev) {
 int smm_bgp_exchange_dev(void* ctx, const void* gathered_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !gathered_dev) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
     if (c->iter < 1) return fail(c, SMM_ERR_STATE, "exchange before the first local step");
     if (c->pending) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
     try {
@@ -977,13 +1036,13 @@ int smm_eval_batch(void* ctx, const double* params, int32_t M, double* value, do
         HIPCHK(hipMemcpyAsync(dp.p, params, (size_t)P.np * M * 8, hipMemcpyHostToDevice, c->stream));
         constexpr int CT = 8;
         if (is_sim(c->obj))
-            hipLaunchKernelGGL((k_eval_batch<1, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp.p, M, dv.p,
+            hipLaunchKernelGGL((k_eval_batch<1, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem_base(c, CT), c->stream, P, dp.p, M, dv.p,
                                dm.p, ds.p);
         else if (c->obj == SMM_OBJ_DENSE)
-            hipLaunchKernelGGL((k_eval_batch<2, 16>), dim3((M + 15) / 16), dim3(WG), tile_smem(c, 16), c->stream, P, dp.p, M, dv.p, dm.p,
+            hipLaunchKernelGGL((k_eval_batch<2, 16>), dim3((M + 15) / 16), dim3(WG), tile_smem_base(c, 16), c->stream, P, dp.p, M, dv.p, dm.p,
                                ds.p);
         else
-            hipLaunchKernelGGL((k_eval_batch<0, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem(c, CT), c->stream, P, dp.p, M, dv.p,
+            hipLaunchKernelGGL((k_eval_batch<0, CT>), dim3((M + CT - 1) / CT), dim3(WG), tile_smem_base(c, CT), c->stream, P, dp.p, M, dv.p,
                                dm.p, ds.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(value, dv.p, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1141,6 +1200,11 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
             HIPCHK(hipMemcpy(P.hrec + (size_t)t * N * HW, row.data(), row.size() * 8, hipMemcpyHostToDevice));
         }
         c->iter = s->iter;
+        if (c->failed) {   // a state from before the failure: the run may go on
+            const unsigned long long e = ERR_NONE;
+            HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
+            c->failed = 0;
+        }
         c->rec_external = false; c->pending_ext = false; c->unresolved = false;
         c->pending = false;
         c->prev_open = false;

@@ -137,6 +137,133 @@ def test_error_no_draw_in_support(S, O):
     assert eh.value.code == eo.value.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT
 
 
+def test_hard_error_stops_the_run_at_the_failing_iteration(S, O):
+    # AlgoBGP.jl:409 aborts run! inside the failing iteration.  Here: the failing iteration completes, every later launch of
+    # the same step sees the sticky error word and stores nothing, iter reports the failing iteration, the context refuses
+    # to go on.  Injected normals throw every try of iteration 5 out of the box.
+    N, T, tfail = 20, 12, 5
+    prob, opts = cm.serial_normal(N=N, T=T, ns=200)
+    tab = cm.random_tables(prob, opts, tries=3)
+    tab.prop_normals[tfail - 1] = 1e9
+    h, o = make_pair(S, O, prob, opts, tab)
+    with pytest.raises(A.SMMHipError) as eh:
+        h.step(9)
+    with pytest.raises(A.SMMHipError) as eo:
+        o.step(9)
+    assert eh.value.code == eo.value.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT
+    assert "iteration %d" % tfail in str(eh.value) and "chain 1," in str(eh.value)   # the first failing chain, deterministically
+    st = h.state()
+    assert st.iter == tfail and o.state().iter == tfail - 1   # (the oracle, like the reference, never finishes the failing iteration)
+    hh = h.history(0, T)
+    ho = o.history(0, T)
+    for f in cm.INT_FIELDS:   # iterations before the failing one: complete and equal (incl. their exchanges)
+        np.testing.assert_array_equal(getattr(hh, f)[:tfail - 1], getattr(ho, f)[:tfail - 1], err_msg=f)
+    for f in cm.F64_FIELDS:
+        np.testing.assert_allclose(getattr(hh, f)[:tfail - 1], getattr(ho, f)[:tfail - 1], rtol=1e-12, err_msg=f)
+    # iterations after the failing one: untouched (the constructor's fill)
+    assert np.isnan(hh.value[tfail:]).all() and (hh.status[tfail:] == 0).all() and (hh.accepted[tfail:] == 0).all()
+    assert (hh.best_id[tfail:] == -1).all() and (hh.exchanged[tfail:] == 0).all() and np.isinf(hh.curr_val[tfail:]).all()
+    assert (hh.exchanged[tfail - 1] == 0).all()           # exchangeMoves! of the failing iteration never ran
+    for call in (lambda: h.step(1), h.local_step):           # sticky
+        with pytest.raises(A.SMMHipError) as e2:
+            call()
+        assert e2.value.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT
+    # negative / NaN objective (AlgoBGP.jl:341) through the general kernel as well (np = 4)
+    prob4, opts4 = cm.general_normal(4, N=6, T=8, ns=100)
+    prob4.mom[1] = np.nan
+    g = S.hip_context(prob4, opts4)
+    with pytest.raises(A.SMMHipError) as e4:
+        g.step(6)
+    assert e4.value.code == A.SMM_ERR_NEGATIVE_OBJECTIVE and g.state().iter == 2
+    assert np.isnan(g.history(0, 8).value[2:]).all()
+
+
+def test_three_phase_calls_after_step(S, O):
+    # smm_bgp_step leaves the exchange of its last iteration to the next chain kernel; local_step / export
+    # must settle it first.  step(5) then three iterations through the three-phase calls == step(8).
+    import torch
+    prob, opts = cm.serial_normal(N=48, T=8, ns=300)
+    a, o = run_both(S, O, prob, opts, None)
+    b = S.hip_context(prob, opts)
+    b.step(5)
+    buf = torch.empty((48, b.record_doubles()), dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        b.local_step()
+        b.export_records_dev(buf.data_ptr())
+        b.sync()
+        b.exchange_dev(buf.data_ptr())
+        b.sync()
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_history_equal(b.history(), o.history())
+    # and the export alone after a step sees the records AFTER that step's last exchange
+    c = S.hip_context(prob, opts)
+    c.step(5)
+    c.export_records_dev(buf.data_ptr())
+    c.sync()
+    o5 = O.OracleContext(prob, opts, S.Tables(Z=c.Z()))
+    o5.step(5)
+    np.testing.assert_allclose(buf.cpu().numpy()[:, 0], o5.state().la_value, rtol=1e-9)
+
+
+@pytest.mark.parametrize("npar,N,T", [(2, 5, 30), (2, 16, 30), (2, 17, 25), (2, 100, 40), (2, 4096, 12), (1, 37, 30), (2, 5000, 8)])
+def test_norm_kernel_equals_general_kernel(S, O, npar, N, T, monkeypatch):
+    # k_chain_iter_norm (16-chain tiles, np == nm <= 2) against the general k_chain_iter on the same problem: bit-identical
+    if npar == 2:
+        prob, opts = cm.serial_normal(N=N, T=T, ns=1000 if N > 1000 else 10000, objective_id=A.SMM_OBJ_NORM_FAILBOX,
+                                      obj_params=[0.5, 0.9], sigma0=0.2)
+    else:
+        prob, opts = cm.general_normal(1, N=N, T=T, ns=777)
+    a = S.hip_context(prob, opts)
+    a.step(T)
+    monkeypatch.setenv("SMMHIP_NORM_FAST", "0")
+    b = S.hip_context(prob, opts)
+    b.step(T)
+    monkeypatch.delenv("SMMHIP_NORM_FAST")
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_state_equal(a.state(), b.state(), rtol=0)
+    hh = a.history()
+    assert (hh.exchanged != 0).any() or N == 1
+    if npar == 2:
+        assert (hh.status == -2).any()
+    if N <= 100:
+        o = O.OracleContext(prob, opts, S.Tables(Z=a.Z()))
+        o.step(T)
+        cm.assert_history_equal(hh, o.history())
+        cm.assert_state_equal(a.state(), o.state())
+
+
+@pytest.mark.parametrize("tries", [1, 3, 5, 24])
+def test_norm_kernel_injected_tries(S, O, tries):
+    # the try groups of the 4-lane proposal (tries 0-3, 4-7, later ones from memory; exhausted tables are a hard error)
+    prob, opts = cm.serial_normal(N=40, T=30, ns=300, sigma0=0.6, smpl_iters=50)
+    tab = cm.random_tables(prob, opts, tries=tries)
+    h, o = make_pair(S, O, prob, opts, tab)
+    eh = eo = None
+    try:
+        h.step(30)
+    except A.SMMHipError as e:
+        eh = e
+    try:
+        o.step(30)
+    except A.SMMHipError as e:
+        eo = e
+    assert (eh is None) == (eo is None)
+    if eh is not None:
+        assert eh.code == eo.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT
+        assert h.state().iter == o.state().iter + 1
+    else:
+        cm.assert_history_equal(h.history(), o.history(), rtol=1e-12)
+    assert tries > 3 or eh is not None       # sigma0 = 0.6: three tries do not last 30 iterations x 40 chains
+
+
+def test_norm_kernel_rng_tries_beyond_the_pregenerated(S, O):
+    # sigma so large that chains regularly need more than the 8 pre-generated tries: the in-kernel generator path
+    prob, opts = cm.serial_normal(N=33, T=25, ns=100, sigma0=1.5, smpl_iters=100000)
+    h, o = run_both(S, O, prob, opts, None)
+    cm.assert_history_equal(h.history(), o.history())
+    cm.assert_state_equal(h.state(), o.state())
+
+
 def test_maxiter_guard(S):
     prob, opts = cm.serial_normal(N=3, T=4, ns=100)
     h = S.hip_context(prob, opts)
@@ -391,6 +518,74 @@ def test_c3_population_8_temperature_levels(S, O):
     cm.assert_history_equal(hh, o.history())
     lev = (np.nonzero(hh.exchanged)[1] // R_, (hh.exchanged[hh.exchanged != 0] - 1) // R_)
     assert (lev[0] != lev[1]).any()  # exchanges between temperature levels happened
+
+
+def _all_cores(O):
+    import os
+    return max(1, min(O.max_threads(), len(os.sched_getaffinity(0))))
+
+
+def c3_opts(L=8, R_=4096, T=50):
+    """BASELINE config 3: 8 temperature levels x 4096 replicas"""
+    from smm_jl_amd import BGPOpts
+    return BGPOpts(N=L * R_, maxiter=T, sigma=np.repeat(0.05 * np.linspace(1, 5, L), R_),
+                   acc_tuner=np.repeat(np.geomspace(20, 1, L), R_), min_improve=np.zeros(L * R_))
+
+
+def test_c3_real_workload_32768_chains_ns10000(S, O):
+    # BASELINE config 3 on its own workload (VERDICT r1 #1): 32768 chains, ns = 10000, 50 iterations, whole history
+    # against the oracle -- the big-population plan / walk kernels with the real objective behind them
+    T = 50
+    prob, _ = cm.serial_normal(N=3, T=T, ns=10000)
+    opts = c3_opts(T=T)
+    h, o = make_pair(S, O, prob, opts, threads=_all_cores(O))
+    h.step(T); o.step(T)
+    hh = h.history()
+    # (atol: a simulated moment is a mean of O(1) draws and can come out at 1e-7; a one-ulp difference of the proposal --
+    # ocml vs glibc sincos/log in the built-in generator -- is 1e-16 absolute there)
+    cm.assert_history_equal(hh, o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+    ex = hh.exchanged
+    assert (ex[0] == 0).all() and (ex[1:] != 0).mean() > 0.05
+    t, c = np.nonzero(ex)
+    assert (ex[t, ex[t, c] - 1] != 0).all()                      # partners are marked too
+    assert (np.diff(hh.best_val, axis=0) <= 0).all()
+    lev = (c // 4096, (ex[t, c] - 1) // 4096)
+    assert (lev[0] != lev[1]).any()                              # exchanges between temperature levels happened
+
+
+def test_n20000_real_workload_ns10000(S, O):
+    # 8192 < N_global <= 65535 with the real objective: 20000 chains, ns = 10000, 25 iterations
+    prob, opts = cm.serial_normal(N=20000, T=25, ns=10000)
+    h, o = make_pair(S, O, prob, opts, threads=_all_cores(O))
+    h.step(25); o.step(25)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+    assert (h.history().exchanged != 0).sum() > 0
+
+
+def test_c3_fused_sharded_8x4096_real_workload(S, O):
+    # the 8-GPU form of C3 emulated on one GPU: 8 shards x 4096 chains, ns = 10000, through smm_bgp_sharded_step; 70
+    # iterations cross a look-ahead window (60 iterations at this size) with an exchange open.  Every shard against
+    # the oracle's single-population run.
+    T, G, n = 70, 8, 4096
+    prob, _ = cm.serial_normal(N=3, T=T, ns=10000)
+    opts = c3_opts(T=T)
+    ctxs = sharded_run_fused(S, prob, opts, G, T)
+    o = O.OracleContext(prob, opts, S.Tables(Z=ctxs[0].Z()), threads=_all_cores(O))
+    o.step(T)
+    ho, so = o.history(), o.state()
+    for r, c in enumerate(ctxs):
+        hr, sr = c.history(), c.state()
+        sl = slice(r * n, (r + 1) * n)
+        for f in cm.INT_FIELDS:
+            assert np.array_equal(getattr(hr, f), getattr(ho, f)[..., sl]), (f, r)
+        for f in cm.F64_FIELDS:
+            np.testing.assert_allclose(getattr(hr, f), getattr(ho, f)[..., sl], rtol=1e-9, atol=1e-13, equal_nan=True, err_msg="%s shard %d" % (f, r))
+        assert np.array_equal(sr.n_noex, so.n_noex[sl]) and np.array_equal(sr.n_acc_noex, so.n_acc_noex[sl])
+        np.testing.assert_allclose(sr.sigma, so.sigma[sl], rtol=1e-12)
+        np.testing.assert_allclose(sr.la_value, so.la_value[sl], rtol=1e-9, atol=1e-13)
+    assert (ho.exchanged != 0).mean() > 0.05
 
 
 def test_exchange_worst_case_star_pairs(S, O):

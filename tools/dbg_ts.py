@@ -7,7 +7,7 @@ prob, opts = cm.serial_normal(N=4096, T=700)
 ctx = S.hip_context(prob, opts)
 ctx.step(150)
 lib = S._abi.load()
-nwg = 512
+nwg = int(os.environ.get("TS_NWG", "256"))   # tiles: 256 with k_chain_iter_norm (16-chain tiles), 512 with the general kernel
 buf = np.zeros((nwg, 8), np.uint64)
 lib.smm_debug_ts(ctx._ctx, buf.ctypes.data_as(C.c_void_p), nwg)
 ts = buf.astype(np.float64) / 100.0  # wall_clock64 = 100 MHz -> us
