@@ -5,16 +5,44 @@
 // 64-lane total of accumulator acc_index<CT>(l), combined by the canonical halving tree (offsets
 // 32,16,8,4,2,1; IEEE addition is commutative so both partners compute the same bits).
 // ------------------------------------------------------------------------------------------
+// One step of the tree for two accumulators at once with gfx950's lane swaps: v_permlane32_swap exchanges the upper half of
+// its first operand with the lower half of its second, v_permlane16_swap the odd rows of the first with the even rows of the
+// second.  Afterwards, in the lanes whose bit OFF is clear, x = own x and y = the partner lane's x; in the other lanes
+// x = the partner lane's y and y = own y: x + y is "mine + received" for the accumulator the lane keeps (3 instructions per
+// pair of 64-bit accumulators instead of 4 selects, 2 LDS permutes and the add).
+template <int OFF>
+__device__ inline double swap_add(double x, double y) {
+    static_assert(OFF == 32 || OFF == 16, "lane swaps exist for offsets 32 and 16");
+    const unsigned long long ux = __builtin_bit_cast(unsigned long long, x), uy = __builtin_bit_cast(unsigned long long, y);
+    unsigned xl, xh, yl, yh;
+    if constexpr (OFF == 32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ux, (unsigned)uy, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ux >> 32), (unsigned)(uy >> 32), false, false);
+        xl = lo[0]; yl = lo[1]; xh = hi[0]; yh = hi[1];
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ux, (unsigned)uy, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ux >> 32), (unsigned)(uy >> 32), false, false);
+        xl = lo[0]; yl = lo[1]; xh = hi[0]; yh = hi[1];
+    }
+    const double x2 = __builtin_bit_cast(double, ((unsigned long long)xh << 32) | xl);
+    const double y2 = __builtin_bit_cast(double, ((unsigned long long)yh << 32) | yl);
+    return x2 + y2;
+}
 template <int CT, int NN, int OFF>
 __device__ inline void wave_reduce_step(double (&a)[CT], int lane) {
     if constexpr (NN > 1) {
-        const bool upper = (lane & OFF) != 0;
+        if constexpr (OFF >= 16) {
 #pragma unroll
-        for (int i = 0; i < NN / 2; ++i) {
-            const double mine = upper ? a[i + NN / 2] : a[i];
-            const double send = upper ? a[i] : a[i + NN / 2];
-            const double recv = __shfl_xor(send, OFF, 64);
-            a[i] = mine + recv;
+            for (int i = 0; i < NN / 2; ++i) a[i] = swap_add<OFF>(a[i], a[i + NN / 2]);
+        } else {
+            const bool upper = (lane & OFF) != 0;
+#pragma unroll
+            for (int i = 0; i < NN / 2; ++i) {
+                const double mine = upper ? a[i + NN / 2] : a[i];
+                const double send = upper ? a[i] : a[i + NN / 2];
+                const double recv = __shfl_xor(send, OFF, 64);
+                a[i] = mine + recv;
+            }
         }
         wave_reduce_step<CT, NN / 2, OFF / 2>(a, lane);
     } else if constexpr (OFF >= 1) {
@@ -347,7 +375,7 @@ struct __attribute__((aligned(16))) XSlot {  // one chain during the walk: 16 by
 __host__ __device__ inline size_t walk_slot_bytes(int Ng) { return (size_t)Ng * sizeof(XSlot); }
 
 template <int NT>
-__device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsigned char* lds, const int tid) {
+__device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsigned char* lds, const int tid, const int ts_tile = 0) {
     const int Ng = P.Ng, K = P.plan_K;
     const int w = tx - P.plan_t0;
     XSlot* slot = (XSlot*)lds;                              // [Ng]
@@ -403,6 +431,7 @@ __device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsign
         ltail = wide ? 64 - __builtin_clzll(wide) : 0;
     }
     __syncthreads();
+    if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
     uint32_t b = 0;
     uint32_t e = nlev > 0 ? level_end(0) : 0u;
     uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
@@ -455,6 +484,138 @@ __device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsign
         }
         __syncthreads();
     }
+}
+
+// The same walk with the level loop written for latency: a level is ONE LDS round trip (both 16-byte slots of a pair with a
+// ds_read_b128 each), the compare, the two 16-byte writes of a swap and the barrier; the next level's pair word is fetched
+// ahead; nothing else is in the loop (thresholds: a scalar when min_improve is uniform — the loop is instantiated twice).
+// The level walk is latency, not bandwidth: a level with a handful of pairs costs almost what a level with a thousand does
+// (measured per level of the first form: 1784 cycles for 1000 pairs, ~850 for 50), so what counts is the dependent chain
+// per level.  FINAL_BARRIER = false: only the walking wave 0 reads the result (its own LDS operations complete in order).
+#ifndef SMM_EXP_WALK_SKIP
+#define SMM_EXP_WALK_SKIP 0
+#endif
+constexpr uint32_t XNOPAIR = 0xffffffffu;   // i == j == 0xffff never occurs (chain ids < XLVL_MAX)
+// (inline asm: left to itself the compiler reads only the 8 value bytes first and fetches src with a second, dependent LDS
+// read inside the swap branch — two round trips per level instead of one.  The asm's own LDS operations are invisible to the
+// compiler's counters, hence the explicit waits: after the reads, and walk_wait_lds() before every barrier.)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ inline void walk_pair(const uint32_t slot_base, const uint32_t pw, const double m) {
+    const uint32_t i = pw & 0xffffu, j = pw >> 16;
+    const uint32_t ai = slot_base + i * 16u, aj = slot_base + j * 16u;
+    u32x4_t si, sj;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
+    const double vi = __builtin_bit_cast(double, ((unsigned long long)si.y << 32) | si.x);
+    const double vj = __builtin_bit_cast(double, ((unsigned long long)sj.y << 32) | sj.x);
+    if (vi - vj > m) {                                   // dist_fun = -, AlgoBGP.jl:688
+        u32x4_t ni = sj, nj = si;                        // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+        ni.w = j + 1; nj.w = i + 1;
+        asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
+    }
+}
+__device__ inline void walk_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int NT, bool MI_U, bool FINAL_BARRIER>
+__device__ inline void walk_levels(const KParams& P, const uint32_t slot, const uint32_t* pairs, const double* __restrict__ g_mi, const uint32_t ev,
+                                   const uint32_t* __restrict__ g_off, const int nlev, const int ltail, const int tid) {
+    const double mi_v = P.mi_value;
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
+    // (level ends and this wave's first position are scalars: a wave without a pair in a level runs no vector instruction for it)
+    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63);
+    uint32_t b = 0;
+    uint32_t e = nlev > 0 ? level_end(0) : 0u;
+    uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
+    uint32_t pw = (b + tid < e) ? pairs[b + tid] : XNOPAIR;
+    double m = MI_U ? mi_v : ((b + tid < e) ? g_mi[b + tid] : 0.0);
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < ltail; ++l) {
+        const uint32_t e3 = level_end(l + 2);
+        uint32_t pw2 = XNOPAIR;
+        double m2 = mi_v;
+        if (!SMM_EXP_WALK_SKIP || e + wbase < e2) {   // this thread's first pair of the next level
+            pw2 = (e + tid < e2) ? pairs[e + tid] : XNOPAIR;
+            if constexpr (!MI_U) m2 = (e + tid < e2) ? g_mi[e + tid] : 0.0;
+        }
+        if (!SMM_EXP_WALK_SKIP || b + wbase < e) {
+            if (pw != XNOPAIR) walk_pair(slot, pw, m);
+            for (uint32_t pos = b + tid + NT; pos < e; pos += NT) walk_pair(slot, pairs[pos], MI_U ? mi_v : g_mi[pos]);   // levels wider than the workgroup
+        }
+        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+        walk_wait_lds();
+        __syncthreads();
+        if (P.ts && tid == 0 && blockIdx.x == 0 && l < 30) P.ts[(size_t)8 * 60000 + 16 + l] = clock64();
+    }
+    if (P.ts && tid == 0 && blockIdx.x == 0) { P.ts[(size_t)8 * 60000 + 14] = (unsigned long long)ltail; P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev; }
+    if (ltail < nlev) {
+        if (tid < 64) {   // the narrow tail: wave 0 alone, no barriers (pw, m hold this lane's pair of level ltail, e its end, e2 the next end)
+#pragma clang loop unroll(disable)
+            for (int l = ltail; l < nlev; ++l) {
+                const uint32_t e3 = level_end(l + 2);
+                const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : XNOPAIR;
+                double m2 = mi_v;
+                if constexpr (!MI_U) m2 = (e + tid < e2) ? g_mi[e + tid] : 0.0;
+                if (pw != XNOPAIR) walk_pair(slot, pw, m);
+                __builtin_amdgcn_wave_barrier();
+                pw = pw2; m = m2; e = e2; e2 = e3;
+                if (P.ts && tid == 0 && blockIdx.x == 0 && l < 30) { walk_wait_lds(); P.ts[(size_t)8 * 60000 + 16 + l] = clock64(); }
+            }
+            walk_wait_lds();
+        }
+        if constexpr (FINAL_BARRIER) __syncthreads();
+    }
+}
+
+template <int NT, bool FINAL_BARRIER>
+__device__ inline void exchange_walk_fast(const KParams& P, const int tx, unsigned char* lds, const int tid, const int ts_tile) {
+    const int Ng = P.Ng, K = P.plan_K;
+    const int w = tx - P.plan_t0;
+    uint4* slot = (uint4*)lds;                                  // [Ng] {value lo, value hi, src, partner}
+    uint32_t* pairs = (uint32_t*)(lds + walk_slot_bytes(Ng));   // [K]
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    constexpr int PT = XLVL_MAX / NT;
+    const int lane = tid & 63;
+    double v_[PT];
+    uint32_t pq_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {   // one round trip of global loads
+        const int g = tid + r * NT;
+        v_[r] = g < Ng ? P.vals[g] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * NT;
+        pq_[r] = q < K ? g_pairs[q] : 0u;
+    }
+    const uint32_t ev = g_off[min(lane, K)];   // lane l: end of level l
+    const int nlev = (int)g_off[K + 1];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        const unsigned long long uv = __builtin_bit_cast(unsigned long long, v_[r]);
+        if (g < Ng) slot[g] = make_uint4((uint32_t)uv, (uint32_t)(uv >> 32), (uint32_t)g, 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = tid + r * NT;
+        if (q < K) pairs[q] = pq_[r];
+    }
+    for (int q = tid + PT * NT; q < K; q += NT) pairs[q] = g_pairs[q];   // injected pair lists longer than XLVL_MAX
+    // the narrow tail (every remaining level <= 64 pairs) is walked by wave 0 alone
+    int ltail = nlev;
+    if (nlev > 0 && nlev <= 64) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)ev, 1, 64);
+        const unsigned long long wide = __ballot(lane < nlev && ev - (lane > 0 ? lo : 0u) > 64u);
+        ltail = wide ? 64 - __builtin_clzll(wide) : 0;
+    }
+    __syncthreads();
+    if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
+    const uint32_t slot_base = (uint32_t)(size_t)lds;   // LDS byte address of the chain slots
+    if (P.mi_uniform) walk_levels<NT, true, FINAL_BARRIER>(P, slot_base, pairs, g_mi, ev, g_off, nlev, ltail, tid);
+    else walk_levels<NT, false, FINAL_BARRIER>(P, slot_base, pairs, g_mi, ev, g_off, nlev, ltail, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -525,7 +686,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         if (flags & F_WALK_INLINE) {
             // exchangeMoves! of iteration t-1, by all lanes of the tile, while the level-1 blocks are in flight
             // (the tile's own LDS blocks overlay the walk's pair list: nothing of the tile is written before this returns)
-            exchange_walk_tile<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x);
+            exchange_walk_tile<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, tile);
             if (valid) {
                 const XSlot sv = ((const XSlot*)smem)[gc];
                 xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);

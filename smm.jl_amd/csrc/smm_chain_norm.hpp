@@ -19,7 +19,13 @@
 constexpr int NORM_CT = 16;           // chains per tile
 constexpr int NORM_NR = 4;            // lanes per chain in the control wave
 constexpr int NORM_WG = 2 * WG;       // 1024 lanes
-constexpr int NORM_ZU = 4;            // shock rows per chunk: 16 accumulators + 16 means + two chunk buffers must stay under 128 VGPRs
+#ifndef SMM_EXP_SGPR_MU
+#define SMM_EXP_SGPR_MU 0
+#endif
+#ifndef SMM_EXP_NORM_ZU
+#define SMM_EXP_NORM_ZU 4
+#endif
+constexpr int NORM_ZU = SMM_EXP_NORM_ZU;   // shock rows per chunk (the 16 means sit in SGPRs: 16 accumulators + two chunk buffers = 64 VGPRs)
 
 template <int ZK>
 __device__ inline void sim_load_chunk_n(const ZBuf& zb, const KParams& P, int k, int ch, double (&z)[ZK]) {
@@ -65,9 +71,14 @@ __device__ inline double quad_bcast_dyn(double v, int lane, int q) {   // q: wav
 // the simulation for a tile of 16 chains: half h (512 lanes, l = lane of the half) sums the draws of the moments
 // k = h, h+2, ...; lane l takes the draws l, l+512, ... in that order (numerical contract).  s_part [NP][8][16].
 template <int NP>
-__device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb, const double* s_theta, double* s_part, const int h, const int wih, const int l,
+__device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const double* s_theta, double* s_part, const int h, const int wih,
                                        double (&zc)[NORM_ZU]) {
     constexpr int ZU = NORM_ZU;
+    // lane of the half, derived anew from mbcnt and the scalar wave id (nothing of the prologue stays live in a vector register)
+    const int l = wih * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    ZBuf zb;
+    zb.rsrc = zb0.rsrc;
+    zb.lane_off = l * (int)sizeof(double);
     constexpr int CT = NORM_CT;
     const int ns = P.ns;
     const int nch = (ns + ZU * WG - 1) / (ZU * WG);
@@ -77,7 +88,17 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb, const d
     for (int k = h; k < NP; k += 2) {
         double acc[CT], mu[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { acc[c] = 0.0; mu[c] = s_theta[c * NP + k]; }
+        for (int c = 0; c < CT; ++c) {
+            // the proposal's k-th component is the same in every lane: into a scalar register pair (v_add_f64 takes one SGPR operand)
+#if SMM_EXP_SGPR_MU
+            const unsigned long long um = __builtin_bit_cast(unsigned long long, s_theta[c * NP + k]);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)um), hi = __builtin_amdgcn_readfirstlane((unsigned)(um >> 32));
+            mu[c] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+#else
+            mu[c] = s_theta[c * NP + k];
+#endif
+            acc[c] = 0.0;
+        }
         auto add_full = [&](const double (&z)[ZU]) {
 #pragma unroll
             for (int u = 0; u < ZU; ++u) {
@@ -90,8 +111,7 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb, const d
         };
         auto add_last = [&](const double (&z)[ZU]) {
             if (!ragged) { add_full(z); return; }
-            int ll = l;   // laundered: the row masks are computed here, not hoisted above the main loop where they cost registers
-            asm volatile("" : "+v"(ll));
+            const int ll = wih * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (not hoisted: see above)
 #pragma unroll
             for (int u = 0; u < ZU; ++u) {
                 if (ll + u * WG < last_draws) {
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
     }
     if constexpr (WALK) {
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
-        exchange_walk_tile<NORM_WG>(P, t - 1, (unsigned char*)smem, tid);
+        exchange_walk_fast<NORM_WG, false>(P, t - 1, (unsigned char*)smem, tid, tile);
         if (valid) {
             const XSlot sv = ((const XSlot*)smem)[gc];
             xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
     TS_MARK(2);
 
     // ---- simulation: every lane, ns draws x its half's moments x 16 chains ----
-    if (simw) simulate_tile16<NP>(P, zb, s_theta, s_part, h, wave & 7, l, za);
+    if (simw) simulate_tile16<NP>(P, zb, s_theta, s_part, h, wave & 7, za);
     // No workgroup barrier: only the control wave consumes the partial sums.  Every wave announces its partials with one
     // LDS add and is done; the control wave waits for the announcements of the waves that had a moment.
     // (lane ids are derived anew from mbcnt and the scalar wave id: no register of the prologue stays live across the simulation)

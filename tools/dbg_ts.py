@@ -16,8 +16,8 @@ print("phase stamps relative to first WG start (us): mean / min / max over %d WG
 for i, name in enumerate(["start", "after loads", "after proposal+barrier", "after sim", "end"]):
     v = ts[:, i] - t0
     print("%-24s %7.2f %7.2f %7.2f" % (name, v.mean(), v.min(), v.max()))
-seq = [0, 1, 5, 6, 2, 3, 7, 4]
-names2 = ["loads(L1+L2)+LDS stage+barrier1", "settle prev", "proposal", "barrier2", "sim", "objective+accept", "stores issued"]
+seq = [0, 5, 1, 6, 2, 3, 7, 4]
+names2 = ["start -> walk inputs staged in LDS", "walk levels (+ slot read)", "record load + settle + proposal", "barrier", "sim", "objective+accept", "stores issued"]
 tt = ts[:, seq]
 dd = np.diff(tt, axis=1)
 print("fine phases (us) mean/min/max:")
@@ -37,6 +37,7 @@ xs = x.astype(np.float64) / 100.0
 print("resolve kernel (thread 0): loads+init %.2f  levels %.2f  store %.2f us" % (xs[1]-xs[0], xs[3]-xs[1], xs[4]-xs[3]))
 print("resolve: %d levels, %d shader cycles over %.2f us -> %.0f MHz" % (int(x[7]), int(x[6]), xs[4]-xs[0], x[6]/(xs[4]-xs[0])))
 
+nl=int(x[7]); print("inline walk of WG 0: %d levels, %d with barriers; cycles per level:" % (nl, int(x[14])), np.diff(x[15:16+nl].astype(np.int64)).tolist())
 print("cycles at level ends (thread 0, shader clock):", [int(v) for v in x[15:15+int(x[7])+1]])
 print("ltail", int(x[14]))
 print("per level:", np.diff(x[15:15+int(x[7])+1].astype(np.int64)).tolist())

@@ -194,6 +194,35 @@ __global__ __launch_bounds__(512, 4) void k_tile8_512(const Args A) {
     STAMP1();
 }
 
+
+// E: as B, the 16 means in SGPRs (uniform per wave): frees 32 VGPRs
+template <int MODE, int ZU>
+__global__ __launch_bounds__(1024, 4) void k_tile16_split_smu(const Args A) {
+    const int h = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 9), l = threadIdx.x & 511, lane = l & 63, wave = l >> 6;
+    const int c0 = blockIdx.x * 16;
+    double zc[ZU];
+    ZBuf zb; zb.init(A, l);
+    load_chunk<MODE, ZU>(A, zb, h, 0, l, zc);
+    STAMP0();
+#pragma clang loop unroll(disable)
+    for (int k = h; k < NM; k += 2) {
+        double mu[16], acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const double m = A.theta[(c0 + c) * NM + k];
+            const unsigned long long um = __builtin_bit_cast(unsigned long long, m);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)um), hi = __builtin_amdgcn_readfirstlane((unsigned)(um >> 32));
+            mu[c] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+            acc[c] = 0.0;
+        }
+        sim_moment<16, MODE, ZU>(A, zb, k, k + 2 < NM ? k + 2 : k, l, mu, acc, zc);
+        STAMPMID();
+        const double tot = wave_reduce_t<16>(acc, lane);
+        if ((lane & 3) == 0) A.out[((size_t)(c0 + (lane >> 2)) * NM + k) * 8 + wave] = tot;
+    }
+    STAMP1();
+}
+
 template <class K>
 void run(const char* name, K kern, int grid, int block, Args A, int mode, int reps = 200) {
     A.mode = mode; A.chmask = mode == 1 ? 0 : ~0;
@@ -263,6 +292,8 @@ int main() {
     RUN1("tile16split zu8", (k_tile16_split<M, 8>), 256, 1024, mode) \
     RUN1("tile16split zu4", (k_tile16_split<M, 4>), 256, 1024, mode) \
     RUN1("tile16split zu2", (k_tile16_split<M, 2>), 256, 1024, mode) \
+    RUN1("t16split smu zu8", (k_tile16_split_smu<M, 8>), 256, 1024, mode) \
+    RUN1("t16split smu zu4", (k_tile16_split_smu<M, 4>), 256, 1024, mode) \
     RUN1("tile16/512 zu8", (k_tile16_512<M, 8>), 256, 512, mode) \
     RUN1("tile8/512x2 zu8", (k_tile8_512<M, 8>), 512, 512, mode)
     bool have_ref = false;
