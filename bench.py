@@ -29,26 +29,43 @@ PEAK_FP64_ADD_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3: 256 CU x 4 SIMD x 16
 PEAK_HBM_GBS = 8000.0
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the device sources: ties a committed PMC summary to the build it was taken from"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "smm.jl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
-    """HBM bytes per k_chain_iter launch from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
+    """HBM bytes per k_chain_iter_norm launch from the newest committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are KB per launch; gfx950's FETCH_SIZE tallies wide coalesced reads at half their size
-    (MI355X_MICROARCH.md, HBM) so it is doubled.  None when no profile is committed."""
+    (MI355X_MICROARCH.md, HBM) so it is doubled.  Counters cannot be read from inside the timed process, so the number
+    comes from the profile file; `stale` says whether that profile was taken from other device sources than this build
+    (the summary carries the source hash).  (None, ...) when no profile is committed."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
     if not files:
-        return None, None
+        return None, None, None
     fetch = write = None
+    src_hash = None
     for line in open(files[-1]):
-        if "k_chain_iter<1, 8>" in line or "k_chain_iter<1," in line:
+        m = re.match(r"#\s*kernel_source_sha16=([0-9a-f]+)", line)
+        if m:
+            src_hash = m.group(1)
+        if "k_chain_iter_norm<2, true>" in line or ("k_chain_iter<1," in line and fetch is None):
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+launches=\s*\d+\s+mean_per_launch=\s*([0-9.]+)", line)
             if m and m.group(1) == "FETCH_SIZE":
                 fetch = float(m.group(2))
             elif m:
                 write = float(m.group(2))
     if fetch is None or write is None:
-        return None, None
-    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT)
+        return None, None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT), (src_hash != kernel_source_hash())
 
 
 def host_cores():
@@ -64,20 +81,35 @@ def host_cores():
 
 
 def cpu_baseline(threads):
-    """the oracle (C port of the reference path) on the host cores, bounded sample, 'faithful' mode:
-    every evaluation regenerates its 2 x 10000 normals like ObjExamples.jl:74-79."""
+    """the oracle (C port of the reference path, oracle/smm_oracle.c) on the host cores the cgroup grants.
+    value: the FULL workload of the metric (4096 chains x 200 iterations) with the shock matrix drawn once and cached -- an
+    upper bound for any CPU run of the reference path, which redraws its 2 x 10000 normals inside every evaluation
+    (ObjExamples.jl:74-79).  regen_value: a bounded sample with those draws regenerated per evaluation by the port's
+    generator (Philox + Box-Muller, both outputs used): a lower bound (Julia's ziggurat randn is several times cheaper)."""
     import common as cm
     from oracle import oracle as O
-    n, t = 512, 40
-    prob, opts = cm.serial_normal(N=n, T=t)
-    o = O.OracleContext(prob, opts, threads=threads, regen_z=True)
-    t0 = time.perf_counter(); o.step(t); dt = time.perf_counter() - t0
-    o2 = O.OracleContext(prob, opts, threads=threads, regen_z=False)
-    t0 = time.perf_counter(); o2.step(t); dt2 = time.perf_counter() - t0
+    n, t = CHAINS_PER_GPU, ITERS_PER_STEP
+    reps_max = 400
+    prob, opts = cm.serial_normal(N=n, T=t * reps_max)
+    o = O.OracleContext(prob, opts, threads=threads, regen_z=False)
+    o.step(t)                                   # warm-up job
+    reps, t0 = 0, time.perf_counter()
+    while reps < reps_max - 1 and (reps == 0 or time.perf_counter() - t0 < 10.0):   # whole 4096 x 200 jobs for ~10 s
+        o.step(t); reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    n2, t2 = 512, 20
+    prob2, opts2 = cm.serial_normal(N=n2, T=t2 * 200)
+    o2 = O.OracleContext(prob2, opts2, threads=threads, regen_z=True)
+    reps2, t0 = 0, time.perf_counter()
+    while reps2 < 199 and (reps2 == 0 or time.perf_counter() - t0 < 8.0):
+        o2.step(t2); reps2 += 1
+    dt2 = (time.perf_counter() - t0) / reps2
     return {"value": n * t / dt, "unit": "chain-evals/s", "cores": threads, "kind": "port",
-            "sample": "%d chains x %d iters of the same workload, OpenMP over chains, faithful mode (each "
-                      "evaluation regenerates its 2x10000 normals as ObjExamples.jl:74-79 does)" % (n, t),
-            "cached_Z_value": n * t / dt2}
+            "sample": "the whole workload: %d chains x %d iterations, OpenMP over chains (%d threads), AVX2, shock matrix "
+                      "cached (no per-evaluation RNG: an upper bound for the reference's CPU path); %d such jobs, %.2f s each" % (n, t, threads, reps, dt),
+            "regen_value": n2 * t2 / dt2,
+            "regen_sample": "%d chains x %d iterations with the 2x10000 normals of every evaluation regenerated "
+                            "(ObjExamples.jl:74-79) by the port's Philox/Box-Muller: a lower bound; %d repetitions, %.2f s each" % (n2, t2, reps2, dt2)}
 
 
 def main():
@@ -195,17 +227,17 @@ def main():
         byts = n_loc * BYTES_PER_EVAL
         ach = flops / (k_us * 1e-6) / 1e12
         hbm = byts / (k_us * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic()
-        roof = {"bound": "valu_fp64", "kernel": "k_chain_iter", "achieved": ach, "peak": PEAK_FP64_ADD_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_FP64_ADD_TFLOPS, "traffic": traffic,
+        traffic, traffic_src, traffic_stale = pmc_traffic()
+        roof = {"bound": "valu_fp64", "kernel": "k_chain_iter_norm<2, true>", "achieved": ach, "peak": PEAK_FP64_ADD_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_FP64_ADD_TFLOPS, "traffic": traffic, "traffic_stale": traffic_stale,
                 "traffic_note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from %s; algorithmic: %d B"
                                 % (traffic_src, byts),
                 "avg_kernel_us": k_us, "avg_exchange_us": x_us,
                 "net_kernel_us": k_net_us, "net_exchange_us": x_net_us, "event_bracket_overhead_us": null_us,
                 "timing_note": "avg_*: per-kernel start/stop events (dispatch duration, what rocprofv3 reports; used for "
                                "'achieved'); net_*: event brackets minus the empty-bracket overhead",
-                "kernel_contents": "one launch per iteration: exchangeMoves! of the previous iteration (level walk, every "
-                                   "tile, LDS/latency bound, no flops) + next_eval of 4096 chains",
+                "kernel_contents": "one launch per iteration: exchangeMoves! of the previous iteration (level walk by every "
+                                   "workgroup, LDS/latency bound, no flops) + next_eval of 4096 chains (16 per workgroup)",
                 "unfused": unfused,
                 "profiled_step_ms": tm.step_ms,
                 "note": "2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes "

@@ -48,8 +48,13 @@ def load():
 
 
 class OracleContext(S.BGPContext):
+    """the oracle behind the product's context interface: the same method bodies drive liboracle's `orc_` twins of the ABI
+    entry points (the redirection lives here, in test infrastructure: the product's BGPContext only knows libsmmhip.so)"""
+    _p = "orc_"
+
     def __init__(self, problem, opts, tables=None, threads=1, regen_z=False):
-        super().__init__(load(), "orc_", problem, opts, tables)
+        self._lib = load()
+        self._create(problem, opts, tables)
         self._lib.orc_set_mode(self._ctx, threads, int(regen_z))
 
     def set_mode(self, threads=1, regen_z=False):

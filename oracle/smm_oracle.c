@@ -270,16 +270,36 @@ static void objfunc_norm(int nm, int ns, const double* theta, const double* Z, i
                          const double* mom, const double* w, double* simM, double* value, int8_t* status) {
     double part[ORC_REDUCE_LANES];
     double vsum = 0.0;
+    double* zbuf = NULL;
+    if (regen) {
+        /* the reference draws its ns x nm normals inside every evaluation (ObjExamples.jl:74-79).  Same draws as the cached
+         * matrix: one Philox block + Box-Muller yields the shocks of moments 2q and 2q+1 of draw s (both outputs are used). */
+        zbuf = (double*)malloc((size_t)nm * ns * sizeof(double));
+        uint32_t key[2];
+        stream_key(seed, STREAM_Z, key);
+        for (int q = 0; 2 * q < nm; ++q)
+            for (int s = 0; s < ns; ++s) {
+                uint32_t ctr[4] = {(uint32_t)s, (uint32_t)q, 0, 0}, x[4];
+                double z[2];
+                philox4x32_10(ctr, key, x);
+                box_muller(x, z);
+                zbuf[(size_t)(2 * q) * ns + s] = z[0];
+                if (2 * q + 1 < nm) zbuf[(size_t)(2 * q + 1) * ns + s] = z[1];
+            }
+        Z = zbuf;
+    }
     for (int k = 0; k < nm; ++k) {
         const double mu = theta[k];
-        for (int l = 0; l < ORC_REDUCE_LANES; ++l) {
-            double acc = 0.0;
-            for (int s = l; s < ns; s += ORC_REDUCE_LANES) {
-                double z = regen ? rng_Z(seed, (uint32_t)k, (uint32_t)s) : Z[(size_t)k * ns + s];
-                double x = z + mu;
-                acc = acc + x;
+        const double* zk = Z + (size_t)k * ns;
+        /* lane l sums its draws l, l+512, ... in that order (numerical contract); walking the draws row by row keeps the 512
+         * running sums contiguous, so that the compiler vectorises the inner loop (independent accumulators: same bits) */
+        for (int l = 0; l < ORC_REDUCE_LANES; ++l) part[l] = 0.0;
+        for (int base = 0; base < ns; base += ORC_REDUCE_LANES) {
+            const int n = ns - base < ORC_REDUCE_LANES ? ns - base : ORC_REDUCE_LANES;
+            for (int l = 0; l < n; ++l) {
+                const double x = zk[base + l] + mu;
+                part[l] = part[l] + x;
             }
-            part[l] = acc;
         }
         double tot = reduce_partials(part);
         simM[k] = tot / (double)ns;
@@ -288,6 +308,7 @@ static void objfunc_norm(int nm, int ns, const double* theta, const double* Z, i
         double v = d * d;
         vsum = (k == 0) ? v : vsum + v;
     }
+    free(zbuf);
     *value = vsum / (double)nm;
     *status = 1;
 }

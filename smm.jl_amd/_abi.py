@@ -148,7 +148,7 @@ def load():
     """dlopen libsmmhip.so (built by __graft_entry__.build() / csrc/Makefile). Fails loudly."""
     global _lib
     if _lib is None:
-        path = os.environ.get("SMMHIP_LIB", LIB_PATH)   # development hook: an alternative build of the same library
+        path = LIB_PATH
         if not os.path.exists(path):
             raise ImportError(
                 "libsmmhip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,9 +1,5 @@
-"""Thin object wrapper over the C ABI of include/smmhip.h.
-
-`BGPContext` drives any shared library that exports that ABI under a symbol prefix; the
-package itself only ever instantiates it on libsmmhip.so (prefix "smm_") through
-`hip_context(...)`.  There is deliberately no CPU code path in here.
-"""
+"""Thin object wrapper over the C ABI of include/smmhip.h (libsmmhip.so).
+There is deliberately no CPU code path in here."""
 import ctypes as C
 
 import numpy as np
@@ -82,11 +78,15 @@ class Tables:
 
 
 class BGPContext:
-    """One device context = the chains of one MAlgoBGP shard."""
+    """One device context of libsmmhip.so = the chains of one MAlgoBGP shard."""
 
-    def __init__(self, lib, prefix, problem, opts, tables=None):
-        self._lib = lib
-        self._p = prefix
+    _p = "smm_"   # symbol prefix of the C ABI
+
+    def __init__(self, problem, opts, tables=None):
+        self._lib = A.load()
+        self._create(problem, opts, tables)
+
+    def _create(self, problem, opts, tables):
         self.problem, self.opts = problem, opts
         self.tables = tables
         self._ctx = C.c_void_p()
@@ -221,5 +221,5 @@ def register_user_objective(source, n_sums=None, lanes=256):
 
 
 def hip_context(problem, opts, tables=None):
-    """The product constructor: a BGPContext on libsmmhip.so. Raises if the library is missing."""
-    return BGPContext(A.load(), "smm_", problem, opts, tables)
+    """A BGPContext on libsmmhip.so. Raises if the library is missing."""
+    return BGPContext(problem, opts, tables)

@@ -531,6 +531,21 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
     if (opts->batch_size < 1 || opts->batch_size > np || (np % opts->batch_size) != 0)
         return fail(nullptr, SMM_ERR_BAD_BATCH, "batch_size must divide the number of parameters (AlgoBGP.jl:95-103)");
     if (opts->sigma_update_steps < 1) return fail(nullptr, SMM_ERR_INVALID_ARG, "sigma_update_steps < 1");
+    if (opts->smpl_iters < 1) return fail(nullptr, SMM_ERR_INVALID_ARG, "smpl_iters < 1 (AlgoBGP.jl:521: at least one proposal try)");
+    // the exchange of iteration t reads the history of iteration t-1: the reference starts at algo.i >= 2 (AlgoBGP.jl:637)
+    if (opts->exchange_from_iter < 2) return fail(nullptr, SMM_ERR_INVALID_ARG, "exchange_from_iter < 2 (AlgoBGP.jl:637)");
+    if (!prob->init || !prob->lb || !prob->ub || !prob->mom || !prob->w)
+        return fail(nullptr, SMM_ERR_INVALID_ARG, "smm_problem_t: init / lb / ub / mom / w must not be NULL");
+    if (!opts->sigma || !opts->acc_tuner || !opts->min_improve)
+        return fail(nullptr, SMM_ERR_INVALID_ARG, "smm_bgp_opts_t: sigma / acc_tuner / min_improve must not be NULL (length N_global)");
+    if (prob->n_obj_params > 0 && !prob->obj_params) return fail(nullptr, SMM_ERR_INVALID_ARG, "n_obj_params > 0 but obj_params is NULL");
+    if (tab && tab->pairs && tab->n_pairs > 0) {   // injected pair lists: 0 <= i < j < N_global (16-bit packing in the plans)
+        for (size_t q = 0; q < (size_t)T * tab->n_pairs; ++q) {
+            const int32_t i = tab->pairs[2 * q], j = tab->pairs[2 * q + 1];
+            if (i < 0 || j <= i || j >= Ng) return fail(nullptr, SMM_ERR_INVALID_ARG, "smm_tables_t.pairs: need 0 <= i < j < N_global");
+        }
+    }
+    if (tab && tab->prop_normals && tab->prop_tries < 1) return fail(nullptr, SMM_ERR_INVALID_ARG, "prop_normals given but prop_tries < 1");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, SMM_ERR_NO_DEVICE, "no HIP device available: libsmmhip has no CPU fallback");

@@ -58,7 +58,7 @@ class ShardedBGP:
         self.local = engine.new_tensor((engine.N, engine.R))
         self.gathered = engine.new_tensor((self.world, engine.N, engine.R))  # == [N_global][R] in global chain order
         self.fused = hasattr(engine, "fused_step")
-        self.inplace_ok = True
+        self.inplace_ok = self._probe_inplace() if (self.fused and self.world > 1) else False
         if self.fused:   # two gather buffers alternate: iteration t reads donors from one, writes its records to the other
             self.gbuf = [self.gathered, engine.new_tensor((self.world, engine.N, engine.R))]
             self.gcur = None   # index of the buffer holding the gathered records of the last iteration
@@ -83,17 +83,29 @@ class ShardedBGP:
                     dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
                 e.exchange(self.gathered)
 
+    def _probe_inplace(self):
+        """ONE probe at construction: does the backend accept the aliased form (ncclAllGather with sendbuff == recvbuff +
+        rank * count; RCCL does, gloo does not)?  The answer is a property of the backend, so it is settled here, on a
+        scratch tensor, and never revisited: a failing collective during the run is an error, not a mode switch."""
+        t = self.e.new_tensor((self.world, 2))
+        try:
+            with self.e.stream_ctx():
+                dist.all_gather_into_tensor(t.view(-1), t[self.rank].view(-1), group=self.group)
+            ok = True
+        except (RuntimeError, ValueError):
+            ok = False
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=t.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)   # all ranks take the same path
+        return bool(flag.item())
+
     def _all_gather(self, buf):
-        """in place: this rank's slice is already where the collective wants it (ncclAllGather with
-        sendbuff == recvbuff + rank * count).  A backend that refuses aliased buffers gets a staged copy instead."""
+        """in place where the backend allows it: this rank's slice is already where the collective wants it; otherwise
+        through a staging copy of the slice.  Errors propagate."""
         if self.inplace_ok:
-            try:
-                dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].view(-1), group=self.group)
-                return
-            except RuntimeError:
-                self.inplace_ok = False
-        self.local.copy_(buf[self.rank])
-        dist.all_gather_into_tensor(buf.view(-1), self.local.view(-1), group=self.group)
+            dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].view(-1), group=self.group)
+        else:
+            self.local.copy_(buf[self.rank])
+            dist.all_gather_into_tensor(buf.view(-1), self.local.view(-1), group=self.group)
 
     def sync(self):
         """settle the last iteration into the context (history/state readable afterwards) and wait for the device"""

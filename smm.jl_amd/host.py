@@ -233,19 +233,27 @@ def fill(p, ev):
         setattr(p, k, v)
 
 
-_eval_ctx_cache = {}
+def _eval_context(m, prob):
+    """the device context behind evaluateObjective, kept on the MProb and rebuilt when anything it holds a device copy
+    of changes (dimensions, objective, data moments, weights, objective parameters; byte-wise, so NaN weights compare equal)"""
+    op = b"" if prob.obj_params is None else prob.obj_params.tobytes()
+    key = (prob.np, prob.nm, prob.ns, prob.objective_id, prob.mom.tobytes(), prob.w.tobytes(), op,
+           prob.init.tobytes(), prob.lb.tobytes(), prob.ub.tobytes())
+    cached = getattr(m, "_eval_ctx", None)
+    if cached is None or cached[0] != key:
+        if cached is not None:
+            cached[1].close()
+        opts = BGPOpts(N=1, maxiter=1, sigma=[0.05], acc_tuner=[1.0], min_improve=[0.0])
+        cached = (key, hip_context(prob, opts))
+        m._eval_ctx = cached
+    return cached[1]
 
 
 def evaluateObjective(m, p_or_ev):
     """evaluateObjective(m, p) / (m, ev), mprob.jl:175-205, as a batch of one on the device."""
     ev = p_or_ev if isinstance(p_or_ev, Eval) else Eval(m, p_or_ev)
     prob = _flat_problem(m)
-    key = id(m)
-    ctx = _eval_ctx_cache.get(key)
-    if ctx is None or ctx[0] != (prob.np, prob.nm, prob.ns, prob.objective_id, tuple(prob.mom), tuple(prob.w)):
-        opts = BGPOpts(N=1, maxiter=1, sigma=[0.05], acc_tuner=[1.0], min_improve=[0.0])
-        ctx = ((prob.np, prob.nm, prob.ns, prob.objective_id, tuple(prob.mom), tuple(prob.w)), hip_context(prob, opts))
-        _eval_ctx_cache[key] = ctx
+    ctx = (None, _eval_context(m, prob))
     names = ps2s_names(m)
     theta = np.array([[ev.params[k]] for k in names], float)
     t0 = _time.time()
@@ -417,7 +425,7 @@ class MAlgoBGP:
         bo = BGPOpts(N=N, maxiter=int(opts["maxiter"]), sigma=sigma, acc_tuner=self._acc_tuner,
                      min_improve=self._min_improve, batch_size=opts.get("batch_size", None),
                      seed=int(opts.get("seed", 12)), device=int(opts.get("device", 0)), **self._flat)
-        self._prob, self._bopts = prob, bo
+        self._prob, self._bopts, self._tables = prob, bo, tables
         self._ctx = hip_context(prob, bo, tables)
         self._hist = None
         self._st = None
@@ -443,9 +451,12 @@ class MAlgoBGP:
 
 
 def computeNextIteration(algo):
-    """computeNextIteration!(algo::MAlgoBGP), AlgoBGP.jl:589-640; run() sets algo.i beforehand"""
+    """computeNextIteration!(algo::MAlgoBGP), AlgoBGP.jl:589-640: one iteration of all chains + exchangeMoves!.
+    The reference's run! sets algo.i = i before the call (AlgoAbstract.jl:38-45); here algo.i is set to the iteration the
+    device has completed, so both `algo.i = i; computeNextIteration(algo)` and a bare call keep chains/history in step."""
     algo._ctx.step(1)
     algo._invalidate()
+    algo.i = algo._ctx.state().iter
 
 
 def run(algo):
@@ -503,7 +514,7 @@ def restart(algo, extra_iter):
     bo = algo._bopts
     bo.maxiter = algo.opts["maxiter"]
     algo._ctx.close()
-    algo._ctx = hip_context(algo._prob, bo)
+    algo._ctx = hip_context(algo._prob, bo, algo._tables)   # (injected randomness tables cover the old maxiter only)
     s.iter = algo.i
     algo._ctx.set_state(s, h)
     algo._invalidate()
@@ -514,12 +525,24 @@ def restart(algo, extra_iter):
 # Example drivers: Examples.jl:118-153 (serialNormal), :373-446 (snorm_impl)
 # ------------------------------------------------------------------------------------------
 def snorm_impl(opts, niter=200, npar=2):
-    if npar != 2:
-        raise NotImplementedError("snorm_impl(npar>2) draws its bounds from Julia's seeded global RNG (Examples.jl:390-405)")
+    """snorm_impl(opts, niter; npar), Examples.jl:373-416.  For npar > 2 the reference draws the extra parameters' bounds,
+    start values and target moments from Julia's global generator after Random.seed!(12) (:390-405); that stream cannot be
+    reproduced here, so the same construction draws from numpy's default_rng(12) (same ranges, different numbers)."""
     pb = OrderedDict()
     pb["p1"] = [0.2, -3, 3]
     pb["p2"] = [-0.2, -20, 20]
     moms = {"name": ["mu1", "mu2"], "value": [-1.0, 10.0], "weight": [1.0, 1.0]}
+    if npar > 2:
+        rng = np.random.default_rng(12)
+
+        def map_range(a1, a2, b1, b2, x):
+            return b1 + (x - a1) * (b2 - b1) / (a2 - a1)
+        spaces = np.concatenate([rng.random(2), [4.0 ** -4], (np.linspace(0.25, 0.45, npar - 1) ** -4.0)[::-1]])   # :391
+        for j in range(3, npar + 1):
+            sp = float(spaces[j - 1])
+            pb["p%d" % j] = [map_range(0, 1, -sp, sp, rng.random()), -sp, sp]
+            y = map_range(0, 1, -sp, sp, rng.random())
+            moms["name"].append("mu%d" % j); moms["value"].append(y); moms["weight"].append(y)
     mprob = MProb()
     addSampledParam(mprob, pb)
     addMoment(mprob, moms)

@@ -85,6 +85,53 @@ def test_invalid_arguments_are_rejected_before_touching_the_device():
     assert e.value.code == A.SMM_ERR_INVALID_ARG
 
 
+def test_zero_initialised_structs_and_bad_tables_are_rejected():
+    """a C or Julia caller with a zero-initialised opts struct, NULL vectors or an out-of-range injected pair list
+    gets SMM_ERR_INVALID_ARG with a message, not a segfault or a silently different algorithm (exchanges from iteration 1)"""
+    import numpy as np
+    import smm_jl_amd as S
+    import common as cm
+    lib = A.load()
+
+    def create(prob, opts, tab=None):
+        ps, os_ = prob.struct(), opts.struct(prob.np)
+        ts = tab.struct() if tab is not None else None
+        return ps, os_, ts
+
+    def rc_of(ps, os_, ts=None):
+        ctx = C.c_void_p()
+        rc = lib.smm_ctx_create(C.byref(ps), C.byref(os_), C.byref(ts) if ts is not None else None, C.byref(ctx))
+        assert not ctx.value
+        return rc, lib.smm_last_error(None).decode()
+
+    prob, opts = cm.serial_normal(N=3, T=4)
+    for field, value, word in (("exchange_from_iter", 0, "exchange_from_iter"), ("exchange_from_iter", 1, "exchange_from_iter"),
+                               ("smpl_iters", 0, "smpl_iters"), ("sigma_update_steps", 0, "sigma_update_steps")):
+        ps, os_, _ = create(prob, opts)
+        setattr(os_, field, value)
+        rc, msg = rc_of(ps, os_)
+        assert rc == A.SMM_ERR_INVALID_ARG and word in msg, (field, rc, msg)
+    for field in ("sigma", "acc_tuner", "min_improve"):
+        ps, os_, _ = create(prob, opts)
+        setattr(os_, field, None)
+        rc, msg = rc_of(ps, os_)
+        assert rc == A.SMM_ERR_INVALID_ARG and "NULL" in msg, field
+    for field in ("init", "lb", "ub", "mom", "w"):
+        ps, os_, _ = create(prob, opts)
+        setattr(ps, field, None)
+        rc, msg = rc_of(ps, os_)
+        assert rc == A.SMM_ERR_INVALID_ARG and "NULL" in msg, field
+    zero = A.smm_bgp_opts_t()      # all zeros
+    ps, _, _ = create(prob, opts)
+    assert rc_of(ps, zero)[0] in (A.SMM_ERR_INVALID_ARG, A.SMM_ERR_BAD_BATCH)
+    for bad in ([[0, 3]], [[2, 1]], [[1, 1]], [[-1, 2]]):
+        pairs = np.tile(np.array([[0, 1], [0, 2], [1, 2]], np.int32), (4, 1, 1))
+        pairs[2, 1] = bad[0]
+        ps, os_, ts = create(prob, opts, S.Tables(pairs=pairs))
+        rc, msg = rc_of(ps, os_, ts)
+        assert rc == A.SMM_ERR_INVALID_ARG and "pairs" in msg, bad
+
+
 def test_product_does_not_reference_the_oracle():
     """only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may touch oracle/"""
     pkg = os.path.join(ROOT, "smm.jl_amd")

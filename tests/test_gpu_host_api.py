@@ -103,3 +103,53 @@ def test_save_load_and_restart(tmp_path, O):
     assert MB.i == 25
     for f in S._abi.HistoryBuffers.FIELDS:
         assert np.array_equal(getattr(MB._history(), f), getattr(MC._history(), f), equal_nan=True), f
+
+
+def test_compute_next_iteration_direct_calls():
+    # computeNextIteration!(algo) called directly (the seam README.md:105-107 documents) keeps algo.i, chains
+    # and history in step with the device; equals run!
+    o = {"N": 3, "maxiter": 12, "maxtemp": 5, "smpl_iters": 1000, "min_improve": [0.0] * 3, "acc_tuners": [20.0, 2.0, 1.0]}
+    MA = S.MAlgoBGP(make_mprob(), dict(o))
+    for i in range(1, 13):
+        MA.i = i                      # as run! does, AlgoAbstract.jl:38-45
+        S.computeNextIteration(MA)
+        assert MA.i == i and MA.chains[0].iter == i and len(S.history(MA.chains[1])) == i
+    MB = S.MAlgoBGP(make_mprob(), dict(o))
+    for i in range(12):
+        S.computeNextIteration(MB)    # bare calls
+    MC = S.MAlgoBGP(make_mprob(), dict(o))
+    S.run(MC)
+    for f in S._abi.HistoryBuffers.FIELDS:
+        assert np.array_equal(getattr(MA._history(), f), getattr(MC._history(), f), equal_nan=True), f
+        assert np.array_equal(getattr(MB._history(), f), getattr(MC._history(), f), equal_nan=True), f
+
+
+def test_evaluate_objective_cache_follows_the_problem():
+    # the cached evaluation context must notice changed objective parameters / moments, and NaN weights must not
+    # rebuild it on every call
+    m = make_mprob()
+    m.objfunc = S.objfunc_norm
+    e1 = S.evaluateObjective(m, {"p1": 0.2, "p2": -0.2})
+    c1 = m._eval_ctx[1]
+    e2 = S.evaluateObjective(m, {"p1": 0.2, "p2": -0.2})
+    assert m._eval_ctx[1] is c1 and e1.value == e2.value
+    S.addMoment(m, "mu1", 5.0, 1.0)                      # a data moment changes: new device copy
+    e3 = S.evaluateObjective(m, {"p1": 0.2, "p2": -0.2})
+    assert m._eval_ctx[1] is not c1 and e3.value != e1.value
+    mn = S.MProb()
+    S.addSampledParam(mn, OrderedDict([("a", [0.0, -1, 1]), ("b", [0.0, -1, 1])]))
+    S.addMoment(mn, "mu1", 0.0, None); S.addMoment(mn, "mu2", 0.0, None)   # no weights: NaN
+    S.addEvalFunc(mn, S.objfunc_norm)
+    S.evaluateObjective(mn, {"a": 0.0, "b": 0.0})
+    cn = mn._eval_ctx[1]
+    S.evaluateObjective(mn, {"a": 0.1, "b": 0.0})
+    assert mn._eval_ctx[1] is cn
+
+
+def test_snorm_impl_more_parameters():
+    # snorm_impl(opts, niter; npar = 4), Examples.jl:390-405 (bounds from our own seeded generator): runs on the general kernel
+    opts = {"N": 4, "maxiter": 30, "maxtemp": 3, "smpl_iters": 1000, "min_improve": [0.0] * 4, "acc_tuners": [10.0, 5.0, 2.0, 1.0]}
+    MA = S.snorm_impl(opts, 30, npar=4)
+    h = S.history(MA.chains[0])
+    assert h.shape == (30, 11) and list(h.columns)[-4:] == ["p1", "p2", "p3", "p4"] and MA.i == 30
+    assert np.isfinite(h["value"]).all() and (np.diff(h["best_val"]) <= 0).all()
