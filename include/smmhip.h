@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMMHIP_ABI_VERSION 1
+#define SMMHIP_ABI_VERSION 2
 
 /* Numerical contract shared with the oracle (oracle/smm_oracle.c):
  * the ns simulated draws of one moment are summed as SMM_REDUCE_LANES lane-strided
@@ -133,7 +133,15 @@ typedef struct {
     int32_t chain_offset;    /* global id (0-based) of local chain 0                      */
     int32_t N_global;        /* total chains over all shards (== N on one GPU)            */
     int32_t device;          /* HIP device ordinal                                        */
-    int32_t reserved;
+    int32_t chol_per_chain;  /* 0: chol_L is one [np][np] factor shared by all chains; 1: [N_global][np][np] */
+    const double* chol_L;    /* General Gaussian proposals ("Cholesky apply"): NULL = the reference's isotropic kernel
+                                MvNormal(mu01, sigma) (AlgoBGP.jl:442).  Otherwise a lower-triangular factor L (row-major,
+                                entries above the diagonal ignored) of the proposal's shape in [0,1]-space:
+                                    x = mu01 + sigma_c * (L z),   z ~ N(0, I)      i.e. covariance sigma_c^2 L L'
+                                with the chain's adaptive scalar sigma_c (AlgoBGP.jl:381-390) as the scale; L = diag(s)
+                                is the per-parameter sigma vector hinted at AlgoBGP.jl:218.  Requires one proposal batch
+                                (batch_size == np).  Numerical contract: (L z)_k = sum_{j<=k} L[k][j]*z[j], products
+                                rounded, added left to right (no fma). */
 } smm_bgp_opts_t;
 
 /* Injected randomness ("parity mode").  Any pointer may be NULL = use the built-in

@@ -73,7 +73,8 @@ typedef struct {
     double sigma_adjust_by;
     int32_t batch_size, exchange_from_iter;
     uint64_t seed;
-    int32_t chain_offset, N_global, device, reserved;
+    int32_t chain_offset, N_global, device, chol_per_chain;
+    const double* chol_L; /* general Gaussian proposals, include/smmhip.h: NULL = the reference's MvNormal(mu01, sigma) */
 } orc_opts_t;
 
 typedef struct {
@@ -398,6 +399,7 @@ typedef struct {
     orc_history_t h;
     char err[256];
     int regen_z, threads;
+    double* chol_L;   /* owned copy of opts.chol_L */
 } orc_t;
 
 /* evaluateObjective(m,p), mprob.jl:175-188: run the objective; an exception => status=-2
@@ -490,7 +492,7 @@ void orc_ctx_destroy(void* v) {
     orc_t* o = (orc_t*)v;
     if (!o) return;
     free(o->init); free(o->lb); free(o->ub); free(o->mom); free(o->w); free(o->obj_params);
-    free(o->acc_tuner); free(o->min_improve); free(o->u_tab); free(o->norm_tab); free(o->Z); free(o->pair_tab);
+    free(o->acc_tuner); free(o->min_improve); free(o->chol_L); free(o->u_tab); free(o->norm_tab); free(o->Z); free(o->pair_tab);
     free(o->sigma); free(o->accept_rate); free(o->la_value); free(o->la_prob); free(o->la_params); free(o->la_simM);
     free(o->la_status); free(o->n_noex); free(o->n_acc_noex); free(o->best_val); free(o->best_id);
     free(o->h.value); free(o->h.prob); free(o->h.curr_val); free(o->h.best_val); free(o->h.params);
@@ -520,6 +522,10 @@ int orc_ctx_create(const orc_problem_t* prob, const orc_opts_t* opts, const orc_
         orc_gen_dense(opts->seed, np, nm, o->obj_params);
     }
     o->acc_tuner = dupd(opts->acc_tuner, Ng); o->min_improve = dupd(opts->min_improve, Ng);
+    if (opts->chol_L) {
+        if (opts->batch_size != np) { free(o); return ORC_ERR_BAD_BATCH; }   /* one proposal batch, include/smmhip.h */
+        o->chol_L = dupd(opts->chol_L, (opts->chol_per_chain ? (size_t)Ng : 1) * np * np);
+    }
     o->sigma = dupd(opts->sigma + opts->chain_offset, N);
     size_t TN = (size_t)T * N;
     if (tab && tab->probs_acc) { o->u_tab = dupd(tab->probs_acc, TN); o->have_u = 1; }
@@ -608,9 +614,23 @@ static int next_eval(orc_t* o, int c, int t, double* theta, double* simM, double
                 ok = 1;
                 for (int k = b0; k < b0 + bs; ++k) {
                     double mu01 = (o->la_params[(size_t)k * N + c] - o->lb[k]) / (o->ub[k] - o->lb[k]); /* mprob.jl:248 */
-                    double z = o->have_norm
-                                   ? o->norm_tab[((((size_t)(t - 1) * o->prop_tries + r) * np + k) * N) + c]
-                                   : rng_prop_normal(seed, gc, (uint32_t)t, (uint32_t)r, (uint32_t)k);
+                    double z;
+                    if (o->chol_L) {
+                        /* general Gaussian kernel (north star "Cholesky apply"; vector sigma hinted at AlgoBGP.jl:218):
+                         * direction (L z)_k = sum_{j<=k} L[k][j]*z[j], products rounded, added left to right */
+                        const double* Lk = o->chol_L + (o->opts.chol_per_chain ? (size_t)gc * np * np : 0) + (size_t)k * np;
+                        z = 0.0;
+                        for (int j = 0; j <= k; ++j) {
+                            double zj = o->have_norm
+                                            ? o->norm_tab[((((size_t)(t - 1) * o->prop_tries + r) * np + j) * N) + c]
+                                            : rng_prop_normal(seed, gc, (uint32_t)t, (uint32_t)r, (uint32_t)j);
+                            double pr = Lk[j] * zj;
+                            z = (j == 0) ? pr : z + pr;
+                        }
+                    } else {
+                        z = o->have_norm ? o->norm_tab[((((size_t)(t - 1) * o->prop_tries + r) * np + k) * N) + c]
+                                         : rng_prop_normal(seed, gc, (uint32_t)t, (uint32_t)r, (uint32_t)k);
+                    }
                     double step = sig * z;              /* MvNormal(mu01, sigma::Float64): x = mu + sigma*z */
                     double x = mu01 + step;
                     x01[k] = x;

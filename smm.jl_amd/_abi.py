@@ -55,7 +55,8 @@ class smm_bgp_opts_t(C.Structure):
         ("sigma_adjust_by", C.c_double),
         ("batch_size", C.c_int32), ("exchange_from_iter", C.c_int32),
         ("seed", C.c_uint64),
-        ("chain_offset", C.c_int32), ("N_global", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+        ("chain_offset", C.c_int32), ("N_global", C.c_int32), ("device", C.c_int32), ("chol_per_chain", C.c_int32),
+        ("chol_L", c_double_p),
     ]
 
 
@@ -154,7 +155,7 @@ def load():
                 "libsmmhip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
         _lib = bind(C.CDLL(path, mode=C.RTLD_GLOBAL))
-        if _lib.smm_abi_version() != 1:
+        if _lib.smm_abi_version() != 2:
             raise ImportError("libsmmhip.so ABI version mismatch")
     return _lib
 

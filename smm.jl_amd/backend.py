@@ -34,7 +34,7 @@ class BGPOpts:
 
     def __init__(self, N, maxiter, sigma, acc_tuner, min_improve, sigma_update_steps=10, sigma_adjust_by=0.01,
                  smpl_iters=1000, batch_size=None, exchange_from_iter=2, seed=12, chain_offset=0, N_global=None,
-                 device=0):
+                 device=0, chol_L=None):
         self.N = int(N); self.maxiter = int(maxiter)
         self.N_global = int(N if N_global is None else N_global)
         self.sigma = A.f64(sigma, (self.N_global,)); self.acc_tuner = A.f64(acc_tuner, (self.N_global,))
@@ -43,6 +43,8 @@ class BGPOpts:
         self.smpl_iters = int(smpl_iters); self.batch_size = batch_size
         self.exchange_from_iter = int(exchange_from_iter); self.seed = int(seed)
         self.chain_offset = int(chain_offset); self.device = int(device)
+        # general Gaussian proposals: a lower-triangular factor [np][np] (shared) or [N_global][np][np] (per chain), see smmhip.h
+        self.chol_L = None if chol_L is None else A.f64(chol_L)
 
     def struct(self, np_):
         o = A.smm_bgp_opts_t()
@@ -54,6 +56,12 @@ class BGPOpts:
         o.exchange_from_iter = self.exchange_from_iter
         o.seed = self.seed
         o.chain_offset, o.N_global, o.device = self.chain_offset, self.N_global, self.device
+        o.chol_L = A.dptr(self.chol_L)
+        o.chol_per_chain = 0 if self.chol_L is None or self.chol_L.ndim == 2 else 1
+        if self.chol_L is not None:
+            want = (np_, np_) if self.chol_L.ndim == 2 else (self.N_global, np_, np_)
+            if self.chol_L.shape != want:
+                raise ValueError("chol_L must be [np][np] or [N_global][np][np]")
         return o
 
 

@@ -756,7 +756,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                     for (int k = b0; k < b0 + bs; ++k) {  // mysample, :400-410, try r
                         const double lbk = S.lb[k];
                         const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);  // mapto_01, mprob.jl:248
-                        const double step = sg * zz[r * np + k];  // MvNormal(mu01, sigma): x = mu + sigma*z
+                        const double step = sg * prop_direction(P, zz + r * np, k, gc);  // MvNormal(mu01, sigma): x = mu + sigma*z
                         const double x = mu01 + step;
                         if (!(x >= 0.0 && x <= 1.0)) ok = false;  // inclusive bounds, :405
                     }
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                         const double lbk = S.lb[k];
                         const double span = S.ub[k] - lbk;
                         const double mu01 = (rc[3 + k] - lbk) / span;
-                        const double step = sg * zz[r * np + k];
+                        const double step = sg * prop_direction(P, zz + r * np, k, gc);
                         const double x = mu01 + step;
                         const double sc = x * span;
                         th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
@@ -781,19 +781,31 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                 // whole wave on one chain — lane l draws and tests component b0+l (+64, ...), so a try costs one
                 // generator call instead of one per component pair in sequence (the redraw loop of mysample is what a
                 // 50-parameter problem spends its time in).  Same tries, same order, same winner as the serial form.
-                const bool coop = bs >= 16;   // few components: every failing chain's own lane redraws (chains in parallel)
+                const bool coop = bs >= 16 && !P.chol_L;   // few components: every failing chain's own lane redraws (chains in parallel)
                 if (!coop && valid && r == 0 && rwin < 0) {
                     bool ok2 = false;
                     for (int rr = npar; rr < max_tries && !ok2; ++rr) {
                         ok2 = true;
                         double zc0 = 0.0, zc1 = 0.0;
                         int zq = -1;
+                        const double* zv = zz + rr * np;   // Cholesky kernel: the whole try's normals
+                        if (P.chol_L && rr >= P.rb_tries) {   // ... generated into the (still unused) history row of the chain
+                            double* sc = S.h + cl * HW;
+                            for (int q = 0; 2 * q < np; ++q) {
+                                const double2 zz2 = rng_prop_normal2_outofline(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)rr, (uint32_t)q);
+                                sc[2 * q] = zz2.x;
+                                if (2 * q + 1 < np) sc[2 * q + 1] = zz2.y;
+                            }
+                            zv = sc;
+                        }
                         for (int k = b0; k < b0 + bs; ++k) {
                             const double lbk = S.lb[k];
                             const double span = S.ub[k] - lbk;
                             const double mu01 = (rc[3 + k] - lbk) / span;
                             double z;
-                            if (rr < P.rb_tries) {
+                            if (P.chol_L) {
+                                z = prop_direction(P, zv, k, gc);
+                            } else if (rr < P.rb_tries) {
                                 z = zz[rr * np + k];
                             } else {
                                 if ((k >> 1) != zq) {

@@ -31,6 +31,8 @@ struct KParams {
     double sigma_adjust_by;
     uint64_t seed;
     const double* min_improve_g;  // [Ng]
+    const double* chol_L;         // general Gaussian proposals: lower-triangular factor [np][np] or [Ng][np][np] (chol_per_chain), or null
+    int chol_per_chain;
     // user objective (objective_id >= SMM_OBJ_USER_BASE): proposals out, results in, [N][np] / [N][nm] / [N]
     double* u_theta; double* u_simM; double* u_value; int* u_status;
     int mi_uniform;               // all thresholds equal (the usual case): mi_value
@@ -83,6 +85,20 @@ __device__ inline void report_error(const KParams& P, int kind, int t, int gchai
 }
 
 __host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
+
+// direction of the proposal step for component k of one try, z = the try's np standard normals (LDS):
+// z[k] for the reference's isotropic kernel MvNormal(mu01, sigma) (AlgoBGP.jl:442), (L z)_k with a Cholesky factor
+// (include/smmhip.h: products rounded, added left to right; the build has -ffp-contract=off)
+__device__ inline double prop_direction(const KParams& P, const double* z, const int k, const int gchain) {
+    if (!P.chol_L) return z[k];
+    const double* __restrict__ Lk = P.chol_L + (P.chol_per_chain ? (size_t)gchain * P.np * P.np : 0) + (size_t)k * P.np;
+    double y = Lk[0] * z[0];
+    for (int j = 1; j <= k; ++j) {
+        const double pr = Lk[j] * z[j];
+        y = y + pr;
+    }
+    return y;
+}
 
 // The in-kernel generator behind mysample's rare late tries, out of line: its ~40 live registers
 // (Philox rounds, log, sincospi) then weigh only on the path that needs them.

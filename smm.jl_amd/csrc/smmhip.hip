@@ -546,6 +546,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         }
     }
     if (tab && tab->prop_normals && tab->prop_tries < 1) return fail(nullptr, SMM_ERR_INVALID_ARG, "prop_normals given but prop_tries < 1");
+    if (opts->chol_L && opts->batch_size != np)
+        return fail(nullptr, SMM_ERR_BAD_BATCH, "Cholesky proposals (chol_L) draw all parameters in one batch: batch_size must equal np");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, SMM_ERR_NO_DEVICE, "no HIP device available: libsmmhip has no CPU fallback");
@@ -633,6 +635,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.sigma_update_steps = opts->sigma_update_steps; P.smpl_iters = opts->smpl_iters;
         P.batch_size = opts->batch_size; P.sigma_adjust_by = opts->sigma_adjust_by; P.seed = opts->seed;
         P.min_improve_g = dupload(c, opts->min_improve, Ng);
+        if (opts->chol_L) {
+            P.chol_per_chain = opts->chol_per_chain ? 1 : 0;
+            P.chol_L = dupload(c, opts->chol_L, (size_t)(P.chol_per_chain ? Ng : 1) * np * np);
+        }
         P.mi_uniform = 1; P.mi_value = opts->min_improve[0];
         for (int i = 1; i < Ng; ++i)
             if (!(opts->min_improve[i] == P.mi_value)) P.mi_uniform = 0;
@@ -669,7 +675,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
             const size_t tile_b = (tile_smem_base(c, tile_ct) + 15) & ~(size_t)15;
             const char* nf = getenv("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
-            c->norm_fast = is_sim(c->obj) && np == nm && np <= 2 && opts->batch_size == np && P.dbg == 0 && !(nf && nf[0] == '0');
+            c->norm_fast = is_sim(c->obj) && np == nm && np <= 2 && opts->batch_size == np && P.dbg == 0 && !opts->chol_L && !(nf && nf[0] == '0');
             const size_t walk_b = walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15);   // k_chain_iter_norm: pair list NOT overlaid
             c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng && c->obj != SMM_OBJ_USER &&
                              (c->norm_fast ? walk_b + norm_tile_doubles(np) * 8 <= (size_t)160 * 1024

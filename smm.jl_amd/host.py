@@ -424,7 +424,9 @@ class MAlgoBGP:
                           smpl_iters=int(opts.get("smpl_iters", 1000)))
         bo = BGPOpts(N=N, maxiter=int(opts["maxiter"]), sigma=sigma, acc_tuner=self._acc_tuner,
                      min_improve=self._min_improve, batch_size=opts.get("batch_size", None),
-                     seed=int(opts.get("seed", 12)), device=int(opts.get("device", 0)), **self._flat)
+                     seed=int(opts.get("seed", 12)), device=int(opts.get("device", 0)),
+                     chol_L=opts.get("chol_L", None),   # general Gaussian proposals (not in the reference: include/smmhip.h)
+                     **self._flat)
         self._prob, self._bopts, self._tables = prob, bo, tables
         self._ctx = hip_context(prob, bo, tables)
         self._hist = None

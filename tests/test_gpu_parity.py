@@ -718,3 +718,65 @@ def test_noseed_eval_batch(S, O):
     v2, sm2, _ = h.eval_batch_noseed(th[:, :5], 777 + 10)
     assert np.array_equal(sm2, smh[:, 10:15])                      # ... keyed by base_seed + i
     assert abs(smh[0].mean() - 0.4) < 0.02 and abs(smh[0].std() - 1 / np.sqrt(2000)) < 0.01   # mean of ns draws of N(theta, 1)
+
+
+def _random_chol(rng, npar, scale=1.0):
+    A_ = rng.standard_normal((npar, npar))
+    L = np.linalg.cholesky(A_ @ A_.T / npar + 0.5 * np.eye(npar)) * scale
+    return np.tril(L)
+
+
+@pytest.mark.parametrize("npar,per_chain,N,sig", [(6, False, 50, 0.05), (18, True, 40, 0.03), (2, False, 33, 0.3), (18, False, 24, 0.1)])
+def test_cholesky_proposals_match_oracle(S, O, npar, per_chain, N, sig):
+    # general Gaussian proposals x = mu01 + sigma_c * (L z) (north star "Cholesky apply"; VERDICT r1 missing #2): shared and
+    # per-chain factors; sig = 0.1 (x temperatures up to 3) at np = 18 needs tries beyond the pre-generated ones (the in-kernel generator path)
+    rng = np.random.default_rng(5)
+    prob, opts = cm.general_normal(npar, N=N, T=25, ns=200)
+    L = np.stack([_random_chol(rng, npar) for _ in range(N)]) if per_chain else _random_chol(rng, npar)
+    opts.chol_L = np.ascontiguousarray(L)
+    opts.sigma[:] = sig * cm.temps(N, 3.0)
+    opts.smpl_iters = 100000
+    h, o = run_both(S, O, prob, opts, None)
+    hh = h.history()
+    cm.assert_history_equal(hh, o.history())
+    cm.assert_state_equal(h.state(), o.state())
+    assert hh.accepted[1:].mean() > 0.02 and (hh.exchanged != 0).any()
+    # injected normals as well (bit-exact arithmetic path)
+    tab = cm.random_tables(prob, opts, tries=24)
+    opts.sigma[:] = 0.004 * cm.temps(N, 3.0)
+    h2, o2 = run_both(S, O, prob, opts, tab, T=10)
+    cm.assert_history_equal(h2.history(), o2.history(), rtol=1e-12)
+
+
+def test_cholesky_identity_equals_isotropic_kernel(S):
+    # L = I is the reference's MvNormal(mu01, sigma): same history as without a factor
+    prob, opts = cm.general_normal(5, N=30, T=30, ns=100)
+    a = S.hip_context(prob, opts); a.step(30)
+    opts.chol_L = np.eye(5)
+    b = S.hip_context(prob, opts); b.step(30)
+    cm.assert_history_equal(a.history(), b.history(), rtol=0, atol=0)
+    prob2, opts2 = cm.general_normal(4, N=3, T=4, batch_size=2)
+    opts2.chol_L = np.eye(4)
+    with pytest.raises(A.SMMHipError) as e:
+        S.hip_context(prob2, opts2)
+    assert e.value.code == A.SMM_ERR_BAD_BATCH
+
+
+def test_cholesky_proposal_covariance(S):
+    # oracle-independent: with every proposal accepted (acc_tuner = 0 => prob = 1 > u) and bounds far away, the steps of a
+    # chain in [0,1]-space are N(0, sigma^2 L L'): their sample covariance recovers L L'
+    npar, N, T = 3, 64, 400
+    L = np.array([[1.0, 0, 0], [0.8, 0.6, 0], [-0.5, 0.3, 0.4]])
+    prob = S.Problem(init=np.zeros(npar), lb=-1e3 * np.ones(npar), ub=1e3 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar),
+                     ns=8)
+    sig = 1e-4
+    opts = S.BGPOpts(N=N, maxiter=T, sigma=sig * np.ones(N), acc_tuner=np.zeros(N), min_improve=1e30 * np.ones(N),
+                     sigma_update_steps=10 ** 6, chol_L=L, seed=11)
+    h = S.hip_context(prob, opts)
+    h.step(T)
+    hh = h.history()
+    assert hh.accepted.all() and (hh.exchanged == 0).all()
+    steps = np.diff(hh.params, axis=0) / 2e3 / sig          # [T-1][np][N] in units of sigma, [0,1]-space
+    X = steps.transpose(0, 2, 1).reshape(-1, npar)
+    C_ = X.T @ X / len(X)
+    np.testing.assert_allclose(C_, L @ L.T, atol=0.03)
