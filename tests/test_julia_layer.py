@@ -1,0 +1,161 @@
+"""The Julia host layer (julia/SMMHip.jl, julia/SMMHipBackend.jl) cannot be executed here (no julia binary in the image).
+What can be checked without one: the `struct` blocks mirror include/smmhip.h field for field (names, order, C offsets,
+sizes — against a compiled probe of the header), every `ccall` names an exported symbol with the header's argument count,
+the glue has the reference's field names and defines the methods SMM.jl dispatches on, and the block structure of both
+files is balanced (a coarse syntax check)."""
+import os
+import re
+import subprocess
+import tempfile
+
+from smm_jl_amd import _abi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAW = os.path.join(ROOT, "julia", "SMMHip.jl")
+GLUE = os.path.join(ROOT, "julia", "SMMHipBackend.jl")
+HEADER = os.path.join(ROOT, "include", "smmhip.h")
+
+JL2C = {"SmmProblem": "smm_problem_t", "SmmBgpOpts": "smm_bgp_opts_t", "SmmTables": "smm_tables_t",
+        "SmmHistory": "smm_history_t", "SmmState": "smm_state_t", "SmmTiming": "smm_timing_t"}
+# Julia type -> (size, alignment, C spelling as it appears in the header)
+JLTYPES = {"Cint": (4, 4, "int32_t"), "Int32": (4, 4, "int32_t"), "Cdouble": (8, 8, "double"), "UInt64": (8, 8, "uint64_t"),
+           "Int64": (8, 8, "int64_t"), "UInt8": (1, 1, "uint8_t"), "Int8": (1, 1, "int8_t")}
+PTR_TARGET = {"Cdouble": "double", "Int32": "int32_t", "UInt8": "uint8_t", "Int8": "int8_t", "Cvoid": "void"}
+
+
+def strip_julia(src):
+    """drop comments, docstrings and string literals (keeps the code's block structure)"""
+    src = re.sub(r'"""(?:.|\n)*?"""', '""', src)
+    src = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', src)
+    src = re.sub(r"#=(?:.|\n)*?=#", "", src)
+    return "\n".join(l.split("#", 1)[0] for l in src.splitlines())
+
+
+def julia_structs(path):
+    src = strip_julia(open(path).read())
+    out = {}
+    for m in re.finditer(r"^\s*(?:mutable\s+)?struct\s+(\w+)(?:\s*<:\s*[\w.]+)?\s*\n(.*?)^\s*end\b", src, re.S | re.M):
+        fields = []
+        for line in m.group(2).splitlines():
+            for part in line.split(";"):
+                part = part.strip()
+                if not part:
+                    continue
+                fm = re.match(r"(\w+)\s*::\s*(.+)$", part)
+                assert fm, (m.group(1), part)
+                fields.append((fm.group(1), fm.group(2).strip()))
+        out[m.group(1)] = fields
+    return out
+
+
+def header_structs():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", src, re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            dm = re.match(r"(?:const\s+)?(\w+)\s*(\*?)\s*(\w+)$", decl)
+            assert dm, decl
+            fields.append((dm.group(3), dm.group(1) + ("*" if dm.group(2) else "")))
+        out[m.group(2)] = fields
+    return out
+
+
+def test_struct_mirrors_match_the_header_field_for_field():
+    js, hs = julia_structs(RAW), header_structs()
+    assert set(JL2C) <= set(js), "SMMHip.jl lacks a struct: %s" % (set(JL2C) - set(js))
+    # offsets and sizes of the C side, from the compiler
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "smmhip.h"', "int main(void) {"]
+    for cname, fields in hs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in fields:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines.append("return 0; }")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write("\n".join(lines))
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
+        c = dict(l.rsplit(" ", 1) for l in subprocess.check_output([os.path.join(d, "p")]).decode().strip().splitlines())
+    for jname, cname in JL2C.items():
+        jf, hf = js[jname], hs[cname]
+        assert [f for f, _ in jf] == [f for f, _ in hf], "%s: field names / order differ from %s" % (jname, cname)
+        off = 0
+        maxal = 1
+        for (fname, jt), (_, ct) in zip(jf, hf):
+            pm = re.match(r"Ptr\{(\w+)\}$", jt)
+            if pm:
+                size, al = 8, 8
+                assert ct.endswith("*") and ct[:-1] == PTR_TARGET[pm.group(1)], "%s.%s: %s vs %s" % (jname, fname, jt, ct)
+            else:
+                assert jt in JLTYPES, "%s.%s: unknown Julia type %s" % (jname, fname, jt)
+                size, al, cspell = JLTYPES[jt]
+                assert ct == cspell, "%s.%s: %s vs %s" % (jname, fname, jt, ct)
+            off = (off + al - 1) // al * al
+            assert off == int(c["%s.%s" % (cname, fname)]), "%s.%s: offset %d, C has %s" % (jname, fname, off, c["%s.%s" % (cname, fname)])
+            off += size
+            maxal = max(maxal, al)
+        assert (off + maxal - 1) // maxal * maxal == int(c[cname]), "%s: size" % jname
+
+
+def test_every_ccall_names_an_exported_symbol_with_the_right_arity():
+    table = {name: args for name, _, args in A.SYMBOLS}
+    seen = set()
+    for path in (RAW, GLUE):
+        src = strip_julia(open(path).read())
+        for m in re.finditer(r"ccall\(\s*(?:sym\(:(\w+)\)|Libdl\.dlsym\(LIB\[\],\s*:(\w+)\))\s*,\s*(\w+)\s*,\s*\(([^()]*(?:\{[^()]*\}[^()]*)*)\)", src):
+            name = m.group(1) or m.group(2)
+            args = [a for a in (x.strip() for x in m.group(4).split(",")) if a]
+            assert name in table, "ccall of %s: not a symbol of include/smmhip.h" % name
+            assert len(args) == len(table[name]), "ccall of %s passes %d arguments, the header declares %d" % (name, len(args), len(table[name]))
+            seen.add(name)
+    need = {"smm_abi_version", "smm_ctx_create", "smm_ctx_destroy", "smm_last_error", "smm_bgp_step", "smm_get_history", "smm_get_state",
+            "smm_set_state", "smm_eval_batch", "smm_register_user_objective"}
+    assert need <= seen, need - seen
+    assert "ABI_VERSION = %d" % A.load().smm_abi_version() in open(RAW).read()
+
+
+def test_glue_has_the_reference_shape():
+    glue = strip_julia(open(GLUE).read())
+    st = julia_structs(GLUE)["MAlgoBGPHip"]
+    # the fields the reference's generic code touches, in the reference's order (MAlgoBGP, src/mopt/AlgoBGP.jl:497-503)
+    assert [f for f, _ in st][:6] == ["m", "opts", "i", "chains", "anim", "dist_fun"]
+    assert dict(st)["chains"] == "Vector{BGPChain}" and dict(st)["m"] == "MProb" and dict(st)["i"] == "Int"
+    assert re.search(r"mutable struct MAlgoBGPHip <: MAlgo", glue)
+    # the method SMM.jl dispatches on (src/mopt/AlgoAbstract.jl:45) and the readers / persistence of src/SMM.jl:31-57
+    for sig in (r"function computeNextIteration!\(algo::MAlgoBGPHip\)", r"function run!\(algo::MAlgoBGPHip\)",
+                r"summary\(algo::MAlgoBGPHip\)", r"save\(algo::MAlgoBGPHip, filename::AbstractString\)",
+                r"function restart!\(algo::MAlgoBGPHip, extraIter::Int\)", r"function MAlgoBGPHip\(m::MProb, opts::Dict\)",
+                r"function MAlgoBGPHip\(ref::MAlgoBGP;", r"function getproperty\(algo::MAlgoBGPHip, s::Symbol\)",
+                r"function sync_chains!\(algo::MAlgoBGPHip\)"):
+        assert re.search(sig, glue), sig
+    imports = re.search(r"import SMM:([^\n]*\n[^\n]*)", glue).group(1)
+    for name in ("computeNextIteration!", "run!", "summary", "save", "restart!", "MAlgo", "BGPChain", "Eval", "MProb"):
+        assert name in imports, name
+    # every BGPChain field the sync fills exists in the reference's struct (src/mopt/AlgoBGP.jl:42-60)
+    for f in ("evals", "accepted", "exchanged", "best_val", "best_id", "curr_val", "iter", "sigma", "accept_rate"):
+        assert re.search(r"\bc\.%s\b" % f, glue), f
+    for f in ("value", "prob", "accepted", "status", "params", "simMoments"):      # Eval fields, src/mopt/Eval.jl
+        assert re.search(r"\bev\.%s\b" % f, glue), f
+
+
+def test_block_structure_is_balanced():
+    """coarse syntax check: block openers at bracket depth 0 and `end`s balance, brackets balance"""
+    openers = {"module", "struct", "function", "if", "for", "while", "begin", "let", "try", "do", "macro", "quote"}
+    for path in (RAW, GLUE):
+        src = strip_julia(open(path).read())
+        depth, blocks = 0, 0
+        for tok in re.findall(r"[A-Za-z_]\w*!?|[()\[\]{}]", src):
+            if tok in "([{":
+                depth += 1
+            elif tok in ")]}":
+                depth -= 1
+                assert depth >= 0, path
+            elif tok == "end":
+                if depth == 0:      # a[end] / x[1:end] inside brackets is an index, not a block end
+                    blocks -= 1
+                    assert blocks >= 0, path
+            elif tok in openers and depth == 0:
+                blocks += 1
+        assert depth == 0 and blocks == 0, (path, depth, blocks)
