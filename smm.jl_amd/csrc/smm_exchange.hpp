@@ -584,3 +584,216 @@ __global__ void k_exch_apply(const KParams P, const int t, const double* __restr
     for (int k = 0; k < P.np + P.nm; ++k) hrec[H_PARAMS + k] = donor[3 + k];
     for (int f = 0; f < RW; ++f) rec[(size_t)c * RW + f] = donor[f];
 }
+
+// ------------------------------------------------------------------------------------------
+// k_exch_resolve_key: exchangeMoves! for 8192 < N_global <= 32768 (the 4- and 8-GPU populations) with the walk's state in
+// LDS.  A chain's slot is 4 bytes — src (16 bits: whose record sits here) and a 16-bit ORDER KEY of that record's value — so
+// 32768 chains take 128 KB.  The key is a bucket number of the value's high word (exponent | 20 mantissa bits, monotone for
+// values >= 0) on a fixed scale (order_key16).  A pair whose two buckets decide the test `value_i - value_j > min_improve_i` (AlgoBGP.jl:688) for
+// every pair of values in them is resolved from LDS alone; an undecided pair reads the two exact values from memory.  Swaps
+// exchange the 4-byte slots and set the pair's bit in an LDS bitmap; the last exchange partner of every chain
+// (set_exchanged!, :747-748) is recovered afterwards with one LDS atomic max per swapped endpoint (ordered by the position in
+// the level order, which respects every chain's own order).  Same plan, same result as the other kernels.
+// (The level walk of k_exch_resolve_lvl_big keeps 16-byte slots in global memory: one CU's address path bounds it at ~100 us
+// for 32768 chains.)
+// ------------------------------------------------------------------------------------------
+constexpr int XKEY_MAX = 32768;
+// up to XKEY_PARTNER_MAX chains the last partner of every chain has its own 2-byte LDS array, written in the swap itself
+constexpr int XKEY_PARTNER_MAX = 24576;
+__host__ __device__ inline size_t resolve_key_bytes(int Ng, int K) {
+    return (size_t)Ng * 4 + (Ng <= XKEY_PARTNER_MAX ? (size_t)(Ng + 4) * 2 : (((size_t)K + 63) / 64) * 8) + 256;
+}
+
+// Order keys are computed from the HIGH WORD of the value (sign, exponent, 20 mantissa bits): for finite values >= 0 it is a
+// monotone function of the value, and 32-bit integer arithmetic is all the key needs.  The scale is fixed: buckets of 2^10
+// high-word steps (a factor 1 + 2^-10 apart, ~3 decimal digits) from 2^-48 upwards, 0xfff0 of them (up to 2^15.9 ~ 6e4);
+// smaller values share bucket 0, larger ones the last bucket — undecided among themselves, still ordered against the rest.
+// Negative values (the -1.0 of a failed objective, Eval.jl:84) and non-finite ones get the undecidable mark 0xffff.
+constexpr uint32_t XKEY_BASE = (1023u - 48u) << 20, XKEY_SHIFT = 10, XKEY_TOP = 0xfff0u;
+__host__ __device__ inline uint32_t order_key16(const double v) {
+    const uint32_t hw = (uint32_t)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    if (hw >= 0x7ff00000u) return 0xffffu;                   // negative, infinite or NaN: always the exact values
+    if (hw < XKEY_BASE) return 0u;
+    const uint32_t k = 1u + ((hw - XKEY_BASE) >> XKEY_SHIFT);
+    return k < XKEY_TOP ? k : XKEY_TOP;
+}
+// bounds of a bucket: lo inclusive, hi exclusive (bucket 0: [0, 2^-48); the last bucket: up to +inf)
+__device__ inline double order_key_lo(const uint32_t k) { return k == 0 ? 0.0 : __hiloint2double((int)(XKEY_BASE + ((k - 1) << XKEY_SHIFT)), 0); }
+__device__ inline double order_key_hi(const uint32_t k) {
+    return k >= XKEY_TOP ? INFINITY : __hiloint2double((int)(XKEY_BASE + (k << XKEY_SHIFT)), 0);
+}
+
+// k_exch_keys: by the whole chip, before the one resolving workgroup starts: the value column of the gathered records
+// ([Ng][RW], or the compact array of a single shard with RW = 1) as a compact array, and every chain's initial 4-byte slot
+// (src = itself | key << 16).  A strided read and 32768 key computations by ONE workgroup cost more than the walk itself.
+__global__ void k_exch_keys(const double* __restrict__ gathered, const int RW, const int Ng, double* __restrict__ vals_out,
+                            uint32_t* __restrict__ slots_out) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= Ng) return;
+    const double v = gathered[(size_t)g * RW];
+    if (vals_out != gathered) vals_out[g] = v;
+    slots_out[g] = (uint32_t)g | (order_key16(v) << 16);
+}
+
+template <bool PLDS>   // PLDS: partners in LDS (N_global <= XKEY_PARTNER_MAX); else the bitmap + partner pass
+__global__ __launch_bounds__(XWG) void k_exch_resolve_key(const KParams P, const int t, const double* __restrict__ vals,
+                                                          const uint32_t* __restrict__ slots0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ng = P.Ng, K = P.plan_K;
+    const int w = t - P.plan_t0;
+    uint32_t* state = (uint32_t*)xsm;                                   // [Ng] src | key << 16
+    unsigned long long* bits = (unsigned long long*)(state + Ng + (Ng & 1));   // [(K+63)/64] swapped pairs, by level-order position
+    uint16_t* partner = (uint16_t*)bits;                                // PLDS: [Ng] last exchange partner + 1 instead
+    const int nwords = PLDS ? 0 : (K + 63) / 64;
+    const uint32_t* __restrict__ g_off = P.lv_off + (size_t)w * (K + 2);
+    const uint32_t* __restrict__ g_pairs = P.lv_pairs + (size_t)w * K;
+    const double* __restrict__ g_mi = P.lv_mi + (size_t)w * K;
+    const bool mi_u = P.mi_uniform != 0;
+    const double mi_v = P.mi_value;
+    const uint32_t ev = g_off[min(lane, K)];   // lane l: end of level l
+    const int nlev = (int)g_off[K + 1];
+    constexpr int PT = XKEY_MAX / XWG;
+    XTS(0);
+    const unsigned long long cyc0 = clock64();
+    // This thread's pairs are the list positions tid, tid + 1024, ... (a level is a contiguous range of positions).  Pair n sits
+    // in register q[n mod 3], requested three pairs ahead: the register a pair is consumed from is refilled at once with the
+    // pair three further on, so no load is ever waited for inside a level (a queue that shifts would wait at every shift).
+    uint32_t pn = (uint32_t)tid;                 // this lane's next position
+    uint32_t q0 = pn < (uint32_t)K ? g_pairs[pn] : 0u;
+    uint32_t q1 = pn + XWG < (uint32_t)K ? g_pairs[pn + XWG] : 0u;
+    uint32_t q2 = pn + 2 * XWG < (uint32_t)K ? g_pairs[pn + 2 * XWG] : 0u;
+    {
+        typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
+        const u32x4s_t* __restrict__ s4 = (const u32x4s_t*)slots0;     // the initial slots, made by k_exch_keys: 16 bytes per lane
+        u32x4s_t* d4 = (u32x4s_t*)state;
+        constexpr int P4 = PT / 4;
+        u32x4s_t v_[P4];
+#pragma unroll
+        for (int r = 0; r < P4; ++r) {
+            const int g4 = tid + r * XWG;
+            v_[r] = 4 * g4 + 3 < Ng ? s4[g4] : u32x4s_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int r = 0; r < P4; ++r) {
+            const int g4 = tid + r * XWG;
+            if (4 * g4 + 3 < Ng) d4[g4] = v_[r];
+        }
+        for (int g = (Ng & ~3) + tid; g < Ng; g += XWG) state[g] = slots0[g];   // a ragged tail
+    }
+    for (int q = tid; q < nwords; q += XWG) bits[q] = 0ull;
+    if constexpr (PLDS)
+        for (int g = tid; g < (Ng + 1) / 2; g += XWG) ((uint32_t*)partner)[g] = 0u;
+    auto level_end = [&](int l) -> uint32_t {
+        const int lc = min(l, nlev - 1);
+        return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
+    };
+    __syncthreads();
+    XTS(1);
+    if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + 15] = clock64() - cyc0;
+    uint32_t e = 0;
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < nlev; ++l) {
+        e = level_end(l);
+        // A wave's lanes hold consecutive positions, but a level may end inside them: the lower lanes are then one pair ahead.
+        // Trips are counted from the position of the lane furthest behind (lane 63); a lane takes part in the trip that
+        // covers its own position, so that bit k of the ballot below always belongs to position pb + k.
+        const uint32_t pb0 = (uint32_t)__builtin_amdgcn_readlane((int)pn, 63) - 63u;
+        auto trip = [&](uint32_t& q, const uint32_t pb) {
+            const bool live = pn == pb + (uint32_t)lane && pn < e;
+            const uint32_t pw = q;
+            const double m = mi_u ? mi_v : (live ? g_mi[pn] : 0.0);
+            const uint32_t i = pw & 0xffffu, j = pw >> 16;
+            const uint32_t si = live ? state[i] : 0u, sj = live ? state[j] : 0u;
+            const uint32_t ki = si >> 16, kj = sj >> 16;
+            bool sure, swap;
+            if (ki == 0xffffu || kj == 0xffffu) {
+                sure = false; swap = false;
+            } else if (m == 0.0) {            // distinct buckets order the values themselves: v_i > v_j <=> v_i - v_j > 0
+                sure = ki != kj; swap = ki > kj;
+            } else {                          // every (v_i, v_j) of the two buckets on the same side of the threshold?
+                const bool yes = (order_key_lo(ki) - order_key_hi(kj)) > m, no = (order_key_hi(ki) - order_key_lo(kj)) <= m;   // rounding is monotone: bounds carry over
+                sure = yes || no; swap = yes;
+            }
+            if (live && !sure) {              // the exact values (AlgoBGP.jl:688)
+                const double vi = vals[si & 0xffffu], vj = vals[sj & 0xffffu];
+                swap = vi - vj > m;
+            }
+            swap = swap && live;
+            if (swap) {                       // swap_ev_ij!, :739-744
+                state[i] = sj; state[j] = si;
+                if constexpr (PLDS) { partner[i] = (uint16_t)(j + 1); partner[j] = (uint16_t)(i + 1); }   // set_exchanged!, :747-748
+            }
+            if constexpr (!PLDS) {
+                const unsigned long long mask = __ballot(swap);
+                if (mask && lane == 0) {      // bits pb .. pb+63 of the bitmap (two words; other waves share them)
+                    const uint32_t wi = pb >> 6, sh = pb & 63u;
+                    atomicOr(&bits[wi], mask << sh);
+                    if (sh && (int)wi + 1 < nwords) atomicOr(&bits[wi + 1], mask >> (64u - sh));
+                }
+            }
+            if (live) {                       // this lane's pair is done: its register takes the pair three further on
+                pn += XWG;
+                q = pn + 2 * XWG < (uint32_t)K ? g_pairs[pn + 2 * XWG] : 0u;
+            }
+        };
+        for (uint32_t pb = pb0; pb < e; pb += XWG) {
+            const uint32_t nm = ((pb - (uint32_t)(wave * 64)) / XWG) % 3u;   // wave-uniform
+            if (nm == 0) trip(q0, pb);
+            else if (nm == 1) trip(q1, pb);
+            else trip(q2, pb);
+        }
+        __syncthreads();
+        if (P.ts && tid == 0 && l < 40) P.ts[(size_t)8 * 60000 + 16 + l] = clock64() - cyc0;
+    }
+    XTS(2);
+    if (P.ts && tid == 0) { P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev; P.ts[(size_t)8 * 60000 + 14] = (unsigned long long)XKEY_SHIFT; }
+    // ---- result: src from the slots; the last exchange partner from the bitmap ----
+    uint32_t src_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * XWG;
+        src_[r] = g < Ng ? (state[g] & 0xffffu) : 0u;
+    }
+    if constexpr (PLDS) {
+        XTS(3);
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int g = tid + r * XWG;
+            if (g < Ng) P.xres[g] = (unsigned long long)src_[r] | ((unsigned long long)partner[g] << 32);
+        }
+    } else {
+        uint32_t pr_[PT];
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {       // the pair list once more, one round trip
+            const int p0 = tid + r * XWG;
+            pr_[r] = p0 < K ? g_pairs[p0] : 0u;
+        }
+        __syncthreads();
+        uint32_t* last = state;                   // [Ng] max over the chain's swapped pairs of (position + 1) << 16 | (partner + 1)
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int g = tid + r * XWG;
+            if (g < Ng) last[g] = 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int p0 = tid + r * XWG;
+            if (p0 < K && ((bits[p0 >> 6] >> (p0 & 63)) & 1ull)) {
+                const uint32_t i = pr_[r] & 0xffffu, j = pr_[r] >> 16;
+                atomicMax(&last[i], ((uint32_t)(p0 + 1) << 16) | (j + 1));   // set_exchanged!, :747-748: the later pair wins
+                atomicMax(&last[j], ((uint32_t)(p0 + 1) << 16) | (i + 1));
+            }
+        }
+        __syncthreads();
+        XTS(3);
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int g = tid + r * XWG;
+            if (g < Ng) P.xres[g] = (unsigned long long)src_[r] | ((unsigned long long)(last[g] & 0xffffu) << 32);
+        }
+    }
+    XTS(4);
+    if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + 6] = clock64() - cyc0;
+}

@@ -181,6 +181,7 @@ struct Ctx {
     bool rec_external = false;  // the records after the last accept step were written to the caller's gather buffer (sharded_step)
     bool unresolved = false;    // exchangeMoves! of iteration `iter` is still to be resolved (inline, or by resolve_now)
     bool big_exchange = false;   // 8192 < N_global <= 65535: level plan and walk in global memory
+    bool key_exchange = false;   // ... up to 32768: the walk in LDS on 4-byte slots (src + 16-bit order key), k_exch_resolve_key
     uint32_t* big_scratch = nullptr;
     int lvl_wg = 1024;
     int rng_t0 = 0, rng_w = 0;    // window currently held: iterations [t0, t0+w)
@@ -362,7 +363,19 @@ void launch_resolve(Ctx* c, int t, const double* gathered) {
         hipLaunchKernelGGL(k_exch_resolve_lvl_soa<1024>, dim3(1), dim3(1024), resolve_lvl_soa_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
     else if (c->lds_exchange)
         hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), resolve_lds_bytes(P.Ng), c->stream, P, t, gathered);
-    else if (c->big_exchange)
+    else if (c->key_exchange) {
+        // values and initial slots by the whole chip (gathered records: their value column; single shard: the compact array)
+        const double* src = gathered ? gathered : (const double*)P.vals;
+        double* vals = gathered ? P.xval : P.vals;
+        hipLaunchKernelGGL(k_exch_keys, dim3((P.Ng + 255) / 256), dim3(256), 0, c->stream, src, gathered ? P.RW : 1, P.Ng, vals,
+                           (uint32_t*)P.xsrc);
+        if (P.Ng <= XKEY_PARTNER_MAX)
+            hipLaunchKernelGGL(k_exch_resolve_key<true>, dim3(1), dim3(XWG), resolve_key_bytes(P.Ng, P.plan_K), c->stream, P, t,
+                               (const double*)vals, (const uint32_t*)P.xsrc);
+        else
+            hipLaunchKernelGGL(k_exch_resolve_key<false>, dim3(1), dim3(XWG), resolve_key_bytes(P.Ng, P.plan_K), c->stream, P, t,
+                               (const double*)vals, (const uint32_t*)P.xsrc);
+    } else if (c->big_exchange)
         hipLaunchKernelGGL(k_exch_resolve_lvl_big, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
     else
         hipLaunchKernelGGL(k_exch_resolve_any, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
@@ -670,6 +683,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const bool force_big = be && be[0] == '1';
             c->big_exchange = Ng > 1 && Ng <= 65535 && K >= 1 && K <= Ng && !c->force_any_exchange && (force_big || !c->lds_exchange);
             if (c->big_exchange) { c->lds_exchange = false; c->lvl_exchange = false; c->lvl_soa_exchange = false; }
+            const char* ke = getenv("SMMHIP_KEY_EXCHANGE");   // test hook: "0" keeps the global-memory walk
+            c->key_exchange = c->big_exchange && Ng <= XKEY_MAX && K <= XKEY_MAX && !(ke && ke[0] == '0');
             // inline exchange walk: single shard, level plan available, and two tiles must still share a CU's 160 KB LDS
             const char* iw = getenv("SMMHIP_INLINE_WALK");
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
@@ -746,6 +761,13 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         {
             const unsigned long long e = ERR_NONE;
             HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
+        }
+        if (c->key_exchange)
+        {
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_key<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_key_bytes(XKEY_MAX, XKEY_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_key<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_key_bytes(XKEY_PARTNER_MAX, XKEY_PARTNER_MAX)));
         }
         if (c->lds_exchange) {
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -865,7 +887,7 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
                     c->unresolved = true;   // resolved in the prologue of the next chain kernel (or by resolve_now)
                 } else {
                     if (kscoped) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
-                    launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange) ? nullptr : c->rec[c->cur]);
+                    launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange || c->key_exchange) ? nullptr : c->rec[c->cur]);
                     c->kev0 = c->kev1 = nullptr;
                 }
                 c->pending = true;

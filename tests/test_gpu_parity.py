@@ -780,3 +780,35 @@ def test_cholesky_proposal_covariance(S):
     X = steps.transpose(0, 2, 1).reshape(-1, npar)
     C_ = X.T @ X / len(X)
     np.testing.assert_allclose(C_, L @ L.T, atol=0.03)
+
+
+@pytest.mark.parametrize("N,mi", [(9000, 0.0), (20000, 0.3), (32768, 0.0), (12000, -0.05)])
+def test_key_exchange_kernel_equals_global_memory_walk(S, O, N, mi, monkeypatch):
+    # k_exch_resolve_key (4-byte LDS slots: src + 16-bit order key, exact values only for undecided pairs) against the
+    # global-memory level walk it replaces for 8192 < N_global <= 32768, and against the oracle; thresholds 0, > 0, < 0
+    prob, opts = cm.serial_normal(N=N, T=8, ns=64, min_improve=mi)
+    a = S.hip_context(prob, opts)
+    a.step(8)
+    monkeypatch.setenv("SMMHIP_KEY_EXCHANGE", "0")
+    b = S.hip_context(prob, opts)
+    b.step(8)
+    monkeypatch.delenv("SMMHIP_KEY_EXCHANGE")
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    assert (a.history().exchanged != 0).mean() > 0.02
+    o = O.OracleContext(prob, opts, S.Tables(Z=a.Z()), threads=_all_cores(O))
+    o.step(8)
+    cm.assert_history_equal(a.history(), o.history(), atol=1e-13)
+
+
+def test_key_exchange_kernel_ties_failures_and_small_populations(S, O, monkeypatch):
+    # forced for a small population (SMMHIP_BIG_EXCHANGE): equal values (iteration 1: every chain at the start value), the
+    # failed-objective value -1.0 (negative order keys) and per-chain thresholds
+    monkeypatch.setenv("SMMHIP_BIG_EXCHANGE", "1")
+    N, T = 300, 25
+    prob, opts = cm.serial_normal(N=N, T=T, ns=100, objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[0.4, 1.2], sigma0=0.3,
+                                  min_improve=np.linspace(-0.2, 0.4, N))
+    h, o = run_both(S, O, prob, opts, None)
+    hh = h.history()
+    assert (hh.status == -2).any() and (hh.exchanged != 0).any()
+    cm.assert_history_equal(hh, o.history())
+    cm.assert_state_equal(h.state(), o.state())
