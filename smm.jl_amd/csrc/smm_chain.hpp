@@ -222,10 +222,29 @@ __device__ inline void dense_tile(const KParams& P, const double* s_theta, doubl
 // value / simulated moments / status for one chain from its reduced sums
 // (ObjExamples.jl:79-110; banana :251-265; "exception" -> status -2, mprob.jl:183-186).
 // s_mom / s_w: data moments and weights staged in LDS.
+// moment k of chain ci from the reduced sums: the 8 wave totals left to right, mean, deviation over the weight, square
+// (ObjExamples.jl:79-100).  Independent across k: the lanes that serve a chain share the moments.
+template <int CT>
+__device__ inline void moment_term(const KParams& P, const double* s_part, const double* s_mom, const double* s_w, const int ci,
+                                   const int k, double& m_out, double& v_out) {
+    const bool dense = P.obj == SMM_OBJ_DENSE;
+    const int nmp = P.dense_nOt * 16;
+    double tot = dense ? s_part[((size_t)0 * nmp + k) * 16 + ci] : s_part[(0 * CT + ci) * P.nm + k];
+#pragma unroll
+    for (int wv = 1; wv < WG / 64; ++wv)
+        tot = tot + (dense ? s_part[((size_t)wv * nmp + k) * 16 + ci] : s_part[(wv * CT + ci) * P.nm + k]);
+    const double m = dense ? tot : tot / (double)P.ns;
+    m_out = m;
+    double d = m - s_mom[k];
+    const double wk = s_w[k];
+    if (!isnan(wk)) d = d / wk;
+    v_out = d * d;
+}
+
 template <int CT>
 __device__ inline void finish_objective(const KParams& P, const double* theta /*LDS [np]*/, const double* s_part,
                                         const double* s_mom, const double* s_w, int ci, double* simM /*[nm] out, LDS*/,
-                                        double& value, int& status, int c_local = 0) {
+                                        double& value, int& status, int c_local = 0, const double* vk = nullptr) {
     if (P.obj == SMM_OBJ_USER) {  // evaluated by the user's kernel between the proposal and the accept launch
         for (int k = 0; k < P.nm; ++k) simM[k] = P.u_simM[(size_t)c_local * P.nm + k];
         value = P.u_value[c_local];
@@ -253,19 +272,10 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
         return;
     }
     double vsum = 0.0;
-    const bool dense = P.obj == SMM_OBJ_DENSE;
-    const int nmp = P.dense_nOt * 16;
     for (int k = 0; k < P.nm; ++k) {
-        double tot = dense ? s_part[((size_t)0 * nmp + k) * 16 + ci] : s_part[(0 * CT + ci) * P.nm + k];
-#pragma unroll
-        for (int wv = 1; wv < WG / 64; ++wv)
-            tot = tot + (dense ? s_part[((size_t)wv * nmp + k) * 16 + ci] : s_part[(wv * CT + ci) * P.nm + k]);
-        const double m = dense ? tot : tot / (double)P.ns;
-        simM[k] = m;
-        double d = m - s_mom[k];
-        const double wk = s_w[k];
-        if (!isnan(wk)) d = d / wk;
-        const double v = d * d;
+        double v;
+        if (vk) v = vk[k];                      // mean and squared deviation already there (moment_term by the chain's lanes)
+        else moment_term<CT>(P, s_part, s_mom, s_w, ci, k, simM[k], v);
         vsum = (k == 0) ? v : vsum + v;
     }
     value = vsum / (double)P.nm;
@@ -353,8 +363,11 @@ __device__ inline void make_swapped_history(const KParams& P, double* hrec /*[HW
     else { bestv = bpp; bestid = bppid; }
     hrec[H_VALUE] = value; hrec[H_PROB] = donor[1]; hrec[H_CURR] = value; hrec[H_BEST] = bestv;
     hrec[H_BESTID] = bestid; hrec[H_EXCH] = (double)partner; hrec[H_ACC] = 1.0; hrec[H_STATUS] = donor[2];
-    const int nv = P.np + P.nm;
-    for (int k = 0; k < nv; ++k) hrec[H_PARAMS + k] = donor[3 + k];
+    // (the parameters and moments of the donor's record are copied by all lanes of the chain: copy_strided below)
+}
+// dst[k] = src[k] for k = r, r + nr, ... < n: a copy shared by the nr lanes that serve one chain
+__device__ inline void copy_strided(double* dst, const double* src, const int n, const int r, const int nr) {
+    for (int k = r; k < n; k += nr) dst[k] = src[k];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -659,8 +672,10 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     unsigned long long err_word = ERR_NONE;
     if (ctl) err_word = *(const volatile unsigned long long*)P.err;
     // wave 1: problem constants, requested now and written to LDS after the walk
-    const bool wave1 = tid >= 64 && tid < 128;
-    const int k1 = tid - 64;
+    // (objectives without a simulation are launched with the control wave only, 64 lanes per tile: it loads the constants itself)
+    const bool slim = KIND == 0 && blockDim.x == 64;
+    const bool wave1 = slim ? ctl : (tid >= 64 && tid < 128);
+    const int k1 = slim ? tid : tid - 64;
     double c_lb = 0.0, c_ub = 0.0, c_init = 0.0, c_mom = 0.0, c_w = 0.0;
     if (wave1) {
         if (k1 < np) { c_lb = P.lb[k1]; c_ub = P.ub[k1]; c_init = P.init[k1]; }
@@ -733,6 +748,8 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         csb[CS_NNOEX] = (double)nn; csb[CS_NACC] = (double)na; csb[CS_BEST] = bp; csb[CS_BESTID] = bpid;
         csb[CS_PARTNER] = (double)partner;
     }
+    if (valid && t > 1 && partner != 0)   // parameters and moments of the donor's record into the rewritten history row, NR lanes per chain
+        copy_strided(S.hp + cl * HW + H_PARAMS, S.rec + cl * RW + 3, np + nm, r, NR);
     TS_MARK(5);
     // ---- proposal(c), AlgoBGP.jl:424-471: lane (cl, r) evaluates try r of chain cl ----
     if (ctl) {
@@ -750,12 +767,20 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             const double sg = S.cs[cl * CSW + CS_SIGMA];
             const double* zz = S.rb + cl * RBW + 1;  // [tries][np]
             const int lane = tid & 63;
+            // mapto_01 (mprob.jl:248) once per chain and parameter — one division each, shared by all tries —, computed by the
+            // NR lanes of the chain and kept in the (still unused) output record block
+            double* m01 = S.rout + cl * RW;
+            if (valid)
+                for (int k = r; k < np; k += NR) {
+                    const double lbk = S.lb[k];
+                    m01[k] = (rc[3 + k] - lbk) / (S.ub[k] - lbk);
+                }
+            __builtin_amdgcn_wave_barrier();
             for (int b0 = 0; b0 < np; b0 += bs) {
                 bool ok = valid && r < npar;
                 if (ok) {
                     for (int k = b0; k < b0 + bs; ++k) {  // mysample, :400-410, try r
-                        const double lbk = S.lb[k];
-                        const double mu01 = (rc[3 + k] - lbk) / (S.ub[k] - lbk);  // mapto_01, mprob.jl:248
+                        const double mu01 = m01[k];
                         const double step = sg * prop_direction(P, zz + r * np, k, gc);  // MvNormal(mu01, sigma): x = mu + sigma*z
                         const double x = mu01 + step;
                         if (!(x >= 0.0 && x <= 1.0)) ok = false;  // inclusive bounds, :405
@@ -770,7 +795,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                     for (int k = b0; k < b0 + bs; ++k) {
                         const double lbk = S.lb[k];
                         const double span = S.ub[k] - lbk;
-                        const double mu01 = (rc[3 + k] - lbk) / span;
+                        const double mu01 = m01[k];
                         const double step = sg * prop_direction(P, zz + r * np, k, gc);
                         const double x = mu01 + step;
                         const double sc = x * span;
@@ -801,7 +826,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                         for (int k = b0; k < b0 + bs; ++k) {
                             const double lbk = S.lb[k];
                             const double span = S.ub[k] - lbk;
-                            const double mu01 = (rc[3 + k] - lbk) / span;
+                            const double mu01 = m01[k];
                             double z;
                             if (P.chol_L) {
                                 z = prop_direction(P, zv, k, gc);
@@ -828,7 +853,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                 while (fm) {
                     const int cf = __ffsll((long long)fm) - 1;
                     fm &= fm - 1;
-                    const double* rcf = S.rec + cf * RW;
+                    const double* m01f = S.rout + cf * RW;
                     const double sgf = S.cs[cf * CSW + CS_SIGMA];
                     const double* zzf = S.rb + cf * RBW + 1;
                     double* thf = S.theta + cf * np;
@@ -846,7 +871,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                             }
                             const double lbk = S.lb[k];
                             const double span = S.ub[k] - lbk;
-                            const double mu01 = (rcf[3 + k] - lbk) / span;
+                            const double mu01 = m01f[k];
                             const double step = sgf * z;
                             const double x = mu01 + step;
                             if (!(x >= 0.0 && x <= 1.0)) okl = false;
@@ -889,7 +914,15 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     if (P.dbg & 4) return;
     if (err_word != ERR_NONE) return;
 
-    // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245): chain lanes ----
+    // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245) ----
+    // the moments of a chain (wave totals -> mean -> squared weighted deviation) are independent: its NR lanes share them
+    const bool sumsq = KIND != 0 && P.obj != SMM_OBJ_USER && P.obj != SMM_OBJ_BANANA;
+    if (valid && sumsq) {
+        double* smk = S.h + cl * HW + H_PARAMS + np;
+        double* vkk = S.rout + cl * RW;          // (the proposal's scratch: free again)
+        for (int k = r; k < nm; k += NR) moment_term<CT>(P, S.part, S.mom, S.w, cl, k, smk[k], vkk[k]);
+    }
+    __builtin_amdgcn_wave_barrier();
     if (chain_lane) {
         const double* th = S.theta + cl * np;
         const double* rc = S.rec + cl * RW;
@@ -899,7 +932,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         double* sm = hr + H_PARAMS + np;
         double value;
         int status;
-        finish_objective<CT>(P, th, S.part, S.mom, S.w, cl, sm, value, status, c);
+        finish_objective<CT>(P, th, S.part, S.mom, S.w, cl, sm, value, status, c, sumsq ? S.rout + cl * RW : nullptr);
         const double sig = csb[CS_SIGMA], bp = csb[CS_BEST], bpid = csb[CS_BESTID], atun = csb[CS_ATUN];
         const int nn = (int)csb[CS_NNOEX], na = (int)csb[CS_NACC];
         const double u = t > 1 ? S.rb[cl * RBW] : 0.0;  // probs_acc[iter], :85
@@ -938,16 +971,22 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         csb[CS_BESTP] = bp; csb[CS_BESTPID] = bpid;  // best after t-1: needed if iteration t gets exchanged
         hr[H_VALUE] = value; hr[H_PROB] = prob; hr[H_CURR] = currv; hr[H_BEST] = bestv; hr[H_BESTID] = bestid;
         hr[H_EXCH] = 0.0; hr[H_ACC] = acc ? 1.0 : 0.0; hr[H_STATUS] = (double)status;
-        for (int k = 0; k < np; ++k) hr[H_PARAMS + k] = th[k];
-        // the chain's last accepted record (lastAccepted :209-215) = input of the exchange step
-        if (acc) {
-            ro[0] = value; ro[1] = prob; ro[2] = (double)status;
-            for (int k = 0; k < np; ++k) ro[3 + k] = th[k];
-            for (int k = 0; k < nm; ++k) ro[3 + np + k] = sm[k];
-        } else {
-            for (int f = 0; f < RW; ++f) ro[f] = rc[f];
-        }
+        // the chain's last accepted record (lastAccepted :209-215) = input of the exchange step: its head here, the
+        // parameter and moment arrays (and the history row's parameters) by all lanes of the chain below
+        if (acc) { ro[0] = value; ro[1] = prob; ro[2] = (double)status; }
+        else { ro[0] = rc[0]; ro[1] = rc[1]; ro[2] = rc[2]; }
         P.vals[c] = acc ? value : old;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+        const bool acc = S.h[cl * HW + H_ACC] != 0.0;
+        copy_strided(S.h + cl * HW + H_PARAMS, S.theta + cl * np, np, r, NR);
+        if (acc) {
+            copy_strided(S.rout + cl * RW + 3, S.theta + cl * np, np, r, NR);
+            copy_strided(S.rout + cl * RW + 3 + np, S.h + cl * HW + H_PARAMS + np, nm, r, NR);
+        } else {
+            copy_strided(S.rout + cl * RW + 3, S.rec + cl * RW + 3, RW - 3, r, NR);
+        }
     }
     // ---- the control wave stores the tile's result blocks ----
     if (valid) {

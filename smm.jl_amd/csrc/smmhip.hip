@@ -273,7 +273,11 @@ template <int KIND, int CT, int TPW = 1>
 void launch_chain_iter_ct(Ctx* c, int t, int flags) {
     const KParams& P = c->P;
     const int tiles = (P.N + CT - 1) / CT;
-    const dim3 grid((tiles + TPW - 1) / TPW), block(WG * TPW);
+    // an objective without a simulation (banana, user objectives) has work for the tile's control wave only: unless the exchange
+    // walk runs inline (all lanes stage its inputs) the tile is launched as that one wave, so that every tile of a large
+    // population is resident at once instead of queueing behind 448 idle lanes each
+    const bool slim = KIND == 0 && TPW == 1 && !(flags & F_WALK_INLINE) && !c->inline_walk;
+    const dim3 grid((tiles + TPW - 1) / TPW), block(slim ? 64 : WG * TPW);
     const double* rin = c->ext_rec_in ? c->ext_rec_in : (const double*)c->rec[c->cur];
     double* rout = c->ext_rec_out ? c->ext_rec_out : c->rec[c->cur ^ 1];
     if (c->kev0)   // profiling mode 2: begin/end of this dispatch as the command processor stamps them
