@@ -22,6 +22,9 @@ constexpr int NORM_WG = 2 * WG;       // 1024 lanes
 #ifndef SMM_EXP_SGPR_MU
 #define SMM_EXP_SGPR_MU 0
 #endif
+#ifndef SMM_EXP_SETPRIO
+#define SMM_EXP_SETPRIO 1
+#endif
 #ifndef SMM_EXP_NORM_ZU
 #define SMM_EXP_NORM_ZU 4
 #endif
@@ -128,6 +131,11 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
         int ch = 0;
 #pragma clang loop unroll(disable)
         for (; ch + 2 <= nch; ch += 2) {
+#if SMM_EXP_SETPRIO
+            // a wave that is ahead yields to the ones behind (the arbiter prefers the oldest wave: left alone, the four waves of
+            // a SIMD finish one after the other and the last one issues FP64 on its own, at 57 % of the rate)
+            if (ch == 0) __builtin_amdgcn_s_setprio(3); else if (ch == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+#endif
             sim_load_chunk_n<ZU>(zb, P, k, ch + 1, zn);
             add_full(zc);
             const bool last = (ch + 2 == nch);
@@ -135,6 +143,9 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
             if (last) add_last(zn); else add_full(zn);
         }
         if (ch < nch) {
+#if SMM_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             sim_load_chunk_n<ZU>(zb, P, knext, 0, zn);
             add_last(zc);
 #pragma unroll
