@@ -580,8 +580,11 @@ __device__ inline void walk_levels(const KParams& P, const uint32_t slot, const 
     }
 }
 
-template <int NT, bool FINAL_BARRIER>
-__device__ inline void exchange_walk_fast(const KParams& P, const int tx, unsigned char* lds, const int tid, const int ts_tile) {
+struct WalkNoWork { __device__ inline void operator()() const {} };
+// while_loading: work of the caller that needs no memory (it runs between the request of the walk's inputs and their arrival)
+template <int NT, bool FINAL_BARRIER, class F = WalkNoWork>
+__device__ inline void exchange_walk_fast(const KParams& P, const int tx, unsigned char* lds, const int tid, const int ts_tile,
+                                          F while_loading = F()) {
     const int Ng = P.Ng, K = P.plan_K;
     const int w = tx - P.plan_t0;
     uint4* slot = (uint4*)lds;                                  // [Ng] {value lo, value hi, src, partner}
@@ -605,6 +608,7 @@ __device__ inline void exchange_walk_fast(const KParams& P, const int tx, unsign
     }
     const uint32_t ev = g_off[min(lane, K)];   // lane l: end of level l
     const int nlev = (int)g_off[K + 1];
+    while_loading();
 #pragma unroll
     for (int r = 0; r < PT; ++r) {
         const int g = tid + r * NT;

@@ -43,11 +43,11 @@ struct NormLayout {
     static constexpr int RW = (3 + 2 * NP + 1) & ~1;
     static constexpr int HW = (H_PARAMS + 2 * NP + 1) & ~1;
     static constexpr int PARKW = 8 + RW;   // sigma, acc_tuner, u, best, best_id, n_noex, n_acc, partner, record[RW]
-    static constexpr size_t doubles = (size_t)NORM_CT * NP + (size_t)NP * 8 * NORM_CT + (size_t)NORM_CT * PARKW + 2;
+    static constexpr size_t doubles = (size_t)NORM_CT * NP + (size_t)NP * 8 * NORM_CT + (size_t)NORM_CT * PARKW + 2 + 64 * (1 + NP) + 2;
 };
 __host__ __device__ inline size_t norm_tile_doubles(int np) {
     const int RW = (3 + 2 * np + 1) & ~1;
-    return (size_t)NORM_CT * np + (size_t)np * 8 * NORM_CT + (size_t)NORM_CT * (8 + RW) + 2;
+    return (size_t)NORM_CT * np + (size_t)np * 8 * NORM_CT + (size_t)NORM_CT * (8 + RW) + 2 + 64 * (1 + np) + 2;
 }
 
 // one of four values by the lane's position in its quad
@@ -179,6 +179,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
     double* s_part = s_theta + CT * NP;                   // [NP][8][CT]
     double* s_park = s_part + NP * 8 * CT;                // [CT][PARKW]
     unsigned* s_arrived = (unsigned*)(s_park + CT * PARKW);   // + 1: the poisoned flag
+    double* s_rng = s_park + CT * PARKW + 2;               // [64][1 + NP]: u and the normals of try r, made by wave 1
+    unsigned* s_rng_ready = (unsigned*)(s_rng + 64 * (1 + NP));
     const bool ctl = tid < 64;
     const int cl = lane >> 2, r = lane & 3;               // control wave: chain of the tile, position in its quad
     const int c = tile * CT + cl;
@@ -199,11 +201,16 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
 #pragma unroll
     for (int k = 0; k < NP; ++k) { zA[k] = 0.0; zB[k] = 0.0; }
     if (ctl) err_word = *(const volatile unsigned long long*)P.err;
+    // this iteration's randomness (the MH uniform, the normals of the tries this lane evaluates): generated right here unless
+    // tables are injected — the counter generator needs nothing but (seed, chain, iteration, try), the control wave would
+    // otherwise just wait for the exchange inputs, and 144 bytes per chain and iteration need not be written and read back
+    const bool rng_here = !P.user_ntab && !P.user_utab;
+    const int rb_tries = rng_here ? NORM_NR : P.rb_tries;   // tries held in registers or memory; later ones come from the generator
     if (valid) {
         const double2* g_cs = (const double2*)(P.cs + (size_t)c * CSW);
 #pragma unroll
         for (int i = 0; i < 6; ++i) csq[i] = g_cs[i];
-        if (t > 1) {
+        if (t > 1 && !rng_here) {
             const double* g_rb = P.rb + ((size_t)(t - P.rb_t0) * N + c) * P.RBW;
             u = g_rb[0];
 #pragma unroll
@@ -214,6 +221,10 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
         }
         if (!WALK && (flags & F_HAS_PENDING)) xr = P.xres[gc];
     }
+    // (LDS survives from workgroup to workgroup: the hand-over flags are reset before anybody can look at them — the walk's first
+    // barrier, or the one below, orders the reset)
+    if (tid == 64) { *s_arrived = 0u; *s_rng_ready = 0u; }
+    if constexpr (!WALK) __syncthreads();
     if constexpr (WALK) {
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
         exchange_walk_fast<NORM_WG, false>(P, t - 1, (unsigned char*)smem, tid, tile);
@@ -222,7 +233,25 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
             xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
         }
     }
-    if (tid == 64) *s_arrived = 0u;
+    // This iteration's randomness, by wave 1 (lane = the control wave's lane: chain, try): it has nothing to do from here to the
+    // simulation, and the control wave needs the numbers only once the record it continues from has arrived (~1 us from now).
+    if (rng_here && t > 1 && tid >= 64 && tid < 128) {
+        const int c1 = tile * CT + (lane >> 2);
+        if (c1 < N) {
+            const uint32_t g1 = (uint32_t)(P.offset + c1);
+            double* o = s_rng + lane * (1 + NP);
+            o[0] = rng_u(P.seed, g1, (uint32_t)t);                     // probs_acc[iter], AlgoBGP.jl:85
+#pragma unroll
+            for (int q = 0; 2 * q < NP; ++q) {                          // rand(RAND, d) of try r, :404
+                double z0, z1;
+                rng_prop_normal2(P.seed, g1, (uint32_t)t, (uint32_t)(lane & 3), (uint32_t)q, z0, z1);
+                o[1 + 2 * q] = z0;
+                if (2 * q + 1 < NP) o[1 + 2 * q + 1] = z1;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(s_rng_ready, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     TS_MARK(1);
 
     // ---- control wave: the record the chain continues from, settle iteration t-1, propose (AlgoBGP.jl:424-471) ----
@@ -232,6 +261,14 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
         const int partner = (int)(xr >> 32);
         double mu01[NP], th[NP];
         const double sigma = csq[0].x;
+        if (rng_here && t > 1) {   // wave 1's numbers (the stamp is the iteration: nothing to reset between launches... LDS is per launch anyway)
+            while (__hip_atomic_load(s_rng_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)t) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const double* o = s_rng + lane * (1 + NP);
+            u = o[0];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) zA[k] = o[1 + k];
+        }
         {
             // its own record, or its donor's (swap_ev_ij!, :734-749): the one dependent memory level of the iteration
             double rc[RW];
@@ -307,14 +344,14 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
                     if (j0 == 0) {
 #pragma unroll
                         for (int k = 0; k < NP; ++k) z[k] = zA[k];
-                    } else if (j0 == NORM_NR) {
+                    } else if (j0 == NORM_NR && !rng_here) {
 #pragma unroll
                         for (int k = 0; k < NP; ++k) z[k] = zB[k];
-                    } else if (j < P.rb_tries) {
+                    } else if (j < rb_tries) {
 #pragma unroll
                         for (int k = 0; k < NP; ++k) z[k] = g_rb[1 + j * NP + k];
                     }
-                    if (j >= P.rb_tries) {   // past the pre-generated tries: the in-kernel generator (never with injected normals)
+                    if (j >= rb_tries) {   // past the pre-generated tries: the in-kernel generator (never with injected normals)
 #pragma unroll
                         for (int q = 0; 2 * q < NP; ++q) {
                             const double2 zz2 = rng_prop_normal2_outofline(P.seed, (uint32_t)gc, (uint32_t)t, (uint32_t)j, (uint32_t)q);

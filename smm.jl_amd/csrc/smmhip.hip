@@ -243,7 +243,9 @@ bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P
 // make the look-ahead tables cover iteration t (1-based): a new window simply starts at t
 void ensure_windows(Ctx* c, int t) {
     KParams& P = c->P;
-    if (!(t >= c->rng_t0 && t < c->rng_t0 + c->rng_w)) {
+    // (k_chain_iter_norm generates its randomness itself unless tables are injected: no randomness blocks)
+    const bool pregen = !(c->norm_fast && !P.user_ntab && !P.user_utab);
+    if (pregen && !(t >= c->rng_t0 && t < c->rng_t0 + c->rng_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
         const size_t Q = (size_t)(P.np + 1) / 2;
         const size_t total = (size_t)W * P.rb_tries * Q * P.N;
