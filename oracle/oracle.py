@@ -25,7 +25,7 @@ _ORC_ONLY = [
     ("orc_set_user_objective_lanes", None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
 ]
 _SHARED = ["smm_ctx_create", "smm_ctx_destroy", "smm_last_error", "smm_bgp_step", "smm_bgp_local_step",
-           "smm_bgp_record_doubles", "smm_eval_batch", "smm_eval_batch_noseed", "smm_get_history", "smm_get_state", "smm_get_Z"]
+           "smm_bgp_record_doubles", "smm_eval_batch", "smm_eval_batch_noseed", "smm_get_history", "smm_get_state", "smm_set_state", "smm_get_Z"]
 
 _lib = None
 

@@ -881,6 +881,29 @@ int orc_get_state(void* v, orc_state_t* s) {
     return ORC_OK;
 }
 
+/* the twin of smm_set_state (include/smmhip.h): restart! (AlgoBGP.jl:804-884) — the chains' state and the history of the
+ * iterations before s->iter come from the caller */
+int orc_set_state(void* v, const orc_state_t* s, const orc_history_t* hin) {
+    orc_t* o = (orc_t*)v;
+    const size_t N = o->opts.N, np = o->prob.np, nm = o->prob.nm;
+    if (!s || s->iter < 0 || s->iter > o->opts.maxiter || (s->iter > 0 && !hin)) return ORC_ERR_INVALID_ARG;
+    const size_t nt = (size_t)s->iter;
+    memcpy(o->sigma, s->sigma, N * 8); memcpy(o->accept_rate, s->accept_rate, N * 8);
+    memcpy(o->la_value, s->la_value, N * 8); memcpy(o->la_prob, s->la_prob, N * 8);
+    memcpy(o->la_params, s->la_params, N * np * 8); memcpy(o->la_simM, s->la_sim_moments, N * nm * 8);
+    memcpy(o->la_status, s->la_status, N); memcpy(o->n_noex, s->n_noex, N * 4); memcpy(o->n_acc_noex, s->n_acc_noex, N * 4);
+    memcpy(o->best_val, s->best_val, N * 8); memcpy(o->best_id, s->best_id, N * 4);
+    if (nt) {
+        memcpy(o->h.value, hin->value, nt * N * 8); memcpy(o->h.prob, hin->prob, nt * N * 8);
+        memcpy(o->h.curr_val, hin->curr_val, nt * N * 8); memcpy(o->h.best_val, hin->best_val, nt * N * 8);
+        memcpy(o->h.params, hin->params, nt * N * np * 8); memcpy(o->h.sim_moments, hin->sim_moments, nt * N * nm * 8);
+        memcpy(o->h.best_id, hin->best_id, nt * N * 4); memcpy(o->h.exchanged, hin->exchanged, nt * N * 4);
+        memcpy(o->h.accepted, hin->accepted, nt * N); memcpy(o->h.status, hin->status, nt * N);
+    }
+    o->iter = s->iter;
+    return ORC_OK;
+}
+
 int orc_get_Z(void* v, double* Z) {
     orc_t* o = (orc_t*)v;
     memcpy(Z, o->Z, (size_t)o->prob.nm * o->prob.ns * sizeof(double));

@@ -558,7 +558,7 @@ __device__ inline void walk_levels(const KParams& P, const uint32_t slot, const 
         b = e; e = e2; e2 = e3; pw = pw2; m = m2;
         walk_wait_lds();
         __syncthreads();
-        if (P.ts && tid == 0 && blockIdx.x == 0 && l < 30) P.ts[(size_t)8 * 60000 + 16 + l] = clock64();
+        if (P.ts_levels && tid == 0 && blockIdx.x == 0 && l < 30) P.ts[(size_t)8 * 60000 + 16 + l] = clock64();
     }
     if (P.ts && tid == 0 && blockIdx.x == 0) { P.ts[(size_t)8 * 60000 + 14] = (unsigned long long)ltail; P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev; }
     if (ltail < nlev) {
@@ -572,7 +572,7 @@ __device__ inline void walk_levels(const KParams& P, const uint32_t slot, const 
                 if (pw != XNOPAIR) walk_pair(slot, pw, m);
                 __builtin_amdgcn_wave_barrier();
                 pw = pw2; m = m2; e = e2; e2 = e3;
-                if (P.ts && tid == 0 && blockIdx.x == 0 && l < 30) { walk_wait_lds(); P.ts[(size_t)8 * 60000 + 16 + l] = clock64(); }
+                if (P.ts_levels && tid == 0 && blockIdx.x == 0 && l < 30) { walk_wait_lds(); P.ts[(size_t)8 * 60000 + 16 + l] = clock64(); }
             }
             walk_wait_lds();
         }

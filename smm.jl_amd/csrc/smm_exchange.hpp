@@ -604,24 +604,7 @@ __host__ __device__ inline size_t resolve_key_bytes(int Ng, int K) {
     return (size_t)Ng * 4 + (Ng <= XKEY_PARTNER_MAX ? (size_t)(Ng + 4) * 2 : (((size_t)K + 63) / 64) * 8) + 256;
 }
 
-// Order keys are computed from the HIGH WORD of the value (sign, exponent, 20 mantissa bits): for finite values >= 0 it is a
-// monotone function of the value, and 32-bit integer arithmetic is all the key needs.  The scale is fixed: buckets of 2^10
-// high-word steps (a factor 1 + 2^-10 apart, ~3 decimal digits) from 2^-48 upwards, 0xfff0 of them (up to 2^15.9 ~ 6e4);
-// smaller values share bucket 0, larger ones the last bucket — undecided among themselves, still ordered against the rest.
-// Negative values (the -1.0 of a failed objective, Eval.jl:84) and non-finite ones get the undecidable mark 0xffff.
-constexpr uint32_t XKEY_BASE = (1023u - 48u) << 20, XKEY_SHIFT = 10, XKEY_TOP = 0xfff0u;
-__host__ __device__ inline uint32_t order_key16(const double v) {
-    const uint32_t hw = (uint32_t)(__builtin_bit_cast(unsigned long long, v) >> 32);
-    if (hw >= 0x7ff00000u) return 0xffffu;                   // negative, infinite or NaN: always the exact values
-    if (hw < XKEY_BASE) return 0u;
-    const uint32_t k = 1u + ((hw - XKEY_BASE) >> XKEY_SHIFT);
-    return k < XKEY_TOP ? k : XKEY_TOP;
-}
-// bounds of a bucket: lo inclusive, hi exclusive (bucket 0: [0, 2^-48); the last bucket: up to +inf)
-__device__ inline double order_key_lo(const uint32_t k) { return k == 0 ? 0.0 : __hiloint2double((int)(XKEY_BASE + ((k - 1) << XKEY_SHIFT)), 0); }
-__device__ inline double order_key_hi(const uint32_t k) {
-    return k >= XKEY_TOP ? INFINITY : __hiloint2double((int)(XKEY_BASE + (k << XKEY_SHIFT)), 0);
-}
+// (order_key16 and the bounds of its buckets: smm_params.hpp)
 
 // k_exch_keys: by the whole chip, before the one resolving workgroup starts: the value column of the gathered records
 // ([Ng][RW], or the compact array of a single shard with RW = 1) as a compact array, and every chain's initial 4-byte slot

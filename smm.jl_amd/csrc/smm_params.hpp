@@ -60,12 +60,21 @@ struct KParams {
     const uint32_t* lv_pairs;        // [W][K]: pi | pj<<16, level by level
     const double* lv_mi;             // [W][K]: min_improve of chain pi, same order
     const uint32_t* lv_off;          // [W][K+2]: lv_off[l] = first position of level l; entry K+1 = number of levels
+    // ... and for the lean walk of k_chain_iter_norm (N_global, K <= 4096, min_improve == 0; null otherwise):
+    const uint32_t* lv_pairs_p;      // [W][plan_Kp]: level by level, every level padded to a multiple of 64 words with dummy pairs; a
+                                     //          word = the LDS byte offsets of the pair's two 8-byte chain slots, 8 pi | 8 pj << 16
+    const uint32_t* lv_offp;         // [W][LV_OFFP]: entry l = first word of level l (entry nlev: the padded length); [33] = nlev;
+                                     //          [34] = 1 when the plan fits this form (at most 31 levels)
+    const uint16_t* lv_adj;          // [W][Ng][32]: entry l = 1 + the partner of the chain in its pair of level l - 1 (l = 1..31)
+    int plan_Kp;
     int plan_t0, plan_K;
     // state
     double* cs;                // [N][CSW]
     unsigned long long* xres;  // [Ng]
     double* vals;              // [N] value of every chain's last accepted record after the accept step, contiguous
                                //     (what the single-shard exchange resolution reads: 8 B per chain instead of a record)
+    uint2* slot8;              // [N] the chain's initial slot of the lean walk: {order_key32(vals[c]), c} (k_chain_iter_norm, or null)
+    uint32_t* walk_flags;      // bit 0 (sticky): a NaN value entered vals[]: order keys do not cover it, the 16-byte walk runs
     // scratch of the any-size exchange kernel
     int32_t *xsrc, *xpartner, *xnext, *xpairs;
     double* xval;
@@ -75,7 +84,35 @@ struct KParams {
     unsigned long long* err;
     int dbg;                 // SMMHIP_DBG timing experiments (results invalid when != 0)
     unsigned long long* ts;  // SMMHIP_TS=1: per-workgroup phase timestamps of k_chain_iter (tools/)
+    int ts_levels;           // SMMHIP_TS=2: and one per level of the inline exchange walk
 };
+
+// Order keys are computed from the HIGH WORD of the value (sign, exponent, 20 mantissa bits): for finite values >= 0 it is a
+// monotone function of the value, and 32-bit integer arithmetic is all the key needs.  The scale is fixed: buckets of 2^10
+// high-word steps (a factor 1 + 2^-10 apart, ~3 decimal digits) from 2^-48 upwards, 0xfff0 of them (up to 2^15.9 ~ 6e4);
+// smaller values share bucket 0, larger ones the last bucket — undecided among themselves, still ordered against the rest.
+// Negative values (the -1.0 of a failed objective, Eval.jl:84) and non-finite ones get the undecidable mark 0xffff.
+constexpr uint32_t XKEY_BASE = (1023u - 48u) << 20, XKEY_SHIFT = 10, XKEY_TOP = 0xfff0u;
+__host__ __device__ inline uint32_t order_key16(const double v) {
+    const uint32_t hw = (uint32_t)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    if (hw >= 0x7ff00000u) return 0xffffu;                   // negative, infinite or NaN: always the exact values
+    if (hw < XKEY_BASE) return 0u;
+    const uint32_t k = 1u + ((hw - XKEY_BASE) >> XKEY_SHIFT);
+    return k < XKEY_TOP ? k : XKEY_TOP;
+}
+// bounds of a bucket: lo inclusive, hi exclusive (bucket 0: [0, 2^-48); the last bucket: up to +inf)
+__device__ inline double order_key_lo(const uint32_t k) { return k == 0 ? 0.0 : __hiloint2double((int)(XKEY_BASE + ((k - 1) << XKEY_SHIFT)), 0); }
+__device__ inline double order_key_hi(const uint32_t k) {
+    return k >= XKEY_TOP ? INFINITY : __hiloint2double((int)(XKEY_BASE + (k << XKEY_SHIFT)), 0);
+}
+
+constexpr int LV_OFFP = 40, LV_MAXLEV = 31;
+// 32-bit order key of a chain value: for any two non-NaN doubles, key(a) > key(b) implies a > b and key(a) < key(b) implies a < b
+// (the high word of the double, made monotone across the sign; -0.0 counts as +0.0); equal keys decide nothing.
+__host__ __device__ inline uint32_t order_key32(const double v) {
+    const uint32_t hw = v == 0.0 ? 0u : (uint32_t)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    return (hw & 0x80000000u) ? ~hw : (hw | 0x80000000u);
+}
 
 #define TS_MARK(i) do { if (P.ts && tid == 0) P.ts[(size_t)tile * 8 + (i)] = wall_clock64(); } while (0)
 

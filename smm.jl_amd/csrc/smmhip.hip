@@ -165,7 +165,8 @@ struct Ctx {
     double* win_rb = nullptr;
     unsigned long long* win_plan = nullptr;
     double* win_plan_mi = nullptr;
-    uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr;
+    uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr, *win_lv_pairs_p = nullptr, *win_lv_offp = nullptr;
+    uint16_t* win_lv_adj = nullptr;   // (the lean walk of k_chain_iter_norm)
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
     bool lvl_soa_exchange = false;   // XLVL_MAX < N_global <= XLDS_MAX: level walk on split chain slots
@@ -264,10 +265,11 @@ void ensure_windows(Ctx* c, int t) {
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
         hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
-                           c->win_plan_mi, c->win_lv_pairs, c->win_lv_mi, c->win_lv_off);
+                           c->win_plan_mi, c->win_lv_pairs, c->win_lv_mi, c->win_lv_off, c->win_lv_pairs_p, c->win_lv_offp, c->win_lv_adj);
         c->plan_t0 = t; c->plan_w = W;
         P.plan = c->win_plan; P.plan_mi = c->win_plan_mi; P.plan_t0 = t;
         P.lv_pairs = c->win_lv_pairs; P.lv_mi = c->win_lv_mi; P.lv_off = c->win_lv_off;
+        P.lv_pairs_p = c->win_lv_pairs_p; P.lv_offp = c->win_lv_offp; P.lv_adj = c->win_lv_adj;
     }
 }
 
@@ -587,7 +589,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* d = getenv("SMMHIP_DBG");
             P.dbg = d ? atoi(d) : 0;
             const char* tsv = getenv("SMMHIP_TS");
-            if (tsv && tsv[0] == '1') P.ts = dalloc<unsigned long long>(c, (size_t)8 * 65536);
+            if (tsv && (tsv[0] == '1' || tsv[0] == '2')) P.ts = dalloc<unsigned long long>(c, (size_t)8 * 65536);
+            P.ts_levels = tsv && tsv[0] == '2';   // also a stamp per level of the inline walk (the stamps stretch the levels: not with '1')
             c->ct = 8;   // chains per simulation tile (4 and 16 were measured and rejected: more shock traffic / spills)
         }
         P.np = np; P.nm = nm; P.ns = ns; P.obj = c->obj;
@@ -697,7 +700,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const size_t tile_b = (tile_smem_base(c, tile_ct) + 15) & ~(size_t)15;
             const char* nf = getenv("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
             c->norm_fast = is_sim(c->obj) && np == nm && np <= 2 && opts->batch_size == np && P.dbg == 0 && !opts->chol_L && !(nf && nf[0] == '0');
-            const size_t walk_b = walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15);   // k_chain_iter_norm: pair list NOT overlaid
+            // k_chain_iter_norm: pair list NOT overlaid; room for either walk (16-byte slots, 4-byte slots + value table)
+            const size_t walk_b = std::max(walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15), (lean_walk_bytes(Ng, K) + 15) & ~(size_t)15);
             c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng && c->obj != SMM_OBJ_USER &&
                              (c->norm_fast ? walk_b + norm_tile_doubles(np) * 8 <= (size_t)160 * 1024
                                            : walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024);
@@ -730,6 +734,17 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->win_cap * K);
                 c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
                 c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
+                // the lean walk of k_chain_iter_norm: min_improve == 0 for every chain, chain ids and list positions in 12 bits
+                const char* kw = getenv("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walk on 16-byte slots
+                if (c->norm_fast && c->inline_walk && P.mi_uniform && P.mi_value == 0.0 && Ng <= XLVL_MAX && K <= XLVL_MAX && !(kw && kw[0] == '0')) {
+                    P.plan_Kp = lean_walk_Kp(K);
+                    c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->win_cap * P.plan_Kp);
+                    c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->win_cap * LV_OFFP);
+                    c->win_lv_adj = dalloc<uint16_t>(c, (size_t)c->win_cap * Ng * 32);
+                    P.slot8 = dalloc<uint2>(c, (size_t)N + 4);
+                    P.walk_flags = dalloc<uint32_t>(c, 4);
+                    HIPCHK(hipMemset(P.walk_flags, 0, 16));
+                }
             }
         }
         {   // chain state blocks and records (BGPChain ctor, AlgoBGP.jl:78-109: best = Inf, best_id = -1, ...)
@@ -746,7 +761,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             for (int b = 0; b < 2; ++b) c->rec[b] = dupload(c, rec.data(), rec.size());
         }
         P.xres = dalloc<unsigned long long>(c, Ng);
-        P.vals = dalloc<double>(c, N);
+        P.vals = dalloc<double>(c, (size_t)N + 4);   // (+4: read as 16-byte pieces)
         if (!c->lds_exchange) {
             const int Kmax = std::max(K, 1);
             P.xval = dalloc<double>(c, Ng); P.xnext = dalloc<int32_t>(c, Ng); P.xpairs = dalloc<int32_t>(c, (size_t)Kmax * 2);
@@ -1257,6 +1272,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         c->rec_external = false; c->pending_ext = false; c->unresolved = false;
         c->pending = false;
         c->prev_open = false;
+        if (P.walk_flags) HIPCHK(hipMemset(P.walk_flags, 0, 16));   // (the values the next exchange sees are written by the next accept step)
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }

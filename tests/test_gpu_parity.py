@@ -812,3 +812,94 @@ def test_key_exchange_kernel_ties_failures_and_small_populations(S, O, monkeypat
     assert (hh.status == -2).any() and (hh.exchanged != 0).any()
     cm.assert_history_equal(hh, o.history())
     cm.assert_state_equal(h.state(), o.state())
+
+
+@pytest.mark.parametrize("N,npar,failbox", [(4096, 2, False), (1000, 2, True), (333, 1, False), (17, 2, True)])
+def test_key_walk_equals_slot_walk(S, O, monkeypatch, N, npar, failbox):
+    # k_chain_iter_norm's lean exchange walk (8-byte slots: 32-bit order key of the value, src, level of the last swap; padded
+    # level plan) against the same kernel on 16-byte slots (SMMHIP_KEY_WALK=0) and, for the small ones, the oracle; failbox:
+    # the -1.0 of a failed objective (negative keys) and, at iteration 1, every chain at the same value (equal keys: the
+    # exact values decide)
+    T = 40
+    kw = dict(objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[0.4, 1.2], sigma0=0.3) if failbox else {}
+    if npar == 2:
+        prob, opts = cm.serial_normal(N=N, T=T, ns=300, **kw)
+    else:
+        prob, opts = cm.general_normal(1, N=N, T=T, ns=300)
+    a = S.hip_context(prob, opts)
+    a.step(T)
+    monkeypatch.setenv("SMMHIP_KEY_WALK", "0")
+    b = S.hip_context(prob, opts)
+    b.step(T)
+    monkeypatch.delenv("SMMHIP_KEY_WALK")
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_state_equal(a.state(), b.state(), rtol=0)
+    hh = a.history()
+    assert (hh.exchanged != 0).mean() > 0.02
+    if failbox:
+        assert (hh.status == -2).any()
+    if N <= 1000:
+        o = O.OracleContext(prob, opts, S.Tables(Z=a.Z()), threads=_all_cores(O))
+        o.step(T)
+        cm.assert_history_equal(hh, o.history())
+        cm.assert_state_equal(a.state(), o.state())
+
+
+def test_key_walk_deep_plan_falls_back(S, O):
+    # an injected pair list in which one chain takes part in 40 pairs of an iteration: 40 dependency levels do not fit the
+    # slot's 5 bits, the plan says so and that launch walks on 16-byte slots; iterations with an ordinary list use the lean walk
+    N, T = 64, 12
+    prob, opts = cm.serial_normal(N=N, T=T, ns=200)
+    rng = np.random.default_rng(5)
+    pairs = np.zeros((T, N, 2), np.int32)
+    for t in range(T):
+        for q in range(N):
+            if t % 3 == 0 and q < 40:
+                i, j = 0, 1 + (q % (N - 1))          # chain 0 in 40 pairs
+            else:
+                i, j = sorted(rng.choice(N, 2, replace=False))
+            pairs[t, q] = (i, j)                     # 0-based, i < j (include/smmhip.h)
+    tab = S.Tables(pairs=pairs)
+    h, o = run_both(S, O, prob, opts, tab)
+    hh = h.history()
+    assert (hh.exchanged != 0).any()
+    cm.assert_history_equal(hh, o.history())
+    cm.assert_state_equal(h.state(), o.state())
+
+
+@pytest.mark.parametrize("nan", [False, True])
+def test_key_walk_special_values(S, O, monkeypatch, nan):
+    # last accepted values that the order keys must not get wrong, planted through set_state: values that share the high word
+    # of the double (equal keys: the exact values are read), -0.0 against +0.0 (equal), the -1.0 of a failed objective, Inf,
+    # and (nan) NaN, which no key covers: the accept step raises the sticky flag and the launches walk on 16-byte slots
+    N, T0, T1 = 96, 4, 14
+    prob, opts = cm.serial_normal(N=N, T=T0 + T1, ns=200, acc_tuners=np.full(96, 400.0))
+    a = S.hip_context(prob, opts)
+    a.step(T0)
+    st, hist = a.state(), a.history()
+    v = st.la_value
+    v[0:32] = 1.0 + np.arange(32) * 2.0 ** -45          # one high word, 32 low words
+    v[32:36] = [-0.0, 0.0, -0.0, 0.0]
+    v[36:40] = [-1.0, np.inf, -1.0, np.inf]
+    v[40:48] = 3.0e-300                                   # equal values
+    if nan:
+        v[48:52] = np.nan
+    runs = []
+    for env in (None, "0"):
+        if env is not None:
+            monkeypatch.setenv("SMMHIP_KEY_WALK", env)
+        b = S.hip_context(prob, opts)
+        b.set_state(st, hist)
+        b.step(T1)
+        runs.append(b)
+        if env is not None:
+            monkeypatch.delenv("SMMHIP_KEY_WALK")
+    cm.assert_history_equal(runs[0].history(), runs[1].history(), exact_floats=True)
+    cm.assert_state_equal(runs[0].state(), runs[1].state(), rtol=0)
+    o = O.OracleContext(prob, opts, S.Tables(Z=a.Z()))
+    o.set_state(st, hist)
+    o.step(T1)
+    hh = runs[0].history()
+    assert (hh.exchanged[T0:] != 0).any()
+    cm.assert_history_equal(hh, o.history())
+    cm.assert_state_equal(runs[0].state(), o.state())

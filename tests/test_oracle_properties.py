@@ -243,3 +243,17 @@ def test_sharded_oracle_equals_single(O):
         hr = s.history()
         for f in A.HistoryBuffers.FIELDS:
             assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * 4:(r + 1) * 4], equal_nan=True), f
+
+
+def test_restart_resumes_bit_exactly(O):
+    # save / readMalgo / restart! (AlgoAbstract.jl:83-102, AlgoBGP.jl:804-884) on the oracle itself: stop after 12 iterations,
+    # hand state and history to a new context, resume — the same history as the uninterrupted run
+    prob, opts = cm.serial_normal(N=10, T=30, ns=300)
+    tab = Tables(Z=O.gen_Z(opts.seed, 2, 300))
+    full = run(O, prob, opts, tab)
+    a = run(O, prob, opts, tab, T=12)
+    b = O.OracleContext(prob, opts, tab)
+    b.set_state(a.state(), a.history())
+    b.step(18)
+    cm.assert_history_equal(full.history(), b.history(), exact_floats=True)
+    cm.assert_state_equal(full.state(), b.state(), rtol=0)

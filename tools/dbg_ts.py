@@ -1,6 +1,6 @@
 import sys, os, ctypes as C
 import numpy as np
-os.environ["SMMHIP_TS"] = "1"
+os.environ.setdefault("SMMHIP_TS", "1")   # "2": also a stamp per level of the inline walk (stretches the levels)
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import smm_jl_amd as S, common as cm
 prob, opts = cm.serial_normal(N=4096, T=700)
@@ -40,4 +40,7 @@ print("resolve: %d levels, %d shader cycles over %.2f us -> %.0f MHz" % (int(x[7
 nl=int(x[7]); print("inline walk of WG 0: %d levels, %d with barriers; cycles per level:" % (nl, int(x[14])), np.diff(x[15:16+nl].astype(np.int64)).tolist())
 print("cycles at level ends (thread 0, shader clock):", [int(v) for v in x[15:15+int(x[7])+1]])
 print("ltail", int(x[14]))
+print("level ends:", [int(v) for v in x[50:50+nl]])
 print("per level:", np.diff(x[15:15+int(x[7])+1].astype(np.int64)).tolist())
+print("walk of WG 0: %d shader cycles (s_memtime) in %.2f us (s_memrealtime, 100 MHz) -> %.0f MHz" % (int(x[42]) - int(x[40]), (int(x[43]) - int(x[41])) / 100.0, (int(x[42]) - int(x[40])) / max((int(x[43]) - int(x[41])) / 100.0, 1e-9)))
+print("probe: 16 dependent ds_read_b32 of one wave: %d cycles -> %.0f per read" % (int(x[44]), int(x[44]) / 16.0))
