@@ -158,39 +158,7 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// exchange_walk_lean: the level walk of exchange_walk_fast, written for the number of INSTRUCTIONS per level.
-// Measured (SMMHIP_TS=2, s_memtime per level): a level of the walk costs what one wave needs from barrier to barrier, and that
-// is not the LDS round trip (71 cycles for a dependent ds_read_b32 in this kernel) but the wave's own instruction stream:
-// ~8 cycles per instruction and ~25 per taken branch for a lone wave — 556 cycles for the ~65 instructions of a level in the
-// straightforward loop (fetch the pair word, test for "no pair", take it apart, address arithmetic, test for undecided keys,
-// carry the partner), whatever the slot size.  So the plan and the slot format take the work out of the loop:
-//   * the plan (k_exch_plan) pads every level to whole waves with dummy pairs that never swap: no lane asks whether it has a
-//     pair, a wave without pairs skips the level on a scalar compare;
-//   * a pair word is the two LDS byte offsets of its slots (one AND, one shift);
-//   * a slot is 8 bytes: {32-bit order key of the value, src | level of the chain's last swap << 12}.  `value_i - value_j > 0`
-//     (min_improve == 0 for every chain: the host checks) is ONE unsigned compare of the keys; equal keys (same high word of
-//     the doubles: rare) read the exact values from memory;
-//   * set_exchanged! (AlgoBGP.jl:747-748) costs nothing per pair: a swap stamps the level (a scalar) into the slot, and the
-//     control wave looks the partner up afterwards in the plan's table lv_adj[chain][level];
-//   * the next level's pair word is requested together with the slots (one LDS round trip per level).
-// LDS: slots uint2[Ng4 + 4] | pair words u32[plan_Kp]  (Ng4 = N_global rounded up to 4); 57 KB at 4096 chains.
-// ------------------------------------------------------------------------------------------
-__host__ __device__ inline int lean_walk_Kp(int K) { return (K + 64 * LV_MAXLEV + 3) & ~3; }
-__host__ __device__ inline size_t lean_walk_bytes(int Ng, int K) { return (size_t)(((Ng + 3) & ~3) + 4) * 8 + (size_t)lean_walk_Kp(K) * 4; }
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-// one pair: slots at the LDS offsets of pw (the slots start at LDS address 0: checked by the caller)
-__device__ inline void walk_pair_lean(const KParams& P, const uint32_t pw, const uint32_t lvl_bits) {
-    const uint32_t ai = pw & 0xffffu, aj = pw >> 16;
-    u32x2_t si, sj;
-    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
-    bool swap = si.x > sj.x;
-    if (si.x == sj.x) swap = P.vals[si.y & 0xfffu] - P.vals[sj.y & 0xfffu] > 0.0;   // the keys do not decide (dist_fun = -, AlgoBGP.jl:688)
-    if (swap) {   // swap_ev_ij!, :739-744; the level stands for set_exchanged!, :747-748
-        const u32x2_t ni = {sj.x, (sj.y & 0xfffu) | lvl_bits}, nj = {si.x, (si.y & 0xfffu) | lvl_bits};
-        asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
-    }
-}
+// (the lean exchange walk itself: smm_walk_lean.hpp)
 // false (nothing done): this iteration's plan does not fit the form (more than 31 levels), a NaN value is among the chains',
 // or the dynamic LDS does not start at address 0 — the caller runs the 16-byte walk.  The result is in LDS (slots at lds);
 // only wave 0 may read it without a barrier.
@@ -218,70 +186,11 @@ __device__ inline bool exchange_walk_lean(const KParams& P, const int tx, unsign
     if (4 * tid < P.plan_Kp) ((uint4*)(lds + pbase))[tid] = p0;
     if (4 * (tid + NT) < P.plan_Kp) ((uint4*)(lds + pbase))[tid + NT] = p1;
     if (tid == 0) ((uint4*)lds)[2 * (Ng4 / 4)] = make_uint4(1u, 0u, 2u, 0u);   // the two dummy slots: keys 1 < 2, "no swap"
-    // the narrow tail (every remaining level one wave wide) is walked by wave 0 alone
-    int ltail = 0;
-    {
-        const uint32_t nx = (uint32_t)__shfl_down((int)ov, 1, 64);
-        const unsigned long long wide = __ballot(lane < nlev && nx - ov > 64u);
-        ltail = wide ? 64 - __builtin_clzll(wide) : 0;
-    }
+    const int ltail = lean_walk_tail(ov, nlev, lane);
     __syncthreads();
     if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
     if (P.ts && tid == 0 && blockIdx.x == 0) { P.ts[(size_t)8 * 60000 + 40] = clock64(); P.ts[(size_t)8 * 60000 + 41] = wall_clock64(); }
-    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63);   // this wave's first word within a level
-    const uint32_t tid4p = pbase + 4u * (uint32_t)tid;
-    uint32_t st = 0u, st1 = (uint32_t)__builtin_amdgcn_readlane((int)ov, 1);     // first words of the levels l, l+1
-    uint32_t pw = 0u;
-    if (nlev > 0) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pw) : "v"(tid4p) : "memory");   // (garbage past the level: not used)
-    // (written for the common case to fall through: every taken branch costs a lone wave ~25 cycles)
-    auto level = [&](const int l, const bool lone) {
-        const uint32_t st2 = (uint32_t)__builtin_amdgcn_readlane((int)ov, l + 2);   // (l + 2 <= 33; past the last level: anything)
-        const uint32_t width = st1 - st;
-        if (__builtin_expect(wbase < width, 1)) {
-            const uint32_t ai = pw & 0xffffu, aj = pw >> 16;
-            const uint32_t nptr = tid4p + 4u * st1;       // this lane's word of the next level (garbage past it: not used)
-            uint32_t lvl_bits;                            // in a vector register: v_and_or_b32 takes one scalar operand, the mask
-            asm volatile("v_mov_b32 %0, %1" : "=v"(lvl_bits) : "s"((uint32_t)(l + 1) << 12));
-            u32x2_t si, sj;
-            uint32_t pwn;
-            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(si), "=&v"(sj), "=&v"(pwn) : "v"(ai), "v"(aj), "v"(nptr) : "memory");
-            bool swap = si.x > sj.x;
-            const bool tie = si.x == sj.x;
-            if (__builtin_expect(__ballot(tie) != 0ull, 0)) {   // the keys do not decide: the exact values (dist_fun = -, AlgoBGP.jl:688)
-                if (tie) swap = P.vals[si.y & 0xfffu] - P.vals[sj.y & 0xfffu] > 0.0;
-            }
-            if (swap) {   // swap_ev_ij!, :739-744; the level stands for set_exchanged!, :747-748
-                const u32x2_t ni = {sj.x, (sj.y & 0xfffu) | lvl_bits}, nj = {si.x, (si.y & 0xfffu) | lvl_bits};
-                asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
-            }
-            pw = pwn;
-            if (__builtin_expect(width > (uint32_t)NT, 0)) {   // a level wider than the workgroup
-                for (uint32_t o = NT; wbase + o < width; o += NT) {
-                    uint32_t pwx;
-                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pwx) : "v"(tid4p + 4u * (st + o)) : "memory");
-                    walk_pair_lean(P, pwx, (uint32_t)(l + 1) << 12);
-                }
-            }
-        } else if (wbase < st2 - st1) {   // idle in this level, not in the next: its word
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pw) : "v"(tid4p + 4u * st1) : "memory");
-        }
-        st = st1; st1 = st2;
-        if (!lone) { walk_wait_lds(); __syncthreads(); }
-    };
-    {   // (two levels per trip of the loop, by hand: the compiler does not unroll across the barrier)
-        int l = 0;
-#pragma clang loop unroll(disable)
-        for (; l + 2 <= ltail; l += 2) { level(l, false); level(l + 1, false); }
-        if (l < ltail) level(l, false);
-    }
-    if (ltail < nlev && tid < 64) {   // the narrow tail: wave 0 alone, no barriers (its own LDS operations complete in order)
-        int l = ltail;
-#pragma clang loop unroll(disable)
-        for (; l + 2 <= nlev; l += 2) { level(l, true); level(l + 1, true); }
-        if (l < nlev) level(l, true);
-        walk_wait_lds();
-    }
+    lean_walk_levels<NORM_WG, 0>(P.vals, 1, pbase, ov, nlev, tid, ltail);
     if (P.ts && tid == 0 && blockIdx.x == 0) {
         P.ts[(size_t)8 * 60000 + 42] = clock64(); P.ts[(size_t)8 * 60000 + 43] = wall_clock64();
         P.ts[(size_t)8 * 60000 + 14] = (unsigned long long)ltail; P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev;
@@ -356,7 +265,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
     // barrier, or the one below, orders the reset)
     if (tid == 64) { *s_arrived = 0u; *s_rng_ready = 0u; }
     if constexpr (!WALK) __syncthreads();
-    uint32_t klev = 0;   // lean walk: 1 + the level of the chain's last swap (its partner is looked up together with the record)
+
+    uint32_t kmeta = 0u;   // lean walk: src | stamp << 16 of the chain's slot (the partner is looked up while the record is on its way)
     if constexpr (WALK) {
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
         const bool lean = P.lv_pairs_p && exchange_walk_lean(P, t - 1, (unsigned char*)smem, tid, tile);
@@ -367,9 +277,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
                 xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
             }
         } else if (valid) {
-            const uint32_t meta = ((const uint2*)smem)[gc].y;
-            xr = (unsigned long long)(meta & 0xfffu);
-            klev = (meta >> 12) & 31u;
+            kmeta = ((const uint2*)smem)[gc].y;
+            xr = (unsigned long long)(kmeta & 0xffffu);
         }
     }
     // This iteration's randomness, by wave 1 (lane = the control wave's lane: chain, try): it has nothing to do from here to the
@@ -416,7 +325,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
                 const double2* g_rec = (const double2*)(rec_in + (size_t)s * RW);
 #pragma unroll
                 for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc[2 * i] = q.x; rc[2 * i + 1] = q.y; }
-                if (WALK && klev) partner = (int)P.lv_adj[((size_t)(t - 1 - P.plan_t0) * P.Ng + gc) * 32 + klev];   // set_exchanged!, :747-748
+                if (WALK && (kmeta >> 16))   // set_exchanged!, :747-748: from the pair word the swap stamped into the slot
+                    partner = (int)lean_partner<0>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc);
             } else {
 #pragma unroll
                 for (int f = 0; f < RW; ++f) rc[f] = 0.0;

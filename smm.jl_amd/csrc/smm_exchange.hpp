@@ -205,8 +205,7 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const
 // same arithmetic; the chain slots are split (8-byte value, 4-byte src | partner << 16) so that 8192 chains and
 // their pair list take 128 KB of LDS.  Thresholds: one scalar when min_improve is uniform, else from the plan.
 template <int LWG>
-__global__ __launch_bounds__(LWG) void k_exch_resolve_lvl_soa(const KParams P, const int t, const double* __restrict__ gathered) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+__device__ inline void resolve_lvl_soa_body(const KParams& P, const int t, const double* __restrict__ gathered, unsigned char* xsm) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int Ng = P.Ng, RW = P.RW, K = P.plan_K;
     const int w = t - P.plan_t0;
@@ -278,6 +277,88 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl_soa(const KParams P, c
         const uint32_t s_ = sp[g];
         P.xres[g] = (unsigned long long)(s_ & 0xffffu) | ((unsigned long long)(s_ >> 16) << 32);
     }
+}
+
+template <int LWG>
+__global__ __launch_bounds__(LWG) void k_exch_resolve_lvl_soa(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    resolve_lvl_soa_body<LWG>(P, t, gathered, xsm);
+}
+
+// k_exch_resolve_lean: the lean walk of smm_walk_lean.hpp as a kernel of its own (one workgroup): min_improve == 0 for every
+// chain, N_global <= 8192 — the sharded path at 1 and 2 GPUs x 4096 chains, single shards whose chain kernel does not walk
+// inline (8192 chains; objectives other than objfunc_norm).  Same result as k_exch_resolve_lvl_soa, which it falls back to
+// (as a function, in the same launch) when this iteration's plan has more than 31 levels or a chain value is NaN.
+__global__ __launch_bounds__(XWG) void k_exch_resolve_lean(const KParams P, const int t, const double* __restrict__ gathered) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int Ng = P.Ng;
+    const int w = t - P.plan_t0;
+    const uint32_t* __restrict__ g_offp = P.lv_offp + (size_t)w * LV_OFFP;
+    const uint4* __restrict__ g_pairs = (const uint4*)(P.lv_pairs_p + (size_t)w * P.plan_Kp);
+    const double* __restrict__ vsrc = gathered ? gathered : P.vals;
+    const int vstride = gathered ? P.RW : 1;
+    const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
+    const uint32_t pbase = 8u * (Ng4 + 4u);
+    constexpr int PT = XLDS_MAX / XWG;                 // chains per lane
+    constexpr int PR = (XLDS_MAX + 64 * LV_MAXLEV + 4 * XWG - 1) / (4 * XWG);   // rounds of 16-byte loads for the pair words
+    XTS(0);
+    const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
+    double v_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {   // one round trip: the chains' values (a strided read of the gathered records) and the pair words
+        const int g = tid + r * XWG;
+        v_[r] = g < Ng ? vsrc[(size_t)g * vstride] : 0.0;
+    }
+    uint4 p_[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int q4 = tid + r * XWG;
+        p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t* s_nan = (uint32_t*)(xsm + 8u * (Ng4 + 2u));   // (a spare slot behind the dummy pair's)
+    if (tid == 0) *s_nan = 0u;
+    __syncthreads();
+    bool nan = false;
+#pragma unroll
+    for (int r = 0; r < PT; ++r) nan = nan || v_[r] != v_[r];
+    if (nan) *s_nan = 1u;
+    const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
+    const bool fits = __builtin_amdgcn_readlane((int)ov, 34) != 0 && (uint32_t)(size_t)xsm == 0u;
+    __syncthreads();
+    const bool has_nan = *s_nan != 0u;
+    __syncthreads();
+    if (!fits || has_nan) { resolve_lvl_soa_body<XWG>(P, t, gathered, xsm); return; }
+    uint2* slot = (uint2*)xsm;
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * XWG;
+        if (g < Ng) slot[g] = make_uint2(order_key32(v_[r]), (uint32_t)g);
+    }
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int q4 = tid + r * XWG;
+        if (4 * q4 < P.plan_Kp) ((uint4*)(xsm + pbase))[q4] = p_[r];
+    }
+    if (tid == 0) { slot[Ng4] = make_uint2(1u, 0u); slot[Ng4 + 1] = make_uint2(2u, 0u); }   // the dummy pair's slots: keys 1 < 2, "no swap"
+    const int ltail = lean_walk_tail(ov, nlev, lane);
+    __syncthreads();
+    XTS(1);
+    if (P.lean_unit == 8) lean_walk_levels<XWG, 0>(vsrc, vstride, pbase, ov, nlev, tid, ltail);
+    else lean_walk_levels<XWG, 1>(vsrc, vstride, pbase, ov, nlev, tid, ltail);
+    __syncthreads();
+    XTS(2);
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * XWG;
+        if (g < Ng) {
+            const uint32_t meta = slot[g].y;
+            const uint32_t partner = P.lean_unit == 8 ? lean_partner<0>(xsm, pbase, meta, (uint32_t)g) : lean_partner<1>(xsm, pbase, meta, (uint32_t)g);
+            P.xres[g] = (unsigned long long)(meta & 0xffffu) | ((unsigned long long)partner << 32);
+        }
+    }
+    XTS(4);
+    if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nlev;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -45,7 +45,7 @@ __global__ void k_pregen_rng(const KParams P, const int t0, const int W, double*
 __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0, unsigned long long* __restrict__ plan,
                                                    double* __restrict__ plan_mi, uint32_t* __restrict__ lv_pairs,
                                                    double* __restrict__ lv_mi, uint32_t* __restrict__ lv_off,
-                                                   uint32_t* __restrict__ lv_pairs_p, uint32_t* __restrict__ lv_offp, uint16_t* __restrict__ lv_adj) {
+                                                   uint32_t* __restrict__ lv_pairs_p, uint32_t* __restrict__ lv_offp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = t0 + blockIdx.x;
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
     // o_off[l] = end of the l-th level (0-based) = start of 1-based level l+2
     for (int l = tid; l < nlev; l += XWG) o_off[l] = (l + 2 <= nlev) ? lhist[l + 2] : (uint32_t)K;
     if (tid == 0) o_off[K + 1] = (uint32_t)nlev;
-    // the same list for the lean walk of k_chain_iter_norm: every level padded to whole waves (so that no lane has to ask
-    // whether it has a pair), pair words that are LDS byte offsets, and every chain's partner by level
+    // the same list for the lean walk (smm_walk_lean.hpp): every level padded to whole waves (so that no lane has to ask
+    // whether it has a pair), pair words that are LDS offsets of the chains' slots
     __shared__ uint32_t s_lst[LV_MAXLEV + 2], s_pst[LV_MAXLEV + 2];   // first (padded) position of 1-based level c
     const bool lean = lv_pairs_p != nullptr && nlev <= LV_MAXLEV;
     uint32_t* o_pp = lv_pairs_p ? lv_pairs_p + (size_t)blockIdx.x * P.plan_Kp : nullptr;
@@ -256,14 +256,14 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         }
     }
     __syncthreads();
+    const uint32_t sc8 = (uint32_t)P.lean_unit;   // a word holds 8 i (byte offsets of the 8-byte slots) or, for more than 8190 chains, 4 i
     if (lean) {
         const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
-        const uint32_t dummy = (8u * Ng4) | ((8u * (Ng4 + 1u)) << 16);   // two slots behind the chains' whose keys say "no swap"
+        const uint32_t dummy = (sc8 * Ng4) | ((sc8 * (Ng4 + 1u)) << 16);   // two slots behind the chains' whose keys say "no swap"
         for (uint32_t q = tid; q < s_pst[nlev + 1]; q += XWG) o_pp[q] = dummy;
     }
     __syncthreads();
     uint32_t* o_pairs = lv_pairs + (size_t)blockIdx.x * K;
-    uint16_t* o_adj = (lean && lv_adj) ? lv_adj + (size_t)blockIdx.x * Ng * 32 : nullptr;
     double* o_mi = lv_mi + (size_t)blockIdx.x * K;
 #pragma unroll
     for (int m = 0; m < MAXPP; ++m) {
@@ -274,10 +274,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
             const uint32_t i = pi[q], j = pj[q];
             o_pairs[pos] = i | (j << 16);
             o_mi[pos] = P.min_improve_g[i];
-            if (lean) {
-                o_pp[s_pst[lv] + (pos - s_lst[lv])] = (8u * i) | ((8u * j) << 16);
-                if (o_adj) { o_adj[(size_t)i * 32 + lv] = (uint16_t)(j + 1); o_adj[(size_t)j * 32 + lv] = (uint16_t)(i + 1); }
-            }
+            if (lean) o_pp[s_pst[lv] + (pos - s_lst[lv])] = (sc8 * i) | ((sc8 * j) << 16);
         }
     }
 }

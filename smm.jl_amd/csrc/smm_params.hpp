@@ -60,13 +60,12 @@ struct KParams {
     const uint32_t* lv_pairs;        // [W][K]: pi | pj<<16, level by level
     const double* lv_mi;             // [W][K]: min_improve of chain pi, same order
     const uint32_t* lv_off;          // [W][K+2]: lv_off[l] = first position of level l; entry K+1 = number of levels
-    // ... and for the lean walk of k_chain_iter_norm (N_global, K <= 4096, min_improve == 0; null otherwise):
+    // ... and for the lean walk (smm_walk_lean.hpp; N_global, K <= 8192, min_improve == 0; null otherwise):
     const uint32_t* lv_pairs_p;      // [W][plan_Kp]: level by level, every level padded to a multiple of 64 words with dummy pairs; a
-                                     //          word = the LDS byte offsets of the pair's two 8-byte chain slots, 8 pi | 8 pj << 16
+                                     //          word = lean_unit * pi | lean_unit * pj << 16 (lean_unit = 8: the LDS byte offsets of the 8-byte slots)
     const uint32_t* lv_offp;         // [W][LV_OFFP]: entry l = first word of level l (entry nlev: the padded length); [33] = nlev;
                                      //          [34] = 1 when the plan fits this form (at most 31 levels)
-    const uint16_t* lv_adj;          // [W][Ng][32]: entry l = 1 + the partner of the chain in its pair of level l - 1 (l = 1..31)
-    int plan_Kp;
+    int plan_Kp, lean_unit;          // words per iteration in lv_pairs_p; 8, or 4 when 8 * N_global does not fit 16 bits (smm_walk_lean.hpp)
     int plan_t0, plan_K;
     // state
     double* cs;                // [N][CSW]

@@ -52,6 +52,7 @@ using namespace smm;
 
 #include "smm_params.hpp"
 #include "smm_chain.hpp"
+#include "smm_walk_lean.hpp"
 #include "smm_chain_norm.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
@@ -166,7 +167,7 @@ struct Ctx {
     unsigned long long* win_plan = nullptr;
     double* win_plan_mi = nullptr;
     uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr, *win_lv_pairs_p = nullptr, *win_lv_offp = nullptr;
-    uint16_t* win_lv_adj = nullptr;   // (the lean walk of k_chain_iter_norm)
+    bool lean_resolve = false;   // min_improve == 0, N_global <= 8192: k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
     bool lvl_soa_exchange = false;   // XLVL_MAX < N_global <= XLDS_MAX: level walk on split chain slots
@@ -265,11 +266,11 @@ void ensure_windows(Ctx* c, int t) {
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
         hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
-                           c->win_plan_mi, c->win_lv_pairs, c->win_lv_mi, c->win_lv_off, c->win_lv_pairs_p, c->win_lv_offp, c->win_lv_adj);
+                           c->win_plan_mi, c->win_lv_pairs, c->win_lv_mi, c->win_lv_off, c->win_lv_pairs_p, c->win_lv_offp);
         c->plan_t0 = t; c->plan_w = W;
         P.plan = c->win_plan; P.plan_mi = c->win_plan_mi; P.plan_t0 = t;
         P.lv_pairs = c->win_lv_pairs; P.lv_mi = c->win_lv_mi; P.lv_off = c->win_lv_off;
-        P.lv_pairs_p = c->win_lv_pairs_p; P.lv_offp = c->win_lv_offp; P.lv_adj = c->win_lv_adj;
+        P.lv_pairs_p = c->win_lv_pairs_p; P.lv_offp = c->win_lv_offp;
     }
 }
 
@@ -354,9 +355,17 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
     if (!c->ext_rec_out) c->cur ^= 1;
 }
 
+size_t resolve_lean_bytes(int Ng, int K) { return std::max(lean_walk_bytes(Ng, K), resolve_lvl_soa_bytes(Ng, K)); }
+
 void launch_resolve(Ctx* c, int t, const double* gathered) {
     const KParams& P = c->P;
-    if (c->lvl_exchange)
+    if (c->lean_resolve)
+        if (c->kev0)
+            hipExtLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K), c->stream, c->kev0, c->kev1, 0, P, t,
+                                  gathered);
+        else
+            hipLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+    else if (c->lvl_exchange)
         if (c->lvl_wg == 256)
             hipLaunchKernelGGL(k_exch_resolve_lvl<256>, dim3(1), dim3(256), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
         else if (c->lvl_wg == 512)
@@ -734,16 +743,19 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->win_cap * K);
                 c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
                 c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
-                // the lean walk of k_chain_iter_norm: min_improve == 0 for every chain, chain ids and list positions in 12 bits
-                const char* kw = getenv("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walk on 16-byte slots
-                if (c->norm_fast && c->inline_walk && P.mi_uniform && P.mi_value == 0.0 && Ng <= XLVL_MAX && K <= XLVL_MAX && !(kw && kw[0] == '0')) {
+                // the lean walk (smm_walk_lean.hpp): min_improve == 0 for every chain
+                const char* kw = getenv("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walks on 16-byte / split slots
+                if (P.mi_uniform && P.mi_value == 0.0 && K <= XLDS_MAX && !(kw && kw[0] == '0')) {
                     P.plan_Kp = lean_walk_Kp(K);
+                    P.lean_unit = lean_walk_unit(Ng);
                     c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->win_cap * P.plan_Kp);
                     c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->win_cap * LV_OFFP);
-                    c->win_lv_adj = dalloc<uint16_t>(c, (size_t)c->win_cap * Ng * 32);
-                    P.slot8 = dalloc<uint2>(c, (size_t)N + 4);
-                    P.walk_flags = dalloc<uint32_t>(c, 4);
-                    HIPCHK(hipMemset(P.walk_flags, 0, 16));
+                    c->lean_resolve = true;
+                    if (c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) {   // ... in the prologue of k_chain_iter_norm
+                        P.slot8 = dalloc<uint2>(c, (size_t)N + 4);
+                        P.walk_flags = dalloc<uint32_t>(c, 4);
+                        HIPCHK(hipMemset(P.walk_flags, 0, 16));
+                    }
                 }
             }
         }
@@ -803,6 +815,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (int)resolve_lvl_soa_bytes(XLDS_MAX, XLDS_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lean, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_lean_bytes(XLDS_MAX, XLDS_MAX)));
         }
         {   // tiles of problems with many parameters need more than the default 64 KiB of dynamic LDS
             const int lim = 160 * 1024;
