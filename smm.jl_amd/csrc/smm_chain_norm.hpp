@@ -173,15 +173,16 @@ __device__ inline bool exchange_walk_lean(const KParams& P, const int tx, unsign
     const uint32_t pbase = 8u * (Ng4 + 4u);   // LDS offset of the pair words
     // one round trip of 16-byte loads: the slots of the chains 4 tid .. 4 tid + 3, the pair words 4 tid .. and 4 (tid + NT) ..
     // (the arrays are padded; words past the padded length are never looked at)
+    // (everything is requested before anything is looked at: a load issued behind the first wait is a round trip of its own)
+    const uint32_t wflags = P.walk_flags[tid & 3];   // (word 0 is looked at; a per-lane address keeps it a vector load among the others)
     const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
     uint4 s0 = make_uint4(0u, 0u, 0u, 0u), s1 = s0;
     if (4 * tid < Ng) { s0 = ((const uint4*)P.slot8)[2 * tid]; s1 = ((const uint4*)P.slot8)[2 * tid + 1]; }
     uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0;
     if (4 * tid < P.plan_Kp) p0 = g_pairs[tid];
     if (4 * (tid + NT) < P.plan_Kp) p1 = g_pairs[tid + NT];
-    const uint32_t wflags = *P.walk_flags;
     const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
-    if (__builtin_amdgcn_readlane((int)ov, 34) == 0 || __builtin_amdgcn_readfirstlane((int)wflags) != 0 || (uint32_t)(size_t)lds != 0u) return false;
+    if (__builtin_amdgcn_readlane((int)ov, 34) == 0 || __builtin_amdgcn_readlane((int)wflags, 0) != 0 || (uint32_t)(size_t)lds != 0u) return false;
     if (4 * tid < Ng) { ((uint4*)lds)[2 * tid] = s0; ((uint4*)lds)[2 * tid + 1] = s1; }
     if (4 * tid < P.plan_Kp) ((uint4*)(lds + pbase))[tid] = p0;
     if (4 * (tid + NT) < P.plan_Kp) ((uint4*)(lds + pbase))[tid + NT] = p1;
@@ -240,7 +241,9 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
     unsigned long long xr = (unsigned long long)(unsigned)gc;
 #pragma unroll
     for (int k = 0; k < NP; ++k) { zA[k] = 0.0; zB[k] = 0.0; }
-    if (ctl) err_word = *(const volatile unsigned long long*)P.err;
+    // (a plain load, looked at after the walk: a volatile one is a system-scope round trip the control wave waits for at once,
+    // before it has requested anything else — and the staging barrier waits for the control wave)
+    if (ctl) err_word = *(const unsigned long long*)P.err;
     // this iteration's randomness (the MH uniform, the normals of the tries this lane evaluates): generated right here unless
     // tables are injected — the counter generator needs nothing but (seed, chain, iteration, try), the control wave would
     // otherwise just wait for the exchange inputs, and 144 bytes per chain and iteration need not be written and read back
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
     TS_MARK(1);
 
     // ---- control wave: the record the chain continues from, settle iteration t-1, propose (AlgoBGP.jl:424-471) ----
+    asm volatile("" : "+v"(err_word));   // (looked at only here: the compiler would otherwise wait for it right behind the load)
     const bool poisoned = err_word != ERR_NONE;   // an earlier iteration raised a hard error: nothing is stored any more
     if (ctl) {
         if (tid == 0) s_park[CT * PARKW + 1] = poisoned ? 1.0 : 0.0;
