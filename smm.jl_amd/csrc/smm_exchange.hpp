@@ -411,7 +411,8 @@ __device__ inline void block_excl_scan(uint32_t* a, int n, uint32_t* wsum, int t
 
 __global__ __launch_bounds__(XWG) void k_exch_plan_big(const KParams P, const int t0, uint32_t* __restrict__ scratch,
                                                        uint32_t* __restrict__ lv_pairs, double* __restrict__ lv_mi,
-                                                       uint32_t* __restrict__ lv_off) {
+                                                       uint32_t* __restrict__ lv_off, uint32_t* __restrict__ lv_rows,
+                                                       uint32_t* __restrict__ lv_rowinfo) {
     __shared__ uint32_t wsum[XWG / 64];
     __shared__ uint32_t s_nlev;
     const int tid = threadIdx.x;
@@ -495,14 +496,45 @@ __global__ __launch_bounds__(XWG) void k_exch_plan_big(const KParams P, const in
     uint32_t* o_off = lv_off + (size_t)blockIdx.x * (K + 2);
     for (int l = tid; l < nlev; l += XWG) o_off[l] = (l + 2 <= nlev) ? S.cnt[l + 2] : (uint32_t)K;
     if (tid == 0) o_off[K + 1] = (uint32_t)nlev;
+    // the same list for k_exch_resolve_rows: every level padded to whole rows of 1024 words with dummy pairs that never swap (no
+    // lane asks whether it has a pair; a lane's words are tid, tid + 1024, ...: a plain stride to fetch ahead)
+    __shared__ uint32_t s_ls[LV_MAXLEV + 2], s_rs[LV_MAXLEV + 2];   // compact start / first row of 1-based level c
+    __shared__ uint32_t s_rows_ok;
+    if (tid == 0) {
+        uint32_t ok = lv_rows != nullptr && nlev <= LV_MAXLEV ? 1u : 0u, rows = 0;
+        unsigned long long endmask = 0ull;
+        if (ok) {
+            for (int c = 1; c <= nlev; ++c) {
+                s_ls[c] = S.cnt[c]; s_rs[c] = rows;
+                rows += ((c + 1 <= nlev ? S.cnt[c + 1] : (uint32_t)K) - S.cnt[c] + (uint32_t)XWG - 1u) / (uint32_t)XWG;
+                if (rows >= 1u && rows <= 64u) endmask |= 1ull << (rows - 1u);
+            }
+            s_rs[nlev + 1] = rows;
+            if (rows > (uint32_t)P.rows_cap || rows > 63u) ok = 0u;
+        }
+        s_rows_ok = ok;
+        if (lv_rowinfo) {
+            uint32_t* o = lv_rowinfo + (size_t)blockIdx.x * 4;
+            o[0] = rows; o[1] = (uint32_t)endmask; o[2] = (uint32_t)(endmask >> 32); o[3] = ok;
+        }
+    }
+    __syncthreads();
+    const bool rows_ok = s_rows_ok != 0u;
+    uint32_t* o_rows = lv_rows ? lv_rows + (size_t)blockIdx.x * P.rows_cap * XWG : nullptr;
+    if (rows_ok) {
+        const uint32_t dummy = (uint32_t)Ng | ((uint32_t)(Ng + 1) << 16);   // the two slots behind the chains': their keys say "no swap"
+        for (uint32_t q = tid; q < s_rs[nlev + 1] * (uint32_t)XWG; q += XWG) o_rows[q] = dummy;
+    }
     __syncthreads();
     uint32_t* o_pairs = lv_pairs + (size_t)blockIdx.x * K;
     double* o_mi = lv_mi + (size_t)blockIdx.x * K;
     for (int q = tid; q < K; q += XWG) {
-        const uint32_t pos = atomicAdd(&S.cnt[S.lvl[q]], 1u);
+        const uint32_t lv = S.lvl[q];
+        const uint32_t pos = atomicAdd(&S.cnt[lv], 1u);
         const uint32_t i = S.pi[q], j = S.pj[q];
         o_pairs[pos] = i | (j << 16);
         o_mi[pos] = P.min_improve_g[i];
+        if (rows_ok) o_rows[s_rs[lv] * (uint32_t)XWG + (pos - s_ls[lv])] = i | (j << 16);
     }
 }
 
@@ -690,19 +722,25 @@ __host__ __device__ inline size_t resolve_key_bytes(int Ng, int K) {
 // k_exch_keys: by the whole chip, before the one resolving workgroup starts: the value column of the gathered records
 // ([Ng][RW], or the compact array of a single shard with RW = 1) as a compact array, and every chain's initial 4-byte slot
 // (src = itself | key << 16).  A strided read and 32768 key computations by ONE workgroup cost more than the walk itself.
+// (slots17_out / nan_flags: for k_exch_resolve_rows — key17 << 15 | src, and two words used in turn by iteration parity: this
+// launch raises word t & 1 when a value is NaN and clears the other one for the next iteration)
 __global__ void k_exch_keys(const double* __restrict__ gathered, const int RW, const int Ng, double* __restrict__ vals_out,
-                            uint32_t* __restrict__ slots_out) {
+                            uint32_t* __restrict__ slots_out, uint32_t* __restrict__ slots17_out, uint32_t* __restrict__ nan_flags, const int t) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0 && nan_flags) nan_flags[(t + 1) & 1] = 0u;
     if (g >= Ng) return;
     const double v = gathered[(size_t)g * RW];
     if (vals_out != gathered) vals_out[g] = v;
     slots_out[g] = (uint32_t)g | (order_key16(v) << 16);
+    if (slots17_out) {
+        slots17_out[g] = (uint32_t)g | (order_key17(v) << 15);
+        if (v != v) atomicOr(&nan_flags[t & 1], 1u);
+    }
 }
 
 template <bool PLDS>   // PLDS: partners in LDS (N_global <= XKEY_PARTNER_MAX); else the bitmap + partner pass
-__global__ __launch_bounds__(XWG) void k_exch_resolve_key(const KParams P, const int t, const double* __restrict__ vals,
-                                                          const uint32_t* __restrict__ slots0) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+__device__ inline void resolve_key_body(const KParams& P, const int t, const double* __restrict__ vals, const uint32_t* __restrict__ slots0,
+                                        unsigned char* xsm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ng = P.Ng, K = P.plan_K;
     const int w = t - P.plan_t0;
@@ -860,4 +898,181 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_key(const KParams P, const
     }
     XTS(4);
     if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + 6] = clock64() - cyc0;
+}
+
+template <bool PLDS>
+__global__ __launch_bounds__(XWG) void k_exch_resolve_key(const KParams P, const int t, const double* __restrict__ vals,
+                                                          const uint32_t* __restrict__ slots0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    resolve_key_body<PLDS>(P, t, vals, slots0, xsm);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_exch_resolve_rows: exchangeMoves! for 8192 < N_global <= 32768 with min_improve == 0 for every chain (the 4- and 8-GPU
+// populations), written like the lean walk of smm_walk_lean.hpp for the number of instructions per pair — with 32768 pairs on one
+// CU the walk is bound by the instructions its 16 waves can issue (k_exch_resolve_key: ~40 per wave and 64 pairs).
+//   * the plan (k_exch_plan_big) pads every level to whole rows of 1024 words with dummy pairs that never swap: every lane has a
+//     pair in every row, a lane's words are tid, tid + 1024, ... (all of them — at most 63 — fetched into registers at the start),
+//     and one bit per row says whether a barrier follows (the last row of a level);
+//   * a chain slot is 4 bytes in LDS, order_key17(value) << 15 | src: `value_i - value_j > 0` is one unsigned compare of the two
+//     slots whenever their keys differ (one XOR and one compare tell), else the exact values are read from memory; a swap
+//     exchanges the two words;
+//   * set_exchanged! (AlgoBGP.jl:747-748): a wave's ballot of the swaps of a row is one 8-byte LDS word of its own (no atomics);
+//     the last partner of every chain is recovered afterwards (one LDS max per swapped endpoint, the later pair wins).
+// Falls back to k_exch_resolve_key's body when the plan does not fit (more than 31 levels or 63 rows) or a value is NaN.
+// LDS: slots u32[Ng + 2 (+ pad)] | swap ballots u64[rows_cap][16].
+// ------------------------------------------------------------------------------------------
+constexpr int XROWS_MAX = 63;
+__host__ __device__ inline size_t resolve_rows_bytes(int Ng, int K, int rows_cap) {
+    const size_t a = (((size_t)Ng + 2 + 3) & ~(size_t)3) * 4 + (Ng <= XKEY_PARTNER_MAX ? ((size_t)Ng + 4) * 2 : (size_t)rows_cap * 16 * 8);
+    const size_t b = resolve_key_bytes(Ng, K);
+    return a > b ? a : b;
+}
+template <bool PLDS>   // PLDS: the last partner of every chain in a 2-byte LDS array of its own, written by the swap (N_global <= XKEY_PARTNER_MAX)
+__global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, const int t, const double* __restrict__ vals,
+                                                           const uint32_t* __restrict__ slots16, const uint32_t* __restrict__ slots17,
+                                                           const uint32_t* __restrict__ nan_flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ng = P.Ng;
+    const int w = t - P.plan_t0;
+    const uint32_t* __restrict__ info = P.lv_rowinfo + (size_t)w * 4;
+    const uint32_t* __restrict__ g_rows = P.lv_rows + (size_t)w * P.rows_cap * XWG + tid;
+    XTS(0);
+    const int nrows = (int)info[0];
+    const unsigned long long endmask = (unsigned long long)info[1] | ((unsigned long long)info[2] << 32);
+    if (info[3] == 0u || nan_flags[t & 1] != 0u) {
+        resolve_key_body<PLDS>(P, t, vals, slots16, xsm);
+        return;
+    }
+    uint32_t* slot = (uint32_t*)xsm;
+    const uint32_t sl_words = ((uint32_t)Ng + 2u + 3u) & ~3u;
+    unsigned long long* bits = (unsigned long long*)(xsm + 4u * sl_words);   // !PLDS: [nrows][16] ballots of the swaps
+    uint16_t* partner = (uint16_t*)(xsm + 4u * sl_words);                     // PLDS: [Ng] last exchange partner + 1
+    const uint32_t pbase = 4u * sl_words;
+    constexpr int PT = XKEY_MAX / XWG;   // chains per lane
+    // this lane's pair words: row r sits in register q[r mod 3], requested three rows ahead
+    uint32_t q0 = nrows > 0 ? g_rows[0] : 0u, q1 = nrows > 1 ? g_rows[XWG] : 0u, q2 = nrows > 2 ? g_rows[2 * XWG] : 0u;
+    {
+        typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
+        const u32x4s_t* __restrict__ s4 = (const u32x4s_t*)slots17;     // made by k_exch_keys: 16 bytes per lane and round
+        constexpr int P4 = PT / 4;
+        u32x4s_t v_[P4];
+#pragma unroll
+        for (int r = 0; r < P4; ++r) {
+            const int g4 = tid + r * XWG;
+            v_[r] = 4 * g4 < Ng ? s4[g4] : u32x4s_t{0u, 0u, 0u, 0u};   // (the array is padded to a multiple of 4)
+        }
+#pragma unroll
+        for (int r = 0; r < P4; ++r) {
+            const int g4 = tid + r * XWG;
+            if (4 * g4 < Ng) ((u32x4s_t*)slot)[g4] = v_[r];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { slot[Ng] = 1u << 15; slot[Ng + 1] = 2u << 15; }   // the dummy pair's slots: keys 1 < 2, "no swap" (behind the staged words)
+    if constexpr (PLDS)
+        for (int g = tid; g < (Ng + 1) / 2; g += XWG) ((uint32_t*)partner)[g] = 0u;
+    __syncthreads();
+    XTS(1);
+    auto row = [&](const uint32_t pw, const int r) {
+        const uint32_t ai = (pw & 0xffffu) << 2, aj = (pw >> 16) << 2;
+        uint32_t si, sj;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
+        bool swap = si > sj;
+        const bool tie = (si ^ sj) < 0x8000u;
+        if (__builtin_expect(__ballot(tie) != 0ull, 0)) {   // the keys do not decide: the exact values (dist_fun = -, AlgoBGP.jl:688)
+            if (tie) swap = vals[si & 0x7fffu] - vals[sj & 0x7fffu] > 0.0;
+        }
+        if (swap) {   // swap_ev_ij!, :739-744
+            asm volatile("ds_write_b32 %0, %2\n\tds_write_b32 %1, %3" :: "v"(ai), "v"(aj), "v"(sj), "v"(si) : "memory");
+            if constexpr (PLDS) {   // set_exchanged!, :747-748
+                const uint32_t pi = pbase + (ai >> 1), pj = pbase + (aj >> 1);
+                asm volatile("ds_write_b16 %0, %2\n\tds_write_b16 %1, %3" :: "v"(pi), "v"(pj), "v"((pw >> 16) + 1u), "v"((pw & 0xffffu) + 1u) : "memory");
+            }
+        }
+        if constexpr (!PLDS) {
+            const unsigned long long m = __ballot(swap);
+            if (lane == 0) bits[r * 16 + wave] = m;
+        }
+        if ((endmask >> r) & 1ull) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // the level ends here
+    };
+    {
+        int r = 0;
+#pragma clang loop unroll(disable)
+        for (; r + 3 <= nrows; r += 3) {
+            row(q0, r);
+            q0 = r + 3 < nrows ? g_rows[(size_t)(r + 3) * XWG] : 0u;
+            row(q1, r + 1);
+            q1 = r + 4 < nrows ? g_rows[(size_t)(r + 4) * XWG] : 0u;
+            row(q2, r + 2);
+            q2 = r + 5 < nrows ? g_rows[(size_t)(r + 5) * XWG] : 0u;
+        }
+        if (r < nrows) row(q0, r);
+        if (r + 1 < nrows) row(q1, r + 1);
+    }
+    __syncthreads();
+    XTS(2);
+    // ---- result: src from the slots; the last exchange partner from the swap's own array, or from the ballots ----
+    uint32_t src_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * XWG;
+        src_[r] = g < Ng ? (slot[g] & 0x7fffu) : 0u;
+    }
+    if constexpr (PLDS) {
+        XTS(3);
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int g = tid + r * XWG;
+            if (g < Ng) P.xres[g] = (unsigned long long)src_[r] | ((unsigned long long)partner[g] << 32);
+        }
+    } else {
+        __syncthreads();
+        uint32_t* last = slot;   // [Ng] 1 + the chain's partner in its last swapped pair
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int g = tid + r * XWG;
+            if (g < Ng) last[g] = 0u;
+        }
+        __syncthreads();
+        // the rows once more (from the L2), in order: the pairs of a level touch disjoint chains, so plain stores do, with a
+        // barrier where a level ends — a later pair overwrites an earlier one (LDS atomics: 9.5 us for this pass at 32768 chains)
+        auto prow = [&](const uint32_t pw, const int r) {
+            const unsigned long long m = bits[r * 16 + wave];
+            if ((m >> lane) & 1ull) {   // set_exchanged!, :747-748
+                const uint32_t ai = (pw & 0xffffu) << 2, aj = (pw >> 16) << 2;
+                asm volatile("ds_write_b32 %0, %2\n\tds_write_b32 %1, %3" :: "v"(ai), "v"(aj), "v"((pw >> 16) + 1u), "v"((pw & 0xffffu) + 1u) : "memory");
+            }
+            if ((endmask >> r) & 1ull) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        };
+        {   // (eight rows ahead: a row of this pass is too short for three to cover the way from the L2)
+            constexpr int D = 8;
+            uint32_t pq[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) pq[d] = d < nrows ? g_rows[(size_t)d * XWG] : 0u;
+            int r = 0;
+#pragma clang loop unroll(disable)
+            for (; r + D <= nrows; r += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    prow(pq[d], r + d);
+                    pq[d] = r + d + D < nrows ? g_rows[(size_t)(r + d + D) * XWG] : 0u;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (r + d < nrows) prow(pq[d], r + d);
+        }
+        __syncthreads();
+        XTS(3);
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int g = tid + r * XWG;
+            if (g < Ng) P.xres[g] = (unsigned long long)src_[r] | ((unsigned long long)last[g] << 32);
+        }
+    }
+    XTS(4);
+    if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nrows;
 }

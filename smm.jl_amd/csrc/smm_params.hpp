@@ -66,6 +66,10 @@ struct KParams {
     const uint32_t* lv_offp;         // [W][LV_OFFP]: entry l = first word of level l (entry nlev: the padded length); [33] = nlev;
                                      //          [34] = 1 when the plan fits this form (at most 31 levels)
     int plan_Kp, lean_unit;          // words per iteration in lv_pairs_p; 8, or 4 when 8 * N_global does not fit 16 bits (smm_walk_lean.hpp)
+    // ... and for k_exch_resolve_rows (8192 < N_global <= 32768, min_improve == 0; null otherwise):
+    const uint32_t* lv_rows;         // [W][rows_cap][1024]: level by level, every level padded to whole rows of 1024 words with dummy pairs; pi | pj << 16
+    const uint32_t* lv_rowinfo;      // [W][4]: rows; bit r of words 1 (low) and 2 (high): row r is the last of its level; 1 when the plan fits the form
+    int rows_cap;
     int plan_t0, plan_K;
     // state
     double* cs;                // [N][CSW]
@@ -111,6 +115,17 @@ constexpr int LV_OFFP = 40, LV_MAXLEV = 31;
 __host__ __device__ inline uint32_t order_key32(const double v) {
     const uint32_t hw = v == 0.0 ? 0u : (uint32_t)(__builtin_bit_cast(unsigned long long, v) >> 32);
     return (hw & 0x80000000u) ? ~hw : (hw | 0x80000000u);
+}
+
+// 17-bit order key of a chain value on a fixed scale (buckets a factor 1 + 2^-11 apart from 2^-48 to 2^16): for non-NaN values a
+// larger key means a larger value, equal keys decide nothing.  Everything below 2^-48 — zero, negative values, -Inf — shares bucket
+// 0, everything from 2^16 up, +Inf included, the last one.
+constexpr uint32_t XKEY17_SHIFT = 9, XKEY17_TOP = 0x1ffffu;
+__host__ __device__ inline uint32_t order_key17(const double v) {
+    const uint32_t hw = (uint32_t)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    if ((hw & 0x80000000u) || hw < XKEY_BASE) return 0u;
+    const uint32_t k = 1u + ((hw - XKEY_BASE) >> XKEY17_SHIFT);
+    return k < XKEY17_TOP ? k : XKEY17_TOP;
 }
 
 #define TS_MARK(i) do { if (P.ts && tid == 0) P.ts[(size_t)tile * 8 + (i)] = wall_clock64(); } while (0)

@@ -167,6 +167,8 @@ struct Ctx {
     unsigned long long* win_plan = nullptr;
     double* win_plan_mi = nullptr;
     uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr, *win_lv_pairs_p = nullptr, *win_lv_offp = nullptr;
+    bool rows_exchange = false;  // min_improve == 0, 8192 < N_global <= 32768: k_exch_resolve_rows (falls back to k_exch_resolve_key's walk)
+    uint32_t *win_lv_rows = nullptr, *win_lv_rowinfo = nullptr, *slots17 = nullptr, *nan_flags = nullptr;
     bool lean_resolve = false;   // min_improve == 0, N_global <= 8192: k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
@@ -258,9 +260,10 @@ void ensure_windows(Ctx* c, int t) {
     if (c->big_exchange && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
         hipLaunchKernelGGL(k_exch_plan_big, dim3(W), dim3(XWG), 0, c->stream, P, t, c->big_scratch, c->win_lv_pairs, c->win_lv_mi,
-                           c->win_lv_off);
+                           c->win_lv_off, c->win_lv_rows, c->win_lv_rowinfo);
         c->plan_t0 = t; c->plan_w = W;
         P.plan_t0 = t;
+        P.lv_rows = c->win_lv_rows; P.lv_rowinfo = c->win_lv_rowinfo;
         P.lv_pairs = c->win_lv_pairs; P.lv_mi = c->win_lv_mi; P.lv_off = c->win_lv_off;
     }
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
@@ -385,8 +388,14 @@ void launch_resolve(Ctx* c, int t, const double* gathered) {
         const double* src = gathered ? gathered : (const double*)P.vals;
         double* vals = gathered ? P.xval : P.vals;
         hipLaunchKernelGGL(k_exch_keys, dim3((P.Ng + 255) / 256), dim3(256), 0, c->stream, src, gathered ? P.RW : 1, P.Ng, vals,
-                           (uint32_t*)P.xsrc);
-        if (P.Ng <= XKEY_PARTNER_MAX)
+                           (uint32_t*)P.xsrc, c->rows_exchange ? c->slots17 : (uint32_t*)nullptr, c->nan_flags, t);
+        if (c->rows_exchange && P.Ng <= XKEY_PARTNER_MAX)
+            hipLaunchKernelGGL(k_exch_resolve_rows<true>, dim3(1), dim3(XWG), resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap), c->stream, P, t,
+                               (const double*)vals, (const uint32_t*)P.xsrc, (const uint32_t*)c->slots17, (const uint32_t*)c->nan_flags);
+        else if (c->rows_exchange)
+            hipLaunchKernelGGL(k_exch_resolve_rows<false>, dim3(1), dim3(XWG), resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap), c->stream, P, t,
+                               (const double*)vals, (const uint32_t*)P.xsrc, (const uint32_t*)c->slots17, (const uint32_t*)c->nan_flags);
+        else if (P.Ng <= XKEY_PARTNER_MAX)
             hipLaunchKernelGGL(k_exch_resolve_key<true>, dim3(1), dim3(XWG), resolve_key_bytes(P.Ng, P.plan_K), c->stream, P, t,
                                (const double*)vals, (const uint32_t*)P.xsrc);
         else
@@ -736,6 +745,16 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
                 c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
                 c->big_scratch = dalloc<uint32_t>(c, (size_t)c->win_cap * BigPlanScratch::words(Ng, K));
+                const char* kw = getenv("SMMHIP_KEY_WALK");   // test hook: "0" keeps k_exch_resolve_key
+                if (c->key_exchange && P.mi_uniform && P.mi_value == 0.0 && !(kw && kw[0] == '0')) {
+                    c->rows_exchange = true;
+                    P.rows_cap = std::min(XROWS_MAX, (K + XWG - 1) / XWG + LV_MAXLEV);
+                    c->win_lv_rows = dalloc<uint32_t>(c, (size_t)c->win_cap * P.rows_cap * XWG);
+                    c->win_lv_rowinfo = dalloc<uint32_t>(c, (size_t)c->win_cap * 4);
+                    c->slots17 = dalloc<uint32_t>(c, (size_t)Ng + 4);
+                    c->nan_flags = dalloc<uint32_t>(c, 4);
+                    HIPCHK(hipMemset(c->nan_flags, 0, 16));
+                }
             }
             if (c->lds_exchange) {
                 c->win_plan = dalloc<unsigned long long>(c, (size_t)c->win_cap * K);
@@ -801,6 +820,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (int)resolve_key_bytes(XKEY_MAX, XKEY_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_key<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_key_bytes(XKEY_PARTNER_MAX, XKEY_PARTNER_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_rows_bytes(XKEY_MAX, XKEY_MAX, XROWS_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_rows_bytes(XKEY_PARTNER_MAX, XKEY_PARTNER_MAX, XROWS_MAX)));
         }
         if (c->lds_exchange) {
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
