@@ -162,7 +162,9 @@ def main():
         sync = ctx.sync
     else:
         from smm_jl_amd.dist import HipShardEngine, ShardedBGP
-        sh = ShardedBGP(HipShardEngine(ctx, torch.device("cuda", local_rank)))
+        # SMM_BENCH_PROTOCOL=values: the two-collective form for long records (all-gather of values + all-to-all of the swapped
+        # records); the default is the one all-gather of records per iteration
+        sh = ShardedBGP(HipShardEngine(ctx, torch.device("cuda", local_rank)), protocol=os.environ.get("SMM_BENCH_PROTOCOL", "records"))
 
         def run_step():
             sh.step(ITERS_PER_STEP)

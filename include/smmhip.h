@@ -48,7 +48,8 @@ typedef enum {
     SMM_ERR_BAD_BATCH = -5,          /* batch_size not a divisor of np: AlgoBGP.jl:95-103 (quirk not replicated) */
     SMM_ERR_MAXITER = -6,            /* step beyond opts.maxiter (history capacity)   */
     SMM_ERR_HIP = -7,
-    SMM_ERR_STATE = -8
+    SMM_ERR_STATE = -8,
+    SMM_ERR_EXCHANGE_CAPACITY = -9   /* values form of the sharded exchange: a (source, destination) block overflowed */
 } smm_status_t;
 
 /* objective_id: device objectives replacing MProb.objfunc (mprob.jl:159,182) */
@@ -232,6 +233,22 @@ int  smm_bgp_local_step(void* ctx);
 int  smm_bgp_record_doubles(void* ctx);
 int  smm_bgp_export_records_dev(void* ctx, void* rec_dev);
 int  smm_bgp_exchange_dev(void* ctx, const void* gathered_dev);
+/* The values form of the exchange phase, for long records: instead of every record, only every chain's
+ * VALUE goes to every rank, and the record a chain continues from goes to that chain's owner alone.  Ranks own equal
+ * blocks of N chains (G = N_global / N ranks).  After smm_bgp_local_step:
+ *   smm_bgp_export_values_dev(ctx, vals [N])              the local chains' last accepted values -> all-gather to [N_global]
+ *   smm_bgp_a2a_pack_dev(ctx, vals_all [N_global], send)  resolves exchangeMoves! from the values and fills this rank's
+ *        send buffer [G][cap][RW]: block b holds, in the order of the receiving chains, the records that chains of rank b
+ *        continue from (cap = smm_bgp_a2a_capacity(ctx) records per block; the block to itself included)
+ *   -> one all-to-all of equal blocks (RCCL: ncclAllToAll / all_to_all_single of cap * RW doubles per pair)
+ *   smm_bgp_a2a_apply_dev(ctx, recv [G][cap][RW])         applies the swaps to the local chains
+ * Same result as smm_bgp_export_records_dev + all-gather + smm_bgp_exchange_dev.  A block that would need more than cap
+ * records raises SMM_ERR_EXCHANGE_CAPACITY at the next smm_sync (cap = min(N, 2 N / G + 64): about four times the expected
+ * count for the reference's pair sampling). */
+int  smm_bgp_a2a_capacity(void* ctx);
+int  smm_bgp_export_values_dev(void* ctx, void* vals_dev);
+int  smm_bgp_a2a_pack_dev(void* ctx, const void* vals_all_dev, void* send_dev);
+int  smm_bgp_a2a_apply_dev(void* ctx, const void* recv_dev);
 /* The same iteration in two enqueues instead of five.  Both buffers are [N_global][RW] in global chain order:
  *   smm_bgp_sharded_step(ctx, gathered_prev, gathered_next): resolves exchangeMoves! of the previous iteration
  *        from gathered_prev (the all-gathered records after that iteration's accept step; may be NULL before

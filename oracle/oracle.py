@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsmm_oracle.so")
 _ORC_ONLY = [
     ("orc_bgp_export_records", None, [C.c_void_p, A.c_double_p]),
     ("orc_bgp_exchange", C.c_int, [C.c_void_p, A.c_double_p]),
+    ("orc_bgp_resolve_values", C.c_int, [C.c_void_p, A.c_double_p, A.c_int32_p, A.c_int32_p]),
     ("orc_set_mode", None, [C.c_void_p, C.c_int, C.c_int]),
     ("orc_gen_Z", None, [C.c_uint64, C.c_int, C.c_int, A.c_double_p]),
     ("orc_gen_pairs", None, [C.c_uint64, C.c_int32, C.c_int32, A.c_int32_p]),
@@ -68,6 +69,13 @@ class OracleContext(S.BGPContext):
     def exchange(self, gathered):
         g = A.f64(gathered)
         self._check(self._lib.orc_bgp_exchange(self._ctx, A.dptr(g)))
+
+    def resolve_values(self, vals_all):
+        """(src, partner) of every chain from every chain's value: the exchange walk alone"""
+        v = A.f64(vals_all)
+        src = np.empty(v.shape[0], np.int32); partner = np.empty(v.shape[0], np.int32)
+        self._check(self._lib.orc_bgp_resolve_values(self._ctx, A.dptr(v), src.ctypes.data_as(A.c_int32_p), partner.ctypes.data_as(A.c_int32_p)))
+        return src, partner
 
 
 def gen_Z(seed, nm, ns):

@@ -797,6 +797,32 @@ int orc_bgp_exchange(void* v, const double* gathered) {
     return ORC_OK;
 }
 
+/* the ordered walk of exchangeMoves! (:662-691) alone, from every chain's value: src_out[g] = whose record chain g continues
+ * from, partner_out[g] = 1 + its last exchange partner (0: none) — what the values form of the sharded exchange
+ * (include/smmhip.h) decides its traffic by */
+int orc_bgp_resolve_values(void* v, const double* vals_all, int32_t* src_out, int32_t* partner_out) {
+    orc_t* o = (orc_t*)v;
+    const int Ng = o->opts.N_global, t = o->iter;
+    for (int g = 0; g < Ng; ++g) { src_out[g] = g; partner_out[g] = 0; }
+    if (!(t >= o->opts.exchange_from_iter && Ng > 1)) return ORC_OK;   /* :637 */
+    const int K = o->have_pairs ? o->n_pairs : n_exchange_pairs(Ng);
+    int32_t* pairs = (int32_t*)malloc((size_t)(K > 0 ? K : 1) * 2 * sizeof(int32_t));
+    if (o->have_pairs) memcpy(pairs, o->pair_tab + (size_t)(t - 1) * K * 2, (size_t)K * 2 * sizeof(int32_t));
+    else orc_gen_pairs(o->opts.seed, t, Ng, pairs);
+    double* val = (double*)malloc((size_t)Ng * sizeof(double));
+    memcpy(val, vals_all, (size_t)Ng * sizeof(double));
+    for (int q = 0; q < K; ++q) {
+        int i = pairs[2 * q], j = pairs[2 * q + 1];
+        if (val[i] - val[j] > o->min_improve[i]) {
+            double tv = val[i]; val[i] = val[j]; val[j] = tv;
+            int32_t ts = src_out[i]; src_out[i] = src_out[j]; src_out[j] = ts;
+            partner_out[i] = j + 1; partner_out[j] = i + 1;
+        }
+    }
+    free(pairs); free(val);
+    return ORC_OK;
+}
+
 /* computeNextIteration!(algo), AlgoBGP.jl:589-640, n_iters times (run!, AlgoAbstract.jl:38-45);
  * single shard only. */
 int orc_bgp_step(void* v, int n_iters) {

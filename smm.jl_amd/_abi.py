@@ -26,6 +26,7 @@ SMM_ERR_BAD_BATCH = -5
 SMM_ERR_MAXITER = -6
 SMM_ERR_HIP = -7
 SMM_ERR_STATE = -8
+SMM_ERR_EXCHANGE_CAPACITY = -9
 
 # smm_objective_t
 SMM_OBJ_NORM = 0
@@ -112,6 +113,10 @@ SYMBOLS = [
     ("smm_bgp_record_doubles", C.c_int, [C.c_void_p]),
     ("smm_bgp_export_records_dev", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smm_bgp_exchange_dev", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("smm_bgp_a2a_capacity", C.c_int, [C.c_void_p]),
+    ("smm_bgp_export_values_dev", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("smm_bgp_a2a_pack_dev", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("smm_bgp_a2a_apply_dev", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smm_bgp_sharded_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("smm_bgp_sharded_finish", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smm_stream", C.c_void_p, [C.c_void_p]),

@@ -148,6 +148,19 @@ class BGPContext:
     def exchange_dev(self, ptr):
         self._check(self._fn("bgp_exchange_dev")(self._ctx, C.c_void_p(ptr)))
 
+    # the values form of the exchange phase (include/smmhip.h): device pointers
+    def a2a_capacity(self):
+        return self._fn("bgp_a2a_capacity")(self._ctx)
+
+    def export_values_dev(self, ptr):
+        self._check(self._fn("bgp_export_values_dev")(self._ctx, C.c_void_p(ptr)))
+
+    def a2a_pack_dev(self, vals_all_ptr, send_ptr):
+        self._check(self._fn("bgp_a2a_pack_dev")(self._ctx, C.c_void_p(vals_all_ptr), C.c_void_p(send_ptr)))
+
+    def a2a_apply_dev(self, recv_ptr):
+        self._check(self._fn("bgp_a2a_apply_dev")(self._ctx, C.c_void_p(recv_ptr)))
+
     def sharded_step(self, prev_ptr, next_ptr):
         """fused sharded iteration (include/smmhip.h): prev/next are device pointers of [N_global][RW] buffers"""
         self._check(self._fn("bgp_sharded_step")(self._ctx, C.c_void_p(prev_ptr or 0), C.c_void_p(next_ptr)))

@@ -1076,3 +1076,95 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
     XTS(4);
     if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + 7] = (unsigned long long)nrows;
 }
+
+// ------------------------------------------------------------------------------------------
+// The values form of the sharded exchange (for long records): only the chains' VALUES travel to every rank (an
+// all-gather of 8 bytes per chain); every rank resolves exchangeMoves! from them, and the record a chain continues from
+// travels to that chain's owner alone — an all-to-all of fixed-size blocks of `cap` records per (source, destination) pair
+// (no host round trip for counts; a block that overflows raises the sticky device error).  Ranks own equal blocks of N chains.
+//   k_a2a_index: one workgroup per peer rank p.  As DESTINATION p: the chains of rank p whose record sits with me, in chain
+//       order -> the rows of my send block p.  As SOURCE p: my chains whose record sits with rank p, in chain order -> where
+//       each finds its row in the received buffer (block p, the same order: both sides count the same chains).
+//       The block to myself goes the same way (the collective copies it), so the apply step reads donors from one place.
+//   k_a2a_pack: the rows into the send buffer [G][cap][RW].
+//   k_a2a_apply: k_exch_apply with the donor rows taken from the received buffer.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline int a2a_capacity(int N, int G) {
+    const int c = 2 * ((N + G - 1) / G) + 64;
+    return c < N ? c : N;
+}
+__device__ inline uint32_t block_excl_count(const bool sel, uint32_t* wsum, const int tid, uint32_t& total) {
+    const unsigned long long m = __ballot(sel);
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t base = 0;
+    total = 0;
+    for (int w = 0; w < XWG / 64; ++w) { const uint32_t v = wsum[w]; if (w < wave) base += v; total += v; }
+    return base + in_wave;
+}
+__global__ __launch_bounds__(XWG) void k_a2a_index(const KParams P, const int t, const int G, const int cap, int32_t* __restrict__ send_idx,
+                                                   int32_t* __restrict__ send_cnt, int32_t* __restrict__ rowidx) {
+    __shared__ uint32_t wsum[XWG / 64];
+    const int tid = threadIdx.x, p = blockIdx.x;
+    const int N = P.N, me = P.offset / P.N;
+    if (*(const volatile unsigned long long*)P.err != ERR_NONE) return;
+    for (int part = 0; part < 2; ++part) {
+        uint32_t base = 0;
+        for (int i0 = 0; i0 < N; i0 += XWG) {
+            const int i = i0 + tid;
+            const int g = (part == 0 ? p : me) * N + i;          // part 0: a chain of rank p; part 1: one of mine
+            unsigned long long xr = 0ull;
+            if (i < N) xr = P.xres[g];
+            const int s = (int)(unsigned)(xr & 0xffffffffu);
+            const bool sel = i < N && (xr >> 32) != 0ull && s / N == (part == 0 ? me : p);
+            uint32_t total;
+            const uint32_t pos = base + block_excl_count(sel, wsum, tid, total);
+            if (sel) {
+                if (pos < (uint32_t)cap) {
+                    if (part == 0) send_idx[(size_t)p * cap + pos] = s - me * N;
+                    else rowidx[i] = p * cap + (int)pos;
+                } else {
+                    atomicMin(P.err, ((unsigned long long)t << 34) | ((unsigned long long)g << 2));   // kind 0: a block overflowed
+                }
+            }
+            base += total;
+        }
+        if (part == 0 && tid == 0) send_cnt[p] = (int32_t)(base < (uint32_t)cap ? base : (uint32_t)cap);
+    }
+}
+__global__ void k_a2a_pack(const KParams P, const int G, const int cap, const int32_t* __restrict__ send_idx, const int32_t* __restrict__ send_cnt,
+                           const double* __restrict__ rec, double* __restrict__ send) {
+    const int RW = P.RW;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // element of the send buffer [G][cap][RW]
+    if (e >= (size_t)G * cap * RW) return;
+    const int f = (int)(e % RW);
+    const size_t row = e / RW;
+    const int b = (int)(row / cap), pos = (int)(row % cap);
+    if (pos >= send_cnt[b]) return;
+    send[e] = rec[(size_t)send_idx[row] * RW + f];
+}
+__global__ void k_a2a_apply(const KParams P, const int t, const double* __restrict__ recv, const int32_t* __restrict__ rowidx,
+                            double* __restrict__ rec) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.N) return;
+    if (*(const volatile unsigned long long*)P.err != ERR_NONE) return;   // the run stopped at the failing iteration
+    const int N = P.N, RW = P.RW, HW = P.HW;
+    const unsigned long long xr = P.xres[P.offset + c];
+    const int partner = (int)(xr >> 32);
+    if (partner == 0) return;
+    const double* __restrict__ donor = recv + (size_t)rowidx[c] * RW;
+    double* csb = P.cs + (size_t)c * CSW;
+    double* hrec = P.hrec + ((size_t)(t - 1) * N + c) * HW;
+    const double value = donor[0];
+    double bestv, bestid;
+    if (value < csb[CS_BESTP]) { bestv = value; bestid = (double)t; }
+    else { bestv = csb[CS_BESTP]; bestid = csb[CS_BESTPID]; }
+    csb[CS_BEST] = bestv; csb[CS_BESTID] = bestid; csb[CS_WASX] = 1.0;
+    hrec[H_VALUE] = value; hrec[H_PROB] = donor[1]; hrec[H_CURR] = value; hrec[H_BEST] = bestv;
+    hrec[H_BESTID] = bestid; hrec[H_EXCH] = (double)partner; hrec[H_ACC] = 1.0; hrec[H_STATUS] = donor[2];
+    for (int k = 0; k < P.np + P.nm; ++k) hrec[H_PARAMS + k] = donor[3 + k];
+    for (int f = 0; f < RW; ++f) rec[(size_t)c * RW + f] = donor[f];
+}

@@ -169,6 +169,9 @@ struct Ctx {
     uint32_t *win_lv_pairs = nullptr, *win_lv_off = nullptr, *win_lv_pairs_p = nullptr, *win_lv_offp = nullptr;
     bool rows_exchange = false;  // min_improve == 0, 8192 < N_global <= 32768: k_exch_resolve_rows (falls back to k_exch_resolve_key's walk)
     uint32_t *win_lv_rows = nullptr, *win_lv_rowinfo = nullptr, *slots17 = nullptr, *nan_flags = nullptr;
+    int32_t *a2a_send_idx = nullptr, *a2a_send_cnt = nullptr, *a2a_rowidx = nullptr;   // the values form of the sharded exchange
+    int a2a_cap = 0, a2a_G = 0;
+    bool a2a_open = false;
     bool lean_resolve = false;   // min_improve == 0, N_global <= 8192: k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
@@ -360,8 +363,10 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
 
 size_t resolve_lean_bytes(int Ng, int K) { return std::max(lean_walk_bytes(Ng, K), resolve_lvl_soa_bytes(Ng, K)); }
 
-void launch_resolve(Ctx* c, int t, const double* gathered) {
-    const KParams& P = c->P;
+void launch_resolve_p(Ctx* c, const KParams& P, int t, const double* gathered);
+void launch_resolve(Ctx* c, int t, const double* gathered) { launch_resolve_p(c, c->P, t, gathered); }
+// (P: the context's parameters, or a copy whose RW is the stride of the value column in `gathered`)
+void launch_resolve_p(Ctx* c, const KParams& P, int t, const double* gathered) {
     if (c->lean_resolve)
         if (c->kev0)
             hipExtLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K), c->stream, c->kev0, c->kev1, 0, P, t,
@@ -439,6 +444,10 @@ int check_device_error(Ctx* c) {
     if (kind == 3) {
         snprintf(b, sizeof b, "internal error: exchange resolution did not converge (iteration %d)", it);
         rc = SMM_ERR_HIP;
+    } else if (kind == 0) {
+        snprintf(b, sizeof b, "values form of the sharded exchange: more than %d records between one pair of ranks (chain %d, iteration %d): "
+                 "use the record all-gather (smm_bgp_exchange_dev / smm_bgp_sharded_step)", c->a2a_cap, chain + 1, it);
+        rc = SMM_ERR_EXCHANGE_CAPACITY;
     } else if (kind == 1) {
         snprintf(b, sizeof b, "AlgoBGP assumes that your objective function returns a non-negative number "
                  "(chain %d, iteration %d)", chain + 1, it);
@@ -452,7 +461,7 @@ int check_device_error(Ctx* c) {
     // The reference aborts inside the failing iteration (AlgoBGP.jl:341,409).  Here that iteration completes for all chains
     // and every later launch of the step sees the error word and stores nothing: the run stands at the failing iteration,
     // its exchange is never applied, and the context refuses to go on until smm_set_state.
-    if (kind != 3 && it >= 1 && it <= c->iter) {
+    if (kind != 3 && kind != 0 && it >= 1 && it <= c->iter) {
         c->iter = it;
         c->pending = false; c->prev_open = false; c->unresolved = false; c->pending_ext = false; c->rec_external = false;
     }
@@ -792,6 +801,14 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             for (int b = 0; b < 2; ++b) c->rec[b] = dupload(c, rec.data(), rec.size());
         }
         P.xres = dalloc<unsigned long long>(c, Ng);
+        if (N > 0 && Ng % N == 0 && opts->chain_offset % N == 0) {   // equal shards: the values form of the sharded exchange is available
+            c->a2a_G = Ng / N;
+            const char* ce = getenv("SMMHIP_A2A_CAP");   // test hook: a small capacity
+            c->a2a_cap = ce ? std::max(1, atoi(ce)) : a2a_capacity(N, c->a2a_G);
+            c->a2a_send_idx = dalloc<int32_t>(c, (size_t)c->a2a_G * c->a2a_cap);
+            c->a2a_send_cnt = dalloc<int32_t>(c, (size_t)c->a2a_G);
+            c->a2a_rowidx = dalloc<int32_t>(c, (size_t)N);
+        }
         P.vals = dalloc<double>(c, (size_t)N + 4);   // (+4: read as 16-byte pieces)
         if (!c->lds_exchange) {
             const int Kmax = std::max(K, 1);
@@ -1107,6 +1124,77 @@ int smm_bgp_exchange_dev(void* ctx, const void* gathered_dev) {
     return SMM_OK;
 }
 
+// ---- the values form of the sharded exchange (include/smmhip.h) ----
+int smm_bgp_a2a_capacity(void* ctx) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return SMM_ERR_INVALID_ARG;
+    return c->a2a_cap;
+}
+
+int smm_bgp_export_values_dev(void* ctx, void* vals_dev) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !vals_dev) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
+    if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
+    if (c->iter < 1) return fail(c, SMM_ERR_STATE, "no iteration yet");
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (c->pending || c->unresolved) flush(c);
+        HIPCHK(hipMemcpyAsync(vals_dev, c->P.vals, (size_t)c->P.N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
+int smm_bgp_a2a_pack_dev(void* ctx, const void* vals_all_dev, void* send_dev) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !vals_all_dev || !send_dev) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
+    if (c->a2a_cap <= 0) return fail(c, SMM_ERR_STATE, "the values form needs equal shards (N_global a multiple of N, chain_offset a multiple of N)");
+    if (c->iter < 1) return fail(c, SMM_ERR_STATE, "exchange before the first local step");
+    if (c->pending || c->a2a_open) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (exchange_active(c, c->iter)) {
+            KParams P1 = c->P;
+            P1.RW = 1;   // (the resolve kernels read value s at gathered[s * RW])
+            launch_resolve_p(c, P1, c->iter, (const double*)vals_all_dev);
+            const KParams& P = c->P;
+            hipLaunchKernelGGL(k_a2a_index, dim3(c->a2a_G), dim3(XWG), 0, c->stream, P, c->iter, c->a2a_G, c->a2a_cap, c->a2a_send_idx,
+                               c->a2a_send_cnt, c->a2a_rowidx);
+            const size_t ne = (size_t)c->a2a_G * c->a2a_cap * P.RW;
+            hipLaunchKernelGGL(k_a2a_pack, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, c->stream, P, c->a2a_G, c->a2a_cap,
+                               (const int32_t*)c->a2a_send_idx, (const int32_t*)c->a2a_send_cnt, (const double*)c->rec[c->cur], (double*)send_dev);
+        }
+        HIPCHK(hipGetLastError());
+        c->a2a_open = true;
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
+int smm_bgp_a2a_apply_dev(void* ctx, const void* recv_dev) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !recv_dev) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
+    if (!c->a2a_open) return fail(c, SMM_ERR_STATE, "smm_bgp_a2a_pack_dev comes first");
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        if (exchange_active(c, c->iter)) {
+            const KParams& P = c->P;
+            hipLaunchKernelGGL(k_a2a_apply, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter, (const double*)recv_dev,
+                               (const int32_t*)c->a2a_rowidx, c->rec[c->cur]);
+        }
+        HIPCHK(hipGetLastError());
+        c->a2a_open = false;
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
 int smm_eval_batch(void* ctx, const double* params, int32_t M, double* value, double* sim_moments, int8_t* status) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !params || M < 0 || !value || !sim_moments || !status) return SMM_ERR_INVALID_ARG;
@@ -1309,6 +1397,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         c->rec_external = false; c->pending_ext = false; c->unresolved = false;
         c->pending = false;
         c->prev_open = false;
+        c->a2a_open = false;
         if (P.walk_flags) HIPCHK(hipMemset(P.walk_flags, 0, 16));   // (the values the next exchange sees are written by the next accept step)
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);

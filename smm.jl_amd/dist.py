@@ -5,6 +5,11 @@ is exchangeMoves! (AlgoBGP.jl:647-716), which needs every chain's last accepted 
 rank owns a contiguous block of chains; per iteration there is ONE collective — an all-gather of
 the fixed-size last-accepted records over RCCL/xGMI — after which every rank resolves the
 identical pair list redundantly and applies the swaps that touch its own chains.
+
+For long records (50 parameters + 50 moments are 816 bytes per chain) there is the
+VALUES form (`protocol="values"`): an all-gather of 8 bytes per chain, the replicated resolution, and an
+all-to-all of fixed-size blocks that carries each swapped record to the owner of the chain that continues
+from it — two collectives, about a quarter of a record per chain on the wire instead of a whole one.
 """
 import torch
 import torch.distributed as dist
@@ -33,6 +38,19 @@ class HipShardEngine:
     def exchange(self, gathered):
         self.ctx.exchange_dev(gathered.data_ptr())
 
+    # values form (include/smmhip.h)
+    def a2a_capacity(self):
+        return self.ctx.a2a_capacity()
+
+    def export_values(self, out):
+        self.ctx.export_values_dev(out.data_ptr())
+
+    def a2a_pack(self, vals_all, send):
+        self.ctx.a2a_pack_dev(vals_all.data_ptr(), send.data_ptr())
+
+    def a2a_apply(self, recv):
+        self.ctx.a2a_apply_dev(recv.data_ptr())
+
     # fused form (two enqueues per iteration, see include/smmhip.h): used by ShardedBGP when the engine offers it
     def fused_step(self, prev, nxt):
         self.ctx.sharded_step(prev.data_ptr() if prev is not None else 0, nxt.data_ptr())
@@ -50,11 +68,26 @@ class HipShardEngine:
 class ShardedBGP:
     """computeNextIteration! (AlgoBGP.jl:589-640) over world_size shards."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, protocol="records"):
+        """protocol: "records" (all-gather of the last-accepted records) or "values" (all-gather of the values + all-to-all of
+        the swapped records: for long records)"""
+        if protocol not in ("records", "values"):
+            raise ValueError("protocol: 'records' or 'values'")
         self.e = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.protocol = protocol
+        if protocol == "values":
+            cap = engine.a2a_capacity()
+            if cap <= 0:
+                raise ValueError("the values form needs equal shards")
+            self.vloc = engine.new_tensor((engine.N,))
+            self.vall = engine.new_tensor((self.world * engine.N,))
+            self.send = engine.new_tensor((self.world, cap, engine.R))
+            self.recv = engine.new_tensor((self.world, cap, engine.R))
+            self.fused = False
+            return
         self.local = engine.new_tensor((engine.N, engine.R))
         self.gathered = engine.new_tensor((self.world, engine.N, engine.R))  # == [N_global][R] in global chain order
         self.fused = hasattr(engine, "fused_step")
@@ -66,6 +99,21 @@ class ShardedBGP:
     def step(self, n_iters=1):
         e = self.e
         with e.stream_ctx():
+            if self.protocol == "values":
+                for _ in range(n_iters):
+                    e.local_step()
+                    e.export_values(self.vloc)
+                    if self.world == 1:
+                        self.vall.copy_(self.vloc)
+                    else:
+                        dist.all_gather_into_tensor(self.vall, self.vloc, group=self.group)
+                    e.a2a_pack(self.vall, self.send)
+                    if self.world == 1:
+                        self.recv.copy_(self.send)
+                    else:
+                        dist.all_to_all_single(self.recv.view(-1), self.send.view(-1), group=self.group)
+                    e.a2a_apply(self.recv)
+                return
             if self.fused:
                 for _ in range(n_iters):
                     nxt = 0 if self.gcur is None else self.gcur ^ 1

@@ -65,6 +65,46 @@ class OracleFusedEngine(OracleShardEngine):
         self.open = False
 
 
+class OracleValuesEngine(OracleShardEngine):
+    """the values form of the exchange phase (include/smmhip.h: export_values / a2a_pack / a2a_apply) on top of the oracle:
+    the walk over the gathered values says which records travel; the blocks are laid out as the library's kernels lay
+    them out (block b of the send buffer: the records the chains of rank b continue from, in the order of those chains)"""
+
+    def __init__(self, ctx, rank, world, cap=None):
+        super().__init__(ctx)
+        self.rank, self.world = rank, world
+        n = self.N
+        self.cap = cap if cap is not None else min(n, 2 * ((n + world - 1) // world) + 64)
+
+    def a2a_capacity(self):
+        return self.cap
+
+    def export_values(self, out):
+        out.copy_(torch.from_numpy(self.ctx.export_records()[:, 0].copy()))
+
+    def a2a_pack(self, vals_all, send):
+        n, me = self.N, self.rank
+        self.vals_all = vals_all.numpy().copy()
+        self.src, self.partner = self.ctx.resolve_values(self.vals_all)
+        rec = self.ctx.export_records()
+        g = np.arange(self.world * n)
+        for b in range(self.world):
+            sel = (g // n == b) & (self.partner != 0) & (self.src // n == me)
+            rows = self.src[sel] - me * n
+            assert len(rows) <= self.cap, "block overflow"
+            send[b, :len(rows)] = torch.from_numpy(rec[rows])
+
+    def a2a_apply(self, recv):
+        n, me = self.N, self.rank
+        full = np.zeros((self.world * n, self.R))
+        full[:, 0] = self.vals_all                      # the walk is repeated from the values; only donor rows are read beyond them
+        mine = np.arange(me * n, (me + 1) * n)
+        for a in range(self.world):
+            sel = (self.partner[mine] != 0) & (self.src[mine] // n == a)
+            full[self.src[mine][sel]] = recv[a, :int(sel.sum())].numpy()
+        self.ctx.exchange(full)
+
+
 def _worker(rank, world, port, N, T, q, fused=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import common as cm
@@ -77,8 +117,12 @@ def _worker(rank, world, port, N, T, q, fused=False):
         n = N // world
         prob, opts = cm.serial_normal(N=N, T=T, ns=100, N_local=n, chain_offset=rank * n)
         octx = O.OracleContext(prob, opts)
-        sh = ShardedBGP(OracleFusedEngine(octx, rank) if fused else OracleShardEngine(octx))
-        assert sh.world == world and sh.rank == rank and sh.fused == fused
+        if fused == "values":
+            sh = ShardedBGP(OracleValuesEngine(octx, rank, world), protocol="values")
+        else:
+            sh = ShardedBGP(OracleFusedEngine(octx, rank) if fused else OracleShardEngine(octx))
+            assert sh.fused == fused
+        assert sh.world == world and sh.rank == rank
         sh.step(T // 2); sh.step(T - T // 2)
         sh.sync()
         hs = sh.e.ctx.history()
@@ -100,7 +144,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,fused", [(2, False), (3, False), (2, True), (3, True)])
+@pytest.mark.parametrize("world,fused", [(2, False), (3, False), (2, True), (3, True), (2, "values"), (3, "values")])
 def test_sharded_gloo_equals_single_process(world, fused):
     N, T = 12 * world, 30
     ctx = mp.get_context("spawn")

@@ -153,3 +153,22 @@ def test_snorm_impl_more_parameters():
     h = S.history(MA.chains[0])
     assert h.shape == (30, 11) and list(h.columns)[-4:] == ["p1", "p2", "p3", "p4"] and MA.i == 30
     assert np.isfinite(h["value"]).all() and (np.diff(h["best_val"]) <= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("protocol", ["records", "values"])
+def test_sharded_protocols_on_one_rank(S, protocol):
+    # ShardedBGP over the library's stream with the device engine, world size 1: both host protocols (the record all-gather in
+    # its fused form; the values form: export_values / a2a_pack / a2a_apply) against the single-shard loop
+    import torch
+    from smm_jl_amd.dist import HipShardEngine, ShardedBGP
+    prob, opts = cm.serial_normal(N=200, T=40, ns=200)
+    a = S.hip_context(prob, opts)
+    a.step(40)
+    b = S.hip_context(prob, opts)
+    sh = ShardedBGP(HipShardEngine(b, torch.device("cuda", 0)), protocol=protocol)
+    sh.step(25); sh.step(15)
+    sh.sync()
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_state_equal(a.state(), b.state(), rtol=0)
+    assert (a.history().exchanged != 0).any()

@@ -903,3 +903,79 @@ def test_key_walk_special_values(S, O, monkeypatch, nan):
     assert (hh.exchanged[T0:] != 0).any()
     cm.assert_history_equal(hh, o.history())
     cm.assert_state_equal(runs[0].state(), o.state())
+
+
+def _slice_state(st, lo, hi):
+    """the chains lo..hi of a state (every per-chain array has the chain as its last axis)"""
+    import copy
+    out = copy.copy(st)
+    for f in A.StateBuffers.FIELDS:
+        setattr(out, f, getattr(st, f)[..., lo:hi])
+    return out
+
+
+def sharded_run_values(S, prob, opts_full, G, T):
+    """the values form of the exchange phase (smm_bgp_export_values_dev / a2a_pack_dev / a2a_apply_dev): G contexts on one GPU
+    emulate G ranks; the all-gather is a concatenation and the all-to-all a transposition of blocks here (the collectives
+    themselves run under gloo in tests/test_dist_gloo.py)"""
+    import torch
+    from smm_jl_amd import BGPOpts
+    N = opts_full.N_global // G
+    ctxs = []
+    for r in range(G):
+        o = BGPOpts(N=N, maxiter=opts_full.maxiter, sigma=opts_full.sigma, acc_tuner=opts_full.acc_tuner,
+                    min_improve=opts_full.min_improve, sigma_update_steps=opts_full.sigma_update_steps,
+                    sigma_adjust_by=opts_full.sigma_adjust_by, smpl_iters=opts_full.smpl_iters,
+                    batch_size=opts_full.batch_size, seed=opts_full.seed, chain_offset=r * N,
+                    N_global=opts_full.N_global)
+        ctxs.append(S.hip_context(prob, o))
+    R, cap = ctxs[0].record_doubles(), ctxs[0].a2a_capacity()
+    assert cap > 0
+    vall = torch.empty((G, N), dtype=torch.float64, device="cuda")
+    send = torch.zeros((G, G, cap, R), dtype=torch.float64, device="cuda")   # [rank][destination]
+    for _ in range(T):
+        for r, c in enumerate(ctxs):
+            c.local_step()
+            c.export_values_dev(vall[r].data_ptr())
+        for c in ctxs:
+            c.sync()
+        for r, c in enumerate(ctxs):
+            c.a2a_pack_dev(vall.data_ptr(), send[r].data_ptr())
+        for c in ctxs:
+            c.sync()
+        recv = send.transpose(0, 1).contiguous()                              # [rank][source]
+        for r, c in enumerate(ctxs):
+            c.a2a_apply_dev(recv[r].data_ptr())
+        for c in ctxs:
+            c.sync()
+    return ctxs
+
+
+@pytest.mark.parametrize("G,N,T,npar", [(2, 32, 25, 2), (4, 400, 40, 2), (8, 4096, 12, 2), (4, 96, 20, 6), (3, 9000, 6, 2)])
+def test_values_form_of_the_sharded_exchange_equals_single(S, O, G, N, T, npar):
+    # 8 x 512: the lean resolve kernel; 3 x 3000: k_exch_resolve_rows; np = 6: the general chain kernel, longer records
+    N -= N % G
+    if npar == 2:
+        prob, opts = cm.serial_normal(N=N, T=T, ns=64 if N > 100 else 300)
+    else:
+        prob, opts = cm.general_normal(npar, N=N, T=T, ns=100)
+    single = S.hip_context(prob, opts)
+    single.step(T)
+    ctxs = sharded_run_values(S, prob, opts, G, T)
+    hs = single.history()
+    n = N // G
+    assert (hs.exchanged != 0).any()
+    for r, c in enumerate(ctxs):
+        hr = c.history()
+        for f in A.HistoryBuffers.FIELDS:
+            assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+        cm.assert_state_equal(c.state(), _slice_state(single.state(), r * n, (r + 1) * n), rtol=0)
+
+
+def test_values_form_block_overflow_is_a_hard_error(S, monkeypatch):
+    # a (source, destination) block that needs more records than its capacity: sticky device error, reported at the next sync
+    monkeypatch.setenv("SMMHIP_A2A_CAP", "1")
+    prob, opts = cm.serial_normal(N=64, T=10, ns=64)
+    with pytest.raises(A.SMMHipError) as e:
+        sharded_run_values(S, prob, opts, 2, 10)
+    assert e.value.code == A.SMM_ERR_EXCHANGE_CAPACITY
