@@ -15,6 +15,8 @@ using Libdl
 
 export HipBGP, hip_create, hip_destroy!, hip_step!, hip_iter, hip_history, hip_state, hip_set_state!, hip_eval_batch,
        hip_register_objective, hip_record_doubles
+export hip_stream, hip_sync, hip_local_step!, hip_export_records!, hip_exchange!, hip_sharded_step!, hip_sharded_finish!,
+       hip_a2a_capacity, hip_export_values!, hip_a2a_pack!, hip_a2a_apply!, hip_record_doubles
 
 const ABI_VERSION = 2
 const LIB = Ref{Ptr{Cvoid}}(C_NULL)
@@ -212,6 +214,24 @@ end
 hip_iter(h::HipBGP) = hip_state(h).iter
 
 hip_record_doubles(h::HipBGP) = Int(ccall(sym(:smm_bgp_record_doubles), Cint, (Ptr{Cvoid},), h.ctx))
+
+# The sharded forms (one HipBGP per GPU and process; device pointers of the caller's communication library, e.g. the
+# buffers of an MPI.jl / RCCL wrapper; everything is enqueued on hip_stream(h)).  include/smmhip.h describes the protocols.
+hip_stream(h::HipBGP) = ccall(sym(:smm_stream), Ptr{Cvoid}, (Ptr{Cvoid},), h.ctx)
+hip_sync(h::HipBGP) = (check(h.ctx, ccall(sym(:smm_sync), Cint, (Ptr{Cvoid},), h.ctx)); h)
+hip_local_step!(h::HipBGP) = (check(h.ctx, ccall(sym(:smm_bgp_local_step), Cint, (Ptr{Cvoid},), h.ctx)); h)
+hip_export_records!(h::HipBGP, rec::Ptr{Cvoid}) = (check(h.ctx, ccall(sym(:smm_bgp_export_records_dev), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, rec)); h)
+hip_exchange!(h::HipBGP, gathered::Ptr{Cvoid}) = (check(h.ctx, ccall(sym(:smm_bgp_exchange_dev), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, gathered)); h)
+hip_sharded_step!(h::HipBGP, prev::Ptr{Cvoid}, next::Ptr{Cvoid}) =
+    (check(h.ctx, ccall(sym(:smm_bgp_sharded_step), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, prev, next)); h)
+hip_sharded_finish!(h::HipBGP, gathered::Ptr{Cvoid}) =
+    (check(h.ctx, ccall(sym(:smm_bgp_sharded_finish), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, gathered)); h)
+# the values form for long records: all-gather of N doubles per rank, then one all-to-all of hip_a2a_capacity(h) * RW doubles per pair
+hip_a2a_capacity(h::HipBGP) = Int(ccall(sym(:smm_bgp_a2a_capacity), Cint, (Ptr{Cvoid},), h.ctx))
+hip_export_values!(h::HipBGP, vals::Ptr{Cvoid}) = (check(h.ctx, ccall(sym(:smm_bgp_export_values_dev), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, vals)); h)
+hip_a2a_pack!(h::HipBGP, vals_all::Ptr{Cvoid}, send::Ptr{Cvoid}) =
+    (check(h.ctx, ccall(sym(:smm_bgp_a2a_pack_dev), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, vals_all, send)); h)
+hip_a2a_apply!(h::HipBGP, recv::Ptr{Cvoid}) = (check(h.ctx, ccall(sym(:smm_bgp_a2a_apply_dev), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, recv)); h)
 
 """
     hip_history(h, t0, t1) -> NamedTuple
