@@ -756,15 +756,15 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         copy_strided(S.hp + cl * HW + H_PARAMS, S.rec + cl * RW + 3, np + nm, r, NR);
     TS_MARK(5);
     // ---- proposal(c), AlgoBGP.jl:424-471: lane (cl, r) evaluates try r of chain cl ----
-    if (ctl) {
+    {
         double* th = S.theta + cl * np;
         const double* rc = S.rec + cl * RW;
         const bool draws = (t > 1) && !(P.dbg & 1);   // uniform: iteration 1 proposes the initial value (:426-427)
-        if (!draws || !valid) {
+        if (ctl && (!draws || !valid)) {
             if (r == 0)
                 for (int k = 0; k < np; ++k) th[k] = !valid ? 0.0 : (t == 1 ? S.init[k] : rc[3 + k]);
         }
-        if (draws) {   // all 64 lanes walk the batches together; lanes of absent chains take no part in the tries
+        if (draws) {   // the control wave's 64 lanes walk the batches together; lanes of absent chains take no part in the tries
             const int bs = P.batch_size;
             const int max_tries = P.user_n ? min(P.rb_tries, P.smpl_iters) : P.smpl_iters;
             const int npar = min(min(NR, P.rb_tries), max_tries);  // tries evaluated side by side
@@ -774,6 +774,63 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             // mapto_01 (mprob.jl:248) once per chain and parameter — one division each, shared by all tries —, computed by the
             // NR lanes of the chain and kept in the (still unused) output record block
             double* m01 = S.rout + cl * RW;
+            // Many components (the whole proposal was 10.5 us per iteration at 50 parameters: one lane per chain and try walking
+            // all the components, then the redraw loop of mysample): every wave of the tile works, a chain is served by
+            // 64 * waves / CT lanes of ONE wave, a lane by the component pairs q = sl, sl + LPC, ... (one generator call per pair
+            // and try).  The tries are taken in order, each one tested by all the chain's lanes at once (a segment of the
+            // wave's ballot); the first one inside the unit box wins: same tries, same order, same winner as the serial form.
+            const bool coop = bs >= 16 && !P.chol_L;   // (uniform)
+            if (coop) {
+                __syncthreads();   // the blocks the control wave staged (records, state, randomness) are every wave's now
+                const int nwv = (int)blockDim.x / (64 * TPW);   // (one wave per tile in the slim launch)
+                const int LPC = 64 * nwv / CT;                   // lanes per chain: 4 .. 64, a power of two
+                const int cc = tid / LPC, sl = tid % LPC;
+                const int cg = tile * CT + cc;
+                const bool vld = cg < N;
+                const int sh = (lane / LPC) * LPC;
+                const unsigned long long seg = (LPC == 64 ? ~0ull : ((1ull << LPC) - 1ull)) << sh;   // this chain's lanes in the wave
+                const double* rcc = S.rec + cc * RW;
+                double* m01c = S.rout + cc * RW;
+                const double* zzc = S.rb + cc * RBW + 1;
+                double* thc = S.theta + cc * np;
+                const double sgc = S.cs[cc * CSW + CS_SIGMA];
+                const uint32_t gcc = (uint32_t)(P.offset + cg);
+                if (vld)
+                    for (int k = sl; k < np; k += LPC) {   // mapto_01 (mprob.jl:248) once per chain and parameter
+                        const double lbk = S.lb[k];
+                        m01c[k] = (rcc[3 + k] - lbk) / (S.ub[k] - lbk);
+                    }
+                __syncthreads();   // (a lane reads the m01 of its pairs, which other lanes of the chain may have written)
+                for (int b0 = 0; b0 < np; b0 += bs) {
+                    bool done = !vld;
+                    for (int rr = 0; rr < max_tries && __ballot(!done) != 0ull; ++rr) {   // mysample, :400-410, try rr
+                        bool okl = true;
+                        if (!done) {
+                            for (int q = sl; 2 * q < b0 + bs; q += LPC) {
+                                if (2 * q + 1 < b0) continue;
+                                double z0, z1;
+                                if (rr < P.rb_tries) { z0 = zzc[rr * np + 2 * q]; z1 = 2 * q + 1 < np ? zzc[rr * np + 2 * q + 1] : 0.0; }
+                                else { const double2 zz2 = rng_prop_normal2_outofline(P.seed, gcc, (uint32_t)t, (uint32_t)rr, (uint32_t)q); z0 = zz2.x; z1 = zz2.y; }
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const int k = 2 * q + e;
+                                    if (k < b0 || k >= b0 + bs) continue;
+                                    const double lbk = S.lb[k];
+                                    const double span = S.ub[k] - lbk;
+                                    const double step = sgc * (e ? z1 : z0);   // MvNormal(mu01, sigma): x = mu + sigma*z
+                                    const double x = m01c[k] + step;
+                                    if (!(x >= 0.0 && x <= 1.0)) okl = false;  // inclusive bounds, :405
+                                    const double sc = x * span;
+                                    thc[k] = sc + lbk;   // mapto_ab, mprob.jl:271: kept if this try wins (or is the last one)
+                                }
+                            }
+                        }
+                        const unsigned long long m = __ballot(okl || done);
+                        if ((m & seg) == seg) done = true;
+                    }
+                    if (!done && sl == 0) report_error(P, 2, t, (int)gcc);  // :409
+                }
+            } else if (ctl) {
             if (valid)
                 for (int k = r; k < np; k += NR) {
                     const double lbk = S.lb[k];
@@ -806,12 +863,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                         th[k] = sc + lbk;  // mapto_ab, mprob.jl:271
                     }
                 }
-                // Chains whose side-by-side tries all left the unit box redraw one try at a time.  Many components: with the
-                // whole wave on one chain — lane l draws and tests component b0+l (+64, ...), so a try costs one
-                // generator call instead of one per component pair in sequence (the redraw loop of mysample is what a
-                // 50-parameter problem spends its time in).  Same tries, same order, same winner as the serial form.
-                const bool coop = bs >= 16 && !P.chol_L;   // few components: every failing chain's own lane redraws (chains in parallel)
-                if (!coop && valid && r == 0 && rwin < 0) {
+                if (valid && r == 0 && rwin < 0) {   // every failing chain's own lane redraws one try at a time (chains in parallel)
                     bool ok2 = false;
                     for (int rr = npar; rr < max_tries && !ok2; ++rr) {
                         ok2 = true;
@@ -853,39 +905,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                     }
                     if (!ok2) report_error(P, 2, t, gc);  // :409
                 }
-                unsigned long long fm = coop ? __ballot(valid && r == 0 && rwin < 0) : 0ull;   // lane index of (cl, r = 0) is cl
-                while (fm) {
-                    const int cf = __ffsll((long long)fm) - 1;
-                    fm &= fm - 1;
-                    const double* m01f = S.rout + cf * RW;
-                    const double sgf = S.cs[cf * CSW + CS_SIGMA];
-                    const double* zzf = S.rb + cf * RBW + 1;
-                    double* thf = S.theta + cf * np;
-                    const int gcf = P.offset + tile * CT + cf;
-                    bool done = false;
-                    for (int rr = npar; rr < max_tries && !done; ++rr) {
-                        bool okl = true;
-                        for (int k = b0 + lane; k < b0 + bs; k += 64) {
-                            double z;
-                            if (rr < P.rb_tries) {
-                                z = zzf[rr * np + k];
-                            } else {
-                                const double2 zz2 = rng_prop_normal2_outofline(P.seed, (uint32_t)gcf, (uint32_t)t, (uint32_t)rr, (uint32_t)(k >> 1));
-                                z = (k & 1) ? zz2.y : zz2.x;
-                            }
-                            const double lbk = S.lb[k];
-                            const double span = S.ub[k] - lbk;
-                            const double mu01 = m01f[k];
-                            const double step = sgf * z;
-                            const double x = mu01 + step;
-                            if (!(x >= 0.0 && x <= 1.0)) okl = false;
-                            const double sc = x * span;
-                            thf[k] = sc + lbk;   // kept if this try wins (or is the last one)
-                        }
-                        done = __all(okl);
-                    }
-                    if (!done && lane == 0) report_error(P, 2, t, gcf);  // :409
-                }
+            }
             }
         }
     }
