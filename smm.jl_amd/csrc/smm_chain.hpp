@@ -272,9 +272,19 @@ __device__ inline void finish_objective(const KParams& P, const double* theta /*
         return;
     }
     double vsum = 0.0;
-    for (int k = 0; k < P.nm; ++k) {
+    int k = 0;
+    if (vk) {   // mean and squared deviation already there (moment_term by the chain's lanes): eight at a time from LDS, added in order
+        for (; k + 8 <= P.nm; k += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = vk[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vsum = (k + u == 0) ? v[u] : vsum + v[u];
+        }
+    }
+    for (; k < P.nm; ++k) {
         double v;
-        if (vk) v = vk[k];                      // mean and squared deviation already there (moment_term by the chain's lanes)
+        if (vk) v = vk[k];
         else moment_term<CT>(P, s_part, s_mom, s_w, ci, k, simM[k], v);
         vsum = (k == 0) ? v : vsum + v;
     }
@@ -344,6 +354,27 @@ __device__ inline void coop_put(double* lds_blk, const double2 (&v)[NI], const d
     }
     for (int i = r + NI * NR; i < W / 2; i += NR) ld[i] = gs[i];
 }
+// ... with nr lanes per block
+template <int NI>
+__device__ inline void coop_fetch_n(double2 (&v)[NI], const double* __restrict__ g, const int W, const int r, const int nr) {
+    const double2* __restrict__ gs = (const double2*)g;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = r + k * nr;
+        v[k] = i < W / 2 ? gs[i] : make_double2(0.0, 0.0);
+    }
+}
+template <int NI>
+__device__ inline void coop_put_n(double* lds_blk, const double2 (&v)[NI], const double* __restrict__ g, const int W, const int r, const int nr) {
+    const double2* __restrict__ gs = (const double2*)g;
+    double2* ld = (double2*)lds_blk;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = r + k * nr;
+        if (i < W / 2) ld[i] = v[k];
+    }
+    for (int i = r + NI * nr; i < W / 2; i += nr) ld[i] = gs[i];
+}
 template <int CT>
 __device__ inline void coop_store(double* __restrict__ g, const double* lds_blk, int W, int r) {
     constexpr int NR = 64 / CT;
@@ -351,6 +382,13 @@ __device__ inline void coop_store(double* __restrict__ g, const double* lds_blk,
     const double2* ld = (const double2*)lds_blk;
 #pragma unroll 2
     for (int i = r; i < W / 2; i += NR) gd[i] = ld[i];
+}
+
+// the same with nr lanes per block
+__device__ inline void coop_store_n(double* __restrict__ g, const double* lds_blk, const int W, const int r, const int nr) {
+    double2* __restrict__ gd = (double2*)g;
+    const double2* ld = (const double2*)lds_blk;
+    for (int i = r; i < W / 2; i += nr) gd[i] = ld[i];
 }
 
 // set_eval!(ci, ej) of swap_ev_ij! (AlgoBGP.jl:734-749) as a history record: the chain's record of
@@ -674,7 +712,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     int partner = 0;
     // a hard error raised by an earlier iteration (AlgoBGP.jl:341,409 abort the run): later launches store nothing
     unsigned long long err_word = ERR_NONE;
-    if (ctl) err_word = *(const volatile unsigned long long*)P.err;
+    if (ctl || KIND == 2) err_word = *(const volatile unsigned long long*)P.err;   // (dense kind: every wave — they meet at barriers behind the exit below)
     // wave 1: problem constants, requested now and written to LDS after the walk
     // (objectives without a simulation are launched with the control wave only, 64 lanes per tile: it loads the constants itself)
     const bool slim = KIND == 0 && blockDim.x == 64;
@@ -692,6 +730,43 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         constexpr int NI_RB = (12 + NR - 1) / NR < NI_MAX ? (12 + NR - 1) / NR : NI_MAX;
         constexpr int NI_REC = (8 + NR - 1) / NR < NI_MAX ? (8 + NR - 1) / NR : NI_MAX;
         double2 v_cs[NI_CS], v_rb[NI_RB], v_rec[NI_REC];
+        // the dense kind (long blocks: 832-byte records, 808 bytes of randomness per chain at 50 parameters) without an inline walk:
+        // every wave of the tile moves the blocks, 32 lanes per chain — two round trips of two or three 16-byte loads per lane
+        // (the control wave alone, 4 lanes per chain: 13 + 13 pieces per lane, most of them load-store round trips: 6 us)
+        const bool wide_load = KIND == 2 && !(flags & F_WALK_INLINE);
+        if (wide_load) {
+            constexpr int L2 = WG / CT;
+            const int ccw = tid / L2, rw = tid % L2;
+            const int cw = tile * CT + ccw;
+            const bool vw = cw < N;
+            const int cwc = vw ? cw : 0;
+            const int gcw = P.offset + cwc;
+            double2 w_cs[1], w_rb[2], w_rec[2];
+            const double* g_csw = P.cs + (size_t)cwc * CSW;
+            const double* g_rbw = P.rb + ((size_t)(t > 1 ? t - P.rb_t0 : 0) * N + cwc) * RBW;
+            const int rbww = t > 1 ? RBW : 0;
+            unsigned long long xrw = (unsigned long long)(unsigned)gcw;
+            if (vw) {
+                if (flags & F_HAS_PENDING) xrw = P.xres[gcw];
+                coop_fetch_n<1>(w_cs, g_csw, CSW, rw, L2);
+                coop_fetch_n<2>(w_rb, g_rbw, rbww, rw, L2);
+            }
+            if (wave1) {  // problem constants into the tile's LDS
+                if (k1 < np) { S.lb[k1] = c_lb; S.ub[k1] = c_ub; S.init[k1] = c_init; }
+                if (k1 < nm) { S.mom[k1] = c_mom; S.w[k1] = c_w; }
+                for (int k = k1 + 64; k < np; k += 64) { S.lb[k] = P.lb[k]; S.ub[k] = P.ub[k]; S.init[k] = P.init[k]; }
+                for (int k = k1 + 64; k < nm; k += 64) { S.mom[k] = P.mom[k]; S.w[k] = P.w[k]; }
+            }
+            if (vw) {
+                const int sw = (int)(unsigned)(xrw & 0xffffffffu) - ((flags & F_GLOBAL_REC) ? 0 : P.offset);
+                const double* g_recw = rec_in + (size_t)sw * RW;
+                coop_fetch_n<2>(w_rec, g_recw, RW, rw, L2);
+                coop_put_n<1>(S.cs + ccw * CSW, w_cs, g_csw, CSW, rw, L2);
+                coop_put_n<2>(S.rb + ccw * RBW, w_rb, g_rbw, rbww, rw, L2);
+                coop_put_n<2>(S.rec + ccw * RW, w_rec, g_recw, RW, rw, L2);
+            }
+            if (valid && (flags & F_HAS_PENDING)) partner = (int)(P.xres[gc] >> 32);   // (the control wave's lanes serve other chains than they loaded)
+        } else {
         const int cc = valid ? c : 0;
         const double* g_cs = P.cs + (size_t)cc * CSW;
         const double* g_rb = P.rb + ((size_t)(t > 1 ? t - P.rb_t0 : 0) * N + cc) * RBW;
@@ -727,6 +802,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             coop_put<CT, NI_CS>(S.cs + cl * CSW, v_cs, g_cs, CSW, r);
             coop_put<CT, NI_RB>(S.rb + cl * RBW, v_rb, g_rb, rbw, r);
             coop_put<CT, NI_REC>(S.rec + cl * RW, v_rec, g_rec, RW, r);
+        }
         }
     }
     TS_MARK(1);
@@ -941,7 +1017,19 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245) ----
     // the moments of a chain (wave totals -> mean -> squared weighted deviation) are independent: its NR lanes share them
     const bool sumsq = KIND != 0 && P.obj != SMM_OBJ_USER && P.obj != SMM_OBJ_BANANA;
-    if (valid && sumsq) {
+    // (the dense kind has all its waves here: the terms, and below the copies and the stores of the long blocks, are shared by the
+    // tile's 512 lanes, 32 per chain — the control wave alone: 7.3 + 3.5 us per iteration at 50 parameters and 50 moments)
+    constexpr int LPC2 = WG / CT;   // lanes per chain when every wave of the tile takes part
+    const int cc2 = tid / LPC2, r2 = tid % LPC2;
+    const bool valid2 = KIND == 2 && tile * CT + cc2 < N;
+    if constexpr (KIND == 2) {
+        if (valid2 && sumsq) {
+            double* smk = S.h + cc2 * HW + H_PARAMS + np;
+            double* vkk = S.rout + cc2 * RW;          // (the proposal's scratch: free again)
+            for (int k = r2; k < nm; k += LPC2) moment_term<CT>(P, S.part, S.mom, S.w, cc2, k, smk[k], vkk[k]);
+        }
+        __syncthreads();
+    } else if (valid && sumsq) {
         double* smk = S.h + cl * HW + H_PARAMS + np;
         double* vkk = S.rout + cl * RW;          // (the proposal's scratch: free again)
         for (int k = r; k < nm; k += NR) moment_term<CT>(P, S.part, S.mom, S.w, cl, k, smk[k], vkk[k]);
@@ -1002,6 +1090,28 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         P.vals[c] = acc ? value : old;
     }
     __builtin_amdgcn_wave_barrier();
+    if constexpr (KIND == 2) {
+        __syncthreads();   // the accept step's results (history head, record head, state block) are every wave's now
+        if (valid2) {      // (a chain's 32 lanes sit in one wave: its copies are in place before its stores read them)
+            const int c2 = tile * CT + cc2;
+            const bool acc = S.h[cc2 * HW + H_ACC] != 0.0;
+            copy_strided(S.h + cc2 * HW + H_PARAMS, S.theta + cc2 * np, np, r2, LPC2);
+            if (acc) {
+                copy_strided(S.rout + cc2 * RW + 3, S.theta + cc2 * np, np, r2, LPC2);
+                copy_strided(S.rout + cc2 * RW + 3 + np, S.h + cc2 * HW + H_PARAMS + np, nm, r2, LPC2);
+            } else {
+                copy_strided(S.rout + cc2 * RW + 3, S.rec + cc2 * RW + 3, RW - 3, r2, LPC2);
+            }
+            __builtin_amdgcn_wave_barrier();
+            coop_store_n(P.cs + (size_t)c2 * CSW, S.cs + cc2 * CSW, CSW, r2, LPC2);
+            coop_store_n(rec_out + (size_t)c2 * RW, S.rout + cc2 * RW, RW, r2, LPC2);
+            coop_store_n(P.hrec + ((size_t)(t - 1) * N + c2) * HW, S.h + cc2 * HW, HW, r2, LPC2);
+            if (t > 1 && S.cs[cc2 * CSW + CS_PARTNER] != 0.0)
+                coop_store_n(P.hrec + ((size_t)(t - 2) * N + c2) * HW, S.hp + cc2 * HW, HW, r2, LPC2);
+        }
+        TS_MARK(4);
+        return;
+    }
     if (valid) {
         const bool acc = S.h[cl * HW + H_ACC] != 0.0;
         copy_strided(S.h + cl * HW + H_PARAMS, S.theta + cl * np, np, r, NR);
