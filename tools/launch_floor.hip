@@ -45,6 +45,23 @@ void run(const char* what, double* vals, unsigned* pairs, double* recs) {
     float ms;
     CHK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-70s %6.2f us per dependent launch\n", what, ms * 1e3 / 2000);
+    // the same 2000 launches as ONE graph of kernel nodes (captured from the stream), launched once
+    hipStream_t st;
+    CHK(hipStreamCreate(&st));
+    hipGraph_t g; hipGraphExec_t ge;
+    CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < 2000; ++i) k<MODE><<<256, 1024, 88064, st>>>(vals, pairs, recs, i, nullptr);
+    CHK(hipStreamEndCapture(st, &g));
+    CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CHK(hipGraphLaunch(ge, st));
+    CHK(hipStreamSynchronize(st));
+    CHK(hipEventRecord(e0, st));
+    CHK(hipGraphLaunch(ge, st));
+    CHK(hipEventRecord(e1, st));
+    CHK(hipEventSynchronize(e1));
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-70s %6.2f us per launch as a node of one graph\n", "", ms * 1e3 / 2000);
+    CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g)); CHK(hipStreamDestroy(st));
 }
 
 int main() {
