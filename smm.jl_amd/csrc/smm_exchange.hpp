@@ -938,12 +938,13 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
     const int Ng = P.Ng;
     const int w = t - P.plan_t0;
     const uint32_t* __restrict__ info = P.lv_rowinfo + (size_t)w * 4;
-    const uint32_t* __restrict__ g_rows = P.lv_rows + (size_t)w * P.rows_cap * XWG + tid;
     XTS(0);
     const int nrows = (int)info[0];
     const unsigned long long endmask = (unsigned long long)info[1] | ((unsigned long long)info[2] << 32);
     if (info[3] == 0u || nan_flags[t & 1] != 0u) {
+#ifndef SMM_EXP_NO_FALLBACK   // (inspection builds: the rows walk's own code without the fallback's)
         resolve_key_body<PLDS>(P, t, vals, slots16, xsm);
+#endif
         return;
     }
     uint32_t* slot = (uint32_t*)xsm;
@@ -953,7 +954,20 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
     const uint32_t pbase = 4u * sl_words;
     constexpr int PT = XKEY_MAX / XWG;   // chains per lane
     // this lane's pair words: row r sits in register q[r mod 3], requested three rows ahead
-    uint32_t q0 = nrows > 0 ? g_rows[0] : 0u, q1 = nrows > 1 ? g_rows[XWG] : 0u, q2 = nrows > 2 ? g_rows[2 * XWG] : 0u;
+    // (inline asm: the compiler, which sees loads in the rare tie branch of a row too, would wait for ALL loads in flight at the head
+    // of the loop — 14 round trips to the L2 in 42 rows; here the wait is for the oldest of the three only.  Fetches past the
+    // last row are clamped to it: always three in flight, so that the count is right.)
+    const int rl = nrows > 0 ? nrows - 1 : 0;
+    // (a buffer load: the row is a scalar offset, the lane a constant vector offset — no address arithmetic per fetch)
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    const unsigned long long rows_base = (unsigned long long)(P.lv_rows + (size_t)w * P.rows_cap * XWG);
+    const i32x4_t rows_rsrc = {(int)(unsigned)rows_base, (int)(unsigned)((rows_base >> 32) & 0xffffu), (int)((unsigned)P.rows_cap * XWG * 4u), 0x00020000};
+    const uint32_t lane_off = 4u * (uint32_t)tid;
+    auto fetch = [&](uint32_t& q, const int rr) {
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(q) : "v"(lane_off), "s"(rows_rsrc), "s"(min(rr, rl) * (XWG * 4)) : "memory");
+    };
+    uint32_t q0, q1, q2;
+    fetch(q0, 0); fetch(q1, 1); fetch(q2, 2);
     {
         typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
         const u32x4s_t* __restrict__ s4 = (const u32x4s_t*)slots17;     // made by k_exch_keys: 16 bytes per lane and round
@@ -1002,65 +1016,93 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
         int r = 0;
 #pragma clang loop unroll(disable)
         for (; r + 3 <= nrows; r += 3) {
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(q0) :: "memory");
             row(q0, r);
-            q0 = r + 3 < nrows ? g_rows[(size_t)(r + 3) * XWG] : 0u;
+            fetch(q0, r + 3);
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(q1) :: "memory");
             row(q1, r + 1);
-            q1 = r + 4 < nrows ? g_rows[(size_t)(r + 4) * XWG] : 0u;
+            fetch(q1, r + 4);
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(q2) :: "memory");
             row(q2, r + 2);
-            q2 = r + 5 < nrows ? g_rows[(size_t)(r + 5) * XWG] : 0u;
+            fetch(q2, r + 5);
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1), "+v"(q2) :: "memory");
         if (r < nrows) row(q0, r);
         if (r + 1 < nrows) row(q1, r + 1);
     }
     __syncthreads();
     XTS(2);
     // ---- result: src from the slots; the last exchange partner from the swap's own array, or from the ballots ----
-    uint32_t src_[PT];
+    // (the bulk passes over the chains in 16-byte LDS operations, four consecutive chains per lane and round — as 4-byte ones they
+    // were a third of the kernel: 1024 LDS instructions per pass)
+    typedef unsigned int u32x4r_t __attribute__((ext_vector_type(4)));
+    constexpr int PT4 = PT / 4;
+    u32x4r_t src4[PT4];
 #pragma unroll
-    for (int r = 0; r < PT; ++r) {
-        const int g = tid + r * XWG;
-        src_[r] = g < Ng ? (slot[g] & 0x7fffu) : 0u;
+    for (int r = 0; r < PT4; ++r) {
+        const int g4 = tid + r * XWG;
+        src4[r] = 4 * g4 < Ng ? ((const u32x4r_t*)slot)[g4] & 0x7fffu : u32x4r_t{0u, 0u, 0u, 0u};
     }
+    auto put4 = [&](const int g4, const u32x4r_t sv, const uint32_t p0, const uint32_t p1, const uint32_t p2, const uint32_t p3) {
+        const int g = 4 * g4;   // chains g .. g + 3 (the last group of a population that is no multiple of 4 is ragged)
+        if (g + 3 < Ng) {
+            ((u32x4r_t*)P.xres)[2 * g4] = u32x4r_t{sv.x, p0, sv.y, p1};
+            ((u32x4r_t*)P.xres)[2 * g4 + 1] = u32x4r_t{sv.z, p2, sv.w, p3};
+        } else {
+            if (g < Ng) P.xres[g] = (unsigned long long)sv.x | ((unsigned long long)p0 << 32);
+            if (g + 1 < Ng) P.xres[g + 1] = (unsigned long long)sv.y | ((unsigned long long)p1 << 32);
+            if (g + 2 < Ng) P.xres[g + 2] = (unsigned long long)sv.z | ((unsigned long long)p2 << 32);
+        }
+    };
     if constexpr (PLDS) {
         XTS(3);
 #pragma unroll
-        for (int r = 0; r < PT; ++r) {
-            const int g = tid + r * XWG;
-            if (g < Ng) P.xres[g] = (unsigned long long)src_[r] | ((unsigned long long)partner[g] << 32);
+        for (int r = 0; r < PT4; ++r) {
+            const int g4 = tid + r * XWG;
+            if (4 * g4 < Ng) {
+                const uint2 pp = ((const uint2*)partner)[g4];   // four 2-byte entries (the array is padded)
+                put4(g4, src4[r], pp.x & 0xffffu, pp.x >> 16, pp.y & 0xffffu, pp.y >> 16);
+            }
         }
     } else {
         __syncthreads();
         uint32_t* last = slot;   // [Ng] 1 + the chain's partner in its last swapped pair
 #pragma unroll
-        for (int r = 0; r < PT; ++r) {
-            const int g = tid + r * XWG;
-            if (g < Ng) last[g] = 0u;
+        for (int r = 0; r < PT4; ++r) {
+            const int g4 = tid + r * XWG;
+            if (4 * g4 < Ng) ((u32x4r_t*)last)[g4] = u32x4r_t{0u, 0u, 0u, 0u};
         }
         __syncthreads();
         // the rows once more (from the L2), in order: the pairs of a level touch disjoint chains, so plain stores do, with a
         // barrier where a level ends — a later pair overwrites an earlier one (LDS atomics: 9.5 us for this pass at 32768 chains)
+        // (lane l holds its wave's ballot of row l; a row's ballot becomes the exec mask of the two stores: no test per lane)
+        const unsigned long long mrow = lane < nrows ? bits[lane * 16 + wave] : 0ull;
+        const uint32_t mlo = (uint32_t)mrow, mhi = (uint32_t)(mrow >> 32);
         auto prow = [&](const uint32_t pw, const int r) {
-            const unsigned long long m = bits[r * 16 + wave];
-            if ((m >> lane) & 1ull) {   // set_exchanged!, :747-748
-                const uint32_t ai = (pw & 0xffffu) << 2, aj = (pw >> 16) << 2;
-                asm volatile("ds_write_b32 %0, %2\n\tds_write_b32 %1, %3" :: "v"(ai), "v"(aj), "v"((pw >> 16) + 1u), "v"((pw & 0xffffu) + 1u) : "memory");
-            }
+            const unsigned long long m = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, r) |
+                                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, r) << 32);
+            const uint32_t ai = (pw & 0xffffu) << 2, aj = (pw >> 16) << 2;
+            unsigned long long saved;
+            asm volatile("s_and_saveexec_b64 %0, %1\n\tds_write_b32 %2, %4\n\tds_write_b32 %3, %5\n\ts_mov_b64 exec, %0"   // set_exchanged!, :747-748
+                         : "=&s"(saved) : "s"(m), "v"(ai), "v"(aj), "v"((pw >> 16) + 1u), "v"((pw & 0xffffu) + 1u) : "memory", "scc");
             if ((endmask >> r) & 1ull) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         };
         {   // (eight rows ahead: a row of this pass is too short for three to cover the way from the L2)
             constexpr int D = 8;
             uint32_t pq[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) pq[d] = d < nrows ? g_rows[(size_t)d * XWG] : 0u;
+            for (int d = 0; d < D; ++d) fetch(pq[d], d);
             int r = 0;
 #pragma clang loop unroll(disable)
             for (; r + D <= nrows; r += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
+                    asm volatile("s_waitcnt vmcnt(7)" : "+v"(pq[d]) :: "memory");
                     prow(pq[d], r + d);
-                    pq[d] = r + d + D < nrows ? g_rows[(size_t)(r + d + D) * XWG] : 0u;
+                    fetch(pq[d], r + d + D);
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pq[0]), "+v"(pq[1]), "+v"(pq[2]), "+v"(pq[3]), "+v"(pq[4]), "+v"(pq[5]), "+v"(pq[6]), "+v"(pq[7]) :: "memory");
 #pragma unroll
             for (int d = 0; d < D; ++d)
                 if (r + d < nrows) prow(pq[d], r + d);
@@ -1068,9 +1110,12 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
         __syncthreads();
         XTS(3);
 #pragma unroll
-        for (int r = 0; r < PT; ++r) {
-            const int g = tid + r * XWG;
-            if (g < Ng) P.xres[g] = (unsigned long long)src_[r] | ((unsigned long long)last[g] << 32);
+        for (int r = 0; r < PT4; ++r) {
+            const int g4 = tid + r * XWG;
+            if (4 * g4 < Ng) {
+                const u32x4r_t l4 = ((const u32x4r_t*)last)[g4];
+                put4(g4, src4[r], l4.x, l4.y, l4.z, l4.w);
+            }
         }
     }
     XTS(4);
