@@ -979,3 +979,23 @@ def test_values_form_block_overflow_is_a_hard_error(S, monkeypatch):
     with pytest.raises(A.SMMHipError) as e:
         sharded_run_values(S, prob, opts, 2, 10)
     assert e.value.code == A.SMM_ERR_EXCHANGE_CAPACITY
+
+
+def test_lean_walk_across_plan_windows(S, O, monkeypatch):
+    # 1000 chains over 600 iterations: the look-ahead plan is rebuilt twice (windows of 256 iterations), every switch settles the
+    # open exchange through the stand-alone kernel; stepping in uneven pieces; lean walk against the 16-byte walk and the oracle
+    N, T = 1000, 600
+    prob, opts = cm.serial_normal(N=N, T=T, ns=64)
+    a = S.hip_context(prob, opts)
+    for n in (1, 254, 3, 255, 87):
+        a.step(n)
+    monkeypatch.setenv("SMMHIP_KEY_WALK", "0")
+    b = S.hip_context(prob, opts)
+    b.step(T)
+    monkeypatch.delenv("SMMHIP_KEY_WALK")
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_state_equal(a.state(), b.state(), rtol=0)
+    o = O.OracleContext(prob, opts, S.Tables(Z=a.Z()), threads=_all_cores(O))
+    o.step(T)
+    cm.assert_history_equal(a.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(a.state(), o.state(), atol=1e-13)
