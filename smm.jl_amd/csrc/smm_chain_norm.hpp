@@ -1,4 +1,4 @@
-// the chain kernel of the bundled objective (objfunc_norm, np == nm <= 2 — the kernel is written for <= 4, the larger two spill —, one proposal batch): k_chain_iter_norm — part of
+// the chain kernel of the bundled objective (objfunc_norm, np == nm <= 4, one proposal batch): k_chain_iter_norm — part of
 // libsmmhip (included by smmhip.hip inside its anonymous namespace; gfx950 device code).
 #pragma once
 // ------------------------------------------------------------------------------------------

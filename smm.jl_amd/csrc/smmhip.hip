@@ -315,7 +315,11 @@ void launch_chain_iter_norm(Ctx* c, int t, int flags) {
         case 2: launch_chain_iter_norm_t<1, false>(c, t, flags); break;
         case 3: launch_chain_iter_norm_t<1, true>(c, t, flags); break;
         case 4: launch_chain_iter_norm_t<2, false>(c, t, flags); break;
-        default: launch_chain_iter_norm_t<2, true>(c, t, flags); break;
+        case 5: launch_chain_iter_norm_t<2, true>(c, t, flags); break;
+        case 6: launch_chain_iter_norm_t<3, false>(c, t, flags); break;
+        case 7: launch_chain_iter_norm_t<3, true>(c, t, flags); break;
+        case 8: launch_chain_iter_norm_t<4, false>(c, t, flags); break;
+        default: launch_chain_iter_norm_t<4, true>(c, t, flags); break;
     }
 }
 
@@ -726,7 +730,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
             const size_t tile_b = (tile_smem_base(c, tile_ct) + 15) & ~(size_t)15;
             const char* nf = getenv("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
-            c->norm_fast = is_sim(c->obj) && np == nm && np <= 2 && opts->batch_size == np && P.dbg == 0 && !opts->chol_L && !(nf && nf[0] == '0');
+            c->norm_fast = is_sim(c->obj) && np == nm && np <= 4 && opts->batch_size == np && P.dbg == 0 && !opts->chol_L && !(nf && nf[0] == '0');
             // k_chain_iter_norm: pair list NOT overlaid; room for either walk (16-byte slots, 4-byte slots + value table)
             const size_t walk_b = std::max(walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15), (lean_walk_bytes(Ng, K) + 15) & ~(size_t)15);
             c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng && c->obj != SMM_OBJ_USER &&
@@ -869,6 +873,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));

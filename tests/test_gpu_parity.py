@@ -205,14 +205,15 @@ def test_three_phase_calls_after_step(S, O):
     np.testing.assert_allclose(buf.cpu().numpy()[:, 0], o5.state().la_value, rtol=1e-9)
 
 
-@pytest.mark.parametrize("npar,N,T", [(2, 5, 30), (2, 16, 30), (2, 17, 25), (2, 100, 40), (2, 4096, 12), (1, 37, 30), (2, 5000, 8)])
+@pytest.mark.parametrize("npar,N,T", [(2, 5, 30), (2, 16, 30), (2, 17, 25), (2, 100, 40), (2, 4096, 12), (1, 37, 30), (2, 5000, 8),
+                                      (3, 50, 30), (4, 100, 30), (3, 4096, 10), (4, 6000, 8)])
 def test_norm_kernel_equals_general_kernel(S, O, npar, N, T, monkeypatch):
     # k_chain_iter_norm (16-chain tiles, np == nm <= 2) against the general k_chain_iter on the same problem: bit-identical
     if npar == 2:
         prob, opts = cm.serial_normal(N=N, T=T, ns=1000 if N > 1000 else 10000, objective_id=A.SMM_OBJ_NORM_FAILBOX,
                                       obj_params=[0.5, 0.9], sigma0=0.2)
     else:
-        prob, opts = cm.general_normal(1, N=N, T=T, ns=777)
+        prob, opts = cm.general_normal(npar, N=N, T=T, ns=777 if N < 1000 else 2000)
     a = S.hip_context(prob, opts)
     a.step(T)
     monkeypatch.setenv("SMMHIP_NORM_FAST", "0")
