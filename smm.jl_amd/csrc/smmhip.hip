@@ -195,7 +195,7 @@ struct Ctx {
     int plan_t0 = 0, plan_w = 0;
     bool lds_exchange = false;
     int ct = 8;
-    bool norm_fast = false;     // objfunc_norm with np == nm <= 2 and one proposal batch: k_chain_iter_norm (16-chain tiles)
+    bool norm_fast = false;     // objfunc_norm with np == nm <= 4 and one proposal batch: k_chain_iter_norm (16-chain tiles)
     int failed = 0;             // a hard device error (AlgoBGP.jl:341,409) stopped the run at iteration `iter`: sticky until smm_set_state
 };
 
