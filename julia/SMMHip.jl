@@ -15,7 +15,7 @@ using Libdl
 
 export HipBGP, hip_create, hip_destroy!, hip_step!, hip_iter, hip_history, hip_state, hip_set_state!, hip_eval_batch,
        hip_register_objective, hip_record_doubles
-export hip_stream, hip_sync, hip_local_step!, hip_export_records!, hip_exchange!, hip_sharded_step!, hip_sharded_finish!,
+export hip_eval_batch_noseed, hip_stream, hip_sync, hip_local_step!, hip_export_records!, hip_exchange!, hip_sharded_step!, hip_sharded_finish!,
        hip_a2a_capacity, hip_export_values!, hip_a2a_pack!, hip_a2a_apply!, hip_record_doubles
 
 const ABI_VERSION = 2
@@ -306,6 +306,24 @@ function hip_eval_batch(h::HipBGP, params::Matrix{Float64})
         check(h.ctx, ccall(sym(:smm_eval_batch), Cint,
                            (Ptr{Cvoid}, Ptr{Cdouble}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int8}),
                            h.ctx, pointer(params), M, pointer(value), pointer(simm), pointer(st)))
+    end
+    return value, simm, st
+end
+
+"""
+    hip_eval_batch_noseed(h, params, base_seed) -> (value, sim_moments, status)
+
+The same with `options[:noseed] = true` (ObjExamples.jl:71-75): evaluation i draws its own shocks, keyed by `base_seed + i` —
+the repetitions of `getSigma` (econometrics.jl:125-145).
+"""
+function hip_eval_batch_noseed(h::HipBGP, params::Matrix{Float64}, base_seed::Integer)
+    M = size(params, 1)
+    size(params, 2) == h.np || throw(ArgumentError("params must be M x np"))
+    value = Vector{Float64}(undef, M); simm = Matrix{Float64}(undef, M, h.nm); st = Vector{Int8}(undef, M)
+    GC.@preserve params value simm st begin
+        check(h.ctx, ccall(sym(:smm_eval_batch_noseed), Cint,
+                           (Ptr{Cvoid}, Ptr{Cdouble}, Cint, UInt64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int8}),
+                           h.ctx, pointer(params), M, UInt64(base_seed), pointer(value), pointer(simm), pointer(st)))
     end
     return value, simm, st
 end

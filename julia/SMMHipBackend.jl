@@ -26,12 +26,12 @@ module SMMHipBackend
 
 using SMM
 using DataStructures: OrderedDict
-import SMM: MAlgo, MAlgoBGP, MProb, Eval, BGPChain, computeNextIteration!, run!, summary, history, save, readMalgo, restart!,
+import SMM: MAlgo, MAlgoBGP, MProb, Eval, BGPChain, Slice, computeNextIteration!, run!, summary, history, save, readMalgo, restart!,
             extendBGPChain!
 import Base: getproperty, show
 using ..SMMHip
 
-export MAlgoBGPHip, sync_chains!, serialNormalHip
+export MAlgoBGPHip, sync_chains!, serialNormalHip, evaluateObjectivesHip, doSlicesHip, FD_gradient_hip, getSigmaHip
 
 """
     MAlgoBGPHip(m::MProb, opts::Dict)
@@ -330,6 +330,103 @@ function serialNormalHip(niter::Int = 200; nchains::Int = 3, acc_tuners = [20.0,
     MA = MAlgoBGPHip(mprob, opts)
     run!(MA)
     return MA
+end
+
+# ------------------------------------------------------------------------------------------
+# The other callers of evaluateObjective (slices.jl, econometrics.jl), as batches on the device: where the reference maps
+# evaluateObjective over a grid (pmap / map), the whole grid is ONE call of smm_eval_batch.  (smm.jl_amd/callers.py is the
+# tested mirror of the same drivers, tests/test_callers.py.)
+# ------------------------------------------------------------------------------------------
+"a one-chain context that only evaluates: `opts` as for MAlgoBGPHip (hip_objective, hip_ns, hip_obj_params, device)"
+function eval_context(m::MProb, opts::Dict = Dict())
+    init = Float64[m.initial_value[k] for k in keys(m.params_to_sample)]
+    lb = Float64[v[:lb] for (k, v) in m.params_to_sample]
+    ub = Float64[v[:ub] for (k, v) in m.params_to_sample]
+    mom = Float64[v[:value] for (k, v) in m.moments]
+    w = Float64[v[:weight] for (k, v) in m.moments]
+    return SMMHip.hip_create(init, lb, ub, mom, w, [0.05], [1.0], [0.0]; maxiter = 1, ns = Int(get(opts, "hip_ns", 10000)),
+                             objective_id = device_objective(m, opts), obj_params = Float64.(get(opts, "hip_obj_params", Float64[])),
+                             device = Int(get(opts, "device", 0)))
+end
+
+"""
+    evaluateObjectivesHip(m, ps; opts = Dict(), noseed_base = nothing) -> Vector{Eval}
+
+`evaluateObjective(m, p)` (mprob.jl:175-205) for every parameter dict of `ps`, as one batch on the device.
+"""
+function evaluateObjectivesHip(m::MProb, ps::Vector; opts::Dict = Dict(), noseed_base = nothing)
+    h = eval_context(m, opts)
+    pk = collect(keys(m.params_to_sample))
+    mk = collect(keys(m.moments))
+    P = Float64[p[k] for p in ps, k in pk]                      # M x np
+    value, simm, st = noseed_base === nothing ? SMMHip.hip_eval_batch(h, P) : SMMHip.hip_eval_batch_noseed(h, P, noseed_base)
+    SMMHip.hip_destroy!(h)
+    evs = Eval[]
+    for (i, p) in enumerate(ps)
+        ev = Eval(m, p)
+        ev.value = value[i]
+        ev.status = Int(st[i])
+        for (j, k) in enumerate(mk)
+            ev.simMoments[k] = simm[i, j]
+        end
+        push!(evs, ev)
+    end
+    return evs
+end
+
+"`doSlices(m, npoints)` (slices.jl:250-290): all np * npoints evaluations in one batch"
+function doSlicesHip(m::MProb, npoints::Int; opts::Dict = Dict())
+    res = Slice(m.initial_value, m.moments)
+    ps = Any[]
+    tags = Symbol[]
+    for (pp, bb) in m.params_to_sample
+        for pval in range(bb[:lb], stop = bb[:ub], length = npoints)
+            p = deepcopy(m.initial_value)
+            p[pp] = pval
+            push!(ps, p)
+            push!(tags, pp)
+        end
+    end
+    for (pp, ev) in zip(tags, evaluateObjectivesHip(m, ps; opts = opts))
+        SMM.add!(res, pp, ev)
+    end
+    return res
+end
+
+"`FD_gradient(m, p)` (econometrics.jl:29-85): the 1 + k (forward) or 2k (central) evaluations in one batch; rows in the order of `p`"
+function FD_gradient_hip(m::MProb, p::Union{Dict,OrderedDict}; step_perc = 0.01, diff_method = :forward, use_range = true, opts::Dict = Dict())
+    diff_method in (:forward, :central) || error("only :central and :foward implemented")
+    rs = SMM.range_length(m)
+    ks = collect(keys(p))
+    hs = Float64[(use_range ? rs[k] : p[k]) * step_perc for k in ks]
+    ps = Any[deepcopy(p)]
+    for (k, h) in zip(ks, hs)
+        if diff_method == :forward
+            q = deepcopy(p); q[k] = p[k] + h; push!(ps, q)
+        else
+            q = deepcopy(p); q[k] = p[k] + 0.5 * h; push!(ps, q)
+            q = deepcopy(p); q[k] = p[k] - 0.5 * h; push!(ps, q)
+        end
+    end
+    evs = evaluateObjectivesHip(m, ps; opts = opts)
+    mk = collect(keys(m.moments))
+    g(ev) = Float64[ev.simMoments[k] for k in mk]
+    gp = g(evs[1])
+    D = zeros(length(ks), length(mk))
+    for (i, h) in enumerate(hs)
+        D[i, :] = diff_method == :forward ? (g(evs[1 + i]) .- gp) ./ h : (g(evs[2 * i]) .- g(evs[2 * i + 1])) ./ h
+    end
+    return D
+end
+
+"`getSigma(m, p, reps)` (econometrics.jl:125-145): `reps` evaluations with their own shock sequences (seed + i) in one batch"
+function getSigmaHip(m::MProb, p::Union{Dict,OrderedDict}, reps::Int; seed::Integer = 0, opts::Dict = Dict())
+    evs = evaluateObjectivesHip(m, Any[deepcopy(p) for i in 1:reps]; opts = opts, noseed_base = seed)
+    mk = collect(keys(m.moments))
+    X = Float64[ev.simMoments[k] for ev in evs, k in mk]
+    mu = sum(X, dims = 1) ./ reps
+    Xc = X .- mu
+    return (Xc' * Xc) ./ (reps - 1)
 end
 
 end # module

@@ -13,5 +13,6 @@ from .host import (CI, BGPChain, Eval, MAlgoBGP, MProb, addEvalFunc, addMoment, 
                    evaluateObjective, fill, dense_sim, history, mean, median, ms_names, objfunc_norm, param, paramd, params,
                    ps2s_names, ps_names, readMalgo, restart, run, save, serialNormal, setMoments, setValue, snorm_impl,
                    summary, user_objective)
+from .callers import (FD_gradient, Slice, doSlices, evaluateObjectives, getSigma, get_stdErrors, optSlices, range_length)
 
 __all__ = [n for n in dir() if not n.startswith("_")] + ["_abi"]
