@@ -3,8 +3,8 @@ slices of the objective (slices.jl: Slice, doSlices, optSlices) and the sandwich
 FD_gradient, getSigma, get_stdErrors).  Where the reference maps evaluateObjective over a grid of parameter vectors (pmap or
 map), here the whole grid is ONE call of smm_eval_batch (include/smmhip.h); the arithmetic on the results is host-side numpy.
 
-`evaluator(m, P [np][M], noseed_base=None) -> (value [M], simM [nm][M], status [M])` can be injected (the parity tests run the
-same drivers over the CPU oracle); the default is the device.
+`evaluator(m, P [np][M], noseed_base=None) -> (value [M], simM [nm][M], status [M])` can be injected (the tests run the
+same drivers over a CPU evaluator); the default is the device.
 """
 import time as _time
 from collections import OrderedDict
