@@ -1,5 +1,6 @@
 """Randomised parity sweep: libsmmhip (default path) against the oracle on random problem shapes.
-python tools/fuzz_parity.py [cases] [seed]   (GPU box; test infrastructure, not part of the product)"""
+python tools/fuzz_parity.py [cases] [seed] [big]   (GPU box; test infrastructure, not part of the product; `big`: populations of
+12000 .. 32768 chains — the stand-alone exchange kernels for 4 and 8 GPUs — with a small objective)"""
 import os
 import sys
 
@@ -15,12 +16,18 @@ from oracle import oracle as O  # noqa: E402
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     bad = 0
     for it in range(cases):
         npar = int(rng.choice([1, 2, 2, 3, 4, 6, 9, 18]))
         N = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 40, 100, 255, 256, 257, 600, 1500, 4096, 4100, 8192, 9001]))
         T = int(rng.integers(3, 50))
         ns = int(rng.choice([1, 17, 64, 511, 512, 513, 1000, 4096, 4097, 10000]))
+        if big:
+            npar = int(rng.choice([1, 2, 2, 3]))
+            N = int(rng.choice([12000, 16384, 20001, 24576, 24577, 30000, 32768]))
+            T = int(rng.integers(3, 9))
+            ns = int(rng.choice([1, 17, 64]))
         divs = [d for d in range(1, npar + 1) if npar % d == 0]
         bs = int(rng.choice(divs))
         half = rng.uniform(1.0, 5.0, npar)
@@ -38,7 +45,7 @@ def main():
         desc = "case %d: np=%d N=%d T=%d ns=%d bs=%d" % (it, npar, N, T, ns, bs)
         try:
             h = S.hip_context(prob, opts)
-            o = O.OracleContext(prob, opts, S.Tables(Z=h.Z()))
+            o = O.OracleContext(prob, opts, S.Tables(Z=h.Z()), threads=O.max_threads() if big else 1)
             split = int(rng.integers(1, T))
             h.step(split); h.step(T - split)
             o.step(T)
