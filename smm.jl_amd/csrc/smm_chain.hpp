@@ -867,7 +867,6 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                 const unsigned long long seg = (LPC == 64 ? ~0ull : ((1ull << LPC) - 1ull)) << sh;   // this chain's lanes in the wave
                 const double* rcc = S.rec + cc * RW;
                 double* m01c = S.rout + cc * RW;
-                const double* zzc = S.rb + cc * RBW + 1;
                 double* thc = S.theta + cc * np;
                 const double sgc = S.cs[cc * CSW + CS_SIGMA];
                 const uint32_t gcc = (uint32_t)(P.offset + cg);
@@ -876,33 +875,87 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                         const double lbk = S.lb[k];
                         m01c[k] = (rcc[3 + k] - lbk) / (S.ub[k] - lbk);
                     }
+                // (a word every tile of the workgroup sees: the number of the last round of shared tries somebody asked for)
+                unsigned long long* round_word = (unsigned long long*)(S.h - (size_t)st * ((tile_smem_doubles(CT, np, nm, RW, HW, RBW, KIND) + 1) & ~(size_t)1)) + 2;
+                if (threadIdx.x == 0) *round_word = 0ull;
+                unsigned long long round_id = 0ull;
                 __syncthreads();   // (a lane reads the m01 of its pairs, which other lanes of the chain may have written)
+                // one try of chain `u` (its lanes: this half-wave or whatever segment serves it), components of the batch
+                // [b0, b0 + bs): the point into `out`, true when inside the unit box
+                auto one_try = [&](const int u, const uint32_t gu, const double sgu, const int rr, const int b0, double* out) -> bool {
+                    const double* m01u = S.rout + u * RW;
+                    const double* zzu = S.rb + u * RBW + 1;
+                    bool okl = true;
+                    for (int q = sl; 2 * q < b0 + bs; q += LPC) {
+                        if (2 * q + 1 < b0) continue;
+                        double z0, z1;
+                        if (rr < P.rb_tries) { z0 = zzu[rr * np + 2 * q]; z1 = 2 * q + 1 < np ? zzu[rr * np + 2 * q + 1] : 0.0; }
+                        else { const double2 zz2 = rng_prop_normal2_outofline(P.seed, gu, (uint32_t)t, (uint32_t)rr, (uint32_t)q); z0 = zz2.x; z1 = zz2.y; }
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int k = 2 * q + e;
+                            if (k < b0 || k >= b0 + bs) continue;
+                            const double lbk = S.lb[k];
+                            const double span = S.ub[k] - lbk;
+                            const double step = sgu * (e ? z1 : z0);   // MvNormal(mu01, sigma): x = mu + sigma*z
+                            const double x = m01u[k] + step;
+                            if (!(x >= 0.0 && x <= 1.0)) okl = false;  // inclusive bounds, :405
+                            const double sc = x * span;
+                            out[k] = sc + lbk;   // mapto_ab, mprob.jl:271
+                        }
+                    }
+                    return okl;
+                };
+                const int n_pre = min(P.rb_tries, max_tries);   // tries whose normals are in the randomness block
                 for (int b0 = 0; b0 < np; b0 += bs) {
                     bool done = !vld;
-                    for (int rr = 0; rr < max_tries && __ballot(!done) != 0ull; ++rr) {   // mysample, :400-410, try rr
+                    for (int rr = 0; rr < n_pre && __ballot(!done) != 0ull; ++rr) {   // mysample, :400-410, try rr
+                        const bool okl = done || one_try(cc, gcc, sgc, rr, b0, thc);   // (kept if this try wins or is the last one)
+                        const unsigned long long m = __ballot(okl);
+                        if ((m & seg) == seg) done = true;
+                    }
+                    // Later tries come from the generator (~1.4 us each: Philox4x32-10 + Box-Muller per component pair), and a
+                    // launch lasts as long as its unluckiest chain — with 50 parameters and adapted sigmas regularly 5-15 tries,
+                    // now and then 50 (C5: 26 us per launch early in a run, 36 us on average, spikes of 130).  So the tile's CT
+                    // lane segments ("slots") all work for the chains still open: open chain number i of n gets the slots
+                    // i, i + n, i + 2n, ..., each evaluating one further try, and the lowest successful try wins — the tries,
+                    // their order and the winner are those of the serial loop.  Scratch: the (still unused) history rows of the
+                    // tile: slot s keeps its candidate in row s, chain u its success mask in the head of row u.
+                    for (int base = n_pre;;) {
+                        unsigned long long* head = (unsigned long long*)(S.h + cc * HW);   // [0]: open, [1]: successful offsets
+                        ++round_id;
+                        if (sl == 0) { head[0] = done ? 0ull : 1ull; head[1] = 0ull; if (!done) *round_word = round_id; }
+                        __syncthreads();
+                        if (*round_word != round_id || base >= max_tries) break;   // (uniform over the workgroup: nobody open, or no try left)
+                        const unsigned long long open = __ballot(lane < CT && *(const unsigned long long*)(S.h + lane * HW) != 0ull);
+                        const int n_open = __popcll(open);
+                        const int per = n_open ? CT / n_open : 0;      // tries per open chain in this round (>= 1)
+                        const int off = n_open ? cc / n_open : 0;
+                        unsigned long long mm = open;
+                        for (int i = n_open ? cc % n_open : 0; i > 0; --i) mm &= mm - 1ull;
+                        const int u = mm ? __ffsll((long long)mm) - 1 : 0;
+                        const int rr = base + off;
+                        const bool active = n_open && off < per && rr < max_tries;
+                        double* cand = S.h + cc * HW + H_PARAMS;
                         bool okl = true;
-                        if (!done) {
-                            for (int q = sl; 2 * q < b0 + bs; q += LPC) {
-                                if (2 * q + 1 < b0) continue;
-                                double z0, z1;
-                                if (rr < P.rb_tries) { z0 = zzc[rr * np + 2 * q]; z1 = 2 * q + 1 < np ? zzc[rr * np + 2 * q + 1] : 0.0; }
-                                else { const double2 zz2 = rng_prop_normal2_outofline(P.seed, gcc, (uint32_t)t, (uint32_t)rr, (uint32_t)q); z0 = zz2.x; z1 = zz2.y; }
-#pragma unroll
-                                for (int e = 0; e < 2; ++e) {
-                                    const int k = 2 * q + e;
-                                    if (k < b0 || k >= b0 + bs) continue;
-                                    const double lbk = S.lb[k];
-                                    const double span = S.ub[k] - lbk;
-                                    const double step = sgc * (e ? z1 : z0);   // MvNormal(mu01, sigma): x = mu + sigma*z
-                                    const double x = m01c[k] + step;
-                                    if (!(x >= 0.0 && x <= 1.0)) okl = false;  // inclusive bounds, :405
-                                    const double sc = x * span;
-                                    thc[k] = sc + lbk;   // mapto_ab, mprob.jl:271: kept if this try wins (or is the last one)
-                                }
+                        if (active) okl = one_try(u, (uint32_t)(P.offset + tile * CT + u), S.cs[u * CSW + CS_SIGMA], rr, b0, cand);
+                        const unsigned long long m = __ballot(okl);
+                        if (active && (m & seg) == seg && sl == 0) atomicOr((unsigned long long*)(S.h + u * HW) + 1, 1ull << off);
+                        __syncthreads();
+                        if (active) {
+                            const unsigned long long won = ((const unsigned long long*)(S.h + u * HW))[1];
+                            if (won ? (__ffsll((long long)won) - 1 == off) : (rr == max_tries - 1)) {   // the winner (or the last try of all)
+                                double* thu = S.theta + u * np;
+                                for (int q = sl; 2 * q < b0 + bs; q += LPC)
+                                    for (int e = 0; e < 2; ++e) {
+                                        const int k = 2 * q + e;
+                                        if (k >= b0 && k < b0 + bs) thu[k] = cand[k];
+                                    }
                             }
                         }
-                        const unsigned long long m = __ballot(okl || done);
-                        if ((m & seg) == seg) done = true;
+                        if (!done && head[1] != 0ull) done = true;
+                        __syncthreads();
+                        base += max(per, 1);
                     }
                     if (!done && sl == 0) report_error(P, 2, t, (int)gcc);  // :409
                 }

@@ -692,6 +692,45 @@ def test_c5_dense_4096_chains(S, O):
     cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
 
 
+@pytest.mark.parametrize("kind,npar,N,sig,smpl,bs", [("dense", 50, 100, 0.08, 100000, None), ("dense", 50, 37, 0.12, 100000, 25),
+                                                      ("dense", 50, 16, 0.3, 40, None), ("norm", 18, 70, 0.12, 100000, None),
+                                                      ("norm", 32, 9, 0.15, 100000, 16), ("dense", 64, 33, 0.06, 100000, None)])
+def test_many_parameters_many_tries(S, O, kind, npar, N, sig, smpl, bs):
+    # proposals of 16 and more components whose tries run far past the pre-generated ones (sigma so wide that a try
+    # seldom lands inside the box): the tile's lane segments share the open chains' further tries; same tries, same
+    # order, same winner as the serial loop (mysample, AlgoBGP.jl:400-410) -- and the same hard error when smpl_iters
+    # tries do not suffice (:409)
+    if kind == "dense":
+        prob, opts = dense_problem(S, O, npar, npar, N=N, T=25)
+    else:
+        prob, opts = cm.general_normal(npar, N=N, T=25, ns=100)
+    opts.sigma[:] = sig * cm.temps(N, 2.0)
+    opts.smpl_iters = smpl
+    if bs:
+        opts.batch_size = bs
+    h, o = make_pair(S, O, prob, opts)
+    eh = eo = None
+    try:
+        h.step(25)
+    except A.SMMHipError as e:
+        eh = e
+    try:
+        o.step(25)
+    except A.SMMHipError as e:
+        eo = e
+    assert (eh is None) == (eo is None) == (smpl > 40)
+    if eh is None:
+        cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+        cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+    else:   # the iterations before the failing one agree
+        assert eh.code == eo.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT
+        assert "iteration 2" in str(eh) and "chain 1," in str(eh)   # (every chain fails: the first one is reported)
+        n = o.state().iter
+        assert h.state().iter == n + 1
+        if n:
+            cm.assert_history_equal(h.history(0, n), o.history(0, n), atol=1e-13)
+
+
 def test_c5_dense_sharded_8(S, O):
     # ... sharded 8 ways (512 chains per shard), against the single-shard run
     prob, opts = dense_problem(S, O, 50, 50, N=4096, T=8)
