@@ -199,13 +199,55 @@ __device__ inline bool exchange_walk_lean(const KParams& P, const int tx, unsign
     return true;
 }
 
+// the wide form (one min_improve > 0 or NaN for all chains): 16-byte slots {value, src | stamp << 16, -} built here from the
+// chains' values (8 bytes per chain from memory, as for the keys).  false: the plan has more than 31 levels.
+__device__ inline bool exchange_walk_lean_wide(const KParams& P, const int tx, unsigned char* lds, const int tid, const int ts_tile) {
+    constexpr int NT = NORM_WG;
+    const int Ng = P.Ng;
+    const int w = tx - P.plan_t0;
+    const uint32_t* __restrict__ g_offp = P.lv_offp + (size_t)w * LV_OFFP;
+    const uint4* __restrict__ g_pairs = (const uint4*)(P.lv_pairs_p + (size_t)w * P.plan_Kp);
+    const int lane = tid & 63;
+    const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
+    const uint32_t pbase = 16u * (Ng4 + 1u);   // LDS offset of the pair words
+    const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
+    constexpr int PT = XLVL_MAX / NT;                     // chains per lane: tid, tid + NT, ... (16-byte LDS writes at a 16-byte lane stride)
+    double v_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        v_[r] = g < Ng ? P.vals[g] : 0.0;
+    }
+    uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0;
+    if (4 * tid < P.plan_Kp) p0 = g_pairs[tid];
+    if (4 * (tid + NT) < P.plan_Kp) p1 = g_pairs[tid + NT];
+    const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
+    if (__builtin_amdgcn_readlane((int)ov, 34) == 0 || (uint32_t)(size_t)lds != 0u) return false;
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        if (g < Ng) ((uint4*)lds)[g] = make_uint4((uint32_t)__double2loint(v_[r]), (uint32_t)__double2hiint(v_[r]), (uint32_t)g, 0u);
+    }
+    if (4 * tid < P.plan_Kp) ((uint4*)(lds + pbase))[tid] = p0;
+    if (4 * (tid + NT) < P.plan_Kp) ((uint4*)(lds + pbase))[tid + NT] = p1;
+    if (tid == 0) ((uint4*)lds)[Ng4] = make_uint4(0u, 0u, 0u, 0u);   // the dummy pair's slot: 0 - 0 > min_improve is false
+    const int ltail = lean_walk_tail(ov, nlev, lane);
+    __syncthreads();
+    if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
+    if (P.lean_unit == 16) lean_walk_levels<NORM_WG, 0, true>(nullptr, 0, pbase, ov, nlev, tid, ltail, P.mi_value);
+    else lean_walk_levels<NORM_WG, 1, true>(nullptr, 0, pbase, ov, nlev, tid, ltail, P.mi_value);
+    return true;
+}
+
 template <int NP>
 __device__ inline void epilogue_norm(const KParams& P, const int t, double* __restrict__ rec_out, const double* s_theta, const double* s_part,
                                      const double* s_park, const int tile, const int tid);
 
-template <int NP, bool WALK>
-__global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P, const int t, const double* __restrict__ rec_in,
-                                                                 double* __restrict__ rec_out, const int flags) {
+// (WIDE: the walk's form for one min_improve > 0 shared by all chains — a kernel of its own, k_chain_iter_norm_wide, so that
+// the registers of the min_improve == 0 kernel stay what they are)
+template <int NP, bool WALK, bool WIDE>
+__device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int t, const double* __restrict__ rec_in,
+                                                     double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using L = NormLayout<NP>;
     constexpr int CT = NORM_CT, RW = L::RW, HW = L::HW, PARKW = L::PARKW;
@@ -272,7 +314,9 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
     uint32_t kmeta = 0u;   // lean walk: src | stamp << 16 of the chain's slot (the partner is looked up while the record is on its way)
     if constexpr (WALK) {
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
-        const bool lean = P.lv_pairs_p && exchange_walk_lean(P, t - 1, (unsigned char*)smem, tid, tile);
+        bool lean;
+        if constexpr (WIDE) lean = exchange_walk_lean_wide(P, t - 1, (unsigned char*)smem, tid, tile);
+        else lean = P.lv_pairs_p && exchange_walk_lean(P, t - 1, (unsigned char*)smem, tid, tile);
         if (!lean) {
             exchange_walk_fast<NORM_WG, false>(P, t - 1, (unsigned char*)smem, tid, tile);
             if (valid) {
@@ -280,7 +324,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
                 xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
             }
         } else if (valid) {
-            kmeta = ((const uint2*)smem)[gc].y;
+            kmeta = WIDE ? ((const uint4*)smem)[gc].z : ((const uint2*)smem)[gc].y;
             xr = (unsigned long long)(kmeta & 0xffffu);
         }
     }
@@ -330,7 +374,9 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
 #pragma unroll
                 for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc[2 * i] = q.x; rc[2 * i + 1] = q.y; }
                 if (WALK && (kmeta >> 16))   // set_exchanged!, :747-748: from the pair word the swap stamped into the slot
-                    partner = (int)lean_partner<0>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc);
+                    partner = !WIDE ? (int)lean_partner<0>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc)
+                              : P.lean_unit == 16 ? (int)lean_partner<0, 4>((const unsigned char*)smem, 16u * ((uint32_t)((P.Ng + 3) & ~3) + 1u), kmeta, (uint32_t)gc)
+                                                  : (int)lean_partner<1, 4>((const unsigned char*)smem, 16u * ((uint32_t)((P.Ng + 3) & ~3) + 1u), kmeta, (uint32_t)gc);
             } else {
 #pragma unroll
                 for (int f = 0; f < RW; ++f) rc[f] = 0.0;
@@ -462,6 +508,16 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P,
     if (P.ts && tid2 == 0) P.ts[(size_t)tile * 8 + 3] = wall_clock64();
     // Epilogue by the control wave: everything it needs comes from LDS (parked by the prologue)
     epilogue_norm<NP>(P, t, rec_out, s_theta, s_part, s_park, tile, tid2);
+}
+template <int NP, bool WALK>
+__global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                 double* __restrict__ rec_out, const int flags) {
+    chain_iter_norm_body<NP, WALK, false>(P, t, rec_in, rec_out, flags);
+}
+template <int NP>
+__global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_wide(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                      double* __restrict__ rec_out, const int flags) {
+    chain_iter_norm_body<NP, true, true>(P, t, rec_in, rec_out, flags);
 }
 
 // objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks

@@ -285,8 +285,8 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl_soa(const KParams P, c
     resolve_lvl_soa_body<LWG>(P, t, gathered, xsm);
 }
 
-// k_exch_resolve_lean: the lean walk of smm_walk_lean.hpp as a kernel of its own (one workgroup): min_improve == 0 for every
-// chain, N_global <= 8192 — the sharded path at 1 and 2 GPUs x 4096 chains, single shards whose chain kernel does not walk
+// k_exch_resolve_lean: the lean walk of smm_walk_lean.hpp as a kernel of its own (one workgroup): one min_improve >= 0 for every
+// chain, N_global <= 8192 (~7400 when it is not 0: 16-byte slots) — the sharded path at 1 and 2 GPUs x 4096 chains, single shards whose chain kernel does not walk
 // inline (8192 chains; objectives other than objfunc_norm).  Same result as k_exch_resolve_lvl_soa, which it falls back to
 // (as a function, in the same launch) when this iteration's plan has more than 31 levels or a chain value is NaN.
 __global__ __launch_bounds__(XWG) void k_exch_resolve_lean(const KParams P, const int t, const double* __restrict__ gathered) {
@@ -315,6 +315,41 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lean(const KParams P, cons
     for (int r = 0; r < PR; ++r) {
         const int q4 = tid + r * XWG;
         p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (P.lean_wide) {   // one min_improve > 0 (or NaN): 16-byte slots of values (smm_walk_lean.hpp)
+        const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
+        if (__builtin_amdgcn_readlane((int)ov, 34) == 0 || (uint32_t)(size_t)xsm != 0u) { resolve_lvl_soa_body<XWG>(P, t, gathered, xsm); return; }
+        const uint32_t pbw = 16u * (Ng4 + 1u);
+        uint4* slot = (uint4*)xsm;
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int g = tid + r * XWG;
+            if (g < Ng) slot[g] = make_uint4((uint32_t)__double2loint(v_[r]), (uint32_t)__double2hiint(v_[r]), (uint32_t)g, 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            const int q4 = tid + r * XWG;
+            if (4 * q4 < P.plan_Kp) ((uint4*)(xsm + pbw))[q4] = p_[r];
+        }
+        if (tid == 0) slot[Ng4] = make_uint4(0u, 0u, 0u, 0u);   // the dummy pair's slot: 0 - 0 > min_improve is false
+        const int ltail = lean_walk_tail(ov, nlev, lane);
+        __syncthreads();
+        XTS(1);
+        if (P.lean_unit == 16) lean_walk_levels<XWG, 0, true>(nullptr, 0, pbw, ov, nlev, tid, ltail, P.mi_value);
+        else lean_walk_levels<XWG, 1, true>(nullptr, 0, pbw, ov, nlev, tid, ltail, P.mi_value);
+        __syncthreads();
+        XTS(2);
+#pragma unroll
+        for (int r = 0; r < PT; ++r) {
+            const int g = tid + r * XWG;
+            if (g < Ng) {
+                const uint32_t meta = slot[g].z;
+                const uint32_t partner = P.lean_unit == 16 ? lean_partner<0, 4>(xsm, pbw, meta, (uint32_t)g) : lean_partner<1, 4>(xsm, pbw, meta, (uint32_t)g);
+                P.xres[g] = (unsigned long long)(meta & 0xffffu) | ((unsigned long long)partner << 32);
+            }
+        }
+        XTS(4);
+        return;
     }
     uint32_t* s_nan = (uint32_t*)(xsm + 8u * (Ng4 + 2u));   // (a spare slot behind the dummy pair's)
     if (tid == 0) *s_nan = 0u;

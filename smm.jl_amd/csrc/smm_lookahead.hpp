@@ -259,7 +259,8 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
     const uint32_t sc8 = (uint32_t)P.lean_unit;   // a word holds 8 i (byte offsets of the 8-byte slots) or, for more than 8190 chains, 4 i
     if (lean) {
         const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
-        const uint32_t dummy = (sc8 * Ng4) | ((sc8 * (Ng4 + 1u)) << 16);   // two slots behind the chains' whose keys say "no swap"
+        // two slots behind the chains' whose keys say "no swap"; wide form: one slot, value 0, as both sides
+        const uint32_t dummy = P.lean_wide ? (sc8 * Ng4) * 0x10001u : (sc8 * Ng4) | ((sc8 * (Ng4 + 1u)) << 16);
         for (uint32_t q = tid; q < s_pst[nlev + 1]; q += XWG) o_pp[q] = dummy;
     }
     __syncthreads();

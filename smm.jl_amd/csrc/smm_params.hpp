@@ -66,6 +66,7 @@ struct KParams {
     const uint32_t* lv_offp;         // [W][LV_OFFP]: entry l = first word of level l (entry nlev: the padded length); [33] = nlev;
                                      //          [34] = 1 when the plan fits this form (at most 31 levels)
     int plan_Kp, lean_unit;          // words per iteration in lv_pairs_p; 8, or 4 when 8 * N_global does not fit 16 bits (smm_walk_lean.hpp)
+    int lean_wide;                   // the lean walk's form for one min_improve > 0 (or NaN) shared by all chains: 16-byte slots, lean_unit 16 or 8
     // ... and for k_exch_resolve_rows (8192 < N_global <= 32768, min_improve == 0; null otherwise):
     const uint32_t* lv_rows;         // [W][rows_cap][1024]: level by level, every level padded to whole rows of 1024 words with dummy pairs; pi | pj << 16
     const uint32_t* lv_rowinfo;      // [W][4]: rows; bit r of words 1 (low) and 2 (high): row r is the last of its level; 1 when the plan fits the form

@@ -1,6 +1,6 @@
-// the lean exchange walk (exchangeMoves!, AlgoBGP.jl:647-716, for min_improve == 0): shared by k_chain_iter_norm (in its
-// prologue, N_global <= 4096) and k_exch_resolve_lean (stand-alone, N_global <= 8192) — part of libsmmhip (included by
-// smmhip.hip inside its anonymous namespace; gfx950 device code).
+// the lean exchange walk (exchangeMoves!, AlgoBGP.jl:647-716, for one min_improve >= 0 shared by all chains): shared by
+// k_chain_iter_norm (in its prologue, N_global <= 4096) and k_exch_resolve_lean (stand-alone, N_global <= 8192) — part of
+// libsmmhip (included by smmhip.hip inside its anonymous namespace; gfx950 device code).
 #pragma once
 // ------------------------------------------------------------------------------------------
 // The level walk written for the number of INSTRUCTIONS per level.
@@ -20,10 +20,18 @@
 //   * the lane's next pair word is requested together with the slots: one LDS round trip per level.
 // LDS: slots uint2[Ng4 + 4] (Ng4 = N_global rounded up to 4; the two slots behind the chains' are the dummy pair's) | pair
 // words u32[plan_Kp].  The slots must start at LDS address 0 (the callers check).
+// min_improve > 0 (the reference's default is 0.5, AlgoBGP.jl:522) — the WIDE form: a key cannot decide `v_i - v_j > m`, so a
+// slot is 16 bytes {value, src | stamp << 16, -} and the test is the subtraction and the compare themselves (NaN values and a
+// NaN threshold need nothing special: the compare is false).  The dummy pair is (d, d) with d one slot behind the chains',
+// value 0: `0 - 0 > m` is false for m >= 0 or NaN (a chain's own slot would not do: another wave's swap could change it between
+// the two reads).  LDS: slots uint4[Ng4 + 1] | pair words u32[plan_Kp]; up to ~7400 chains fit the 160 KB.
 // ------------------------------------------------------------------------------------------
 __host__ __device__ inline int lean_walk_Kp(int K) { return (K + 64 * LV_MAXLEV + 3) & ~3; }
 __host__ __device__ inline size_t lean_walk_bytes(int Ng, int K) { return (size_t)(((Ng + 3) & ~3) + 4) * 8 + (size_t)lean_walk_Kp(K) * 4; }
 __host__ __device__ inline int lean_walk_unit(int Ng) { return 8 * (((Ng + 3) & ~3) + 2) <= 65536 ? 8 : 4; }   // KParams::lean_unit
+__host__ __device__ inline size_t lean_wide_bytes(int Ng, int K) { return (size_t)(((Ng + 3) & ~3) + 1) * 16 + (size_t)lean_walk_Kp(K) * 4; }
+__host__ __device__ inline int lean_wide_unit(int Ng) { return 16 * (((Ng + 3) & ~3) + 1) <= 65536 ? 16 : 8; }    // KParams::lean_unit, wide form (8: up to 8188 chains)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 // LDS byte offsets of the two slots of a pair word (US = 1: the word holds them halved, KParams::lean_unit == 4)
@@ -33,20 +41,31 @@ __device__ inline void lean_decode(const uint32_t pw, uint32_t& ai, uint32_t& aj
     else { ai = (pw & 0xffffu) << US; aj = (pw >> 16) << US; }
 }
 // 1 + the chain's last exchange partner (0: none) from its slot's second word after the walk
-template <int US>
+// (SL: log2 of the slot size, 3 or 4 for the wide form)
+template <int US, int SL = 3>
 __device__ inline uint32_t lean_partner(const unsigned char* lds, const uint32_t pbase, const uint32_t meta, const uint32_t g) {
     const uint32_t stamp = meta >> 16;
     if (stamp == 0u) return 0u;
     const uint32_t pw = *(const uint32_t*)(lds + pbase + 4u * (stamp - 1u));
-    const uint32_t i = (pw & 0xffffu) >> (3 - US), j = (pw >> 16) >> (3 - US);
+    const uint32_t i = (pw & 0xffffu) >> (SL - US), j = (pw >> 16) >> (SL - US);
     return (i == g ? j : i) + 1u;
 }
 
 // one pair, on its own (further words of a level wider than the workgroup)
-template <int US>
-__device__ inline void lean_pair(const double* __restrict__ vsrc, const int vstride, const uint32_t pw, const uint32_t stamp) {
+template <int US, bool WIDE = false>
+__device__ inline void lean_pair(const double* __restrict__ vsrc, const int vstride, const uint32_t pw, const uint32_t stamp, const double thr = 0.0) {
     uint32_t ai, aj;
     lean_decode<US>(pw, ai, aj);
+    if constexpr (WIDE) {
+        u32x4_t si, sj;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
+        const double vi = __hiloint2double((int)si.y, (int)si.x), vj = __hiloint2double((int)sj.y, (int)sj.x);
+        if (vi - vj > thr) {   // dist_fun = -, AlgoBGP.jl:688
+            const u32x4_t ni = {sj.x, sj.y, (sj.z & 0xffffu) | stamp, 0u}, nj = {si.x, si.y, (si.z & 0xffffu) | stamp, 0u};
+            asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
+        }
+        return;
+    }
     u32x2_t si, sj;
     asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
     bool swap = si.x > sj.x;
@@ -65,9 +84,9 @@ __device__ inline int lean_walk_tail(const uint32_t ov, const int nlev, const in
     const unsigned long long wide = __ballot(lane < nlev && nx - ov > 64u);
     return wide ? 64 - __builtin_clzll(wide) : 0;
 }
-template <int NT, int US>
+template <int NT, int US, bool WIDE = false>
 __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const int vstride, const uint32_t pbase, const uint32_t ov,
-                                        const int nlev, const int tid, const int ltail) {
+                                        const int nlev, const int tid, const int ltail, const double thr = 0.0) {
     const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63);   // this wave's first word within a trip
     const uint32_t tid4p = pbase + 4u * (uint32_t)tid;
     const uint32_t tidst = ((uint32_t)tid + 1u) << 16;                           // this lane's stamp at position 0
@@ -85,25 +104,36 @@ __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const i
             asm volatile("v_add_u32 %0, %1, %2" : "=v"(stamp) : "s"(st << 16), "v"(tidst));
             uint32_t ai, aj;
             lean_decode<US>(pw, ai, aj);
-            u32x2_t si, sj;
             uint32_t pwn;
-            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(si), "=&v"(sj), "=&v"(pwn) : "v"(ai), "v"(aj), "v"(nptr) : "memory");
-            bool swap = si.x > sj.x;
-            const bool tie = si.x == sj.x;
-            if (__builtin_expect(__ballot(tie) != 0ull, 0)) {   // the keys do not decide: the exact values (dist_fun = -, AlgoBGP.jl:688)
-                if (tie) swap = vsrc[(size_t)(si.y & 0xffffu) * vstride] - vsrc[(size_t)(sj.y & 0xffffu) * vstride] > 0.0;
-            }
-            if (swap) {   // swap_ev_ij!, :739-744; the stamp stands for set_exchanged!, :747-748
-                const u32x2_t ni = {sj.x, (sj.y & 0xffffu) | stamp}, nj = {si.x, (si.y & 0xffffu) | stamp};
-                asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
+            if constexpr (WIDE) {
+                u32x4_t si, sj;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(si), "=&v"(sj), "=&v"(pwn) : "v"(ai), "v"(aj), "v"(nptr) : "memory");
+                const double vi = __hiloint2double((int)si.y, (int)si.x), vj = __hiloint2double((int)sj.y, (int)sj.x);
+                if (vi - vj > thr) {   // dist_fun = -, AlgoBGP.jl:688; swap_ev_ij!, :739-744; the stamp stands for set_exchanged!, :747-748
+                    const u32x4_t ni = {sj.x, sj.y, (sj.z & 0xffffu) | stamp, 0u}, nj = {si.x, si.y, (si.z & 0xffffu) | stamp, 0u};
+                    asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
+                }
+            } else {
+                u32x2_t si, sj;
+                asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(si), "=&v"(sj), "=&v"(pwn) : "v"(ai), "v"(aj), "v"(nptr) : "memory");
+                bool swap = si.x > sj.x;
+                const bool tie = si.x == sj.x;
+                if (__builtin_expect(__ballot(tie) != 0ull, 0)) {   // the keys do not decide: the exact values (dist_fun = -, AlgoBGP.jl:688)
+                    if (tie) swap = vsrc[(size_t)(si.y & 0xffffu) * vstride] - vsrc[(size_t)(sj.y & 0xffffu) * vstride] > 0.0;
+                }
+                if (swap) {   // swap_ev_ij!, :739-744; the stamp stands for set_exchanged!, :747-748
+                    const u32x2_t ni = {sj.x, (sj.y & 0xffffu) | stamp}, nj = {si.x, (si.y & 0xffffu) | stamp};
+                    asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
+                }
             }
             pw = pwn;
             if (__builtin_expect(width > (uint32_t)NT, 0)) {   // a level wider than the workgroup: its further words, one by one
                 for (uint32_t o = (uint32_t)NT; wbase + o < width; o += (uint32_t)NT) {
                     uint32_t pwx;
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pwx) : "v"(tid4p + 4u * (st + o)) : "memory");
-                    lean_pair<US>(vsrc, vstride, pwx, ((st + o) << 16) + tidst);
+                    lean_pair<US, WIDE>(vsrc, vstride, pwx, ((st + o) << 16) + tidst, thr);
                 }
             }
         } else if (wbase < st2 - st1) {   // idle in this level, not in the next: its word

@@ -172,7 +172,7 @@ struct Ctx {
     int32_t *a2a_send_idx = nullptr, *a2a_send_cnt = nullptr, *a2a_rowidx = nullptr;   // the values form of the sharded exchange
     int a2a_cap = 0, a2a_G = 0;
     bool a2a_open = false;
-    bool lean_resolve = false;   // min_improve == 0, N_global <= 8192: k_exch_resolve_lean is the stand-alone resolve kernel
+    bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
     bool lvl_soa_exchange = false;   // XLVL_MAX < N_global <= XLDS_MAX: level walk on split chain slots
@@ -309,8 +309,28 @@ void launch_chain_iter_norm_t(Ctx* c, int t, int flags) {
     else
         hipLaunchKernelGGL((k_chain_iter_norm<NP, WALK>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
 }
+template <int NP>
+void launch_chain_iter_norm_wide_t(Ctx* c, int t, int flags) {
+    const KParams& P = c->P;
+    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
+    const double* rin = c->ext_rec_in ? c->ext_rec_in : (const double*)c->rec[c->cur];
+    double* rout = c->ext_rec_out ? c->ext_rec_out : c->rec[c->cur ^ 1];
+    if (c->kev0)
+        hipExtLaunchKernelGGL((k_chain_iter_norm_wide<NP>), grid, block, norm_smem(c), c->stream, c->kev0, c->kev1, 0, P, t, rin, rout, flags);
+    else
+        hipLaunchKernelGGL((k_chain_iter_norm_wide<NP>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
+}
 void launch_chain_iter_norm(Ctx* c, int t, int flags) {
     const bool walk = (flags & F_WALK_INLINE) != 0;
+    if (walk && c->P.lean_wide && c->P.lv_pairs_p) {   // one min_improve > 0 for all chains: the walk on 16-byte slots
+        switch (c->P.np) {
+            case 1: launch_chain_iter_norm_wide_t<1>(c, t, flags); break;
+            case 2: launch_chain_iter_norm_wide_t<2>(c, t, flags); break;
+            case 3: launch_chain_iter_norm_wide_t<3>(c, t, flags); break;
+            default: launch_chain_iter_norm_wide_t<4>(c, t, flags); break;
+        }
+        return;
+    }
     switch (c->P.np * 2 + (walk ? 1 : 0)) {
         case 2: launch_chain_iter_norm_t<1, false>(c, t, flags); break;
         case 3: launch_chain_iter_norm_t<1, true>(c, t, flags); break;
@@ -365,7 +385,7 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
     if (!c->ext_rec_out) c->cur ^= 1;
 }
 
-size_t resolve_lean_bytes(int Ng, int K) { return std::max(lean_walk_bytes(Ng, K), resolve_lvl_soa_bytes(Ng, K)); }
+size_t resolve_lean_bytes(int Ng, int K, bool wide) { return std::max(wide ? lean_wide_bytes(Ng, K) : lean_walk_bytes(Ng, K), resolve_lvl_soa_bytes(Ng, K)); }
 
 void launch_resolve_p(Ctx* c, const KParams& P, int t, const double* gathered);
 void launch_resolve(Ctx* c, int t, const double* gathered) { launch_resolve_p(c, c->P, t, gathered); }
@@ -373,10 +393,10 @@ void launch_resolve(Ctx* c, int t, const double* gathered) { launch_resolve_p(c,
 void launch_resolve_p(Ctx* c, const KParams& P, int t, const double* gathered) {
     if (c->lean_resolve)
         if (c->kev0)
-            hipExtLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K), c->stream, c->kev0, c->kev1, 0, P, t,
+            hipExtLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K, P.lean_wide != 0), c->stream, c->kev0, c->kev1, 0, P, t,
                                   gathered);
         else
-            hipLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+            hipLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K, P.lean_wide != 0), c->stream, P, t, gathered);
     else if (c->lvl_exchange)
         if (c->lvl_wg == 256)
             hipLaunchKernelGGL(k_exch_resolve_lvl<256>, dim3(1), dim3(256), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
@@ -732,7 +752,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* nf = getenv("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
             c->norm_fast = is_sim(c->obj) && np == nm && np <= 4 && opts->batch_size == np && P.dbg == 0 && !opts->chol_L && !(nf && nf[0] == '0');
             // k_chain_iter_norm: pair list NOT overlaid; room for either walk (16-byte slots, 4-byte slots + value table)
-            const size_t walk_b = std::max(walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15), (lean_walk_bytes(Ng, K) + 15) & ~(size_t)15);
+            const size_t walk_b = std::max(walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15),
+                                           (std::max(lean_walk_bytes(Ng, K), lean_wide_bytes(Ng, K)) + 15) & ~(size_t)15);
             c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng && c->obj != SMM_OBJ_USER &&
                              (c->norm_fast ? walk_b + norm_tile_doubles(np) * 8 <= (size_t)160 * 1024
                                            : walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024);
@@ -775,15 +796,19 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->win_cap * K);
                 c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
                 c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
-                // the lean walk (smm_walk_lean.hpp): min_improve == 0 for every chain
+                // the lean walk (smm_walk_lean.hpp): one min_improve for every chain — 0: 8-byte slots of order keys; > 0 (or NaN:
+                // nothing ever swaps): 16-byte slots of values, as far as the 160 KB of LDS reach (~7400 chains)
                 const char* kw = getenv("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walks on 16-byte / split slots
-                if (P.mi_uniform && P.mi_value == 0.0 && K <= XLDS_MAX && !(kw && kw[0] == '0')) {
+                const bool keys = P.mi_uniform && P.mi_value == 0.0;
+                const bool wide = P.mi_uniform && !keys && !(P.mi_value < 0.0) && resolve_lean_bytes(Ng, K, true) <= (size_t)160 * 1024;
+                if ((keys || wide) && K <= XLDS_MAX && !(kw && kw[0] == '0')) {
+                    P.lean_wide = wide ? 1 : 0;
                     P.plan_Kp = lean_walk_Kp(K);
-                    P.lean_unit = lean_walk_unit(Ng);
+                    P.lean_unit = wide ? lean_wide_unit(Ng) : lean_walk_unit(Ng);
                     c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->win_cap * P.plan_Kp);
                     c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->win_cap * LV_OFFP);
                     c->lean_resolve = true;
-                    if (c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) {   // ... in the prologue of k_chain_iter_norm
+                    if (keys && c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) {   // ... in the prologue of k_chain_iter_norm
                         P.slot8 = dalloc<uint2>(c, (size_t)N + 4);
                         P.walk_flags = dalloc<uint32_t>(c, 4);
                         HIPCHK(hipMemset(P.walk_flags, 0, 16));
@@ -860,7 +885,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lean, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)resolve_lean_bytes(XLDS_MAX, XLDS_MAX)));
+                                       160 * 1024));
         }
         {   // tiles of problems with many parameters need more than the default 64 KiB of dynamic LDS
             const int lim = 160 * 1024;
@@ -877,6 +902,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));

@@ -945,6 +945,69 @@ def test_key_walk_special_values(S, O, monkeypatch, nan):
     cm.assert_state_equal(runs[0].state(), o.state())
 
 
+@pytest.mark.parametrize("N,npar,mi,failbox", [(4096, 2, 0.05, False), (1000, 2, 0.5, True), (333, 1, 1e-3, False), (17, 2, 0.05, True),
+                                               (64, 2, np.inf, False), (64, 2, np.nan, False), (5, 3, 0.01, False), (2, 2, 0.0005, False)])
+def test_wide_walk_equals_slot_walk(S, O, monkeypatch, N, npar, mi, failbox):
+    # one min_improve > 0 for all chains (the reference's default is 0.5, AlgoBGP.jl:522; Examples.jl:90 uses 0.05): the lean
+    # walk on 16-byte slots {value, src | stamp} (k_chain_iter_norm_wide) against the same run on the older walk
+    # (SMMHIP_KEY_WALK=0) and, for the small ones, the oracle.  Inf / NaN thresholds: nothing ever swaps.
+    T = 40
+    kw = dict(objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[0.4, 1.2], sigma0=0.3) if failbox else {}
+    if npar == 2:
+        prob, opts = cm.serial_normal(N=N, T=T, ns=300, min_improve=mi, **kw)
+    else:
+        prob, opts = cm.general_normal(npar, N=N, T=T, ns=300)
+        opts.min_improve[:] = mi
+    a = S.hip_context(prob, opts)
+    a.step(T)
+    monkeypatch.setenv("SMMHIP_KEY_WALK", "0")
+    b = S.hip_context(prob, opts)
+    b.step(T)
+    monkeypatch.delenv("SMMHIP_KEY_WALK")
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+    cm.assert_state_equal(a.state(), b.state(), rtol=0)
+    hh = a.history()
+    if np.isfinite(mi):
+        assert (hh.exchanged != 0).any()
+    else:
+        assert not (hh.exchanged != 0).any()
+    if failbox:
+        assert (hh.status == -2).any()
+    if N <= 1000:
+        o = O.OracleContext(prob, opts, S.Tables(Z=a.Z()), threads=_all_cores(O))
+        o.step(T)
+        cm.assert_history_equal(hh, o.history())
+        cm.assert_state_equal(a.state(), o.state())
+
+
+@pytest.mark.parametrize("Ng,G", [(6000, 1), (7400, 2), (8192, 2)])
+def test_wide_walk_standalone_and_sharded(S, O, monkeypatch, Ng, G):
+    # the same form as the kernel of its own (k_exch_resolve_lean): single shards too large for the inline walk, and shards of
+    # a sharded run (the walk reads the gathered records); 8192 chains do not fit the LDS on 16-byte slots and keep the older
+    # kernel — all against the run with SMMHIP_KEY_WALK=0
+    T = 12
+    prob, opts = cm.serial_normal(N=Ng, T=T, ns=64, min_improve=0.02)
+    if G == 1:
+        a = S.hip_context(prob, opts); a.step(T)
+        monkeypatch.setenv("SMMHIP_KEY_WALK", "0")
+        b = S.hip_context(prob, opts); b.step(T)
+        monkeypatch.delenv("SMMHIP_KEY_WALK")
+        cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+        cm.assert_state_equal(a.state(), b.state(), rtol=0)
+        assert (a.history().exchanged != 0).any()
+    else:
+        single = S.hip_context(prob, opts); single.step(T)
+        ctxs = sharded_run(S, prob, opts, G, T)
+        hs = single.history()
+        n = Ng // G
+        for r, c in enumerate(ctxs):
+            hr = c.history()
+            for f in cm.INT_FIELDS:
+                np.testing.assert_array_equal(getattr(hr, f), getattr(hs, f)[..., r * n:(r + 1) * n], err_msg=f)
+            np.testing.assert_array_equal(hr.value, hs.value[:, r * n:(r + 1) * n])
+        assert (hs.exchanged != 0).any()
+
+
 def _slice_state(st, lo, hi):
     """the chains lo..hi of a state (every per-chain array has the chain as its last axis)"""
     import copy

@@ -3,7 +3,7 @@ import numpy as np
 os.environ.setdefault("SMMHIP_TS", "1")   # "2": also a stamp per level of the inline walk (stretches the levels)
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import smm_jl_amd as S, common as cm
-prob, opts = cm.serial_normal(N=4096, T=700)
+prob, opts = cm.serial_normal(N=4096, T=700, min_improve=float(os.environ.get("TS_MIN_IMPROVE", "0")))
 ctx = S.hip_context(prob, opts)
 ctx.step(150)
 lib = S._abi.load()
