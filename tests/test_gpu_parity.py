@@ -695,7 +695,7 @@ def test_c5_dense_4096_chains(S, O):
 @pytest.mark.parametrize("kind,npar,N,sig,smpl,bs", [("dense", 50, 100, 0.08, 100000, None), ("dense", 50, 37, 0.12, 100000, 25),
                                                       ("dense", 50, 16, 0.3, 40, None), ("norm", 18, 70, 0.12, 100000, None),
                                                       ("norm", 32, 9, 0.15, 100000, 16), ("dense", 64, 33, 0.06, 100000, None)])
-def test_many_parameters_many_tries(S, O, kind, npar, N, sig, smpl, bs):
+def test_many_parameters_many_tries(S, O, monkeypatch, kind, npar, N, sig, smpl, bs):
     # proposals of 16 and more components whose tries run far past the pre-generated ones (sigma so wide that a try
     # seldom lands inside the box): the tile's lane segments share the open chains' further tries; same tries, same
     # order, same winner as the serial loop (mysample, AlgoBGP.jl:400-410) -- and the same hard error when smpl_iters
@@ -708,6 +708,8 @@ def test_many_parameters_many_tries(S, O, kind, npar, N, sig, smpl, bs):
     opts.smpl_iters = smpl
     if bs:
         opts.batch_size = bs
+    if kind == "norm" and npar == 18:
+        monkeypatch.setenv("SMMHIP_TPW", "2")   # two tiles per workgroup: the rounds of shared tries are workgroup-wide
     h, o = make_pair(S, O, prob, opts)
     eh = eo = None
     try:

@@ -22,3 +22,8 @@ print("tiles: %d; first start .. last end: %.2f us" % (nwg, ts[:, 4].max() - t0)
 print("start of a tile after the first: mean %.2f max %.2f us" % ((ts[:, 0] - t0).mean(), (ts[:, 0] - t0).max()))
 for i, n in enumerate(names):
     print("%-28s mean %7.2f  min %7.2f  max %7.2f us" % (n, dd[:, i].mean(), dd[:, i].min(), dd[:, i].max()))
+tot = ts[:, 4] - ts[:, 0]
+worst = np.argsort(tot)[-6:][::-1]
+print("whole tile: mean %.2f  p50 %.2f  p90 %.2f  max %.2f us" % (tot.mean(), *np.percentile(tot, [50, 90]), tot.max()))
+for wg in worst:
+    print("  tile %4d: %6.2f us = " % (wg, tot[wg]) + "  ".join("%.2f" % x for x in dd[wg]))
