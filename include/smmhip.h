@@ -115,6 +115,14 @@ typedef struct {
     int32_t reserved;
 } smm_problem_t;
 
+/* opts["dist_fun"] (AlgoBGP.jl:494,537): the reference takes any Julia function of two objective values; the device offers a
+ * menu.  value_i belongs to the colder chain i < j of the pair; the pair swaps when the distance exceeds min_improve_i. */
+typedef enum {
+    SMM_DIST_MINUS   = 0,    /* value_i - value_j            (the default `-`: j is better by more than min_improve_i)      */
+    SMM_DIST_ABSDIFF = 1,    /* |value_i - value_j|          (swap whenever the two differ by more than min_improve_i)      */
+    SMM_DIST_RELDIFF = 2     /* (value_i - value_j)/|value_i| (j is better by more than the fraction min_improve_i)         */
+} smm_dist_fun_t;
+
 /* opts Dict of MAlgoBGP (AlgoBGP.jl:505-537) flattened; per-chain vectors are
  * supplied already expanded (sigma[i] = opts["sigma"]*temps[i], AlgoBGP.jl:508,518) and
  * GLOBAL (length N_global); the context uses entries [chain_offset, chain_offset+N). */
@@ -143,6 +151,9 @@ typedef struct {
                                 is the per-parameter sigma vector hinted at AlgoBGP.jl:218.  Requires one proposal batch
                                 (batch_size == np).  Numerical contract: (L z)_k = sum_{j<=k} L[k][j]*z[j], products
                                 rounded, added left to right (no fma). */
+    int32_t dist_fun;        /* smm_dist_fun_t: opts["dist_fun"], AlgoBGP.jl:537 — the exchange test of pair (i, j) is
+                                dist_fun(value_i, value_j) > min_improve_i (:688).  0 = the reference's default `-`.           */
+    int32_t reserved;
 } smm_bgp_opts_t;
 
 /* Injected randomness ("parity mode").  Any pointer may be NULL = use the built-in

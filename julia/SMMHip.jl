@@ -65,6 +65,8 @@ struct SmmBgpOpts
     device::Cint
     chol_per_chain::Cint
     chol_L::Ptr{Cdouble}
+    dist_fun::Cint
+    reserved::Cint
 end
 
 struct SmmTables
@@ -121,6 +123,10 @@ const OBJ_BANANA = Cint(1)
 const OBJ_NORM_FAILBOX = Cint(2)
 const OBJ_DENSE = Cint(3)
 const OBJ_USER_BASE = Cint(1000)
+# smm_dist_fun_t (opts["dist_fun"], AlgoBGP.jl:537)
+const DIST_MINUS = Cint(0)
+const DIST_ABSDIFF = Cint(1)
+const DIST_RELDIFF = Cint(2)
 
 struct SMMHipError <: Exception
     code::Int
@@ -168,7 +174,7 @@ function hip_create(init::Vector{Float64}, lb::Vector{Float64}, ub::Vector{Float
                     obj_params::Vector{Float64} = Float64[], N::Integer = length(sigma), N_global::Integer = length(sigma),
                     chain_offset::Integer = 0, sigma_update_steps::Integer = 10, sigma_adjust_by::Real = 0.01,
                     smpl_iters::Integer = 1000, batch_size::Integer = length(init), seed::Integer = 12, device::Integer = 0,
-                    chol_L::Union{Nothing,Array{Float64}} = nothing)
+                    chol_L::Union{Nothing,Array{Float64}} = nothing, dist_fun::Integer = DIST_MINUS)
     np, nm = length(init), length(mom)
     length(lb) == np && length(ub) == np || throw(ArgumentError("lb / ub need one entry per parameter"))
     length(w) == nm || throw(ArgumentError("w needs one entry per moment"))
@@ -194,7 +200,7 @@ function hip_create(init::Vector{Float64}, lb::Vector{Float64}, ub::Vector{Float
                        isempty(obj_params) ? Ptr{Cdouble}(C_NULL) : pointer(obj_params), length(obj_params), 0)
         o = SmmBgpOpts(N, maxiter, pointer(sigma), pointer(acc_tuner), pointer(min_improve), sigma_update_steps, smpl_iters,
                        Float64(sigma_adjust_by), batch_size, 2, UInt64(seed), chain_offset, N_global, device, per_chain,
-                       isempty(Lrow) ? Ptr{Cdouble}(C_NULL) : pointer(Lrow))
+                       isempty(Lrow) ? Ptr{Cdouble}(C_NULL) : pointer(Lrow), dist_fun, 0)
         rc = ccall(sym(:smm_ctx_create), Cint, (Ref{SmmProblem}, Ref{SmmBgpOpts}, Ptr{SmmTables}, Ref{Ptr{Cvoid}}),
                    p, o, C_NULL, ctx)
         rc == 0 || throw(SMMHipError(Int(rc), last_error(Ptr{Cvoid}(C_NULL))))

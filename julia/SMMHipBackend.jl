@@ -46,7 +46,7 @@ mutable struct MAlgoBGPHip <: MAlgo
     i::Int                        # :500  iteration (set by run!, AlgoAbstract.jl:42)
     chains::Vector{BGPChain}      # :501  real SMM.BGPChain objects, refreshed from the device on access
     anim::Any                     # :502  (plots of the proposal cloud are not produced by the device path)
-    dist_fun::Function            # :503  only `-` runs on the device (:537)
+    dist_fun::Function            # :503  `-` (:537) or the function of the menu entry chosen (device_dist_fun)
     hip::SMMHip.HipBGP            # the device context
     synced::Int                   # iterations already materialised in `chains`
     pnames::Vector{Symbol}        # parameter order on the device = keys(m.params_to_sample)
@@ -93,8 +93,8 @@ function MAlgoBGPHip(m::MProb, opts::Dict)
     temps = N > 1 ? collect(range(1.0, stop = Float64(opts["maxtemp"]), length = N)) : [1.0]      # AlgoBGP.jl:508
     mi = chain_vector(opts, "min_improve", 0.5, N)                                                  # :522
     acc = chain_vector(opts, "acc_tuners", 2.0, N)                                                  # :523
-    dist_fun = get(opts, "dist_fun", -)
-    dist_fun === (-) || throw(ArgumentError("only the default dist_fun `-` (AlgoBGP.jl:537) runs on the device"))
+    dist_fun = get(opts, "dist_fun", -)                                                             # :537
+    dist_id = device_dist_fun(dist_fun)
     pnames = Symbol[Symbol(k) for k in keys(m.params_to_sample)]
     mnames = Symbol[Symbol(k) for k in keys(m.moments)]
     init = Float64[m.initial_value[k] for k in keys(m.params_to_sample)]
@@ -112,9 +112,21 @@ function MAlgoBGPHip(m::MProb, opts::Dict)
                             smpl_iters = Int(get(opts, "smpl_iters", 1000)),
                             batch_size = Int(get(opts, "batch_size", length(init))),
                             seed = Int(get(opts, "seed", 12)), device = Int(get(opts, "device", 0)),
-                            chol_L = get(opts, "chol_L", nothing))
-    return MAlgoBGPHip(m, opts, 0, reference_chains(m, opts, N, temps, mi, acc), nothing, -, hip, 0, pnames, mnames)
+                            chol_L = get(opts, "chol_L", nothing), dist_fun = dist_id)
+    return MAlgoBGPHip(m, opts, 0, reference_chains(m, opts, N, temps, mi, acc), nothing,
+                       dist_fun isa Function ? dist_fun : host_dist_fun(dist_id), hip, 0, pnames, mnames)
 end
+
+# opts["dist_fun"] (AlgoBGP.jl:494,537) -> smm_dist_fun_t.  The reference takes any function of two objective values; inside the
+# exchange kernels only the header's menu runs: `-` (the default), :absdiff (|a - b|), :reldiff ((a - b) / |a|).
+function device_dist_fun(f)
+    f === (-) && return SMMHip.DIST_MINUS
+    f in (:minus, "-", "minus") && return SMMHip.DIST_MINUS
+    f in (:absdiff, "absdiff") && return SMMHip.DIST_ABSDIFF
+    f in (:reldiff, "reldiff") && return SMMHip.DIST_RELDIFF
+    throw(ArgumentError("dist_fun: the device runs `-` (AlgoBGP.jl:537), :absdiff or :reldiff (smm_dist_fun_t), not an arbitrary function"))
+end
+host_dist_fun(id) = id == SMMHip.DIST_ABSDIFF ? ((a, b) -> abs(a - b)) : id == SMMHip.DIST_RELDIFF ? ((a, b) -> (a - b) / abs(a)) : (-)
 
 # ---- the one method SMM.jl dispatches on (AlgoAbstract.jl:45; README.md:105-107) -------------------------------
 """

@@ -75,7 +75,16 @@ typedef struct {
     uint64_t seed;
     int32_t chain_offset, N_global, device, chol_per_chain;
     const double* chol_L; /* general Gaussian proposals, include/smmhip.h: NULL = the reference's MvNormal(mu01, sigma) */
+    int32_t dist_fun, reserved;   /* smm_dist_fun_t (include/smmhip.h): opts["dist_fun"], AlgoBGP.jl:537 */
 } orc_opts_t;
+
+/* algo.dist_fun(evi.value, evj.value), AlgoBGP.jl:688: the default `-` (:537) and the header's two other menu entries */
+static double orc_dist_fun(int kind, double a, double b) {
+    const double d = a - b;
+    if (kind == 0) return d;
+    if (kind == 1) return fabs(d);
+    return d / fabs(a);
+}
 
 typedef struct {
     const double* probs_acc;
@@ -766,7 +775,7 @@ int orc_bgp_exchange(void* v, const double* gathered) {
     for (int g = 0; g < Ng; ++g) { val[g] = gathered[(size_t)g * RW]; src[g] = g; }
     for (int q = 0; q < K; ++q) {                      /* sequential, order dependent: :662-691 */
         int i = pairs[2 * q], j = pairs[2 * q + 1];
-        if (val[i] - val[j] > o->min_improve[i]) {     /* dist_fun = -, :688 */
+        if (orc_dist_fun(o->opts.dist_fun, val[i], val[j]) > o->min_improve[i]) {     /* :688 */
             double tv = val[i]; val[i] = val[j]; val[j] = tv;       /* swap_ev_ij! :739-744 */
             int32_t ts = src[i]; src[i] = src[j]; src[j] = ts;
             partner[i] = j + 1; partner[j] = i + 1;                  /* set_exchanged! :747-748 */
@@ -813,7 +822,7 @@ int orc_bgp_resolve_values(void* v, const double* vals_all, int32_t* src_out, in
     memcpy(val, vals_all, (size_t)Ng * sizeof(double));
     for (int q = 0; q < K; ++q) {
         int i = pairs[2 * q], j = pairs[2 * q + 1];
-        if (val[i] - val[j] > o->min_improve[i]) {
+        if (orc_dist_fun(o->opts.dist_fun, val[i], val[j]) > o->min_improve[i]) {
             double tv = val[i]; val[i] = val[j]; val[j] = tv;
             int32_t ts = src_out[i]; src_out[i] = src_out[j]; src_out[j] = ts;
             partner_out[i] = j + 1; partner_out[j] = i + 1;

@@ -33,6 +33,7 @@ SMM_OBJ_NORM = 0
 SMM_OBJ_BANANA = 1
 SMM_OBJ_NORM_FAILBOX = 2
 SMM_OBJ_DENSE = 3
+SMM_DIST_MINUS, SMM_DIST_ABSDIFF, SMM_DIST_RELDIFF = 0, 1, 2   # smm_dist_fun_t
 SMM_OBJ_USER_BASE = 1000   # objective ids >= this are handles of smm_register_user_objective
 SMM_DENSE_D = 256
 
@@ -58,6 +59,7 @@ class smm_bgp_opts_t(C.Structure):
         ("seed", C.c_uint64),
         ("chain_offset", C.c_int32), ("N_global", C.c_int32), ("device", C.c_int32), ("chol_per_chain", C.c_int32),
         ("chol_L", c_double_p),
+        ("dist_fun", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

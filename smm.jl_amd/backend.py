@@ -34,7 +34,7 @@ class BGPOpts:
 
     def __init__(self, N, maxiter, sigma, acc_tuner, min_improve, sigma_update_steps=10, sigma_adjust_by=0.01,
                  smpl_iters=1000, batch_size=None, exchange_from_iter=2, seed=12, chain_offset=0, N_global=None,
-                 device=0, chol_L=None):
+                 device=0, chol_L=None, dist_fun=0):
         self.N = int(N); self.maxiter = int(maxiter)
         self.N_global = int(N if N_global is None else N_global)
         self.sigma = A.f64(sigma, (self.N_global,)); self.acc_tuner = A.f64(acc_tuner, (self.N_global,))
@@ -45,6 +45,7 @@ class BGPOpts:
         self.chain_offset = int(chain_offset); self.device = int(device)
         # general Gaussian proposals: a lower-triangular factor [np][np] (shared) or [N_global][np][np] (per chain), see smmhip.h
         self.chol_L = None if chol_L is None else A.f64(chol_L)
+        self.dist_fun = int(dist_fun)   # smm_dist_fun_t: 0 `-` (AlgoBGP.jl:537), 1 |a - b|, 2 (a - b) / |a|
 
     def struct(self, np_):
         o = A.smm_bgp_opts_t()
@@ -57,6 +58,7 @@ class BGPOpts:
         o.seed = self.seed
         o.chain_offset, o.N_global, o.device = self.chain_offset, self.N_global, self.device
         o.chol_L = A.dptr(self.chol_L)
+        o.dist_fun = self.dist_fun
         o.chol_per_chain = 0 if self.chol_L is None or self.chol_L.ndim == 2 else 1
         if self.chol_L is not None:
             want = (np_, np_) if self.chol_L.ndim == 2 else (self.N_global, np_, np_)

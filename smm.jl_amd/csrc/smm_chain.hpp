@@ -488,53 +488,58 @@ __device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsign
     uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
     uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
     double m = mi_u ? mi_v : ((b + tid < e) ? g_mi[b + tid] : 0.0);
+    // (the loops twice: the default dist_fun `-` pays nothing for the menu)
+    auto levels = [&](auto gen) {
+        const int dk = decltype(gen)::value ? P.dist_fun : 0;
 #pragma clang loop unroll(disable)
-    for (int l = 0; l < ltail; ++l) {
-        const uint32_t e3 = level_end(l + 2);
-        // this thread's first pair of the next level is fetched while this level runs
-        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
-        const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
-        for (uint32_t pos = b + tid; pos < e; pos += NT) {
-            if (pos != b + tid) { pw = pairs[pos]; m = mi_u ? mi_v : g_mi[pos]; }
-            const uint32_t i = pw & 0xffffu, j = pw >> 16;
-            const XSlot si = slot[i], sj = slot[j];
-            if (si.val - sj.val > m) {                  // dist_fun = -, AlgoBGP.jl:688
-                XSlot ni, nj;                           // swap_ev_ij!, :739-744; set_exchanged!, :747-748
-                ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
-                nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
-                slot[i] = ni;
-                slot[j] = nj;
-            }
-        }
-        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
-        __syncthreads();
-    }
-    if (ltail < nlev) {
-        if (tid < 64) {   // (pw, m) already hold this lane's pair of level ltail, e its end, e2 the next end
-            constexpr uint32_t NOPAIR = 0xffffffffu;   // i == j == 0xffff never occurs (chain ids < XLVL_MAX)
-            uint32_t cpw = (b + tid < e) ? pw : NOPAIR;
-#pragma clang loop unroll(disable)
-            for (int l = ltail; l < nlev; ++l) {
-                const uint32_t e3 = level_end(l + 2);
-                const uint32_t npw = (e + tid < e2) ? pairs[e + tid] : NOPAIR;
-                const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
-                if (cpw != NOPAIR) {
-                    const uint32_t i = cpw & 0xffffu, j = cpw >> 16;
-                    const XSlot si = slot[i], sj = slot[j];
-                    if (si.val - sj.val > m) {
-                        XSlot ni, nj;
-                        ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
-                        nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
-                        slot[i] = ni;
-                        slot[j] = nj;
-                    }
+        for (int l = 0; l < ltail; ++l) {
+            const uint32_t e3 = level_end(l + 2);
+            // this thread's first pair of the next level is fetched while this level runs
+            const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+            const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+            for (uint32_t pos = b + tid; pos < e; pos += NT) {
+                if (pos != b + tid) { pw = pairs[pos]; m = mi_u ? mi_v : g_mi[pos]; }
+                const uint32_t i = pw & 0xffffu, j = pw >> 16;
+                const XSlot si = slot[i], sj = slot[j];
+                if (dist_fun_eval(dk, si.val, sj.val) > m) {   // dist_fun (default -), AlgoBGP.jl:688
+                    XSlot ni, nj;                           // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                    ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                    nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                    slot[i] = ni;
+                    slot[j] = nj;
                 }
-                __builtin_amdgcn_wave_barrier();
-                cpw = npw; m = m2; e = e2; e2 = e3;
             }
+            b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+            __syncthreads();
         }
-        __syncthreads();
-    }
+        if (ltail < nlev) {
+            if (tid < 64) {   // (pw, m) already hold this lane's pair of level ltail, e its end, e2 the next end
+                constexpr uint32_t NOPAIR = 0xffffffffu;   // i == j == 0xffff never occurs (chain ids < XLVL_MAX)
+                uint32_t cpw = (b + tid < e) ? pw : NOPAIR;
+#pragma clang loop unroll(disable)
+                for (int l = ltail; l < nlev; ++l) {
+                    const uint32_t e3 = level_end(l + 2);
+                    const uint32_t npw = (e + tid < e2) ? pairs[e + tid] : NOPAIR;
+                    const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+                    if (cpw != NOPAIR) {
+                        const uint32_t i = cpw & 0xffffu, j = cpw >> 16;
+                        const XSlot si = slot[i], sj = slot[j];
+                        if (dist_fun_eval(dk, si.val, sj.val) > m) {
+                            XSlot ni, nj;
+                            ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                            nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                            slot[i] = ni;
+                            slot[j] = nj;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    cpw = npw; m = m2; e = e2; e2 = e3;
+                }
+            }
+            __syncthreads();
+        }
+    };
+    if (P.dist_fun != 0) levels(std::true_type{}); else levels(std::false_type{});
 }
 
 // The same walk with the level loop written for latency: a level is ONE LDS round trip (both 16-byte slots of a pair with a
@@ -669,6 +674,7 @@ __device__ inline void exchange_walk_fast(const KParams& P, const int tx, unsign
     __syncthreads();
     if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
     const uint32_t slot_base = (uint32_t)(size_t)lds;   // LDS byte address of the chain slots
+    // (dist_fun = - only: k_chain_iter_norm does not walk inline for the other entries of the menu — the host sees to it)
     if (P.mi_uniform) walk_levels<NT, true, FINAL_BARRIER>(P, slot_base, pairs, g_mi, ev, g_off, nlev, ltail, tid);
     else walk_levels<NT, false, FINAL_BARRIER>(P, slot_base, pairs, g_mi, ev, g_off, nlev, ltail, tid);
 }

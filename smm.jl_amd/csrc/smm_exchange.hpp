@@ -59,7 +59,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
             if (ti == ri && tj == rj) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const double vi = val[i], vj = val[j];
-                if (vi - vj > mi) {                         // dist_fun = -, :688
+                if (dist_fun_eval(P.dist_fun, vi, vj) > mi) {   // dist_fun (default -), :688
                     val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744
                     const uint16_t si = src[i];
                     src[i] = src[j]; src[j] = si;
@@ -168,28 +168,33 @@ __global__ __launch_bounds__(LWG) void k_exch_resolve_lvl(const KParams P, const
     uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
     uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
     double m = (b + tid < e) ? mi[b + tid] : 0.0;
+    // (the loop twice: the default dist_fun `-` pays nothing for the menu)
+    auto levels = [&](auto gen) {
+        const int dk = decltype(gen)::value ? P.dist_fun : 0;
 #pragma clang loop unroll(disable)
-    for (int l = 0; l < ltail; ++l) {
-        const uint32_t e3 = level_end(l + 2);
-        // this thread's first pair of the next level (LDS) is fetched while this level runs
-        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
-        const double m2 = (e + tid < e2) ? mi[e + tid] : 0.0;
-        for (uint32_t pos = b + tid; pos < e && !(P.dbg & 32); pos += LWG) {
-            if (pos != b + tid) { pw = pairs[pos]; m = mi[pos]; }
-            const uint32_t i = pw & 0xffffu, j = pw >> 16;
-            const XSlot si = slot[i], sj = slot[j];
-            if (si.val - sj.val > m) {                  // dist_fun = -, AlgoBGP.jl:688
-                XSlot ni, nj;                           // swap_ev_ij!, :739-744; set_exchanged!, :747-748
-                ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
-                nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
-                slot[i] = ni;
-                slot[j] = nj;
+        for (int l = 0; l < ltail; ++l) {
+            const uint32_t e3 = level_end(l + 2);
+            // this thread's first pair of the next level (LDS) is fetched while this level runs
+            const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+            const double m2 = (e + tid < e2) ? mi[e + tid] : 0.0;
+            for (uint32_t pos = b + tid; pos < e && !(P.dbg & 32); pos += LWG) {
+                if (pos != b + tid) { pw = pairs[pos]; m = mi[pos]; }
+                const uint32_t i = pw & 0xffffu, j = pw >> 16;
+                const XSlot si = slot[i], sj = slot[j];
+                if (dist_fun_eval(dk, si.val, sj.val) > m) {   // dist_fun (default -), AlgoBGP.jl:688
+                    XSlot ni, nj;                           // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                    ni.val = sj.val; ni.src = sj.src; ni.partner = j + 1;
+                    nj.val = si.val; nj.src = si.src; nj.partner = i + 1;
+                    slot[i] = ni;
+                    slot[j] = nj;
+                }
             }
+            b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+            if (!(P.dbg & 64)) __syncthreads();
+            if (P.ts && tid == 0) { lts[lvc & 31] = clock64() - cyc0; ++lvc; }
         }
-        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
-        if (!(P.dbg & 64)) __syncthreads();
-        if (P.ts && tid == 0) { lts[lvc & 31] = clock64() - cyc0; ++lvc; }
-    }
+    };
+    if (P.dist_fun != 0) levels(std::true_type{}); else levels(std::false_type{});
     if (P.ts && tid == 0) {
         P.ts[(size_t)8 * 60000 + 15] = lts[63];
         for (int l = 0; l < min(lvc, 32); ++l) P.ts[(size_t)8 * 60000 + 16 + l] = lts[l];
@@ -254,25 +259,30 @@ __device__ inline void resolve_lvl_soa_body(const KParams& P, const int t, const
     uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
     uint32_t pw = (b + tid < e) ? pairs[b + tid] : 0u;
     double m = mi_u ? mi_v : ((b + tid < e) ? g_mi[b + tid] : 0.0);
+    // (the loop twice: the default dist_fun `-` pays nothing for the menu)
+    auto levels = [&](auto gen) {
+        const int dk = decltype(gen)::value ? P.dist_fun : 0;
 #pragma clang loop unroll(disable)
-    for (int l = 0; l < nlev; ++l) {
-        const uint32_t e3 = level_end(l + 2);
-        const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
-        const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
-        for (uint32_t pos = b + tid; pos < e; pos += LWG) {
-            if (pos != b + tid) { pw = pairs[pos]; m = mi_u ? mi_v : g_mi[pos]; }
-            const uint32_t i = pw & 0xffffu, j = pw >> 16;
-            const double vi = val[i], vj = val[j];
-            const uint32_t si = sp[i], sj = sp[j];
-            if (vi - vj > m) {                          // dist_fun = -, AlgoBGP.jl:688
-                val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744; set_exchanged!, :747-748
-                sp[i] = (sj & 0xffffu) | ((j + 1) << 16);
-                sp[j] = (si & 0xffffu) | ((i + 1) << 16);
+        for (int l = 0; l < nlev; ++l) {
+            const uint32_t e3 = level_end(l + 2);
+            const uint32_t pw2 = (e + tid < e2) ? pairs[e + tid] : 0u;
+            const double m2 = mi_u ? mi_v : ((e + tid < e2) ? g_mi[e + tid] : 0.0);
+            for (uint32_t pos = b + tid; pos < e; pos += LWG) {
+                if (pos != b + tid) { pw = pairs[pos]; m = mi_u ? mi_v : g_mi[pos]; }
+                const uint32_t i = pw & 0xffffu, j = pw >> 16;
+                const double vi = val[i], vj = val[j];
+                const uint32_t si = sp[i], sj = sp[j];
+                if (dist_fun_eval(dk, vi, vj) > m) {    // dist_fun (default -), AlgoBGP.jl:688
+                    val[i] = vj; val[j] = vi;               // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                    sp[i] = (sj & 0xffffu) | ((j + 1) << 16);
+                    sp[j] = (si & 0xffffu) | ((i + 1) << 16);
+                }
             }
+            b = e; e = e2; e2 = e3; pw = pw2; m = m2;
+            __syncthreads();
         }
-        b = e; e = e2; e2 = e3; pw = pw2; m = m2;
-        __syncthreads();
-    }
+    };
+    if (P.dist_fun != 0) levels(std::true_type{}); else levels(std::false_type{});
     for (int g = tid; g < Ng; g += LWG) {
         const uint32_t s_ = sp[g];
         P.xres[g] = (unsigned long long)(s_ & 0xffffu) | ((unsigned long long)(s_ >> 16) << 32);
@@ -602,40 +612,45 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lvl_big(const KParams P, c
     __syncthreads();
     uint32_t b = 0;
     constexpr int BATCH = 8;  // pairs of one level are independent: their loads are issued together
+    // (the loop twice: the default dist_fun `-` pays nothing for the menu)
+    auto levels = [&](auto gen) {
+        const int dk = decltype(gen)::value ? P.dist_fun : 0;
 #pragma clang loop unroll(disable)
-    for (int l = 0; l < nlev; ++l) {
-        const uint32_t e = level_end(l);
-        for (uint32_t p0 = b + tid; p0 < e; p0 += XWG * BATCH) {
-            uint32_t pw[BATCH];
-            double m[BATCH];
-            XSlot si[BATCH], sj[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const uint32_t pos = p0 + u * XWG;
-                pw[u] = pos < e ? g_pairs[pos] : 0u;
-                m[u] = mi_u ? mi_v : (pos < e ? g_mi[pos] : 0.0);
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {   // (pair word 0 = chains (0,0): never swaps, see the guard below)
-                si[u] = slot[pw[u] & 0xffffu];
-                sj[u] = slot[pw[u] >> 16];
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const uint32_t pos = p0 + u * XWG;
-                const uint32_t i = pw[u] & 0xffffu, j = pw[u] >> 16;
-                if (pos < e && si[u].val - sj[u].val > m[u]) {  // dist_fun = -, AlgoBGP.jl:688
-                    XSlot ni, nj;                               // swap_ev_ij!, :739-744; set_exchanged!, :747-748
-                    ni.val = sj[u].val; ni.src = sj[u].src; ni.partner = j + 1;
-                    nj.val = si[u].val; nj.src = si[u].src; nj.partner = i + 1;
-                    slot[i] = ni;
-                    slot[j] = nj;
+        for (int l = 0; l < nlev; ++l) {
+            const uint32_t e = level_end(l);
+            for (uint32_t p0 = b + tid; p0 < e; p0 += XWG * BATCH) {
+                uint32_t pw[BATCH];
+                double m[BATCH];
+                XSlot si[BATCH], sj[BATCH];
+    #pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const uint32_t pos = p0 + u * XWG;
+                    pw[u] = pos < e ? g_pairs[pos] : 0u;
+                    m[u] = mi_u ? mi_v : (pos < e ? g_mi[pos] : 0.0);
+                }
+    #pragma unroll
+                for (int u = 0; u < BATCH; ++u) {   // (pair word 0 = chains (0,0): never swaps, see the guard below)
+                    si[u] = slot[pw[u] & 0xffffu];
+                    sj[u] = slot[pw[u] >> 16];
+                }
+    #pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const uint32_t pos = p0 + u * XWG;
+                    const uint32_t i = pw[u] & 0xffffu, j = pw[u] >> 16;
+                    if (pos < e && dist_fun_eval(dk, si[u].val, sj[u].val) > m[u]) {  // dist_fun (default -), AlgoBGP.jl:688
+                        XSlot ni, nj;                               // swap_ev_ij!, :739-744; set_exchanged!, :747-748
+                        ni.val = sj[u].val; ni.src = sj[u].src; ni.partner = j + 1;
+                        nj.val = si[u].val; nj.src = si[u].src; nj.partner = i + 1;
+                        slot[i] = ni;
+                        slot[j] = nj;
+                    }
                 }
             }
+            b = e;
+            __syncthreads();
         }
-        b = e;
-        __syncthreads();
-    }
+    };
+    if (P.dist_fun != 0) levels(std::true_type{}); else levels(std::false_type{});
     for (int g = tid; g < Ng; g += XWG) {
         const XSlot s_ = slot[g];
         P.xres[g] = (unsigned long long)s_.src | ((unsigned long long)s_.partner << 32);
@@ -689,7 +704,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_any(const KParams P, const
             if (__hip_atomic_load(&P.xnext[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == q &&
                 __hip_atomic_load(&P.xnext[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == q) {
                 const double vi = P.xval[i], vj = P.xval[j];
-                if (vi - vj > P.min_improve_g[i]) {  // dist_fun = -, :688
+                if (dist_fun_eval(P.dist_fun, vi, vj) > P.min_improve_g[i]) {  // dist_fun (default -), :688
                     P.xval[i] = vj; P.xval[j] = vi;   // swap_ev_ij!, :739-744
                     const int si = P.xsrc[i];
                     P.xsrc[i] = P.xsrc[j]; P.xsrc[j] = si;

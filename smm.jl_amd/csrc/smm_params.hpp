@@ -66,6 +66,7 @@ struct KParams {
     const uint32_t* lv_offp;         // [W][LV_OFFP]: entry l = first word of level l (entry nlev: the padded length); [33] = nlev;
                                      //          [34] = 1 when the plan fits this form (at most 31 levels)
     int plan_Kp, lean_unit;          // words per iteration in lv_pairs_p; 8, or 4 when 8 * N_global does not fit 16 bits (smm_walk_lean.hpp)
+    int dist_fun;                    // smm_dist_fun_t: the exchange test's distance (AlgoBGP.jl:537,688); the key / lean / rows walks are for 0 (-)
     int lean_wide;                   // the lean walk's form for one min_improve > 0 (or NaN) shared by all chains: 16-byte slots, lean_unit 16 or 8
     // ... and for k_exch_resolve_rows (8192 < N_global <= 32768, min_improve == 0; null otherwise):
     const uint32_t* lv_rows;         // [W][rows_cap][1024]: level by level, every level padded to whole rows of 1024 words with dummy pairs; pi | pj << 16
@@ -110,6 +111,15 @@ __device__ inline double order_key_hi(const uint32_t k) {
     return k >= XKEY_TOP ? INFINITY : __hiloint2double((int)(XKEY_BASE + (k << XKEY_SHIFT)), 0);
 }
 
+// dist_fun(value_i, value_j) of the exchange test (AlgoBGP.jl:537,688; smm_dist_fun_t in include/smmhip.h): 0 is the reference's
+// default `-`; the others are what the header offers in place of an arbitrary Julia function.  (Branches, not selects: the
+// default must not pay for the division.)
+__host__ __device__ inline double dist_fun_eval(const int kind, const double a, const double b) {
+    const double d = a - b;
+    if (__builtin_expect(kind == 0, 1)) return d;
+    if (kind == 1) return fabs(d);
+    return d / fabs(a);
+}
 constexpr int LV_OFFP = 40, LV_MAXLEV = 31;
 // 32-bit order key of a chain value: for any two non-NaN doubles, key(a) > key(b) implies a > b and key(a) < key(b) implies a < b
 // (the high word of the double, made monotone across the sign; -0.0 counts as +0.0); equal keys decide nothing.

@@ -42,6 +42,7 @@
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 #include "../../include/smmhip.h"
 #include "smm_rng.hpp"
@@ -618,6 +619,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         }
     }
     if (tab && tab->prop_normals && tab->prop_tries < 1) return fail(nullptr, SMM_ERR_INVALID_ARG, "prop_normals given but prop_tries < 1");
+    if (opts->dist_fun < SMM_DIST_MINUS || opts->dist_fun > SMM_DIST_RELDIFF)
+        return fail(nullptr, SMM_ERR_INVALID_ARG, "smm_bgp_opts_t.dist_fun: SMM_DIST_MINUS, SMM_DIST_ABSDIFF or SMM_DIST_RELDIFF");
     if (opts->chol_L && opts->batch_size != np)
         return fail(nullptr, SMM_ERR_BAD_BATCH, "Cholesky proposals (chol_L) draw all parameters in one batch: batch_size must equal np");
     int ndev = 0;
@@ -712,6 +715,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             P.chol_per_chain = opts->chol_per_chain ? 1 : 0;
             P.chol_L = dupload(c, opts->chol_L, (size_t)(P.chol_per_chain ? Ng : 1) * np * np);
         }
+        P.dist_fun = opts->dist_fun;
         P.mi_uniform = 1; P.mi_value = opts->min_improve[0];
         for (int i = 1; i < Ng; ++i)
             if (!(opts->min_improve[i] == P.mi_value)) P.mi_uniform = 0;
@@ -744,7 +748,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             c->big_exchange = Ng > 1 && Ng <= 65535 && K >= 1 && K <= Ng && !c->force_any_exchange && (force_big || !c->lds_exchange);
             if (c->big_exchange) { c->lds_exchange = false; c->lvl_exchange = false; c->lvl_soa_exchange = false; }
             const char* ke = getenv("SMMHIP_KEY_EXCHANGE");   // test hook: "0" keeps the global-memory walk
-            c->key_exchange = c->big_exchange && Ng <= XKEY_MAX && K <= XKEY_MAX && !(ke && ke[0] == '0');
+            c->key_exchange = c->big_exchange && Ng <= XKEY_MAX && K <= XKEY_MAX && !(ke && ke[0] == '0') && opts->dist_fun == SMM_DIST_MINUS;   // (the keys order value_i - value_j)
             // inline exchange walk: single shard, level plan available, and two tiles must still share a CU's 160 KB LDS
             const char* iw = getenv("SMMHIP_INLINE_WALK");
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
@@ -755,6 +759,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const size_t walk_b = std::max(walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15),
                                            (std::max(lean_walk_bytes(Ng, K), lean_wide_bytes(Ng, K)) + 15) & ~(size_t)15);
             c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng && c->obj != SMM_OBJ_USER &&
+                             (!c->norm_fast || opts->dist_fun == SMM_DIST_MINUS) &&   // (k_chain_iter_norm's walks are for `-`)
                              (c->norm_fast ? walk_b + norm_tile_doubles(np) * 8 <= (size_t)160 * 1024
                                            : walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024);
             P.tile_off = c->inline_walk ? (int)((c->norm_fast ? walk_b : walk_slot_bytes(Ng)) / sizeof(double)) : 0;
@@ -801,7 +806,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 const char* kw = getenv("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walks on 16-byte / split slots
                 const bool keys = P.mi_uniform && P.mi_value == 0.0;
                 const bool wide = P.mi_uniform && !keys && !(P.mi_value < 0.0) && resolve_lean_bytes(Ng, K, true) <= (size_t)160 * 1024;
-                if ((keys || wide) && K <= XLDS_MAX && !(kw && kw[0] == '0')) {
+                if ((keys || wide) && K <= XLDS_MAX && !(kw && kw[0] == '0') && opts->dist_fun == SMM_DIST_MINUS) {
                     P.lean_wide = wide ? 1 : 0;
                     P.plan_Kp = lean_walk_Kp(K);
                     P.lean_unit = wide ? lean_wide_unit(Ng) : lean_walk_unit(Ng);

@@ -402,6 +402,21 @@ _DEFAULT_OPTS = {"N": 3, "maxiter": 100, "maxtemp": 2, "sigma": 0.05, "sigma_upd
 _IGNORED_OPTS = ("coverage", "mixprob", "acc_tuner", "maxdists")  # read by nothing in the reference either
 
 
+def _dist_fun_id(f):
+    """opts["dist_fun"] (AlgoBGP.jl:494,537: any Julia function of two objective values, default `-`) -> smm_dist_fun_t.
+    The device offers a menu: "-" / operator.sub (default), "absdiff" (|a - b|), "reldiff" ((a - b) / |a|), or the ids
+    themselves; an arbitrary host callable cannot run inside the exchange kernels."""
+    import operator
+    if f is None or f is operator.sub or f in ("-", "minus", "sub", A.SMM_DIST_MINUS):
+        return A.SMM_DIST_MINUS
+    if f in ("absdiff", "abs", A.SMM_DIST_ABSDIFF):
+        return A.SMM_DIST_ABSDIFF
+    if f in ("reldiff", "relative", A.SMM_DIST_RELDIFF):
+        return A.SMM_DIST_RELDIFF
+    raise NotImplementedError("dist_fun: the device runs '-' (AlgoBGP.jl:537), 'absdiff' or 'reldiff' (smm_dist_fun_t, include/smmhip.h), "
+                              "not an arbitrary host function")
+
+
 class MAlgoBGP:
     def __init__(self, m, opts=None, tables=None):
         opts = dict(_DEFAULT_OPTS) if opts is None else opts
@@ -416,8 +431,7 @@ class MAlgoBGP:
         self._acc_tuner = np.asarray(opts.get("acc_tuners", [2.0] * N), float)[:N]      # :523
         if len(self._min_improve) < N or len(self._acc_tuner) < N:
             raise IndexError("min_improve / acc_tuners need one entry per chain (AlgoBGP.jl:522-523)")
-        if opts.get("dist_fun", None) is not None:
-            raise NotImplementedError("only the default dist_fun `-` (AlgoBGP.jl:537) runs on the device")
+        self._dist_fun = _dist_fun_id(opts.get("dist_fun", None))                 # :537
         prob = _flat_problem(m)
         self._flat = dict(sigma_update_steps=int(opts.get("sigma_update_steps", 10)),
                           sigma_adjust_by=float(opts.get("sigma_adjust_by", 0.01)),
@@ -425,6 +439,7 @@ class MAlgoBGP:
         bo = BGPOpts(N=N, maxiter=int(opts["maxiter"]), sigma=sigma, acc_tuner=self._acc_tuner,
                      min_improve=self._min_improve, batch_size=opts.get("batch_size", None),
                      seed=int(opts.get("seed", 12)), device=int(opts.get("device", 0)),
+                     dist_fun=self._dist_fun,
                      chol_L=opts.get("chol_L", None),   # general Gaussian proposals (not in the reference: include/smmhip.h)
                      **self._flat)
         self._prob, self._bopts, self._tables = prob, bo, tables

@@ -178,6 +178,43 @@ def test_exchange_is_order_dependent_and_forwards_records(O):
             np.testing.assert_array_equal(h.params[1, :, c], la)  # the donor's last accepted record was forwarded
 
 
+@pytest.mark.parametrize("dist,mi", [(0, 0.02), (1, 0.02), (2, 0.1), (1, 0.0)])
+def test_dist_fun_menu_replayed_by_hand(O, dist, mi):
+    # opts["dist_fun"] (AlgoBGP.jl:537,688): the exchange test is dist_fun(value_i, value_j) > min_improve_i; the menu of
+    # include/smmhip.h (0: `-`, 1: |a - b|, 2: (a - b) / |a|) replayed in plain Python on the values after the accept step
+    N, T = 24, 6
+    prob, opts = cm.serial_normal(N=N, T=T, ns=100, min_improve=mi)
+    opts.dist_fun = dist
+    o = O.OracleContext(prob, opts)
+    o.step(T)
+    h = o.history()
+    prob2, opts2 = cm.serial_normal(N=N, T=T, ns=100, min_improve=mi)
+    fn = [lambda a, b: a - b, lambda a, b: abs(a - b), lambda a, b: (a - b) / abs(a)][dist]
+    # iteration t's exchange acts on the last accepted values after its accept step: replay every iteration from the state
+    # the oracle itself recorded one step earlier (curr_val after t-1's exchange, then t's accept decisions)
+    swapped_up = 0
+    for t in range(2, T + 1):
+        ref = O.OracleContext(prob, opts)
+        ref.step(t - 1)
+        st, hist = ref.state(), ref.history()
+        opts_off = cm.serial_normal(N=N, T=T, ns=100, min_improve=1e300)[1]   # same iteration without its exchange
+        noex = O.OracleContext(prob, opts_off)
+        noex.set_state(st, hist)
+        noex.step(1)
+        v = noex.state().la_value.copy()
+        partner = [0] * N
+        for i, j in O.gen_pairs(opts.seed, t, N):
+            if fn(v[i], v[j]) > mi:
+                swapped_up += v[i] < v[j]
+                v[i], v[j] = v[j], v[i]
+                partner[i], partner[j] = j + 1, i + 1
+        np.testing.assert_array_equal(h.exchanged[t - 1], partner)
+        np.testing.assert_array_equal(h.curr_val[t - 1], v)
+    assert (h.exchanged != 0).any()
+    if dist == 1:
+        assert swapped_up > 0    # |a - b| also moves the worse value to the colder chain
+
+
 def test_status_minus2_is_a_rejection_with_value_minus1(O):
     # mprob.jl:183-186 + AlgoBGP.jl:336-338; set_eval! still compares the Eval's default value -1 (:236)
     prob, opts = cm.serial_normal(N=6, T=60, ns=100, objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[-0.2, 0.1])

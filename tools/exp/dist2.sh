@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/dist_tests.txt
+python bench.py --no-cpu-baseline > gpurun_out/dist_bench.json 2> gpurun_out/dist_bench.err
+( python tools/exch_time.py 65000; SMMHIP_KEY_WALK=0 python tools/exch_time.py 4096 8192 ) > gpurun_out/dist_exch.txt 2>&1
+TS_MIN_IMPROVE=0.05 SMMHIP_KEY_WALK=0 python tools/dbg_ts.py 2>/dev/null | sed -n 8,14p > gpurun_out/dist_ts_old.txt
+TS_MIN_IMPROVE=0.05 python tools/dbg_ts.py 2>/dev/null | sed -n 8,14p > gpurun_out/dist_ts_wide.txt
