@@ -41,8 +41,9 @@ def main():
         opts = S.BGPOpts(N=N, maxiter=T, sigma=float(rng.choice([0.02, 0.05, 0.3])) * cm.temps(N, float(rng.choice([1.5, 3.0, 8.0]))),
                          acc_tuner=np.geomspace(10.0, 0.5, N) if N > 1 else np.array([2.0]),
                          min_improve=np.broadcast_to(np.asarray(mi, float), (N,)).copy(), seed=int(rng.integers(1, 1 << 30)),
-                         batch_size=bs, sigma_update_steps=int(rng.choice([3, 10])), N_global=N)
-        desc = "case %d: np=%d N=%d T=%d ns=%d bs=%d" % (it, npar, N, T, ns, bs)
+                         batch_size=bs, sigma_update_steps=int(rng.choice([3, 10])), N_global=N,
+                         dist_fun=int(rng.choice([0, 0, 0, 1, 2])))
+        desc = "case %d: np=%d N=%d T=%d ns=%d bs=%d dist_fun=%d mi=%s" % (it, npar, N, T, ns, bs, opts.dist_fun, "per chain" if np.ndim(mi) else mi)
         try:
             h = S.hip_context(prob, opts)
             o = O.OracleContext(prob, opts, S.Tables(Z=h.Z()), threads=O.max_threads() if big else 1)
