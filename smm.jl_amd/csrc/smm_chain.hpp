@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         // parameter and moment arrays (and the history row's parameters) by all lanes of the chain below
         if (acc) { ro[0] = value; ro[1] = prob; ro[2] = (double)status; }
         else { ro[0] = rc[0]; ro[1] = rc[1]; ro[2] = rc[2]; }
-        P.vals[c] = acc ? value : old;
+        P.vals_out[c] = acc ? value : old;
     }
     __builtin_amdgcn_wave_barrier();
     if constexpr (KIND == 2) {

@@ -601,9 +601,9 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
     }
     if (r == 0) {
         const double v = acc ? value : old;
-        P.vals[c] = v;
-        if (P.slot8) {   // the chain's slot at the start of the next exchange walk (exchange_walk_lean)
-            P.slot8[c] = make_uint2(order_key32(v), (uint32_t)gc);
+        P.vals_out[c] = v;
+        if (P.slot8_out) {   // the chain's slot at the start of the next exchange walk (exchange_walk_lean)
+            P.slot8_out[c] = make_uint2(order_key32(v), (uint32_t)gc);
             if (v != v) atomicOr(P.walk_flags, 1u);
         }
     }

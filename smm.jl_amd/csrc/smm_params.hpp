@@ -76,9 +76,14 @@ struct KParams {
     // state
     double* cs;                // [N][CSW]
     unsigned long long* xres;  // [Ng]
-    double* vals;              // [N] value of every chain's last accepted record after the accept step, contiguous
+    double* vals;              // [N] value of every chain's last accepted record after the accept step of the iteration whose
+                               //     exchange is being resolved, contiguous (two buffers by iteration parity: the host points
+                               //     vals at the one to read and vals_out at the one this launch's accept step writes — a
+                               //     workgroup that starts late must not find its neighbours' new values in its walk's input)
+    double* vals_out;
                                //     (what the single-shard exchange resolution reads: 8 B per chain instead of a record)
     uint2* slot8;              // [N] the chain's initial slot of the lean walk: {order_key32(vals[c]), c} (k_chain_iter_norm, or null)
+    uint2* slot8_out;          // (like vals_out)
     uint32_t* walk_flags;      // bit 0 (sticky): a NaN value entered vals[]: order keys do not cover it, the 16-byte walk runs
     // scratch of the any-size exchange kernel
     int32_t *xsrc, *xpartner, *xnext, *xpairs;

@@ -173,6 +173,8 @@ struct Ctx {
     int32_t *a2a_send_idx = nullptr, *a2a_send_cnt = nullptr, *a2a_rowidx = nullptr;   // the values form of the sharded exchange
     int a2a_cap = 0, a2a_G = 0;
     bool a2a_open = false;
+    double* vals_buf[2] = {nullptr, nullptr};   // KParams::vals / vals_out, by iteration parity (point_values)
+    uint2* slot8_buf[2] = {nullptr, nullptr};
     bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
@@ -215,6 +217,8 @@ T* dalloc(Ctx* c, size_t n) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
     c->allocs.push_back(p);
+    if (const char* f = getenv("SMMHIP_FILL"))   // test hook: every allocation starts as this byte (reads of memory nobody wrote show up)
+        HIPCHK(hipMemset(p, atoi(f), (n ? n : 1) * sizeof(T)));
     return (T*)p;
 }
 template <class T>
@@ -226,6 +230,12 @@ T* dupload(Ctx* c, const T* h, size_t n) {
 
 bool is_sim(int obj) { return obj == SMM_OBJ_NORM || obj == SMM_OBJ_NORM_FAILBOX; }
 int obj_kind(int obj) { return is_sim(obj) ? 1 : obj == SMM_OBJ_DENSE ? 2 : 0; }
+
+// the two value arrays (and slot arrays) alternate by iteration: reads of iteration t_read's values, writes of iteration t_write's
+void point_values(const Ctx* c, KParams& P, int t_read, int t_write) {
+    P.vals = c->vals_buf[t_read & 1]; P.vals_out = c->vals_buf[t_write & 1];
+    P.slot8 = c->slot8_buf[t_read & 1]; P.slot8_out = c->slot8_buf[t_write & 1];
+}
 
 size_t tile_smem_base(const Ctx* c, int ct) {
     const KParams& P = c->P;
@@ -358,6 +368,7 @@ void launch_user_kernel(Ctx* c, const double* theta, int n, double* simM, double
 }
 
 void launch_chain_iter(Ctx* c, int t, int flags) {
+    point_values(c, c->P, t - 1, t);   // the inline walk reads what the accept step of t-1 wrote; this accept step writes the other array
     if (c->obj == SMM_OBJ_USER) {
         // proposal launch (stores nothing but the proposals) -> the user's kernel -> accept launch (repeats the
         // deterministic prologue, takes value / moments / status from the user's kernel)
@@ -391,7 +402,9 @@ size_t resolve_lean_bytes(int Ng, int K, bool wide) { return std::max(wide ? lea
 void launch_resolve_p(Ctx* c, const KParams& P, int t, const double* gathered);
 void launch_resolve(Ctx* c, int t, const double* gathered) { launch_resolve_p(c, c->P, t, gathered); }
 // (P: the context's parameters, or a copy whose RW is the stride of the value column in `gathered`)
-void launch_resolve_p(Ctx* c, const KParams& P, int t, const double* gathered) {
+void launch_resolve_p(Ctx* c, const KParams& P_in, int t, const double* gathered) {
+    KParams P = P_in;
+    point_values(c, P, t, t);   // (single shard: the values the accept step of iteration t wrote)
     if (c->lean_resolve)
         if (c->kev0)
             hipExtLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K, P.lean_wide != 0), c->stream, c->kev0, c->kev1, 0, P, t,
@@ -814,7 +827,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                     c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->win_cap * LV_OFFP);
                     c->lean_resolve = true;
                     if (keys && c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) {   // ... in the prologue of k_chain_iter_norm
-                        P.slot8 = dalloc<uint2>(c, (size_t)N + 4);
+                        for (int b = 0; b < 2; ++b) c->slot8_buf[b] = dalloc<uint2>(c, (size_t)N + 4);
+                        P.slot8 = c->slot8_buf[0];
                         P.walk_flags = dalloc<uint32_t>(c, 4);
                         HIPCHK(hipMemset(P.walk_flags, 0, 16));
                     }
@@ -843,7 +857,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             c->a2a_send_cnt = dalloc<int32_t>(c, (size_t)c->a2a_G);
             c->a2a_rowidx = dalloc<int32_t>(c, (size_t)N);
         }
-        P.vals = dalloc<double>(c, (size_t)N + 4);   // (+4: read as 16-byte pieces)
+        for (int b = 0; b < 2; ++b) c->vals_buf[b] = dalloc<double>(c, (size_t)N + 4);   // (+4: read as 16-byte pieces)
+        P.vals = c->vals_buf[0];
         if (!c->lds_exchange) {
             const int Kmax = std::max(K, 1);
             P.xval = dalloc<double>(c, Ng); P.xnext = dalloc<int32_t>(c, Ng); P.xpairs = dalloc<int32_t>(c, (size_t)Kmax * 2);
@@ -1182,7 +1197,7 @@ int smm_bgp_export_values_dev(void* ctx, void* vals_dev) {
     try {
         HIPCHK(hipSetDevice(c->device));
         if (c->pending || c->unresolved) flush(c);
-        HIPCHK(hipMemcpyAsync(vals_dev, c->P.vals, (size_t)c->P.N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(vals_dev, c->vals_buf[c->iter & 1], (size_t)c->P.N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI of libsmmhip.so) against the CPU oracle on the
 same seeded inputs.  Bookkeeping bit-exact, floating point within 1e-9 relative (the
 north star asks for 1e-6)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ import common as cm
 from smm_jl_amd import _abi as A
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def make_pair(S, O, prob, opts, tables=None, **okw):
@@ -1059,6 +1062,35 @@ def test_dist_fun_through_the_host_api(S):
     with pytest.raises(A.SMMHipError) as e:
         S.hip_context(prob, opts)
     assert e.value.code == A.SMM_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("mi", [0.0, 0.3])
+def test_first_launches_of_a_fresh_process(mi):
+    # Found by tools/fuzz_parity.py: the values the exchange walk reads (KParams::vals, the lean walk's slots) used to be ONE array,
+    # read by every workgroup in the prologue and rewritten by each workgroup's accept step — a workgroup that starts late
+    # (cold instruction fetch on the first launches of a process; short kernels: few chains, few draws) found its neighbours' NEW
+    # values in its walk's input and the redundant walks disagreed.  Now two arrays by iteration parity.  The failure needed a
+    # fresh process, hence the child processes (5 of 6 failed before the fix).
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import smm_jl_amd as S, common as cm
+        from oracle import oracle as O
+        # (the case of the sweep: wide proposals, so that a chain's value changes a lot from one iteration to the next)
+        prob = S.Problem(init=[1.4926310430330663], lb=[-3.4640012631720185], ub=[3.4640012631720185], mom=[-1.7242533461784755],
+                         w=[np.nan], ns=4096)
+        opts = S.BGPOpts(N=100, maxiter=14, sigma=0.3 * cm.temps(100, 8.0), acc_tuner=np.geomspace(10.0, 0.5, 100),
+                         min_improve=np.full(100, %r), seed=673502443, batch_size=1, sigma_update_steps=3, N_global=100)
+        h = S.hip_context(prob, opts)
+        o = O.OracleContext(prob, opts, S.Tables(Z=h.Z()))
+        h.step(14); o.step(14)
+        cm.assert_history_equal(h.history(), o.history(), rtol=1e-9, atol=1e-12)
+        print("fresh process ok")
+    """) % (ROOT, os.path.join(ROOT, "tests"), mi)
+    for _ in range(3):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "fresh process ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def _slice_state(st, lo, hi):

@@ -18,6 +18,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     big = len(sys.argv) > 3 and sys.argv[3] == "big"
     bad = 0
+    only = int(os.environ.get("FUZZ_ONLY", "-1"))   # re-run one case of a sweep (same cases / seed arguments)
     for it in range(cases):
         npar = int(rng.choice([1, 2, 2, 3, 4, 6, 9, 18]))
         N = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 40, 100, 255, 256, 257, 600, 1500, 4096, 4100, 8192, 9001]))
@@ -44,7 +45,33 @@ def main():
                          batch_size=bs, sigma_update_steps=int(rng.choice([3, 10])), N_global=N,
                          dist_fun=int(rng.choice([0, 0, 0, 1, 2])))
         desc = "case %d: np=%d N=%d T=%d ns=%d bs=%d dist_fun=%d mi=%s" % (it, npar, N, T, ns, bs, opts.dist_fun, "per chain" if np.ndim(mi) else mi)
+        # now and then as G shards on this one GPU (the three host protocols of the sharded exchange: tests/test_gpu_parity.py)
+        G = int(rng.choice([1, 1, 1, 2, 4, 8])) if N >= 16 else 1
+        mode = str(rng.choice(["records", "fused", "values"]))
+        if G > 1 and N % G:
+            G = 1
+        if G > 1:
+            desc += " sharded %d ways (%s)" % (G, mode)
+        if only >= 0 and it != only:   # FUZZ_ONLY=<case>: the same draws, nothing run
+            if G == 1:
+                rng.integers(1, T)
+            continue
         try:
+            if G > 1:
+                import test_gpu_parity as tg
+                run = {"records": tg.sharded_run, "fused": tg.sharded_run_fused, "values": tg.sharded_run_values}[mode]
+                ctxs = run(S, prob, opts, G, T)
+                o = O.OracleContext(prob, opts, S.Tables(Z=ctxs[0].Z()), threads=O.max_threads())
+                o.step(T)
+                ho, n = o.history(), N // G
+                for r, c in enumerate(ctxs):
+                    hr = c.history()
+                    for f in cm.INT_FIELDS:
+                        np.testing.assert_array_equal(getattr(hr, f), getattr(ho, f)[..., r * n:(r + 1) * n], err_msg="shard %d %s" % (r, f))
+                    for f in cm.F64_FIELDS:
+                        np.testing.assert_allclose(getattr(hr, f), getattr(ho, f)[..., r * n:(r + 1) * n], rtol=1e-9, atol=1e-12, err_msg="shard %d %s" % (r, f))
+                print("ok  ", desc)
+                continue
             h = S.hip_context(prob, opts)
             o = O.OracleContext(prob, opts, S.Tables(Z=h.Z()), threads=O.max_threads() if big else 1)
             split = int(rng.integers(1, T))
@@ -67,6 +94,30 @@ def main():
             else:
                 bad += 1
                 print("FAIL", desc, "->", msg)
+                if only >= 0 and G == 1 and "h" in dir() and "split" in dir():   # where the two part, and whether the 16-byte-slot walks agree with the oracle
+                    for env in ("the failing run itself", None, "0"):
+                        if env == "0":
+                            os.environ["SMMHIP_KEY_WALK"] = env
+                        if env is None or env == "0":
+                            h2 = S.hip_context(prob, opts)
+                            o2 = O.OracleContext(prob, opts, S.Tables(Z=h2.Z()))
+                            h2.step(split); h2.step(T - split); o2.step(T)
+                        else:
+                            h2, o2 = h, o
+                        hh, ho = h2.history(), o2.history()
+                        print("  SMMHIP_KEY_WALK=%s split=%d" % (env, split))
+                        for f in cm.INT_FIELDS + ("curr_val",):
+                            d = np.argwhere(getattr(hh, f) != getattr(ho, f))
+                            print("    %-10s %d mismatches, first (iteration-1, chain) %s" % (f, len(d), d[:4].tolist()))
+                        d = np.argwhere(hh.exchanged != ho.exchanged)
+                        if len(d):   # the first iteration whose exchange differs: both partner rows and the pairs in question
+                            t = int(d[0][0])
+                            cs = sorted(set(int(c) for tt, c in d if tt == t))
+                            print("    iteration %d: chains (0-based) %s: hip partners %s, oracle partners %s" % (t + 1, cs, hh.exchanged[t, cs].tolist(), ho.exchanged[t, cs].tolist()))
+                            for q, (i, j) in enumerate(O.gen_pairs(opts.seed, t + 1, N)):
+                                if i in cs or j in cs:
+                                    print("      pair %d: (%d, %d)  values after the exchange hip %r %r  oracle %r %r  min_improve_i %r" % (
+                                        q, i, j, hh.curr_val[t, i], hh.curr_val[t, j], ho.curr_val[t, i], ho.curr_val[t, j], opts.min_improve[i]))
     print("%d cases, %d failures" % (cases, bad))
     return 1 if bad else 0
 
