@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     __syncthreads();
     TS_MARK(2);
     if (flags & F_PROPOSE_ONLY) {  // user objective: hand the proposals to the user's kernel; nothing has been stored yet, the
-        if (valid && err_word == ERR_NONE)   // accept launch repeats this (deterministic) prologue
+        if (valid && !error_before(err_word, t))   // accept launch repeats this (deterministic) prologue
             for (int k = r; k < np; k += NR) P.u_theta[(size_t)c * np + k] = S.theta[cl * np + k];
         return;
     }
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     }
     TS_MARK(3);
     if (P.dbg & 4) return;
-    if (err_word != ERR_NONE) return;
+    if (error_before(err_word, t)) return;
 
     // ---- objective value, doAcceptReject! (:324-392), set_eval! (:220-245) ----
     // the moments of a chain (wave totals -> mean -> squared weighted deviation) are independent: its NR lanes share them

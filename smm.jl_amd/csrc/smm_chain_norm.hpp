@@ -351,7 +351,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
 
     // ---- control wave: the record the chain continues from, settle iteration t-1, propose (AlgoBGP.jl:424-471) ----
     asm volatile("" : "+v"(err_word));   // (looked at only here: the compiler would otherwise wait for it right behind the load)
-    const bool poisoned = err_word != ERR_NONE;   // an earlier iteration raised a hard error: nothing is stored any more
+    const bool poisoned = error_before(err_word, t);   // an earlier iteration raised a hard error: nothing is stored any more
     if (ctl) {
         if (tid == 0) s_park[CT * PARKW + 1] = poisoned ? 1.0 : 0.0;
         int partner = (int)(xr >> 32);

@@ -146,6 +146,9 @@ __host__ __device__ inline uint32_t order_key17(const double v) {
 
 #define TS_MARK(i) do { if (P.ts && tid == 0) P.ts[(size_t)tile * 8 + (i)] = wall_clock64(); } while (0)
 
+// has an iteration BEFORE t raised a hard error?  (Not "is the word set": a workgroup of iteration t that starts late may find the
+// word set by a faster workgroup of the same launch — the failing iteration itself completes for every chain.)
+__device__ inline bool error_before(const unsigned long long err_word, const int t) { return (err_word >> 34) < (unsigned long long)t; }
 __device__ inline void report_error(const KParams& P, int kind, int t, int gchain) {
     const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)gchain << 2) | (unsigned)kind;
     atomicMin(P.err, key);
