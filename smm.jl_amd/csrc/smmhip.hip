@@ -769,8 +769,9 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* nf = getenv("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
             c->norm_fast = is_sim(c->obj) && np == nm && np <= 4 && opts->batch_size == np && P.dbg == 0 && !opts->chol_L && !(nf && nf[0] == '0');
             // k_chain_iter_norm: pair list NOT overlaid; room for either walk (16-byte slots, 4-byte slots + value table)
+            const bool wide_form = P.mi_uniform && P.mi_value != 0.0 && !(P.mi_value < 0.0);   // (the lean walk on 16-byte slots, below)
             const size_t walk_b = std::max(walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15),
-                                           (std::max(lean_walk_bytes(Ng, K), lean_wide_bytes(Ng, K)) + 15) & ~(size_t)15);
+                                           ((wide_form ? lean_wide_bytes(Ng, K) : lean_walk_bytes(Ng, K)) + 15) & ~(size_t)15);
             c->inline_walk = !(iw && iw[0] == '0') && c->lvl_exchange && N == Ng && c->obj != SMM_OBJ_USER &&
                              (!c->norm_fast || opts->dist_fun == SMM_DIST_MINUS) &&   // (k_chain_iter_norm's walks are for `-`)
                              (c->norm_fast ? walk_b + norm_tile_doubles(np) * 8 <= (size_t)160 * 1024
