@@ -342,6 +342,7 @@ def sharded_run_fused(S, prob, opts_full, G, T, finish_every=None):
         ctxs.append(S.hip_context(prob, o))
     R = ctxs[0].record_doubles()
     bufs = [torch.zeros((G, N, R), dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()   # (the fills run on torch's stream, the contexts on their own)
     cur = None
     for it in range(T):
         nxt = 0 if cur is None else cur ^ 1
@@ -1121,6 +1122,7 @@ def sharded_run_values(S, prob, opts_full, G, T):
     assert cap > 0
     vall = torch.empty((G, N), dtype=torch.float64, device="cuda")
     send = torch.zeros((G, G, cap, R), dtype=torch.float64, device="cuda")   # [rank][destination]
+    torch.cuda.synchronize()   # (the fill runs on torch's stream, the contexts on their own)
     for _ in range(T):
         for r, c in enumerate(ctxs):
             c.local_step()
@@ -1132,6 +1134,7 @@ def sharded_run_values(S, prob, opts_full, G, T):
         for c in ctxs:
             c.sync()
         recv = send.transpose(0, 1).contiguous()                              # [rank][source]
+        torch.cuda.synchronize()   # (torch's stream, not the contexts': the copy must have landed before a2a_apply reads it)
         for r, c in enumerate(ctxs):
             c.a2a_apply_dev(recv[r].data_ptr())
         for c in ctxs:

@@ -1,6 +1,6 @@
 """Randomised parity sweep: libsmmhip (default path) against the oracle on random problem shapes.
-python tools/fuzz_parity.py [cases] [seed] [big]   (GPU box; test infrastructure, not part of the product; `big`: populations of
-12000 .. 32768 chains — the stand-alone exchange kernels for 4 and 8 GPUs — with a small objective)"""
+python tools/fuzz_parity.py [cases] [seed] [big|long]   (GPU box; test infrastructure, not part of the product; `big`: populations of
+12000 .. 32768 chains — the stand-alone exchange kernels for 4 and 8 GPUs — with a small objective; `long`: 260 .. 1500 iterations)"""
 import os
 import sys
 
@@ -17,6 +17,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    long_runs = len(sys.argv) > 3 and sys.argv[3] == "long"
     bad = 0
     only = int(os.environ.get("FUZZ_ONLY", "-1"))   # re-run one case of a sweep (same cases / seed arguments)
     for it in range(cases):
@@ -28,6 +29,10 @@ def main():
             npar = int(rng.choice([1, 2, 2, 3]))
             N = int(rng.choice([12000, 16384, 20001, 24576, 24577, 30000, 32768]))
             T = int(rng.integers(3, 9))
+            ns = int(rng.choice([1, 17, 64]))
+        if long_runs:   # several look-ahead windows (256 iterations each), sigma adaptation over many periods
+            N = int(rng.choice([3, 16, 100, 600, 4096]))
+            T = int(rng.integers(300, 1500)) if N < 4096 else int(rng.integers(260, 400))
             ns = int(rng.choice([1, 17, 64]))
         divs = [d for d in range(1, npar + 1) if npar % d == 0]
         bs = int(rng.choice(divs))
