@@ -309,7 +309,7 @@ def sharded_run(S, prob, opts_full, G, T):
                     min_improve=opts_full.min_improve, sigma_update_steps=opts_full.sigma_update_steps,
                     sigma_adjust_by=opts_full.sigma_adjust_by, smpl_iters=opts_full.smpl_iters,
                     batch_size=opts_full.batch_size, seed=opts_full.seed, chain_offset=r * N,
-                    N_global=opts_full.N_global, dist_fun=opts_full.dist_fun)
+                    N_global=opts_full.N_global, dist_fun=opts_full.dist_fun, chol_L=opts_full.chol_L)
         ctxs.append(S.hip_context(prob, o))
     R = ctxs[0].record_doubles()
     gathered = torch.empty((G, N, R), dtype=torch.float64, device="cuda")
@@ -338,7 +338,7 @@ def sharded_run_fused(S, prob, opts_full, G, T, finish_every=None):
                     min_improve=opts_full.min_improve, sigma_update_steps=opts_full.sigma_update_steps,
                     sigma_adjust_by=opts_full.sigma_adjust_by, smpl_iters=opts_full.smpl_iters,
                     batch_size=opts_full.batch_size, seed=opts_full.seed, chain_offset=r * N,
-                    N_global=opts_full.N_global, dist_fun=opts_full.dist_fun)
+                    N_global=opts_full.N_global, dist_fun=opts_full.dist_fun, chol_L=opts_full.chol_L)
         ctxs.append(S.hip_context(prob, o))
     R = ctxs[0].record_doubles()
     bufs = [torch.zeros((G, N, R), dtype=torch.float64, device="cuda") for _ in range(2)]
@@ -1116,7 +1116,7 @@ def sharded_run_values(S, prob, opts_full, G, T):
                     min_improve=opts_full.min_improve, sigma_update_steps=opts_full.sigma_update_steps,
                     sigma_adjust_by=opts_full.sigma_adjust_by, smpl_iters=opts_full.smpl_iters,
                     batch_size=opts_full.batch_size, seed=opts_full.seed, chain_offset=r * N,
-                    N_global=opts_full.N_global, dist_fun=opts_full.dist_fun)
+                    N_global=opts_full.N_global, dist_fun=opts_full.dist_fun, chol_L=opts_full.chol_L)
         ctxs.append(S.hip_context(prob, o))
     R, cap = ctxs[0].record_doubles(), ctxs[0].a2a_capacity()
     assert cap > 0

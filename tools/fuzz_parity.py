@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import smm_jl_amd as S  # noqa: E402
 import common as cm  # noqa: E402
+from smm_jl_amd import _abi as A  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
@@ -42,14 +43,39 @@ def main():
         w = rng.uniform(0.5, 2.0, npar)
         if rng.random() < 0.2:
             w[rng.integers(npar)] = np.nan
-        prob = S.Problem(init=init, lb=-half, ub=half, mom=mom, w=w, ns=ns)
+        # the objective: mostly objfunc_norm; now and then banana, the dense simulation (FP64 MFMA), the fault-injecting
+        # variant of objfunc_norm (status -2 records), or Cholesky-shaped proposals
+        kind = str(rng.choice(["norm"] * 6 + ["banana", "dense", "failbox", "chol"])) if not big else "norm"
+        chol = None
+        if kind == "banana":
+            prob = S.Problem(init=np.zeros(npar), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1,
+                             objective_id=A.SMM_OBJ_BANANA)
+        elif kind == "dense":
+            npar = int(rng.choice([3, 6, 17, 50]))
+            nmd = int(rng.choice([2, 5, 33, 50]))
+            N = min(N, 1500)
+            divs_d = [d for d in range(1, npar + 1) if npar % d == 0]
+            bs = int(rng.choice(divs_d))
+            objp = np.concatenate([rng.standard_normal(A.SMM_DENSE_D * npar) / np.sqrt(npar),
+                                   rng.standard_normal(nmd * A.SMM_DENSE_D) / np.sqrt(A.SMM_DENSE_D)])
+            prob = S.Problem(init=rng.uniform(-0.3, 0.3, npar), lb=-np.ones(npar), ub=np.ones(npar), mom=rng.uniform(-0.5, 0.5, nmd),
+                             w=rng.uniform(0.5, 2.0, nmd), ns=1, objective_id=A.SMM_OBJ_DENSE, obj_params=objp)
+        elif kind == "failbox" and npar == 2:
+            prob = S.Problem(init=init, lb=-half, ub=half, mom=mom, w=w, ns=ns, objective_id=A.SMM_OBJ_NORM_FAILBOX,
+                             obj_params=[0.4 * half[0], 0.6 * half[1]])
+        else:
+            prob = S.Problem(init=init, lb=-half, ub=half, mom=mom, w=w, ns=ns)
+            if kind == "chol":
+                Am = rng.standard_normal((npar, npar))
+                chol = np.tril(np.linalg.cholesky(Am @ Am.T / npar + 0.5 * np.eye(npar)))
+                bs = npar
         mi = float(rng.choice([0.0, 0.0, -0.1, 0.3])) if rng.random() < 0.6 else rng.uniform(-0.2, 0.5, N)
         opts = S.BGPOpts(N=N, maxiter=T, sigma=float(rng.choice([0.02, 0.05, 0.3])) * cm.temps(N, float(rng.choice([1.5, 3.0, 8.0]))),
                          acc_tuner=np.geomspace(10.0, 0.5, N) if N > 1 else np.array([2.0]),
                          min_improve=np.broadcast_to(np.asarray(mi, float), (N,)).copy(), seed=int(rng.integers(1, 1 << 30)),
                          batch_size=bs, sigma_update_steps=int(rng.choice([3, 10])), N_global=N,
-                         dist_fun=int(rng.choice([0, 0, 0, 1, 2])))
-        desc = "case %d: np=%d N=%d T=%d ns=%d bs=%d dist_fun=%d mi=%s" % (it, npar, N, T, ns, bs, opts.dist_fun, "per chain" if np.ndim(mi) else mi)
+                         dist_fun=int(rng.choice([0, 0, 0, 1, 2])), chol_L=chol)
+        desc = "case %d: %s np=%d N=%d T=%d ns=%d bs=%d dist_fun=%d mi=%s" % (it, kind, npar, N, T, ns, bs, opts.dist_fun, "per chain" if np.ndim(mi) else mi)
         # now and then as G shards on this one GPU (the three host protocols of the sharded exchange: tests/test_gpu_parity.py)
         G = int(rng.choice([1, 1, 1, 2, 4, 8])) if N >= 16 else 1
         mode = str(rng.choice(["records", "fused", "values"]))
