@@ -542,6 +542,66 @@ __device__ inline void exchange_walk_tile(const KParams& P, const int tx, unsign
     if (P.dist_fun != 0) levels(std::true_type{}); else levels(std::false_type{});
 }
 
+// The lean walk of smm_walk_lean.hpp in k_chain_iter (one min_improve >= 0 for all chains, dist_fun = -; the plan in its padded
+// form): 16-byte slots {value, src | stamp << 16} built from the chains' values — with min_improve == 0 too, whose plan (made for
+// the 8-byte key slots: offsets in units of 8, a dummy pair of two slots) is read with doubled offsets and finds two zero-valued
+// slots behind the chains'.  The control wave of every tile of the workgroup takes its chains' result (src | partner << 32, as
+// k_exch_resolve_* write it) into xr before the tile's blocks may overwrite the pair list.  false (nothing done, no barrier
+// passed): this iteration's plan has more than 31 levels — the caller walks with exchange_walk_tile.
+template <int NT>
+__device__ inline bool exchange_walk_tile_lean(const KParams& P, const int tx, unsigned char* lds, const int tid, const bool valid, const int gc,
+                                               unsigned long long& xr, const int ts_tile) {
+    const int Ng = P.Ng;
+    const int w = tx - P.plan_t0;
+    const uint32_t* __restrict__ g_offp = P.lv_offp + (size_t)w * LV_OFFP;
+    const uint4* __restrict__ g_pairs = (const uint4*)(P.lv_pairs_p + (size_t)w * P.plan_Kp);
+    const int lane = tid & 63;
+    const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
+    const uint32_t pbase = 16u * (Ng4 + 2u);              // LDS offset of the pair words
+    constexpr int PT = XLVL_MAX / NT;                     // chains per lane
+    constexpr int PR = (XLVL_MAX + 64 * LV_MAXLEV + 4 * NT - 1) / (4 * NT);   // rounds of 16-byte loads for the pair words
+    const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
+    double v_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        v_[r] = g < Ng ? P.vals[g] : 0.0;
+    }
+    uint4 p_[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int q4 = tid + r * NT;
+        p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
+    if (__builtin_amdgcn_readlane((int)ov, 34) == 0 || (uint32_t)(size_t)lds != 0u) return false;
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        if (g < Ng) ((uint4*)lds)[g] = make_uint4((uint32_t)__double2loint(v_[r]), (uint32_t)__double2hiint(v_[r]), (uint32_t)g, 0u);
+    }
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int q4 = tid + r * NT;
+        if (4 * q4 < P.plan_Kp) ((uint4*)(lds + pbase))[q4] = p_[r];
+    }
+    if (tid < 2) ((uint4*)lds)[Ng4 + tid] = make_uint4(0u, 0u, 0u, 0u);   // the dummy pair's slots: 0 - 0 > min_improve is false
+    const int ltail = lean_walk_tail(ov, nlev, lane);
+    __syncthreads();
+    if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
+    const bool bytes16 = P.lean_wide && P.lean_unit == 16;   // the pair words hold byte offsets of 16-byte slots; else halves of them
+    if (bytes16) lean_walk_levels<NT, 0, true>(nullptr, 0, pbase, ov, nlev, tid, ltail, P.mi_value);
+    else lean_walk_levels<NT, 1, true>(nullptr, 0, pbase, ov, nlev, tid, ltail, P.mi_value);
+    __syncthreads();   // (the narrow tail was wave 0's alone; the control waves of other tiles read now)
+    if (valid) {
+        const uint32_t meta = ((const uint4*)lds)[gc].z;
+        const uint32_t partner = bytes16 ? lean_partner<0, 4>(lds, pbase, meta, (uint32_t)gc) : lean_partner<1, 4>(lds, pbase, meta, (uint32_t)gc);
+        xr = (unsigned long long)(meta & 0xffffu) | ((unsigned long long)partner << 32);
+    }
+    __syncthreads();   // (from here on the tile's blocks may overwrite the pair list)
+    return true;
+}
+
 // The same walk with the level loop written for latency: a level is ONE LDS round trip (both 16-byte slots of a pair with a
 // ds_read_b128 each), the compare, the two 16-byte writes of a swap and the barrier; the next level's pair word is fetched
 // ahead; nothing else is in the loop (thresholds: a scalar when min_improve is uniform — the loop is instantiated twice).
@@ -786,10 +846,12 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         if (flags & F_WALK_INLINE) {
             // exchangeMoves! of iteration t-1, by all lanes of the tile, while the level-1 blocks are in flight
             // (the tile's own LDS blocks overlay the walk's pair list: nothing of the tile is written before this returns)
-            exchange_walk_tile<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, tile);
-            if (valid) {
-                const XSlot sv = ((const XSlot*)smem)[gc];
-                xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
+            if (!(P.gen_lean && exchange_walk_tile_lean<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, tile))) {
+                exchange_walk_tile<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, tile);
+                if (valid) {
+                    const XSlot sv = ((const XSlot*)smem)[gc];
+                    xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
+                }
             }
         }
         if (KIND == 1 && tid == 64) *S.arrived = 0u;

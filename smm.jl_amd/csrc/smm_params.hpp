@@ -67,6 +67,7 @@ struct KParams {
                                      //          [34] = 1 when the plan fits this form (at most 31 levels)
     int plan_Kp, lean_unit;          // words per iteration in lv_pairs_p; 8, or 4 when 8 * N_global does not fit 16 bits (smm_walk_lean.hpp)
     int dist_fun;                    // smm_dist_fun_t: the exchange test's distance (AlgoBGP.jl:537,688); the key / lean / rows walks are for 0 (-)
+    int gen_lean;                    // k_chain_iter: the inline walk on the lean form (exchange_walk_tile_lean)
     int lean_wide;                   // the lean walk's form for one min_improve > 0 (or NaN) shared by all chains: 16-byte slots, lean_unit 16 or 8
     // ... and for k_exch_resolve_rows (8192 < N_global <= 32768, min_improve == 0; null otherwise):
     const uint32_t* lv_rows;         // [W][rows_cap][1024]: level by level, every level padded to whole rows of 1024 words with dummy pairs; pi | pj << 16

@@ -32,6 +32,9 @@ __host__ __device__ inline int lean_walk_unit(int Ng) { return 8 * (((Ng + 3) & 
 __host__ __device__ inline size_t lean_wide_bytes(int Ng, int K) { return (size_t)(((Ng + 3) & ~3) + 1) * 16 + (size_t)lean_walk_Kp(K) * 4; }
 __host__ __device__ inline int lean_wide_unit(int Ng) { return 16 * (((Ng + 3) & ~3) + 1) <= 65536 ? 16 : 8; }    // KParams::lean_unit, wide form (8: up to 8188 chains)
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// k_chain_iter's inline walk on this form: 16-byte slots whatever the threshold, two zero-valued dummy slots (the plan may be the
+// key form's, whose dummy pair names two slots)
+__host__ __device__ inline size_t tile_lean_slot_bytes(int Ng) { return (size_t)(((Ng + 3) & ~3) + 2) * 16; }
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 // LDS byte offsets of the two slots of a pair word (US = 1: the word holds them halved, KParams::lean_unit == 4)

@@ -52,8 +52,8 @@ namespace {
 using namespace smm;
 
 #include "smm_params.hpp"
-#include "smm_chain.hpp"
 #include "smm_walk_lean.hpp"
+#include "smm_chain.hpp"
 #include "smm_chain_norm.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
@@ -175,6 +175,7 @@ struct Ctx {
     bool a2a_open = false;
     double* vals_buf[2] = {nullptr, nullptr};   // KParams::vals / vals_out, by iteration parity (point_values)
     uint2* slot8_buf[2] = {nullptr, nullptr};
+    bool gen_lean = false;       // k_chain_iter walks inline on the lean form (16-byte slots) when the plan fits it
     bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
@@ -248,7 +249,9 @@ size_t tile_smem(const Ctx* c, int ct, int tpw = 1) {   // dynamic LDS of k_chai
     if (c->norm_fast) return norm_smem(c);
     const size_t base = tile_smem_base(c, ct);           // walk its chain slots in front and its pair list under the tiles
     const size_t tiles = (size_t)tpw * ((base + 15) & ~(size_t)15);
-    return c->inline_walk ? walk_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)c->P.plan_K * 4) : tiles;
+    if (!c->inline_walk) return tiles;
+    return c->gen_lean ? tile_lean_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)lean_walk_Kp(c->P.plan_K) * 4)
+                       : walk_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)c->P.plan_K * 4);
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
@@ -777,6 +780,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                              (c->norm_fast ? walk_b + norm_tile_doubles(np) * 8 <= (size_t)160 * 1024
                                            : walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024);
             P.tile_off = c->inline_walk ? (int)((c->norm_fast ? walk_b : walk_slot_bytes(Ng)) / sizeof(double)) : 0;
+            // (the lean plan: the same conditions as further down, where its tables are allocated)
+            const char* kw0 = getenv("SMMHIP_KEY_WALK");
+            const bool lean_plan = P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && !(kw0 && kw0[0] == '0') &&
+                                   (P.mi_value == 0.0 || resolve_lean_bytes(Ng, K, true) <= (size_t)160 * 1024);
             // two tiles per workgroup share one walk (the 2p/2m-style simulation tile of 8 chains only)
             const char* tp = getenv("SMMHIP_TPW");
             int n_cu = 256;
@@ -786,6 +793,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             c->tpw = (c->inline_walk && !c->norm_fast && (is_sim(c->obj) ? c->ct == 8 : c->obj != SMM_OBJ_DENSE) && ((N + 7) / 8 > n_cu || force2) &&
                       !(tp && tp[0] == '1') &&
                       walk_slot_bytes(Ng) + std::max(2 * tile_b, (size_t)K * 4) <= (size_t)160 * 1024) ? 2 : 1;
+            // k_chain_iter on the lean walk (16-byte slots, padded pair list): where its somewhat larger LDS keeps the same budget
+            c->gen_lean = c->inline_walk && !c->norm_fast && lean_plan &&
+                          tile_lean_slot_bytes(Ng) + std::max((size_t)c->tpw * tile_b, (size_t)lean_walk_Kp(K) * 4) <= (size_t)(c->tpw == 2 ? 160 : 80) * 1024;
+            if (c->gen_lean) { P.tile_off = (int)(tile_lean_slot_bytes(Ng) / sizeof(double)); P.gen_lean = 1; }
         }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
             const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 : 0);
