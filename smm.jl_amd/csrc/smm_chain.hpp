@@ -751,7 +751,9 @@ __device__ inline void exchange_walk_fast(const KParams& P, const int tx, unsign
 // TPW tiles per workgroup (TPW = 2 with the inline exchange walk: the two tiles that would share a CU anyway
 // become one workgroup of 1024 lanes, so the CU runs ONE walk with twice the lanes instead of two copies
 // contending for its LDS; everything else is per tile, on the tile-local lane id).
-template <int KIND, int CT, int TPW = 1>
+// (IW: the inline exchange walk is compiled in — contexts that never walk inline, larger populations and shards, run the kernel
+// without it: the walk's code costs the latency-bound prologue registers and scalar spills even when it is never entered)
+template <int KIND, int CT, int TPW = 1, bool IW = true>
 __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, const int t, const double* __restrict__ rec_in,
                                                             double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             coop_fetch<CT, NI_CS>(v_cs, g_cs, CSW, r);
             coop_fetch<CT, NI_RB>(v_rb, g_rb, rbw, r);
         }
-        if (flags & F_WALK_INLINE) {
+        if (IW && (flags & F_WALK_INLINE)) {
             // exchangeMoves! of iteration t-1, by all lanes of the tile, while the level-1 blocks are in flight
             // (the tile's own LDS blocks overlay the walk's pair list: nothing of the tile is written before this returns)
             if (!(P.gen_lean && exchange_walk_tile_lean<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, tile))) {

@@ -305,11 +305,12 @@ void launch_chain_iter_ct(Ctx* c, int t, int flags) {
     const dim3 grid((tiles + TPW - 1) / TPW), block(slim ? 64 : WG * TPW);
     const double* rin = c->ext_rec_in ? c->ext_rec_in : (const double*)c->rec[c->cur];
     double* rout = c->ext_rec_out ? c->ext_rec_out : c->rec[c->cur ^ 1];
+    // (contexts that never walk inline run the kernel compiled without the walk)
+    auto kern = c->inline_walk ? k_chain_iter<KIND, CT, TPW, true> : k_chain_iter<KIND, CT, TPW, false>;
     if (c->kev0)   // profiling mode 2: begin/end of this dispatch as the command processor stamps them
-        hipExtLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, c->kev0, c->kev1, 0, P, t,
-                              rin, rout, flags);
+        hipExtLaunchKernelGGL(kern, grid, block, tile_smem(c, CT, TPW), c->stream, c->kev0, c->kev1, 0, P, t, rin, rout, flags);
     else
-        hipLaunchKernelGGL((k_chain_iter<KIND, CT, TPW>), grid, block, tile_smem(c, CT, TPW), c->stream, P, t, rin, rout, flags);
+        hipLaunchKernelGGL(kern, grid, block, tile_smem(c, CT, TPW), c->stream, P, t, rin, rout, flags);
 }
 
 template <int NP, bool WALK>
@@ -926,6 +927,9 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 8, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
