@@ -245,7 +245,10 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
 
 // (WIDE: the walk's form for one min_improve > 0 shared by all chains — a kernel of its own, k_chain_iter_norm_wide, so that
 // the registers of the min_improve == 0 kernel stay what they are)
-template <int NP, bool WALK, bool WIDE>
+// (LEAN: the walk is one of the lean forms and nothing else — the host launches k_chain_iter_norm_any where a plan of more
+// than 31 levels or a NaN value may turn up (injected pair lists, uploaded states; it knows both): with both walks in one
+// kernel the headline kernel spilled 8 scalar registers in its latency-bound prologue and took 0.3 us longer)
+template <int NP, bool WALK, bool WIDE, bool LEAN>
 __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int t, const double* __restrict__ rec_in,
                                                      double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -314,18 +317,22 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     uint32_t kmeta = 0u;   // lean walk: src | stamp << 16 of the chain's slot (the partner is looked up while the record is on its way)
     if constexpr (WALK) {
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
-        bool lean;
-        if constexpr (WIDE) lean = exchange_walk_lean_wide(P, t - 1, (unsigned char*)smem, tid, tile);
-        else lean = P.lv_pairs_p && exchange_walk_lean(P, t - 1, (unsigned char*)smem, tid, tile);
-        if (!lean) {
+        if constexpr (LEAN) {
+            bool lean;
+            if constexpr (WIDE) lean = exchange_walk_lean_wide(P, t - 1, (unsigned char*)smem, tid, tile);
+            else lean = exchange_walk_lean(P, t - 1, (unsigned char*)smem, tid, tile);
+            if (!lean) {   // (cannot happen: the host launches k_chain_iter_norm_any wherever it can; loud if it does)
+                if (tid == 0) report_error(P, 3, t, gc);
+            } else if (valid) {
+                kmeta = WIDE ? ((const uint4*)smem)[gc].z : ((const uint2*)smem)[gc].y;
+                xr = (unsigned long long)(kmeta & 0xffffu);
+            }
+        } else {
             exchange_walk_fast<NORM_WG, false>(P, t - 1, (unsigned char*)smem, tid, tile);
             if (valid) {
                 const XSlot sv = ((const XSlot*)smem)[gc];
                 xr = (unsigned long long)sv.src | ((unsigned long long)sv.partner << 32);
             }
-        } else if (valid) {
-            kmeta = WIDE ? ((const uint4*)smem)[gc].z : ((const uint2*)smem)[gc].y;
-            xr = (unsigned long long)(kmeta & 0xffffu);
         }
     }
     // This iteration's randomness, by wave 1 (lane = the control wave's lane: chain, try): it has nothing to do from here to the
@@ -373,7 +380,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
                 const double2* g_rec = (const double2*)(rec_in + (size_t)s * RW);
 #pragma unroll
                 for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc[2 * i] = q.x; rc[2 * i + 1] = q.y; }
-                if (WALK && (kmeta >> 16))   // set_exchanged!, :747-748: from the pair word the swap stamped into the slot
+                if (WALK && LEAN && (kmeta >> 16))   // set_exchanged!, :747-748: from the pair word the swap stamped into the slot
                     partner = !WIDE ? (int)lean_partner<0>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc)
                               : P.lean_unit == 16 ? (int)lean_partner<0, 4>((const unsigned char*)smem, 16u * ((uint32_t)((P.Ng + 3) & ~3) + 1u), kmeta, (uint32_t)gc)
                                                   : (int)lean_partner<1, 4>((const unsigned char*)smem, 16u * ((uint32_t)((P.Ng + 3) & ~3) + 1u), kmeta, (uint32_t)gc);
@@ -512,12 +519,18 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
 template <int NP, bool WALK>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P, const int t, const double* __restrict__ rec_in,
                                                                  double* __restrict__ rec_out, const int flags) {
-    chain_iter_norm_body<NP, WALK, false>(P, t, rec_in, rec_out, flags);
+    chain_iter_norm_body<NP, WALK, false, true>(P, t, rec_in, rec_out, flags);
 }
 template <int NP>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_wide(const KParams P, const int t, const double* __restrict__ rec_in,
                                                                       double* __restrict__ rec_out, const int flags) {
-    chain_iter_norm_body<NP, true, true>(P, t, rec_in, rec_out, flags);
+    chain_iter_norm_body<NP, true, true, true>(P, t, rec_in, rec_out, flags);
+}
+// the walk on 16-byte slots {value, src, partner} (exchange_walk_fast): any thresholds, any plan depth, NaN values
+template <int NP>
+__global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_any(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                     double* __restrict__ rec_out, const int flags) {
+    chain_iter_norm_body<NP, true, false, false>(P, t, rec_in, rec_out, flags);
 }
 
 // objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks

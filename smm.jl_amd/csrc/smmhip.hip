@@ -175,6 +175,8 @@ struct Ctx {
     bool a2a_open = false;
     double* vals_buf[2] = {nullptr, nullptr};   // KParams::vals / vals_out, by iteration parity (point_values)
     uint2* slot8_buf[2] = {nullptr, nullptr};
+    bool deep_plan = false;      // an injected pair list has an iteration of more than LV_MAXLEV dependency levels
+    bool nan_values = false;     // the uploaded state holds NaN values (smm_set_state)
     bool gen_lean = false;       // k_chain_iter walks inline on the lean form (16-byte slots) when the plan fits it
     bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
@@ -335,9 +337,32 @@ void launch_chain_iter_norm_wide_t(Ctx* c, int t, int flags) {
     else
         hipLaunchKernelGGL((k_chain_iter_norm_wide<NP>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
 }
+template <int NP>
+void launch_chain_iter_norm_any_t(Ctx* c, int t, int flags) {
+    const KParams& P = c->P;
+    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
+    const double* rin = c->ext_rec_in ? c->ext_rec_in : (const double*)c->rec[c->cur];
+    double* rout = c->ext_rec_out ? c->ext_rec_out : c->rec[c->cur ^ 1];
+    if (c->kev0)
+        hipExtLaunchKernelGGL((k_chain_iter_norm_any<NP>), grid, block, norm_smem(c), c->stream, c->kev0, c->kev1, 0, P, t, rin, rout, flags);
+    else
+        hipLaunchKernelGGL((k_chain_iter_norm_any<NP>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
+}
 void launch_chain_iter_norm(Ctx* c, int t, int flags) {
     const bool walk = (flags & F_WALK_INLINE) != 0;
-    if (walk && c->P.lean_wide && c->P.lv_pairs_p) {   // one min_improve > 0 for all chains: the walk on 16-byte slots
+    // the lean walks need a padded plan of at most 31 levels and values without NaN: where that is not given — per-chain or
+    // negative thresholds (no padded plan), an injected pair list that goes deeper, an uploaded state with NaN values — the
+    // kernel with the walk on 16-byte slots {value, src, partner} runs
+    if (walk && (!c->P.lv_pairs_p || c->deep_plan || c->nan_values)) {
+        switch (c->P.np) {
+            case 1: launch_chain_iter_norm_any_t<1>(c, t, flags); break;
+            case 2: launch_chain_iter_norm_any_t<2>(c, t, flags); break;
+            case 3: launch_chain_iter_norm_any_t<3>(c, t, flags); break;
+            default: launch_chain_iter_norm_any_t<4>(c, t, flags); break;
+        }
+        return;
+    }
+    if (walk && c->P.lean_wide) {   // one min_improve > 0 for all chains: the lean walk on 16-byte slots
         switch (c->P.np) {
             case 1: launch_chain_iter_norm_wide_t<1>(c, t, flags); break;
             case 2: launch_chain_iter_norm_wide_t<2>(c, t, flags); break;
@@ -484,7 +509,7 @@ int check_device_error(Ctx* c) {
     char b[256];
     int rc;
     if (kind == 3) {
-        snprintf(b, sizeof b, "internal error: exchange resolution did not converge (iteration %d)", it);
+        snprintf(b, sizeof b, "internal error: the exchange of iteration %d could not be resolved in the form chosen for it", it);
         rc = SMM_ERR_HIP;
     } else if (kind == 0) {
         snprintf(b, sizeof b, "values form of the sharded exchange: more than %d records between one pair of ranks (chain %d, iteration %d): "
@@ -747,6 +772,18 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         if (tab && tab->pairs && tab->n_pairs > 0) {
             P.n_pairs_tab = tab->n_pairs;
             P.pairtab = dupload(c, tab->pairs, (size_t)T * tab->n_pairs * 2);
+            {   // dependency depth of the injected lists (pairs sharing a chain keep their order): the lean walks hold LV_MAXLEV levels
+                std::vector<int> last((size_t)Ng);
+                for (int it = 0; it < T && !c->deep_plan; ++it) {
+                    std::fill(last.begin(), last.end(), 0);
+                    for (int q = 0; q < tab->n_pairs; ++q) {
+                        const int32_t i = tab->pairs[2 * ((size_t)it * tab->n_pairs + q)], j = tab->pairs[2 * ((size_t)it * tab->n_pairs + q) + 1];
+                        const int lv = std::max(last[i], last[j]) + 1;
+                        last[i] = last[j] = lv;
+                        if (lv > LV_MAXLEV) { c->deep_plan = true; break; }
+                    }
+                }
+            }
         }
         P.RW = even_up(3 + np + nm);
         P.HW = even_up(H_PARAMS + np + nm);
@@ -942,6 +979,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -1433,6 +1474,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         const size_t N = P.N, RW = P.RW, HW = P.HW, np = P.np, nm = P.nm;
         std::vector<double> cs(N * CSW), rec(N * RW, 0.0);
         HIPCHK(hipMemcpy(cs.data(), P.cs, cs.size() * 8, hipMemcpyDeviceToHost));  // keeps acc_tuner
+        bool nan_seen = false;   // (NaN orders under no key: the lean walks are not launched from such a state, launch_chain_iter_norm)
         for (size_t i = 0; i < N; ++i) {
             double* b = cs.data() + i * CSW;
             double* r = rec.data() + i * RW;
@@ -1442,9 +1484,11 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
             b[CS_BEST] = s->best_val[i]; b[CS_BESTID] = (double)s->best_id[i];
             b[CS_BESTP] = s->best_val[i]; b[CS_BESTPID] = (double)s->best_id[i];
             r[0] = s->la_value[i]; r[1] = s->la_prob[i]; r[2] = (double)s->la_status[i];
+            if (s->la_value[i] != s->la_value[i]) nan_seen = true;
             for (size_t k = 0; k < np; ++k) r[3 + k] = s->la_params[k * N + i];
             for (size_t k = 0; k < nm; ++k) r[3 + np + k] = s->la_sim_moments[k * N + i];
         }
+        c->nan_values = nan_seen;
         HIPCHK(hipMemcpy(P.cs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->rec[c->cur], rec.data(), rec.size() * 8, hipMemcpyHostToDevice));
         std::vector<double> row(N * HW, 0.0);
