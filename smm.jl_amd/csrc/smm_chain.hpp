@@ -751,6 +751,10 @@ __device__ inline void exchange_walk_fast(const KParams& P, const int tx, unsign
 // TPW tiles per workgroup (TPW = 2 with the inline exchange walk: the two tiles that would share a CU anyway
 // become one workgroup of 1024 lanes, so the CU runs ONE walk with twice the lanes instead of two copies
 // contending for its LDS; everything else is per tile, on the tile-local lane id).
+// proposal batches of at least this many components are drawn a lane per component pair (below: a lane per try walks them)
+#ifndef SMM_COOP_MIN_BATCH
+#define SMM_COOP_MIN_BATCH 6
+#endif
 // (IW: the inline exchange walk is compiled in — contexts that never walk inline, larger populations and shards, run the kernel
 // without it: the walk's code costs the latency-bound prologue registers and scalar spills even when it is never entered)
 template <int KIND, int CT, int TPW = 1, bool IW = true>
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             // 64 * waves / CT lanes of ONE wave, a lane by the component pairs q = sl, sl + LPC, ... (one generator call per pair
             // and try).  The tries are taken in order, each one tested by all the chain's lanes at once (a segment of the
             // wave's ballot); the first one inside the unit box wins: same tries, same order, same winner as the serial form.
-            const bool coop = bs >= 16 && !P.chol_L;   // (uniform)
+            const bool coop = bs >= SMM_COOP_MIN_BATCH && !P.chol_L;   // (uniform)
             if (coop) {
                 __syncthreads();   // the blocks the control wave staged (records, state, randomness) are every wave's now
                 const int nwv = (int)blockDim.x / (64 * TPW);   // (one wave per tile in the slim launch)
