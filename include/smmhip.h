@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMMHIP_ABI_VERSION 2
+#define SMMHIP_ABI_VERSION 3
 
 /* Numerical contract shared with the oracle (oracle/smm_oracle.c):
  * the ns simulated draws of one moment are summed as SMM_REDUCE_LANES lane-strided
@@ -272,6 +272,27 @@ int  smm_bgp_a2a_apply_dev(void* ctx, const void* recv_dev);
  *        the context; required before smm_get_history / smm_get_state / the three-phase calls. */
 int  smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathered_next_dev);
 int  smm_bgp_sharded_finish(void* ctx, const void* gathered_dev);
+/* The p2p form of the sharded iteration: NO collective call at all.  The xGMI fabric of an MI355X node is point-to-point, so
+ * the all-gather of the last-accepted records is done by the chains' accept step itself: every rank owns a WINDOW of device
+ * memory that all other ranks map (HIP IPC between processes; plain device pointers between contexts of one process), a
+ * chain's accept step stores its record, value and walk slot into every rank's window and counts itself in with one atomic
+ * per tile; the next iteration's kernel waits on the counters of its own window.  An iteration of a shard is ONE launch
+ * (objfunc_norm, np == nm <= 4, min_improve == 0, N_global <= 8192; else chain kernel + push kernel + resolve kernel) and the
+ * host enqueues nothing else.  Same results as every other form (bit-identical to the single shard).
+ *   smm_bgp_p2p_init(ctx, handle_out, window_out): allocates this rank's window (rank = chain_offset / N, equal shards, at most
+ *        8 ranks); handle_out (SMM_P2P_HANDLE_BYTES bytes, may be NULL) receives its hipIpcMemHandle_t for the other
+ *        PROCESSES, window_out (may be NULL) its device pointer for other contexts of THIS process.
+ *   smm_bgp_p2p_attach(ctx, rank, handle, window): rank's window, by IPC handle or by device pointer (exactly one non-NULL).
+ *   smm_bgp_p2p_step(ctx, n): enqueues n iterations and returns (smm_sync waits).  All ranks call it with the same n, in the
+ *        same order relative to each other's p2p calls (the arrival counters count pushes).  A rank whose peers never arrive
+ *        gives up after ~4 s per launch and reports SMM_ERR_HIP at the next smm_sync.
+ *   smm_bgp_p2p_finish(ctx): settles the last iteration into the context (required before smm_get_history / smm_get_state /
+ *        the other stepping forms).  Callers must not destroy a context while a peer may still be stepping. */
+#define SMM_P2P_HANDLE_BYTES 64
+int  smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out);
+int  smm_bgp_p2p_attach(void* ctx, int32_t rank, const void* ipc_handle, void* window_dev);
+int  smm_bgp_p2p_step(void* ctx, int32_t n_iters);
+int  smm_bgp_p2p_finish(void* ctx);
 /* the HIP stream all of the ctx's work is enqueued on (hipStream_t as void*) */
 void* smm_stream(void* ctx);
 

@@ -18,7 +18,7 @@ export HipBGP, hip_create, hip_destroy!, hip_step!, hip_iter, hip_history, hip_s
 export hip_eval_batch_noseed, hip_stream, hip_sync, hip_local_step!, hip_export_records!, hip_exchange!, hip_sharded_step!, hip_sharded_finish!,
        hip_a2a_capacity, hip_export_values!, hip_a2a_pack!, hip_a2a_apply!, hip_record_doubles
 
-const ABI_VERSION = 2
+const ABI_VERSION = 3
 const LIB = Ref{Ptr{Cvoid}}(C_NULL)
 
 "path of the library: ENV[\"SMMHIP_LIBRARY\"] or the in-tree build"

@@ -38,6 +38,7 @@ SMM_OBJ_USER_BASE = 1000   # objective ids >= this are handles of smm_register_u
 SMM_DENSE_D = 256
 
 SMM_REDUCE_LANES = 512
+SMM_P2P_HANDLE_BYTES = 64
 
 
 class smm_problem_t(C.Structure):
@@ -121,6 +122,10 @@ SYMBOLS = [
     ("smm_bgp_a2a_apply_dev", C.c_int, [C.c_void_p, C.c_void_p]),
     ("smm_bgp_sharded_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("smm_bgp_sharded_finish", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("smm_bgp_p2p_init", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("smm_bgp_p2p_attach", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    ("smm_bgp_p2p_step", C.c_int, [C.c_void_p, C.c_int32]),
+    ("smm_bgp_p2p_finish", C.c_int, [C.c_void_p]),
     ("smm_stream", C.c_void_p, [C.c_void_p]),
     ("smm_eval_batch", C.c_int, [C.c_void_p, c_double_p, C.c_int32, c_double_p, c_double_p, c_int8_p]),
     ("smm_eval_batch_noseed", C.c_int, [C.c_void_p, c_double_p, C.c_int32, C.c_uint64, c_double_p, c_double_p, c_int8_p]),
@@ -162,7 +167,7 @@ def load():
                 "libsmmhip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
         _lib = bind(C.CDLL(path, mode=C.RTLD_GLOBAL))
-        if _lib.smm_abi_version() != 2:
+        if _lib.smm_abi_version() != 3:
             raise ImportError("libsmmhip.so ABI version mismatch")
     return _lib
 

@@ -170,6 +170,25 @@ class BGPContext:
     def sharded_finish(self, ptr):
         self._check(self._fn("bgp_sharded_finish")(self._ctx, C.c_void_p(ptr or 0)))
 
+    # the p2p form of the sharded iteration (include/smmhip.h): windows mapped by every rank, no collective
+    def p2p_init(self):
+        """allocate this rank's window; returns (ipc handle bytes, device pointer)"""
+        h = C.create_string_buffer(A.SMM_P2P_HANDLE_BYTES)
+        w = C.c_void_p()
+        self._check(self._fn("bgp_p2p_init")(self._ctx, h, C.byref(w)))
+        return bytes(h.raw), int(w.value)
+
+    def p2p_attach(self, rank, handle=None, window=None):
+        """rank's window: by IPC handle (another process) or device pointer (a context of this process)"""
+        hb = C.create_string_buffer(handle, A.SMM_P2P_HANDLE_BYTES) if handle is not None else None
+        self._check(self._fn("bgp_p2p_attach")(self._ctx, int(rank), hb, C.c_void_p(window) if window is not None else None))
+
+    def p2p_step(self, n_iters=1):
+        self._check(self._fn("bgp_p2p_step")(self._ctx, int(n_iters)))
+
+    def p2p_finish(self):
+        self._check(self._fn("bgp_p2p_finish")(self._ctx))
+
     def stream(self):
         return self._fn("stream")(self._ctx)
 

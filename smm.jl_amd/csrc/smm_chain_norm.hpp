@@ -239,7 +239,61 @@ __device__ inline bool exchange_walk_lean_wide(const KParams& P, const int tx, u
     return true;
 }
 
-template <int NP>
+// the lean walk of a SHARD (the p2p form, smm_p2p.hpp): the slots of all N_global <= 8192 chains come from this rank's window,
+// where every rank's accept step of iteration tx stored them; the plan is requested first (it does not depend on the other ranks),
+// then every wave waits for the arrivals of iteration tx.  false: timed out, the plan does not fit the form, or a NaN value.
+__device__ inline bool exchange_walk_lean_p2p(const KParams& P, const P2PLayout& PL, const int tx, unsigned char* lds, const int tid, const int ts_tile) {
+    constexpr int NT = NORM_WG;
+    constexpr int SR = XLDS_MAX / (4 * NT);                                       // rounds of four slots per lane
+    constexpr int PR = (XLDS_MAX + 64 * LV_MAXLEV + 4 * NT - 1) / (4 * NT);        // rounds of four pair words per lane
+    const int Ng = P.Ng;
+    const int w = tx - P.plan_t0;
+    const uint32_t* __restrict__ g_offp = P.lv_offp + (size_t)w * LV_OFFP;
+    const uint4* __restrict__ g_pairs = (const uint4*)(P.lv_pairs_p + (size_t)w * P.plan_Kp);
+    const int lane = tid & 63;
+    const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
+    const uint32_t pbase = 8u * (Ng4 + 4u);   // LDS offset of the pair words
+    const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
+    uint4 p_[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int q4 = tid + r * NT;
+        p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const bool arrived = p2p_wait_arrivals(P, lane);
+    const unsigned char* mine = P.p2p_self;
+    const uint4* g_slots = (const uint4*)(mine + PL.slot_at(tx & 1));
+    const uint32_t wflags = *(const uint32_t*)(mine + PL.nan + 0 * (size_t)(tid & 1));
+    uint4 s_[2 * SR];
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+        const int q = tid + r * NT;
+        s_[2 * r] = make_uint4(0u, 0u, 0u, 0u); s_[2 * r + 1] = s_[2 * r];
+        if (4 * q < Ng) { s_[2 * r] = g_slots[2 * q]; s_[2 * r + 1] = g_slots[2 * q + 1]; }
+    }
+    const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
+    if (!arrived || __builtin_amdgcn_readlane((int)ov, 34) == 0 || __builtin_amdgcn_readfirstlane((int)wflags) != 0 || (uint32_t)(size_t)lds != 0u) return false;
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+        const int q = tid + r * NT;
+        if (4 * q < Ng) { ((uint4*)lds)[2 * q] = s_[2 * r]; ((uint4*)lds)[2 * q + 1] = s_[2 * r + 1]; }
+    }
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int q4 = tid + r * NT;
+        if (4 * q4 < P.plan_Kp) ((uint4*)(lds + pbase))[q4] = p_[r];
+    }
+    if (tid == 0) ((uint4*)lds)[2 * (Ng4 / 4)] = make_uint4(1u, 0u, 2u, 0u);   // the two dummy slots: keys 1 < 2, "no swap"
+    const int ltail = lean_walk_tail(ov, nlev, lane);
+    __syncthreads();
+    if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
+    const double* vals = (const double*)(mine + PL.val_at(tx & 1));
+    if (P.lean_unit == 8) lean_walk_levels<NORM_WG, 0>(vals, 1, pbase, ov, nlev, tid, ltail);
+    else lean_walk_levels<NORM_WG, 1>(vals, 1, pbase, ov, nlev, tid, ltail);
+    return true;
+}
+
+template <int NP, bool P2P>
 __device__ inline void epilogue_norm(const KParams& P, const int t, double* __restrict__ rec_out, const double* s_theta, const double* s_part,
                                      const double* s_park, const int tile, const int tid);
 
@@ -248,8 +302,10 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
 // (LEAN: the walk is one of the lean forms and nothing else — the host launches k_chain_iter_norm_any where a plan of more
 // than 31 levels or a NaN value may turn up (injected pair lists, uploaded states; it knows both): with both walks in one
 // kernel the headline kernel spilled 8 scalar registers in its latency-bound prologue and took 0.3 us longer)
-template <int NP, bool WALK, bool WIDE, bool LEAN>
-__device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int t, const double* __restrict__ rec_in,
+// (P2P: a shard of the p2p form, smm_p2p.hpp — records, values and walk slots of ALL chains live in this rank's window, the accept
+// step stores its results into every rank's window and arrives; WALK then means "when the launch says so", F_WALK_INLINE)
+template <int NP, bool WALK, bool WIDE, bool LEAN, bool P2P = false>
+__device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int t, const double* __restrict__ rec_in_arg,
                                                      double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     using L = NormLayout<NP>;
@@ -273,6 +329,10 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     const bool valid = ctl && c < N;
     const int gc = P.offset + c;
     const int goff = (flags & F_GLOBAL_REC) ? 0 : P.offset;   // rec_in indexed by global chain id (all-gathered buffer)?
+    P2PLayout PL{};
+    if constexpr (P2P) PL = p2p_layout(P.Ng, RW);
+    const double* __restrict__ rec_in = P2P ? (const double*)(P.p2p_self + PL.rec_at((t - 1) & 1)) : rec_in_arg;
+    const bool walk_now = WALK && (!P2P || (flags & F_WALK_INLINE));
     TS_MARK(0);
 
     // ---- global reads that do not depend on the exchange, all issued before anything waits ----
@@ -307,19 +367,20 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
                 if (NORM_NR + r < P.rb_tries) zB[k] = g_rb[1 + (NORM_NR + r) * NP + k];
             }
         }
-        if (!WALK && (flags & F_HAS_PENDING)) xr = P.xres[gc];
+        if (!walk_now && (flags & F_HAS_PENDING)) xr = P.xres[gc];
     }
     // (LDS survives from workgroup to workgroup: the hand-over flags are reset before anybody can look at them — the walk's first
     // barrier, or the one below, orders the reset)
     if (tid == 64) { *s_arrived = 0u; *s_rng_ready = 0u; }
-    if constexpr (!WALK) __syncthreads();
+    if (!walk_now) __syncthreads();
 
     uint32_t kmeta = 0u;   // lean walk: src | stamp << 16 of the chain's slot (the partner is looked up while the record is on its way)
-    if constexpr (WALK) {
+    if (walk_now) {
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
         if constexpr (LEAN) {
             bool lean;
-            if constexpr (WIDE) lean = exchange_walk_lean_wide(P, t - 1, (unsigned char*)smem, tid, tile);
+            if constexpr (P2P) lean = exchange_walk_lean_p2p(P, PL, t - 1, (unsigned char*)smem, tid, tile);
+            else if constexpr (WIDE) lean = exchange_walk_lean_wide(P, t - 1, (unsigned char*)smem, tid, tile);
             else lean = exchange_walk_lean(P, t - 1, (unsigned char*)smem, tid, tile);
             if (!lean) {   // (cannot happen: the host launches k_chain_iter_norm_any wherever it can; loud if it does)
                 if (tid == 0) report_error(P, 3, t, gc);
@@ -381,7 +442,8 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
 #pragma unroll
                 for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc[2 * i] = q.x; rc[2 * i + 1] = q.y; }
                 if (WALK && LEAN && (kmeta >> 16))   // set_exchanged!, :747-748: from the pair word the swap stamped into the slot
-                    partner = !WIDE ? (int)lean_partner<0>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc)
+                    partner = (P2P && P.lean_unit != 8) ? (int)lean_partner<1>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc)
+                              : !WIDE ? (int)lean_partner<0>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc)
                               : P.lean_unit == 16 ? (int)lean_partner<0, 4>((const unsigned char*)smem, 16u * ((uint32_t)((P.Ng + 3) & ~3) + 1u), kmeta, (uint32_t)gc)
                                                   : (int)lean_partner<1, 4>((const unsigned char*)smem, 16u * ((uint32_t)((P.Ng + 3) & ~3) + 1u), kmeta, (uint32_t)gc);
             } else {
@@ -514,7 +576,8 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     }
     if (P.ts && tid2 == 0) P.ts[(size_t)tile * 8 + 3] = wall_clock64();
     // Epilogue by the control wave: everything it needs comes from LDS (parked by the prologue)
-    epilogue_norm<NP>(P, t, rec_out, s_theta, s_part, s_park, tile, tid2);
+    epilogue_norm<NP, P2P>(P, t, rec_out, s_theta, s_part, s_park, tile, tid2);
+    if constexpr (P2P) p2p_arrive(P, tid2 & 63);   // (every lane of the control wave is back here, whatever its chain did)
 }
 template <int NP, bool WALK>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P, const int t, const double* __restrict__ rec_in,
@@ -533,8 +596,15 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_any(const KParam
     chain_iter_norm_body<NP, true, false, false>(P, t, rec_in, rec_out, flags);
 }
 
-// objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks
+// a shard of the p2p form: the lean key walk inline when the launch says so (N_global <= 8192), results into every rank's window
 template <int NP>
+__global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_p2p(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                     double* __restrict__ rec_out, const int flags) {
+    chain_iter_norm_body<NP, true, false, true, true>(P, t, rec_in, rec_out, flags);
+}
+
+// objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks
+template <int NP, bool P2P>
 __device__ inline void epilogue_norm(const KParams& P, const int t, double* __restrict__ rec_out, const double* s_theta,
                                      const double* s_part, const double* s_park, const int tile, const int tid) {
     using L = NormLayout<NP>;
@@ -612,12 +682,26 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
         if (value < bp) { bestv = value; bestid = (double)t; }
         else { bestv = bp; bestid = bpid; }
     }
+    P2PLayout PL{};
+    if constexpr (P2P) PL = p2p_layout(P.Ng, RW);
+    const int pb = t & 1;
     if (r == 0) {
         const double v = acc ? value : old;
-        P.vals_out[c] = v;
-        if (P.slot8_out) {   // the chain's slot at the start of the next exchange walk (exchange_walk_lean)
-            P.slot8_out[c] = make_uint2(order_key32(v), (uint32_t)gc);
-            if (v != v) atomicOr(P.walk_flags, 1u);
+        if constexpr (P2P) {   // value and walk slot into every rank's window (its own included)
+#pragma unroll
+            for (int p = 0; p < P2P_MAXG; ++p)
+                if (p < P.p2p_G) {
+                    unsigned char* w = P.p2p_win[p];
+                    ((double*)(w + PL.val_at(pb)))[gc] = v;
+                    ((uint2*)(w + PL.slot_at(pb)))[gc] = make_uint2(order_key32(v), (uint32_t)gc);
+                    if (v != v) __hip_atomic_fetch_or((uint32_t*)(w + PL.nan), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+        } else {
+            P.vals_out[c] = v;
+            if (P.slot8_out) {   // the chain's slot at the start of the next exchange walk (exchange_walk_lean)
+                P.slot8_out[c] = make_uint2(order_key32(v), (uint32_t)gc);
+                if (v != v) atomicOr(P.walk_flags, 1u);
+            }
         }
     }
     // ---- result blocks, straight from registers: lane r of the quad stores the 16-byte pieces r, r+4, ... ----
@@ -632,13 +716,18 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
 #pragma unroll
         for (int k = 0; k < NP; ++k) { nr[3 + k] = acc ? th[k] : rc[3 + k]; nr[3 + NP + k] = acc ? sm[k] : rc[3 + NP + k]; }
         if (RW > 3 + 2 * NP) nr[RW - 1] = 0.0;
-        double2* g_ro = (double2*)(rec_out + (size_t)c * RW);
 #pragma unroll
         for (int j = 0; 4 * j < NPC; ++j) {
             const int i = 4 * j + r;
             const double2 v = sel4(r, make_double2(nr[8 * j], nr[8 * j + 1]), make_double2(nr[(8 * j + 2) % RW], nr[(8 * j + 3) % RW]),
                                    make_double2(nr[(8 * j + 4) % RW], nr[(8 * j + 5) % RW]), make_double2(nr[(8 * j + 6) % RW], nr[(8 * j + 7) % RW]));
-            if (i < NPC) g_ro[i] = v;
+            if constexpr (P2P) {   // into every rank's window, global chain order
+#pragma unroll
+                for (int p = 0; p < P2P_MAXG; ++p)
+                    if (p < P.p2p_G && i < NPC) ((double2*)(P.p2p_win[p] + PL.rec_at(pb)) + (size_t)gc * NPC)[i] = v;
+            } else {
+                if (i < NPC) ((double2*)(rec_out + (size_t)c * RW))[i] = v;
+            }
         }
         double hv[HW];
         hv[H_VALUE] = value; hv[H_PROB] = prob; hv[H_CURR] = currv; hv[H_BEST] = bestv; hv[H_BESTID] = bestid;

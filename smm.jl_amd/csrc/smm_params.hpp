@@ -6,6 +6,7 @@ constexpr int MAX_DIM = 64;           // np, nm <= 64
 constexpr int XWG = 1024;             // exchange workgroup
 constexpr int XLDS_MAX = 8192;        // largest N_global resolved in LDS (16 B per chain)
 constexpr unsigned XSPIN_LIMIT = 1u << 22;
+constexpr int P2P_MAXG = 8;           // ranks of the p2p sharded form (one node: 8 GPUs)
 
 // chain state block
 constexpr int CSW = 16;
@@ -96,6 +97,12 @@ struct KParams {
     int dbg;                 // SMMHIP_DBG timing experiments (results invalid when != 0)
     unsigned long long* ts;  // SMMHIP_TS=1: per-workgroup phase timestamps of k_chain_iter (tools/)
     int ts_levels;           // SMMHIP_TS=2: and one per level of the inline exchange walk
+    // the p2p form of the sharded iteration (smm_p2p.hpp): every rank's window (this rank's own at index p2p_rank), mapped through
+    // HIP IPC or, for contexts of one process, plain device pointers
+    unsigned char* p2p_win[P2P_MAXG];
+    unsigned char* p2p_self;       // == p2p_win[p2p_rank] (a member of its own: no dynamic index into the kernel arguments)
+    int p2p_G, p2p_rank;
+    unsigned long long p2p_want;   // arrivals per source rank this launch waits for before it reads its window
 };
 
 // Order keys are computed from the HIGH WORD of the value (sign, exponent, 20 mantissa bits): for finite values >= 0 it is a

@@ -54,6 +54,7 @@ using namespace smm;
 #include "smm_params.hpp"
 #include "smm_walk_lean.hpp"
 #include "smm_chain.hpp"
+#include "smm_p2p.hpp"
 #include "smm_chain_norm.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
@@ -203,6 +204,15 @@ struct Ctx {
     int ct = 8;
     bool norm_fast = false;     // objfunc_norm with np == nm <= 4 and one proposal batch: k_chain_iter_norm (16-chain tiles)
     int failed = 0;             // a hard device error (AlgoBGP.jl:341,409) stopped the run at iteration `iter`: sticky until smm_set_state
+    // the p2p form of the sharded iteration (smm_p2p.hpp)
+    unsigned char* p2p_mine = nullptr;         // this rank's window (null: smm_bgp_p2p_init not called)
+    void* p2p_opened[P2P_MAXG] = {};           // peers' windows opened through HIP IPC (closed with the context)
+    unsigned p2p_attached = 0;                 // bit r: rank r's window is known
+    unsigned long long p2p_seq = 0;            // pushes so far (every rank counts the same)
+    bool p2p_current = false;                  // the windows hold the records after iteration `iter`
+    bool p2p_inline = false;                   // k_chain_iter_norm_p2p walks inline and pushes from its epilogue
+    bool p2p_unwaited = false;                 // nobody has waited for the arrivals of the last push yet
+    double* ext_vals_out = nullptr;            // p2p generic form: the accept step's values go into the window
 };
 
 #define HIPCHK(call)                                                                                  \
@@ -398,6 +408,7 @@ void launch_user_kernel(Ctx* c, const double* theta, int n, double* simM, double
 
 void launch_chain_iter(Ctx* c, int t, int flags) {
     point_values(c, c->P, t - 1, t);   // the inline walk reads what the accept step of t-1 wrote; this accept step writes the other array
+    if (c->ext_vals_out) { c->P.vals_out = c->ext_vals_out; c->P.slot8_out = nullptr; }
     if (c->obj == SMM_OBJ_USER) {
         // proposal launch (stores nothing but the proposals) -> the user's kernel -> accept launch (repeats the
         // deterministic prologue, takes value / moments / status from the user's kernel)
@@ -552,6 +563,52 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
+
+// ---- the p2p form of the sharded iteration (smm_p2p.hpp, include/smmhip.h) ----
+template <int NP>
+void launch_chain_iter_norm_p2p_t(Ctx* c, const KParams& P, int t, int flags, size_t smem) {
+    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
+    if (c->kev0)
+        hipExtLaunchKernelGGL((k_chain_iter_norm_p2p<NP>), grid, block, smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (double*)nullptr, flags);
+    else
+        hipLaunchKernelGGL((k_chain_iter_norm_p2p<NP>), grid, block, smem, c->stream, P, t, (const double*)nullptr, (double*)nullptr, flags);
+}
+size_t p2p_walk_bytes(const Ctx* c) { return (lean_walk_bytes(c->P.Ng, c->P.plan_K) + 15) & ~(size_t)15; }
+void launch_chain_iter_norm_p2p(Ctx* c, int t, int flags) {
+    KParams P = c->P;
+    point_values(c, P, t - 1, t);
+    const bool walk = (flags & F_WALK_INLINE) != 0;
+    P.tile_off = walk ? (int)(p2p_walk_bytes(c) / sizeof(double)) : 0;
+    P.p2p_want = (unsigned long long)p2p_units(P.N) * c->p2p_seq;
+    const size_t smem = (size_t)P.tile_off * sizeof(double) + norm_tile_doubles(P.np) * sizeof(double);
+    switch (P.np) {
+        case 1: launch_chain_iter_norm_p2p_t<1>(c, P, t, flags, smem); break;
+        case 2: launch_chain_iter_norm_p2p_t<2>(c, P, t, flags, smem); break;
+        case 3: launch_chain_iter_norm_p2p_t<3>(c, P, t, flags, smem); break;
+        default: launch_chain_iter_norm_p2p_t<4>(c, P, t, flags, smem); break;
+    }
+}
+// this rank's slice of parity b -> every rank's window; FROM_CTX: out of the context's own record array
+void launch_p2p_push(Ctx* c, int b, const double* rec_src) {
+    KParams P = c->P;
+    if (rec_src) hipLaunchKernelGGL(k_p2p_push<true>, dim3(p2p_units(P.N)), dim3(256), 0, c->stream, P, b, rec_src);
+    else hipLaunchKernelGGL(k_p2p_push<false>, dim3(p2p_units(P.N)), dim3(256), 0, c->stream, P, b, (const double*)nullptr);
+    c->p2p_seq += 1;
+    c->p2p_unwaited = true;
+}
+void launch_p2p_wait(Ctx* c) {
+    KParams P = c->P;
+    P.p2p_want = (unsigned long long)p2p_units(P.N) * c->p2p_seq;
+    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, c->stream, P);
+    c->p2p_unwaited = false;
+}
+// exchangeMoves! of iteration t from the values in this rank's window (complete: somebody has waited for the arrivals)
+void launch_resolve_window(Ctx* c, int t) {
+    const P2PLayout L = p2p_layout(c->P.Ng, c->P.RW);
+    KParams P1 = c->P;
+    P1.RW = 1;   // (the resolve kernels read value s at gathered[s * RW])
+    launch_resolve_p(c, P1, t, (const double*)(c->p2p_mine + L.val[t & 1]));
+}
 }  // namespace
 
 extern "C" {
@@ -619,6 +676,8 @@ void smm_ctx_destroy(void* ctx) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
+    for (void* w : c->p2p_opened) if (w) (void)hipIpcCloseMemHandle(w);
+    if (c->p2p_mine) (void)hipFree(c->p2p_mine);
     if (c->umod) (void)hipModuleUnload(c->umod);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -983,6 +1042,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -1188,6 +1251,185 @@ int smm_bgp_sharded_finish(void* ctx, const void* gathered_dev) {
         HIPCHK(hipGetLastError());
         c->cur ^= 1;
         c->pending = false; c->prev_open = false; c->rec_external = false; c->pending_ext = false;
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
+int smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return SMM_ERR_INVALID_ARG;
+    if (c->a2a_G < 1) return fail(c, SMM_ERR_STATE, "the p2p form needs equal shards (N_global a multiple of N, chain_offset a multiple of N)");
+    if (c->a2a_G > P2P_MAXG) return fail(c, SMM_ERR_INVALID_ARG, "the p2p form serves up to 8 ranks (one node)");
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        KParams& P = c->P;
+        const P2PLayout L = p2p_layout(P.Ng, P.RW);
+        if (!c->p2p_mine) {
+            // uncached device memory: what peers store is never served from a stale line of this device's caches, and what this
+            // device stores goes to memory (IPC-exportable like any device allocation)
+            void* w = nullptr;
+            HIPCHK(hipExtMallocWithFlags(&w, L.total, hipDeviceMallocUncached));
+            c->p2p_mine = (unsigned char*)w;
+            HIPCHK(hipMemset(w, 0, L.total));
+            HIPCHK(hipDeviceSynchronize());
+            P.p2p_G = c->a2a_G;
+            P.p2p_rank = P.offset / P.N;
+            for (int r = 0; r < P2P_MAXG; ++r) P.p2p_win[r] = nullptr;
+            P.p2p_win[P.p2p_rank] = c->p2p_mine;
+            P.p2p_self = c->p2p_mine;
+            c->p2p_attached = 1u << P.p2p_rank;
+            c->p2p_seq = 0;
+            c->p2p_current = false;
+            // one launch per iteration (the lean key walk in the chain kernel's prologue, the push in its epilogue) where the
+            // single shard has it too: objfunc_norm with np == nm <= 4, min_improve == 0, N_global <= 8192
+            c->p2p_inline = c->norm_fast && c->win_lv_pairs_p && !P.lean_wide && P.Ng <= XLDS_MAX && P.plan_K <= XLDS_MAX && !c->deep_plan &&
+                            P.dist_fun == SMM_DIST_MINUS && p2p_walk_bytes(c) + norm_tile_doubles(P.np) * 8 <= (size_t)160 * 1024;
+        }
+        if (ipc_handle_out) {
+            hipIpcMemHandle_t h;
+            HIPCHK(hipIpcGetMemHandle(&h, c->p2p_mine));
+            static_assert(sizeof(hipIpcMemHandle_t) == SMM_P2P_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+            memcpy(ipc_handle_out, &h, sizeof h);
+        }
+        if (window_dev_out) *window_dev_out = c->p2p_mine;
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
+int smm_bgp_p2p_attach(void* ctx, int32_t rank, const void* ipc_handle, void* window_dev) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || (!ipc_handle) == (!window_dev)) return SMM_ERR_INVALID_ARG;
+    if (!c->p2p_mine) return fail(c, SMM_ERR_STATE, "smm_bgp_p2p_init comes first");
+    if (rank < 0 || rank >= c->P.p2p_G || rank == c->P.p2p_rank) return fail(c, SMM_ERR_INVALID_ARG, "smm_bgp_p2p_attach: rank of ANOTHER shard, 0 <= rank < N_global / N");
+    if (c->p2p_attached & (1u << rank)) return fail(c, SMM_ERR_STATE, "smm_bgp_p2p_attach: this rank's window is attached already");
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        void* w = window_dev;
+        if (ipc_handle) {
+            hipIpcMemHandle_t h;
+            memcpy(&h, ipc_handle, sizeof h);
+            HIPCHK(hipIpcOpenMemHandle(&w, h, hipIpcMemLazyEnablePeerAccess));
+            c->p2p_opened[rank] = w;
+        } else {   // a context of this process: on another device the two must see each other
+            hipPointerAttribute_t at;
+            HIPCHK(hipPointerGetAttributes(&at, w));
+            if (at.device != c->device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(at.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e);
+                (void)hipGetLastError();
+            }
+        }
+        c->P.p2p_win[rank] = (unsigned char*)w;
+        c->p2p_attached |= 1u << rank;
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
+int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || n_iters < 0) return SMM_ERR_INVALID_ARG;
+    if (c->failed) return c->failed;
+    if (!c->p2p_mine) return fail(c, SMM_ERR_STATE, "smm_bgp_p2p_init comes first");
+    if (c->p2p_attached != (1u << c->P.p2p_G) - 1u) return fail(c, SMM_ERR_STATE, "smm_bgp_p2p_step: not every rank's window is attached");
+    if (c->iter + n_iters > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
+    if (c->rec_external && !c->p2p_current) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
+    if (c->a2a_open) return fail(c, SMM_ERR_STATE, "smm_bgp_a2a_apply_dev comes first");
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        KParams& P = c->P;
+        const P2PLayout L = p2p_layout(P.Ng, P.RW);
+        if (c->profiling == 2) {
+            while ((int)c->pev.size() < 4 * n_iters) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                c->pev.push_back(e);
+            }
+            c->pev_exch.assign((size_t)n_iters, 0);
+        }
+        c->pev_iters = 0;
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+        if (!c->p2p_current) {   // first publication: the state after iteration `iter`, its exchange settled, into every window
+            flush(c);
+            launch_p2p_push(c, c->iter & 1, c->rec[c->cur]);
+            c->p2p_current = true;
+            c->pending_ext = false;
+        }
+        const bool inl = c->p2p_inline && !c->nan_values;
+        for (int it = 0; it < n_iters; ++it) {
+            const int t = c->iter + 1;
+            const bool prof = c->profiling == 2;
+            int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
+            if (inl) {
+                if (c->pending_ext) flags |= F_HAS_PENDING | F_WALK_INLINE;
+                ensure_windows(c, t);
+                if (prof) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
+                launch_chain_iter_norm_p2p(c, t, flags);
+                c->kev0 = c->kev1 = nullptr;
+                c->p2p_seq += 1;
+                c->p2p_unwaited = true;   // (the next inline kernel waits itself; anybody else launches k_p2p_wait)
+            } else {
+                if (c->pending_ext) {   // exchangeMoves! of iteration t-1 (before its plan window can move on)
+                    if (c->p2p_unwaited) launch_p2p_wait(c);
+                    if (prof && c->lean_resolve) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
+                    launch_resolve_window(c, t - 1);
+                    c->kev0 = c->kev1 = nullptr;
+                    flags |= F_HAS_PENDING;
+                }
+                ensure_windows(c, t);
+                c->ext_rec_in = (const double*)(c->p2p_mine + L.rec[(t - 1) & 1]);
+                c->ext_rec_out = (double*)(c->p2p_mine + L.rec[t & 1]) + (size_t)P.offset * P.RW;
+                c->ext_vals_out = (double*)(c->p2p_mine + L.val[t & 1]) + P.offset;
+                if (prof) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
+                launch_chain_iter(c, t, flags);
+                c->kev0 = c->kev1 = nullptr;
+                c->ext_rec_in = nullptr; c->ext_rec_out = nullptr; c->ext_vals_out = nullptr;
+                launch_p2p_push(c, t & 1, nullptr);
+            }
+            c->prev_open = true;
+            c->pending = false;
+            c->rec_external = true;
+            c->pending_ext = exchange_active(c, t);
+            c->iter = t;
+        }
+        HIPCHK(hipEventRecord(c->ev1, c->stream));
+        HIPCHK(hipGetLastError());
+        if (c->profiling == 2) c->pev_iters = n_iters;
+        c->pending_timing = true;
+        c->timing.iters = n_iters;
+        c->timing.chain_evals = (int64_t)n_iters * P.N;
+    } catch (const std::string& m) {
+        c->kev0 = c->kev1 = nullptr; c->ext_rec_in = nullptr; c->ext_rec_out = nullptr; c->ext_vals_out = nullptr;
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
+
+// settle the last p2p step (its exchange, history, counters) into the context, like smm_bgp_sharded_finish
+int smm_bgp_p2p_finish(void* ctx) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return SMM_ERR_INVALID_ARG;
+    if (!c->p2p_current || !c->rec_external) return SMM_OK;
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        const KParams& P = c->P;
+        const P2PLayout L = p2p_layout(P.Ng, P.RW);
+        int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
+        if (c->p2p_unwaited) launch_p2p_wait(c);   // the donors' records of the last iteration must have landed
+        if (c->pending_ext) {
+            launch_resolve_window(c, c->iter);
+            flags |= F_HAS_PENDING;
+        }
+        hipLaunchKernelGGL(k_flush, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter + 1,
+                           (const double*)(c->p2p_mine + L.rec[c->iter & 1]), c->rec[c->cur ^ 1], flags);
+        HIPCHK(hipGetLastError());
+        c->cur ^= 1;
+        c->pending = false; c->prev_open = false; c->rec_external = false; c->pending_ext = false; c->p2p_current = false;
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
@@ -1515,6 +1757,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         c->pending = false;
         c->prev_open = false;
         c->a2a_open = false;
+        c->p2p_current = false;   // (the next smm_bgp_p2p_step publishes the uploaded state)
         if (P.walk_flags) HIPCHK(hipMemset(P.walk_flags, 0, 16));   // (the values the next exchange sees are written by the next accept step)
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);

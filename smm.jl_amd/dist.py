@@ -10,6 +10,11 @@ For long records (50 parameters + 50 moments are 816 bytes per cha
 VALUES form (`protocol="values"`): an all-gather of 8 bytes per chain, the replicated resolution, and an
 all-to-all of fixed-size blocks that carries each swapped record to the owner of the chain that continues
 from it — two collectives, about a quarter of a record per chain on the wire instead of a whole one.
+
+The P2P form (`protocol="p2p"`) has NO collective in the iteration at all: every rank owns a window of device memory that
+all other ranks map (HIP IPC), a chain's accept step stores its record into every rank's window over the point-to-point
+xGMI links and counts itself in, the next iteration's kernel waits on its own window's counters (include/smmhip.h,
+smm.jl_amd/csrc/smm_p2p.hpp).  torch.distributed is used once, to hand the IPC handles round.
 """
 import torch
 import torch.distributed as dist
@@ -58,6 +63,19 @@ class HipShardEngine:
     def fused_finish(self, gathered):
         self.ctx.sharded_finish(gathered.data_ptr() if gathered is not None else 0)
 
+    # p2p form
+    def p2p_init(self):
+        return self.ctx.p2p_init()
+
+    def p2p_attach(self, rank, handle=None, window=None):
+        self.ctx.p2p_attach(rank, handle=handle, window=window)
+
+    def p2p_step(self, n):
+        self.ctx.p2p_step(n)
+
+    def p2p_finish(self):
+        self.ctx.p2p_finish()
+
     def sync(self):
         self.ctx.sync()
 
@@ -71,13 +89,25 @@ class ShardedBGP:
     def __init__(self, engine, group=None, protocol="records"):
         """protocol: "records" (all-gather of the last-accepted records) or "values" (all-gather of the values + all-to-all of
         the swapped records: for long records)"""
-        if protocol not in ("records", "values"):
-            raise ValueError("protocol: 'records' or 'values'")
+        if protocol not in ("records", "values", "p2p"):
+            raise ValueError("protocol: 'records', 'values' or 'p2p'")
         self.e = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.protocol = protocol
+        if protocol == "p2p":
+            # hand the window handles round once; afterwards the iteration needs no collective
+            handle, _ = engine.p2p_init()
+            if self.world > 1:
+                handles = [None] * self.world
+                dist.all_gather_object(handles, handle, group=group)
+                for r, h in enumerate(handles):
+                    if r != self.rank:
+                        engine.p2p_attach(r, handle=h)
+                dist.barrier(group=group)   # every window is mapped everywhere before anybody stores into one
+            self.fused = False
+            return
         if protocol == "values":
             cap = engine.a2a_capacity()
             if cap <= 0:
@@ -98,6 +128,9 @@ class ShardedBGP:
 
     def step(self, n_iters=1):
         e = self.e
+        if self.protocol == "p2p":
+            e.p2p_step(n_iters)
+            return
         with e.stream_ctx():
             if self.protocol == "values":
                 for _ in range(n_iters):
@@ -157,6 +190,10 @@ class ShardedBGP:
 
     def sync(self):
         """settle the last iteration into the context (history/state readable afterwards) and wait for the device"""
+        if self.protocol == "p2p":
+            self.e.p2p_finish()
+            self.e.sync()
+            return
         if self.fused and self.gcur is not None:
             with self.e.stream_ctx():
                 self.e.fused_finish(self.gbuf[self.gcur])

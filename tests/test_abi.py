@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libsmmhip.so does not export %s" % n
     assert sorted(s[0] for s in A.SYMBOLS) == names  # the ctypes table mirrors the header exactly
-    assert lib.smm_abi_version() == 2
+    assert lib.smm_abi_version() == 3
 
 
 def test_ctypes_layout_matches_the_header():

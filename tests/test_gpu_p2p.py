@@ -1,0 +1,223 @@
+"""The p2p form of the sharded iteration (include/smmhip.h, smm.jl_amd/csrc/smm_p2p.hpp): every shard's accept step stores into
+every shard's window, no collective.  Two layers:
+  * several contexts of THIS process (windows attached by device pointer), stepped in lockstep: the data path — inline walk over
+    the whole population out of the window, epilogue pushes, generic push kernel, resolve from the window — bit-exact against the
+    single shard and the oracle;
+  * several PROCESSES on the one GPU (windows attached through HIP IPC handles), free running: the transport itself — arrival
+    counters, system-scope release/acquire, kernels of different processes waiting for each other."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common as cm
+from smm_jl_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def shard_opts(opts_full, G, r):
+    from smm_jl_amd import BGPOpts
+    N = opts_full.N_global // G
+    return BGPOpts(N=N, maxiter=opts_full.maxiter, sigma=opts_full.sigma, acc_tuner=opts_full.acc_tuner,
+                   min_improve=opts_full.min_improve, sigma_update_steps=opts_full.sigma_update_steps,
+                   sigma_adjust_by=opts_full.sigma_adjust_by, smpl_iters=opts_full.smpl_iters,
+                   batch_size=opts_full.batch_size, seed=opts_full.seed, chain_offset=r * N,
+                   N_global=opts_full.N_global, dist_fun=opts_full.dist_fun, chol_L=opts_full.chol_L)
+
+
+def p2p_contexts(S, prob, opts_full, G, tables=None):
+    ctxs = [S.hip_context(prob, shard_opts(opts_full, G, r), tables[r] if tables else None) for r in range(G)]
+    wins = [c.p2p_init()[1] for c in ctxs]
+    for r, c in enumerate(ctxs):
+        for q in range(G):
+            if q != r:
+                c.p2p_attach(q, window=wins[q])
+    return ctxs
+
+
+def p2p_run_lockstep(ctxs, T, chunk=1, finish_every=None):
+    """every shard enqueues `chunk` iterations, then all are waited for: with chunk == 1 every wait inside a kernel is already
+    satisfied when the kernel starts (contexts of one process may share a hardware queue)"""
+    done = 0
+    while done < T:
+        n = min(chunk, T - done)
+        for c in ctxs:
+            c.p2p_step(n)
+        for c in ctxs:
+            c.sync()
+        done += n
+        if finish_every and done % finish_every == 0 and done < T:
+            for c in ctxs:
+                c.p2p_finish()
+            for c in ctxs:
+                c.sync()
+    for c in ctxs:
+        c.p2p_finish()
+    for c in ctxs:
+        c.sync()
+
+
+def assert_shards_equal_single(ctxs, single):
+    hs, ss = single.history(), single.state()
+    G = len(ctxs)
+    n = hs.value.shape[1] // G
+    for r, c in enumerate(ctxs):
+        hr, st = c.history(), c.state()
+        for f in A.HistoryBuffers.FIELDS:
+            assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+        for f in A.StateBuffers.FIELDS:
+            assert np.array_equal(getattr(st, f), getattr(ss, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+    assert (hs.exchanged != 0).any()
+
+
+@pytest.mark.parametrize("G,N,T,fe", [(1, 48, 20, None), (2, 64, 30, None), (4, 64, 30, 7), (2, 5000, 12, None), (4, 8192, 8, None), (8, 640, 40, 11)])
+def test_p2p_inline_equals_single(S, O, G, N, T, fe):
+    # objfunc_norm 2p/2m, min_improve == 0, N_global <= 8192: one launch per iteration and shard (k_chain_iter_norm_p2p)
+    prob, opts = cm.serial_normal(N=N, T=T, ns=64 if N > 100 else 300)
+    single = S.hip_context(prob, opts)
+    single.step(T)
+    ctxs = p2p_contexts(S, prob, opts, G)
+    p2p_run_lockstep(ctxs, T, finish_every=fe)
+    assert_shards_equal_single(ctxs, single)
+    if N <= 100:
+        o = O.OracleContext(prob, opts, S.Tables(Z=single.Z()))
+        o.step(T)
+        cm.assert_history_equal(single.history(), o.history())
+
+
+@pytest.mark.parametrize("case", ["norm_16384", "norm_mi", "general_np6", "banana", "dense"])
+def test_p2p_generic_equals_single(S, case):
+    # everything the inline form does not cover: chain kernel into the own window + push kernel + resolve from the window
+    G, T = 2, 10
+    if case == "norm_16384":
+        G, T = 4, 5
+        prob, opts = cm.serial_normal(N=16384, T=T, ns=64)
+    elif case == "norm_mi":
+        prob, opts = cm.serial_normal(N=96, T=T, ns=200, min_improve=0.05)
+    elif case == "general_np6":
+        prob, opts = cm.general_normal(6, 96, T, ns=200, batch_size=3)
+    elif case == "banana":
+        npar, N = 10, 256
+        prob = S.Problem(init=np.zeros(npar), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1,
+                         objective_id=A.SMM_OBJ_BANANA)
+        opts = S.BGPOpts(N=N, maxiter=T, sigma=0.01 * cm.temps(N, 4), acc_tuner=np.geomspace(2.0, 0.1, N), min_improve=np.zeros(N),
+                         N_global=N, seed=3, smpl_iters=100000)
+    else:
+        npar = nm = 50; N = 64
+        rng = np.random.default_rng(3)
+        prob = S.Problem(init=rng.uniform(-0.3, 0.3, npar), lb=-np.ones(npar), ub=np.ones(npar), mom=rng.uniform(-0.5, 0.5, nm),
+                         w=rng.uniform(0.5, 2.0, nm), ns=1, objective_id=A.SMM_OBJ_DENSE)
+        opts = S.BGPOpts(N=N, maxiter=T, sigma=0.004 * cm.temps(N, 3), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N),
+                         N_global=N, seed=3, smpl_iters=100000)
+    single = S.hip_context(prob, opts)
+    single.step(T)
+    ctxs = p2p_contexts(S, prob, opts, G)
+    p2p_run_lockstep(ctxs, T)
+    assert_shards_equal_single(ctxs, single)
+
+
+def test_p2p_after_other_forms_and_restart(S):
+    # the windows are (re)published whenever the context was stepped in another form or a state was uploaded
+    G, T = 2, 24
+    prob, opts = cm.serial_normal(N=64, T=T, ns=100)
+    single = S.hip_context(prob, opts)
+    single.step(T)
+    ctxs = p2p_contexts(S, prob, opts, G)
+    import torch
+    R = ctxs[0].record_doubles()
+    gathered = torch.zeros((G, 32, R), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for it in range(6):   # three-phase form first
+        for c in ctxs:
+            c.local_step()
+        for r, c in enumerate(ctxs):
+            c.export_records_dev(gathered[r].data_ptr())
+        for c in ctxs:
+            c.sync()
+        for c in ctxs:
+            c.exchange_dev(gathered.data_ptr())
+        for c in ctxs:
+            c.sync()
+    p2p_run_lockstep(ctxs, 8)
+    saved = [(c.state(), c.history()) for c in ctxs]
+    p2p_run_lockstep(ctxs, 3)                # ... thrown away by the upload:
+    for c, (st, h) in zip(ctxs, saved):
+        c.set_state(st, h)
+    p2p_run_lockstep(ctxs, T - 14, chunk=1)
+    assert_shards_equal_single(ctxs, single)
+
+
+def test_p2p_argument_checks(S):
+    prob, opts = cm.serial_normal(N=32, T=4, ns=50)
+    c = S.hip_context(prob, shard_opts(opts, 2, 0))
+    with pytest.raises(A.SMMHipError):
+        c.p2p_step(1)                         # no window yet
+    _, w = c.p2p_init()
+    with pytest.raises(A.SMMHipError):
+        c.p2p_step(1)                         # rank 1 not attached
+    with pytest.raises(A.SMMHipError):
+        c.p2p_attach(0, window=w)             # its own rank
+    with pytest.raises(A.SMMHipError):
+        c.p2p_attach(5, window=w)
+
+
+WORKER = r"""
+import os, sys, pickle, time
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import smm_jl_amd as S, common as cm
+from test_gpu_p2p import shard_opts
+rank, G, N, T, ns, d = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+prob, opts = cm.serial_normal(N=N, T=T, ns=ns)
+c = S.hip_context(prob, shard_opts(opts, G, rank))
+handle, _ = c.p2p_init()
+def put(tag, data=b""):
+    open(os.path.join(d, "%s_%d.tmp" % (tag, rank)), "wb").write(data); os.rename(os.path.join(d, "%s_%d.tmp" % (tag, rank)), os.path.join(d, "%s_%d" % (tag, rank)))
+def get(tag, r):
+    p = os.path.join(d, "%s_%d" % (tag, r)); t0 = time.time()
+    while not os.path.exists(p):
+        time.sleep(0.002)
+        if time.time() - t0 > 120: raise SystemExit("rank %d: no %s from rank %d" % (rank, tag, r))
+    return open(p, "rb").read()
+put("handle", handle)
+for r in range(G):
+    if r != rank: c.p2p_attach(r, handle=get("handle", r))
+put("mapped"); [get("mapped", r) for r in range(G)]
+c.p2p_step(T // 2); c.p2p_step(T - T // 2)     # free running: kernels of different processes wait for each other on the device
+t0 = time.perf_counter(); c.p2p_finish(); c.sync();
+h, st = c.history(), c.state()
+put("result", pickle.dumps(({{f: getattr(h, f) for f in h.FIELDS}}, {{f: getattr(st, f) for f in st.FIELDS}})))
+[get("result", r) for r in range(G)]            # nobody unmaps a window a peer may still store into
+"""
+
+
+@pytest.mark.parametrize("G,N,ns", [(2, 2048, 1000), (4, 1024, 1000), (2, 512, 64)])
+def test_p2p_processes_over_hip_ipc(S, tmp_path, G, N, ns):
+    # G processes on the one GPU, 16 chains per workgroup: at most 256 workgroups in all, so that waiting kernels cannot keep
+    # the kernels they wait for from starting
+    import pickle
+    T = 40
+    prob, opts = cm.serial_normal(N=N, T=T, ns=ns)
+    single = S.hip_context(prob, opts)
+    single.step(T)
+    hs, ss = single.history(), single.state()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(G), str(N), str(T), str(ns), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(G)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    n = N // G
+    for r in range(G):
+        h, st = pickle.loads((tmp_path / ("result_%d" % r)).read_bytes())
+        for f in A.HistoryBuffers.FIELDS:
+            assert np.array_equal(h[f], getattr(hs, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+        for f in A.StateBuffers.FIELDS:
+            assert np.array_equal(st[f], getattr(ss, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+    assert (hs.exchanged != 0).any()
