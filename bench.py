@@ -1,16 +1,30 @@
 #!/usr/bin/env python
 """bench.py — chain-evals/sec of the BGP hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): serialNormal objective (2 params / 2 moments,
-ns = 10000 simulated draws per moment), 4096 BGP chains per GPU, FP64.  One "step" = one job
-of 200 iterations over all chains (= the metric's "4096 chains x 200 iters"); successive steps
-continue the same chains.  value = N_global * 200 * steps / wall, inputs resident in HBM.
-N > 1: one process per GPU (torch.distributed / RCCL), chains sharded, weak scaling
-(4096 chains per GPU), one all-gather of last-accepted records per iteration.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--protocol auto|p2p|records|values]
+
+Workload (default: BASELINE.json configs[1], "C2"): serialNormal objective (2 params / 2 moments, ns = 10000 simulated draws per
+moment), 4096 BGP chains per GPU, FP64.  One "step" = one job of 200 iterations over all chains (= the metric's "4096 chains x
+200 iters"); successive steps continue the same chains.  value = N_global * 200 * steps / wall, inputs resident in HBM.
+
+N > 1: one process per GPU, chains sharded in contiguous blocks, weak scaling (4096 chains per GPU).  `python bench.py --gpus N`
+launches its N ranks itself (torch.distributed.run, 127.0.0.1); started under a launcher (RANK/WORLD_SIZE set) it is one rank.
+The exchange step between the shards (exchangeMoves!, AlgoBGP.jl:647-716):
+  p2p      every rank's accept step stores its records into every rank's window over xGMI (HIP IPC), no collective (default
+           wherever its self-check against the record form passes)
+  records  one RCCL all-gather of the last-accepted records per iteration
+  values   RCCL all-gather of the values + all-to-all of the swapped records (long records)
+Other BASELINE configurations (--workload): c3 = 32768 chains in 8 temperature levels (N_global fixed, split over the GPUs),
+c4 = banana 10 params, 8192 chains, c5 = dense simulation 50 params on FP64 MFMA, 4096 chains.
+
+On a 1-GPU lease the multi-process form can still be exercised: --same-device puts all N ranks on GPU 0 (gloo bootstrap, p2p
+transport; RCCL refuses duplicate devices), with chains_per_gpu / N chains each so that every rank's kernels are resident at once.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -18,19 +32,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-CHAINS_PER_GPU = 4096
 ITERS_PER_STEP = 200
 NS = 10000
-# algorithmic work per chain evaluation: 2*nm*ns FP64 adds + ~100 for
-# proposal/objective/accept; 128 B of HBM traffic (state read 40 B + history record 88 B)
-FLOP_PER_EVAL = 2 * 2 * NS + 100
-BYTES_PER_EVAL = 128
 PEAK_FP64_ADD_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3: 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz (adds cannot be FMA'd)
+PEAK_FP64_MFMA_TFLOPS = 78.6                         # dense FP64 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+
+# per workload: chains per GPU (weak) or in total (fixed), algorithmic work per chain evaluation and the roofline that bounds it
+WORKLOADS = {
+    # 2*nm*ns FP64 adds + ~100 for proposal/objective/accept; 128 B of HBM traffic (state read 40 B + history record 88 B)
+    "c2": dict(chains=4096, total=False, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
+               kernel="k_chain_iter_norm<2, true>",
+               label="serialNormal objfunc_norm 2 params / 2 moments, ns=10000 (BASELINE configs[1])"),
+    "c3": dict(chains=32768, total=True, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
+               kernel="k_chain_iter_norm<2, false>",
+               label="serialNormal objfunc_norm 2p/2m, ns=10000, 32768 chains = 8 temperature levels x 4096 (BASELINE configs[2])"),
+    # ~80 flop vs (2*10 + 10 + 8) * 8 = 304 B per chain evaluation: an HBM / latency stream
+    "c4": dict(chains=8192, total=False, flop=80, bytes=304, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", kernel="k_chain_iter<0, 64",
+               label="banana / Rosenbrock 10 params / 10 moments, 8192 chains (BASELINE configs[3])"),
+    # 2*256*256 + 2*256*50 flop per chain evaluation on FP64 MFMA
+    "c5": dict(chains=4096, total=False, flop=2 * 256 * 256 + 2 * 256 * 50, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma", peak=PEAK_FP64_MFMA_TFLOPS,
+               unit="TFLOP/s", kernel="k_chain_iter<2, 16",
+               label="synthetic dense simulation 50 params, 256x256 matvec per evaluation on FP64 MFMA, 4096 chains (BASELINE configs[4])"),
+}
 
 
 def kernel_source_hash():
-    """sha256 (16 hex digits) over the device sources: ties a committed PMC summary to the build it was taken from"""
+    """sha256 (16 hex digits) over the device sources: ties a committed profile to the build it was taken from"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "smm.jl_amd", "csrc")
@@ -40,32 +68,57 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic():
-    """HBM bytes per k_chain_iter_norm launch from the newest committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
-    WRITE_SIZE are KB per launch; gfx950's FETCH_SIZE tallies wide coalesced reads at half their size
-    (MI355X_MICROARCH.md, HBM) so it is doubled.  Counters cannot be read from inside the timed process, so the number
-    comes from the profile file; `stale` says whether that profile was taken from other device sources than this build
-    (the summary carries the source hash).  (None, ...) when no profile is committed."""
+def newest_profile(pattern):
     import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
+    WRITE_SIZE are KB per launch; gfx950's FETCH_SIZE tallies wide coalesced reads at half their size (MI355X_MICROARCH.md, HBM)
+    so it is doubled.  Counters cannot be read from inside the timed process, so the number comes from the profile file; `stale`
+    says whether that profile was taken from other device sources than this build (the summary carries the source hash)."""
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
-    if not files:
+    f = newest_profile("r*_pmc_summary.txt")
+    if not f:
         return None, None, None
-    fetch = write = None
-    src_hash = None
-    for line in open(files[-1]):
+    fetch = write = src_hash = None
+    for line in open(f):
         m = re.match(r"#\s*kernel_source_sha16=([0-9a-f]+)", line)
         if m:
             src_hash = m.group(1)
-        if "k_chain_iter_norm<2, true>" in line or ("k_chain_iter<1," in line and fetch is None):
+        if kernel in line:
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+launches=\s*\d+\s+mean_per_launch=\s*([0-9.]+)", line)
-            if m and m.group(1) == "FETCH_SIZE":
+            if m and m.group(1) == "FETCH_SIZE" and fetch is None:
                 fetch = float(m.group(2))
-            elif m:
+            elif m and m.group(1) == "WRITE_SIZE" and write is None:
                 write = float(m.group(2))
     if fetch is None or write is None:
         return None, None, None
-    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT), (src_hash != kernel_source_hash())
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(f, ROOT), (src_hash != kernel_source_hash())
+
+
+def rocprof_kernel_us(kernel):
+    """average duration of the dominant kernel in the newest committed rocprofv3 --kernel-trace --stats summary (profiles/), with
+    the staleness of that file against this build's device sources (a `# kernel_source_sha16=` line next to it)"""
+    import csv
+    f = newest_profile("r*_kernel_stats.csv")
+    if not f:
+        return None, None, None
+    us = None
+    for row in csv.DictReader(l for l in open(f) if not l.startswith("#")):
+        name = row.get("Name") or row.get("KernelName") or ""
+        if kernel in name and "AverageNs" in row:
+            us = float(row["AverageNs"]) / 1e3
+            break
+    tag = f.replace("_kernel_stats.csv", "_pmc_summary.txt")
+    stale = None
+    if os.path.exists(tag):
+        import re
+        m = re.search(r"kernel_source_sha16=([0-9a-f]+)", open(tag).read())
+        stale = (m.group(1) != kernel_source_hash()) if m else None
+    return us, os.path.relpath(f, ROOT), stale
 
 
 def host_cores():
@@ -88,7 +141,7 @@ def cpu_baseline(threads):
     generator (Philox + Box-Muller, both outputs used): a lower bound (Julia's ziggurat randn is several times cheaper)."""
     import common as cm
     from oracle import oracle as O
-    n, t = CHAINS_PER_GPU, ITERS_PER_STEP
+    n, t = 4096, ITERS_PER_STEP
     reps_max = 400
     prob, opts = cm.serial_normal(N=n, T=t * reps_max)
     o = O.OracleContext(prob, opts, threads=threads, regen_z=False)
@@ -105,11 +158,109 @@ def cpu_baseline(threads):
         o2.step(t2); reps2 += 1
     dt2 = (time.perf_counter() - t0) / reps2
     return {"value": n * t / dt, "unit": "chain-evals/s", "cores": threads, "kind": "port",
-            "sample": "the whole workload: %d chains x %d iterations, OpenMP over chains (%d threads), AVX2, shock matrix "
+            "sample": "the whole C2 workload: %d chains x %d iterations, OpenMP over chains (%d threads), AVX2, shock matrix "
                       "cached (no per-evaluation RNG: an upper bound for the reference's CPU path); %d such jobs, %.2f s each" % (n, t, threads, reps, dt),
             "regen_value": n2 * t2 / dt2,
             "regen_sample": "%d chains x %d iterations with the 2x10000 normals of every evaluation regenerated "
                             "(ObjExamples.jl:74-79) by the port's Philox/Box-Muller: a lower bound; %d repetitions, %.2f s each" % (n2, t2, reps2, dt2)}
+
+
+def build_problem(workload, n_loc, n_glob, rank, T, device):
+    """Problem / BGPOpts of one shard of the workload (the same constructions as tests/ and tools/run_objective.py)"""
+    import numpy as np
+    import smm_jl_amd as S
+    import common as cm
+    from smm_jl_amd import _abi as A
+    kw = dict(N=n_loc, maxiter=T, N_global=n_glob, chain_offset=rank * n_loc, device=device)
+    if workload == "c2":
+        return cm.serial_normal(N=n_glob, T=T, N_local=n_loc, chain_offset=rank * n_loc, device=device)
+    if workload == "c3":   # 8 temperature levels x (n_glob / 8) replicas (SURVEY 8d): chain id = level * replicas + r
+        prob, _ = cm.serial_normal(N=3, T=T)
+        L, R = 8, n_glob // 8
+        return prob, S.BGPOpts(sigma=np.repeat(0.05 * np.linspace(1, 5, L), R), acc_tuner=np.repeat(np.geomspace(20, 1, L), R),
+                               min_improve=np.zeros(n_glob), **kw)
+    if workload == "c4":
+        npar = 10
+        prob = S.Problem(init=np.zeros(npar), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1,
+                         objective_id=A.SMM_OBJ_BANANA)
+        return prob, S.BGPOpts(sigma=0.01 * cm.temps(n_glob, 4), acc_tuner=np.geomspace(2.0, 0.1, n_glob), min_improve=np.zeros(n_glob),
+                               seed=3, smpl_iters=100000, **kw)
+    npar = nm = 50
+    rng = np.random.default_rng(3)
+    prob = S.Problem(init=rng.uniform(-0.3, 0.3, npar), lb=-np.ones(npar), ub=np.ones(npar), mom=rng.uniform(-0.5, 0.5, nm),
+                     w=rng.uniform(0.5, 2.0, nm), ns=1, objective_id=A.SMM_OBJ_DENSE)
+    return prob, S.BGPOpts(sigma=0.004 * cm.temps(n_glob, 3), acc_tuner=np.geomspace(20, 1, n_glob), min_improve=np.zeros(n_glob), seed=3,
+                           smpl_iters=100000, **kw)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (one per GPU) and pass rank 0's line through"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(rank, world, local_rank):
+    """no GPU: the ranks meet over gloo and rank 0 reports who came up (the launcher's test)"""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, local_rank, os.getpid()))
+        dist.destroy_process_group()
+    else:
+        seen = [(rank, local_rank, os.getpid())]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks": sorted(r for r, _, _ in seen),
+                          "local_ranks": sorted(l for _, l, _ in seen), "pids": len({p for _, _, p in seen})}))
+
+
+def p2p_self_check(S, cm, torch, dist, rank, world, device, same_device):
+    """a short sharded run through the p2p windows and — where RCCL can run — through the record all-gather: identical histories
+    or the bench takes the collective form.  (rank-local verdicts are reduced: every rank takes the same branch.)"""
+    import numpy as np
+    from smm_jl_amd.dist import HipShardEngine, ShardedBGP
+    ok, why = True, "p2p == records on 64 chains per rank x 24 iterations"
+    try:
+        n, T = 64, 24
+        hist = {}
+        for proto in (("p2p",) if same_device else ("p2p", "records")):
+            prob, opts = cm.serial_normal(N=n * world, T=T, ns=500, N_local=n, chain_offset=rank * n, device=device)
+            ctx = S.hip_context(prob, opts)
+            sh = ShardedBGP(HipShardEngine(ctx, torch.device("cuda", device)), protocol=proto)
+            sh.step(T)
+            sh.sync()
+            h = ctx.history()
+            hist[proto] = [getattr(h, f).copy() for f in h.FIELDS]
+            if world > 1:
+                dist.barrier()   # nobody drops its window while a peer may still store into it
+            del sh, ctx
+        if not same_device:
+            ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(hist["p2p"], hist["records"]))
+            if not ok:
+                why = "p2p and the record all-gather disagree"
+        else:
+            why = "p2p ran (same-device form: no RCCL to compare with; tests/test_gpu_p2p.py holds the bit-exact comparison)"
+    except Exception as e:   # noqa: BLE001 -- any failure of the transport selects the collective form
+        ok, why = False, "p2p failed: %s" % (str(e)[:200],)
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if same_device else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if ok and not bool(flag.item()):
+            why = "p2p failed on another rank"
+        ok = bool(flag.item())
+    return ok, why
 
 
 def main():
@@ -117,19 +268,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--protocol", choices=["auto", "p2p", "records", "values"], default=os.environ.get("SMM_BENCH_PROTOCOL", "auto"))
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--same-device", action="store_true", help="all ranks on GPU 0 (1-GPU lease: gloo bootstrap, p2p transport)")
+    ap.add_argument("--dry-launch", action="store_true", help="bring the ranks up and report them; no GPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unfused", action="store_true", help="skip the reference timing of the unfused kernels (profiling runs)")
-    ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU)
     args = ap.parse_args()
 
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+    if under_launcher and args.gpus != world:
         args.gpus = world
+    if args.dry_launch:
+        return dry_launch(rank, world, local_rank)
 
     import numpy as np
     import torch
@@ -137,40 +294,59 @@ def main():
     import smm_jl_amd as S
     import common as cm
 
-    torch.cuda.set_device(local_rank)
-    if world > 1 or os.environ.get("SMM_BENCH_FORCE_SHARDED") == "1":
+    W = WORKLOADS[args.workload]
+    device = 0 if args.same_device else local_rank
+    torch.cuda.set_device(device)
+    force_sharded = os.environ.get("SMM_BENCH_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU
+    sharded = world > 1 or force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", device))
 
-    n_loc = args.chains
-    n_glob = n_loc * world
-    K, W = args.steps, args.warmup
-    T = ITERS_PER_STEP * (K + W + 2)   # + the two profiled steps
-    prob, opts = cm.serial_normal(N=n_glob, T=T, N_local=n_loc, chain_offset=rank * n_loc, device=local_rank)
+    if W["total"]:
+        n_glob = args.chains * world if args.chains else W["chains"]
+        n_loc = n_glob // world
+    else:
+        n_loc = args.chains or (W["chains"] // world if args.same_device else W["chains"])
+        n_glob = n_loc * world
+    K, Wm = args.steps, args.warmup
+
+    protocol, proto_note = args.protocol, None
+    if sharded and args.same_device and protocol in ("auto", "p2p"):
+        _, proto_note = p2p_self_check(S, cm, torch, dist, rank, world, device, True)
+        protocol = "p2p"
+    elif sharded and protocol == "auto":
+        ok, proto_note = p2p_self_check(S, cm, torch, dist, rank, world, device, False)
+        protocol = "p2p" if ok else "records"
+    elif not sharded:
+        protocol = None
+
+    T = ITERS_PER_STEP * (K + Wm + 2)   # + the two profiled steps
+    prob, opts = build_problem(args.workload, n_loc, n_glob, rank, T, device)
     ctx = S.hip_context(prob, opts)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    force_sharded = os.environ.get("SMM_BENCH_FORCE_SHARDED") == "1"  # exercise the N>1 code path on one GPU
-    if world == 1 and not force_sharded:
+    if not sharded:
         def run_step():
             ctx.step_async(ITERS_PER_STEP)
         sync = ctx.sync
     else:
         from smm_jl_amd.dist import HipShardEngine, ShardedBGP
-        # SMM_BENCH_PROTOCOL=values: the two-collective form for long records (all-gather of values + all-to-all of the swapped
-        # records); the default is the one all-gather of records per iteration
-        sh = ShardedBGP(HipShardEngine(ctx, torch.device("cuda", local_rank)), protocol=os.environ.get("SMM_BENCH_PROTOCOL", "records"))
+        sh = ShardedBGP(HipShardEngine(ctx, torch.device("cuda", device)), protocol=protocol)
 
         def run_step():
             sh.step(ITERS_PER_STEP)
         sync = sh.sync
 
-    for _ in range(W):
+    for _ in range(Wm):
         run_step()
     sync(); torch.cuda.synchronize(); barrier()
     t0 = time.perf_counter()
@@ -179,91 +355,91 @@ def main():
     sync(); torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.same_device else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     evals = n_glob * ITERS_PER_STEP * K
     value = evals / dt
 
-    # roofline of the dominant kernel (k_chain_iter), HIP events on the library's stream
+    # ---- roofline of the dominant kernel: the kernels' own start/stop events (hipExtLaunchKernelGGL on the library's stream):
+    # dispatch begin to end as the command processor stamps it -- the same quantity rocprofv3 --kernel-trace reports
+    ctx.set_profiling(2)
+    run_step(); sync()
+    tm = ctx.timing()
+    ctx.set_profiling(0)
+    barrier()
+    k_us = tm.iter_kernel_ms * 1e3 / ITERS_PER_STEP
+    x_us = tm.exch_kernel_ms * 1e3 / ITERS_PER_STEP
+    step_us = tm.step_ms * 1e3 / ITERS_PER_STEP
     roof = None
-    if world == 1 and not force_sharded:
-        # (a) the kernels' own start/stop events (hipExtLaunchKernelGGL on the library's stream): dispatch begin to
-        #     end as the command processor stamps it -- the same quantity rocprofv3 --kernel-trace reports
-        ctx.set_profiling(2)
-        ctx.step(ITERS_PER_STEP)
-        tm = ctx.timing()
-        k_us = tm.iter_kernel_ms * 1e3 / ITERS_PER_STEP
-        x_us = tm.exch_kernel_ms * 1e3 / ITERS_PER_STEP   # the chains are past iteration 1: every iteration exchanges
-        # (b) event brackets around the kernels minus the measured empty-bracket overhead: the kernels' net cost on
-        #     the stream (excludes the part of dispatch/drain that overlaps with the neighbours)
-        ctx.set_profiling(1)
-        ctx.step(ITERS_PER_STEP)
-        tb = ctx.timing()
-        ctx.set_profiling(0)
-        null_us = tb.null_bracket_ms * 1e3 / ITERS_PER_STEP
-        k_net_us = tb.iter_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
-        x_net_us = tb.exch_kernel_ms * 1e3 / ITERS_PER_STEP - null_us
-        # the same chain kernel without the exchange walk in its prologue (a second context with the stand-alone
-        # resolve kernel): shows what the fused launch consists of
-        unfused = None
-        if os.environ.get("SMMHIP_INLINE_WALK") != "0" and not args.no_unfused:
-            os.environ["SMMHIP_INLINE_WALK"] = "0"
-            try:
-                prob2, opts2 = cm.serial_normal(N=n_glob, T=2 * ITERS_PER_STEP, device=local_rank)
-                c2 = S.hip_context(prob2, opts2)
-            finally:
-                del os.environ["SMMHIP_INLINE_WALK"]
-            c2.step(ITERS_PER_STEP)
-            c2.set_profiling(2)
-            c2.step(ITERS_PER_STEP)
-            t2 = c2.timing()
-            c2.set_profiling(0)
-            ku = t2.iter_kernel_ms * 1e3 / ITERS_PER_STEP
-            unfused = {"chain_kernel_us": ku, "resolve_kernel_us": t2.exch_kernel_ms * 1e3 / ITERS_PER_STEP,
-                       "chain_kernel_frac": n_loc * FLOP_PER_EVAL / (ku * 1e-6) / 1e12 / PEAK_FP64_ADD_TFLOPS,
-                       "note": "SMMHIP_INLINE_WALK=0: k_chain_iter without the exchange walk + k_exch_resolve_lvl as its own "
-                               "launch (the configuration of the earlier round-1 profiles)"}
-            del c2
-        flops = n_loc * FLOP_PER_EVAL
-        byts = n_loc * BYTES_PER_EVAL
-        ach = flops / (k_us * 1e-6) / 1e12
-        hbm = byts / (k_us * 1e-6) / 1e9
-        traffic, traffic_src, traffic_stale = pmc_traffic()
-        roof = {"bound": "valu_fp64", "kernel": "k_chain_iter_norm<2, true>", "achieved": ach, "peak": PEAK_FP64_ADD_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_FP64_ADD_TFLOPS, "traffic": traffic, "traffic_stale": traffic_stale,
+    if k_us > 0:
+        work = n_loc * (W["flop"] if W["bound"] != "hbm" else W["bytes"])
+        ach = work / (k_us * 1e-6) / (1e12 if W["bound"] != "hbm" else 1e9)
+        hbm = n_loc * W["bytes"] / (k_us * 1e-6) / 1e9
+        kernel = W["kernel"] if not sharded else ("k_chain_iter_norm_p2p<2>" if (protocol == "p2p" and args.workload in ("c2", "c3") and n_glob <= 8192)
+                                                  else W["kernel"].replace("true", "false"))
+        traffic, traffic_src, traffic_stale = pmc_traffic(kernel)
+        prof_us, prof_src, prof_stale = rocprof_kernel_us(kernel)
+        roof = {"bound": W["bound"], "kernel": kernel, "achieved": ach, "peak": W["peak"], "unit": W["unit"], "frac": ach / W["peak"],
+                "frac_rocprof": (work / (prof_us * 1e-6) / (1e12 if W["bound"] != "hbm" else 1e9) / W["peak"]) if prof_us else None,
+                "rocprof_kernel_us": prof_us, "rocprof_source": prof_src, "rocprof_stale": prof_stale,
+                "traffic": traffic, "traffic_stale": traffic_stale,
                 "traffic_note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from %s; algorithmic: %d B"
-                                % (traffic_src, byts),
-                "avg_kernel_us": k_us, "avg_exchange_us": x_us,
-                "net_kernel_us": k_net_us, "net_exchange_us": x_net_us, "event_bracket_overhead_us": null_us,
-                "timing_note": "avg_*: per-kernel start/stop events (dispatch duration, what rocprofv3 reports; used for "
-                               "'achieved'); net_*: event brackets minus the empty-bracket overhead",
-                "kernel_contents": "one launch per iteration: exchangeMoves! of the previous iteration (level walk by every "
-                                   "workgroup, LDS/latency bound, no flops) + next_eval of 4096 chains (16 per workgroup)",
-                "unfused": unfused,
-                "profiled_step_ms": tm.step_ms,
-                "note": "2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes "
-                        "x 2.4GHz adds/s (FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)",
-                "hbm": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": hbm / PEAK_HBM_GBS, "traffic": traffic,
-                        "note": "algorithmic 128 B per chain-eval; small by construction"}}
+                                % (traffic_src, n_loc * W["bytes"]),
+                "avg_kernel_us": k_us, "avg_exchange_us": x_us, "iteration_us": step_us,
+                "other_us": max(0.0, step_us - k_us - x_us),
+                "timing_note": "rank 0, one profiled step: avg_kernel_us = the chain kernel's own start/stop events (dispatch duration, what "
+                               "rocprofv3 reports; used for 'achieved' and 'frac'), avg_exchange_us = the stand-alone exchange resolution "
+                               "where there is one, iteration_us = the step's events / 200, other_us = the rest (launch boundaries, push / "
+                               "collective).  frac_rocprof = the same work over the committed rocprofv3 average (the profiler lowers the clock)",
+                "algorithmic_per_launch": {"flop": n_loc * W["flop"], "hbm_bytes": n_loc * W["bytes"]},
+                "hbm": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
+                        "note": "algorithmic %d B per chain-eval" % W["bytes"]}}
+        if args.workload in ("c2", "c3"):
+            roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "
+                            "(FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)")
+    # the same chain kernel without the exchange walk in its prologue (single shard, C2): what the fused launch consists of
+    if roof is not None and not sharded and args.workload == "c2" and not args.no_unfused and os.environ.get("SMMHIP_INLINE_WALK") != "0":
+        os.environ["SMMHIP_INLINE_WALK"] = "0"
+        try:
+            prob2, opts2 = cm.serial_normal(N=n_glob, T=2 * ITERS_PER_STEP, device=device)
+            c2 = S.hip_context(prob2, opts2)
+        finally:
+            del os.environ["SMMHIP_INLINE_WALK"]
+        c2.step(ITERS_PER_STEP)
+        c2.set_profiling(2)
+        c2.step(ITERS_PER_STEP)
+        t2 = c2.timing()
+        ku = t2.iter_kernel_ms * 1e3 / ITERS_PER_STEP
+        if ku > 0:
+            roof["unfused"] = {"chain_kernel_us": ku, "resolve_kernel_us": t2.exch_kernel_ms * 1e3 / ITERS_PER_STEP,
+                               "chain_kernel_frac": n_loc * W["flop"] / (ku * 1e-6) / 1e12 / PEAK_FP64_ADD_TFLOPS,
+                               "note": "the chain kernel without the exchange walk + the stand-alone resolve kernel as its own launch"}
+        del c2
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(host_cores())
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(host_cores())   # (the other ranks idle at the barrier below)
+    barrier()
 
     if rank == 0:
-        out = {"metric": "chain-evals/sec (whole node), serialNormal 2p/2m, 4096 chains x 200 iters",
-               "value": value, "unit": "chain-evals/s", "n_gpus": world, "steps": K, "warmup": W,
-               "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        exch = "every iteration >= 2, N pairs"
+        if sharded:
+            exch += {"p2p": "; shards exchange through windows over xGMI (HIP IPC stores, no collective)",
+                     "records": "; RCCL all-gather of the records", "values": "; RCCL all-gather of values + all-to-all of swapped records"}[protocol]
+        out = {"metric": "chain-evals/sec (whole node), serialNormal 2p/2m, 4096 chains x 200 iters" if args.workload == "c2"
+                         else "chain-evals/sec (whole node), %s" % args.workload,
+               "value": value, "unit": "chain-evals/s", "n_gpus": world, "steps": K, "warmup": Wm,
+               "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if W["total"] else "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "serialNormal objfunc_norm 2 params / 2 moments, ns=10000, %d BGP chains per GPU "
-                                      "(%d total) x %d iterations per step (BASELINE configs[1])"
-                                      % (n_loc, n_glob, ITERS_PER_STEP),
-                          "chains_per_gpu": n_loc, "iters_per_step": ITERS_PER_STEP, "ns": NS,
-                          "exchange": "every iteration >= 2, N pairs" + (", RCCL all-gather" if world > 1 else "")},
+               "config": {"workload": "%s, %d BGP chains per GPU (%d total) x %d iterations per step" % (W["label"], n_loc, n_glob, ITERS_PER_STEP),
+                          "chains_per_gpu": n_loc, "chains_total": n_glob, "iters_per_step": ITERS_PER_STEP, "ns": NS if args.workload in ("c2", "c3") else None,
+                          "exchange": exch, "protocol": protocol, "protocol_check": proto_note,
+                          "same_device": bool(args.same_device), "forced_sharded": force_sharded},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

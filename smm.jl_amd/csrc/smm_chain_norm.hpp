@@ -240,9 +240,15 @@ __device__ inline bool exchange_walk_lean_wide(const KParams& P, const int tx, u
 }
 
 // the lean walk of a SHARD (the p2p form, smm_p2p.hpp): the slots of all N_global <= 8192 chains come from this rank's window,
-// where every rank's accept step of iteration tx stored them; the plan is requested first (it does not depend on the other ranks),
-// then every wave waits for the arrivals of iteration tx.  false: timed out, the plan does not fit the form, or a NaN value.
-__device__ inline bool exchange_walk_lean_p2p(const KParams& P, const P2PLayout& PL, const int tx, unsigned char* lds, const int tid, const int ts_tile) {
+// where every rank's accept step of iteration tx stored them.  Nobody polls first: plan and slots are requested in one batch and
+// every slot says which iteration it is from (p2p_tag); a wave that finds an older one among ITS slots waits for the arrival
+// counters and reads its slots again.  On a key tie the exact values are read: those carry no tag, so the walk's guard waits
+// for the counters first (rare).  false: timed out, the plan does not fit the form, or a NaN value.
+struct P2PTieGuard {
+    const KParams& P; int lane, t;
+    __device__ inline void operator()() const { if (p2p_wait_arrivals(P, lane) == 1 && lane == 0) report_error(P, 3, t, P.offset); }
+};
+__device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, unsigned char* lds, const int tid, const int ts_tile) {
     constexpr int NT = NORM_WG;
     constexpr int SR = XLDS_MAX / (4 * NT);                                       // rounds of four slots per lane
     constexpr int PR = (XLDS_MAX + 64 * LV_MAXLEV + 4 * NT - 1) / (4 * NT);        // rounds of four pair words per lane
@@ -253,30 +259,56 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const P2PLayout&
     const int lane = tid & 63;
     const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
     const uint32_t pbase = 8u * (Ng4 + 4u);   // LDS offset of the pair words
+    const unsigned char* mine = P.p2p_self;
+    const uint4* g_slots = (const uint4*)(mine + p2p_slot_off(P, tx & 1));
     const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
+    uint4 s_[2 * SR];
+    auto load_slots = [&]() {
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const int q = tid + r * NT;
+            s_[2 * r] = make_uint4(0u, 0u, 0u, 0u); s_[2 * r + 1] = s_[2 * r];
+            if (4 * q < Ng) { s_[2 * r] = g_slots[2 * q]; s_[2 * r + 1] = g_slots[2 * q + 1]; }
+        }
+    };
+    load_slots();
+    const uint32_t wflags = *(const uint32_t*)(mine + 128 * (size_t)P2P_MAXG + 0 * (size_t)(tid & 1));
     uint4 p_[PR];
 #pragma unroll
     for (int r = 0; r < PR; ++r) {
         const int q4 = tid + r * NT;
         p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
     }
-    const bool arrived = p2p_wait_arrivals(P, lane);
-    const unsigned char* mine = P.p2p_self;
-    const uint4* g_slots = (const uint4*)(mine + PL.slot_at(tx & 1));
-    const uint32_t wflags = *(const uint32_t*)(mine + PL.nan + 0 * (size_t)(tid & 1));
-    uint4 s_[2 * SR];
+    const uint32_t want_hi = p2p_tag(tx) << 16;
+    auto fresh = [&]() {
+        bool ok = true;
 #pragma unroll
-    for (int r = 0; r < SR; ++r) {
-        const int q = tid + r * NT;
-        s_[2 * r] = make_uint4(0u, 0u, 0u, 0u); s_[2 * r + 1] = s_[2 * r];
-        if (4 * q < Ng) { s_[2 * r] = g_slots[2 * q]; s_[2 * r + 1] = g_slots[2 * q + 1]; }
+        for (int r = 0; r < SR; ++r) {
+            const int g = 4 * (tid + r * NT);
+            if (g < Ng) ok = ok && (s_[2 * r].y & 0xffff0000u) == want_hi;
+            if (g + 1 < Ng) ok = ok && (s_[2 * r].w & 0xffff0000u) == want_hi;
+            if (g + 2 < Ng) ok = ok && (s_[2 * r + 1].y & 0xffff0000u) == want_hi;
+            if (g + 3 < Ng) ok = ok && (s_[2 * r + 1].w & 0xffff0000u) == want_hi;
+        }
+        return __ballot(!ok) == 0ull;
+    };
+    int arrived = 0;
+    if (__builtin_expect(!fresh(), 0)) {   // somebody's stores are still on their way: the counters, then the slots once more
+        arrived = p2p_wait_arrivals(P, lane);
+        load_slots();
+        if (arrived == 0 && !fresh()) arrived = 1;
     }
     const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
-    if (!arrived || __builtin_amdgcn_readlane((int)ov, 34) == 0 || __builtin_amdgcn_readfirstlane((int)wflags) != 0 || (uint32_t)(size_t)lds != 0u) return false;
+    // (a wave that gives up must not leave the others at the barriers below: everybody goes on, the failure is reported)
+    if (arrived == 1 && lane == 0) report_error(P, 3, tx + 1, P.offset);
+    const bool form_ok = __builtin_amdgcn_readlane((int)ov, 34) != 0 && __builtin_amdgcn_readfirstlane((int)wflags) == 0 && (uint32_t)(size_t)lds == 0u;
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
         const int q = tid + r * NT;
-        if (4 * q < Ng) { ((uint4*)lds)[2 * q] = s_[2 * r]; ((uint4*)lds)[2 * q + 1] = s_[2 * r + 1]; }
+        if (4 * q < Ng) {
+            ((uint4*)lds)[2 * q] = make_uint4(s_[2 * r].x, s_[2 * r].y & 0xffffu, s_[2 * r].z, s_[2 * r].w & 0xffffu);
+            ((uint4*)lds)[2 * q + 1] = make_uint4(s_[2 * r + 1].x, s_[2 * r + 1].y & 0xffffu, s_[2 * r + 1].z, s_[2 * r + 1].w & 0xffffu);
+        }
     }
 #pragma unroll
     for (int r = 0; r < PR; ++r) {
@@ -287,9 +319,11 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const P2PLayout&
     const int ltail = lean_walk_tail(ov, nlev, lane);
     __syncthreads();
     if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
-    const double* vals = (const double*)(mine + PL.val_at(tx & 1));
-    if (P.lean_unit == 8) lean_walk_levels<NORM_WG, 0>(vals, 1, pbase, ov, nlev, tid, ltail);
-    else lean_walk_levels<NORM_WG, 1>(vals, 1, pbase, ov, nlev, tid, ltail);
+    if (!form_ok) return false;   // (wave-uniform AND the same in every wave: plan and flag are what they are for the whole launch)
+    const double* vals = (const double*)(mine + p2p_val_off(P, tx & 1));
+    const P2PTieGuard guard{P, lane, tx + 1};
+    if (P.lean_unit == 8) lean_walk_levels<NORM_WG, 0, false, P2PTieGuard>(vals, 1, pbase, ov, nlev, tid, ltail, 0.0, guard);
+    else lean_walk_levels<NORM_WG, 1, false, P2PTieGuard>(vals, 1, pbase, ov, nlev, tid, ltail, 0.0, guard);
     return true;
 }
 
@@ -329,11 +363,12 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     const bool valid = ctl && c < N;
     const int gc = P.offset + c;
     const int goff = (flags & F_GLOBAL_REC) ? 0 : P.offset;   // rec_in indexed by global chain id (all-gathered buffer)?
-    P2PLayout PL{};
-    if constexpr (P2P) PL = p2p_layout(P.Ng, RW);
-    const double* __restrict__ rec_in = P2P ? (const double*)(P.p2p_self + PL.rec_at((t - 1) & 1)) : rec_in_arg;
+    const double* __restrict__ rec_in = P2P ? (const double*)(P.p2p_self + p2p_rec_off(P, (t - 1) & 1)) : rec_in_arg;
     const bool walk_now = WALK && (!P2P || (flags & F_WALK_INLINE));
     TS_MARK(0);
+    if constexpr (P2P) {   // the previous launch's pushes are complete (stream order): count this tile's share in, everywhere
+        if ((flags & F_P2P_ARRIVE) && wave == 2) p2p_arrive<false>(P, lane);
+    }
 
     // ---- global reads that do not depend on the exchange, all issued before anything waits ----
     double za[NORM_ZU];
@@ -375,13 +410,22 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     if (!walk_now) __syncthreads();
 
     uint32_t kmeta = 0u;   // lean walk: src | stamp << 16 of the chain's slot (the partner is looked up while the record is on its way)
+    unsigned long long p2p_peek = ~0ull;   // p2p: this rank's arrival counter of source rank `lane`, requested now, looked at after the walk
+    if constexpr (P2P) {
+        if (walk_now && ctl && lane < P.p2p_G)
+            p2p_peek = __hip_atomic_load((const unsigned long long*)(P.p2p_self + 128 * (size_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (walk_now) {
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
         if constexpr (LEAN) {
             bool lean;
-            if constexpr (P2P) lean = exchange_walk_lean_p2p(P, PL, t - 1, (unsigned char*)smem, tid, tile);
+            if constexpr (P2P) lean = exchange_walk_lean_p2p(P, t - 1, (unsigned char*)smem, tid, tile);
             else if constexpr (WIDE) lean = exchange_walk_lean_wide(P, t - 1, (unsigned char*)smem, tid, tile);
             else lean = exchange_walk_lean(P, t - 1, (unsigned char*)smem, tid, tile);
+            if constexpr (P2P) {   // (asked again now that the walk is over: the answer travels while the slot is read and the partner looked up)
+                if (ctl && lane < P.p2p_G && p2p_peek < P.p2p_want)
+                    p2p_peek = __hip_atomic_load((const unsigned long long*)(P.p2p_self + 128 * (size_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             if (!lean) {   // (cannot happen: the host launches k_chain_iter_norm_any wherever it can; loud if it does)
                 if (tid == 0) report_error(P, 3, t, gc);
             } else if (valid) {
@@ -436,6 +480,11 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
         {
             // its own record, or its donor's (swap_ev_ij!, :734-749): the one dependent memory level of the iteration
             double rc[RW];
+            if constexpr (P2P) {   // records carry no tag: the arrival counters say that they have landed (peeked at while the walk ran)
+                if (walk_now && __ballot(lane < P.p2p_G && p2p_peek < P.p2p_want) != 0ull) {
+                    if (p2p_wait_arrivals(P, lane) == 1 && lane == 0) report_error(P, 3, t, gc);
+                }
+            }
             if (valid) {
                 const int s = (int)(unsigned)(xr & 0xffffffffu) - goff;
                 const double2* g_rec = (const double2*)(rec_in + (size_t)s * RW);
@@ -577,7 +626,6 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     if (P.ts && tid2 == 0) P.ts[(size_t)tile * 8 + 3] = wall_clock64();
     // Epilogue by the control wave: everything it needs comes from LDS (parked by the prologue)
     epilogue_norm<NP, P2P>(P, t, rec_out, s_theta, s_part, s_park, tile, tid2);
-    if constexpr (P2P) p2p_arrive(P, tid2 & 63);   // (every lane of the control wave is back here, whatever its chain did)
 }
 template <int NP, bool WALK>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P, const int t, const double* __restrict__ rec_in,
@@ -682,8 +730,6 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
         if (value < bp) { bestv = value; bestid = (double)t; }
         else { bestv = bp; bestid = bpid; }
     }
-    P2PLayout PL{};
-    if constexpr (P2P) PL = p2p_layout(P.Ng, RW);
     const int pb = t & 1;
     if (r == 0) {
         const double v = acc ? value : old;
@@ -692,9 +738,9 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
             for (int p = 0; p < P2P_MAXG; ++p)
                 if (p < P.p2p_G) {
                     unsigned char* w = P.p2p_win[p];
-                    ((double*)(w + PL.val_at(pb)))[gc] = v;
-                    ((uint2*)(w + PL.slot_at(pb)))[gc] = make_uint2(order_key32(v), (uint32_t)gc);
-                    if (v != v) __hip_atomic_fetch_or((uint32_t*)(w + PL.nan), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    p2p_store8((double*)(w + p2p_val_off(P, pb)) + gc, __builtin_bit_cast(unsigned long long, v));
+                    p2p_store8((uint2*)(w + p2p_slot_off(P, pb)) + gc, p2p_slot_word(v, (uint32_t)gc, t));
+                    if (v != v) __hip_atomic_fetch_or((uint32_t*)(w + 128 * (size_t)P2P_MAXG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
         } else {
             P.vals_out[c] = v;
@@ -724,7 +770,7 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
             if constexpr (P2P) {   // into every rank's window, global chain order
 #pragma unroll
                 for (int p = 0; p < P2P_MAXG; ++p)
-                    if (p < P.p2p_G && i < NPC) ((double2*)(P.p2p_win[p] + PL.rec_at(pb)) + (size_t)gc * NPC)[i] = v;
+                    if (p < P.p2p_G && i < NPC) p2p_store16((double2*)(P.p2p_win[p] + p2p_rec_off(P, pb)) + (size_t)gc * NPC + i, v);
             } else {
                 if (i < NPC) ((double2*)(rec_out + (size_t)c * RW))[i] = v;
             }

@@ -18,7 +18,7 @@ enum : int { H_VALUE = 0, H_PROB, H_CURR, H_BEST, H_BESTID, H_EXCH, H_ACC, H_STA
 // error word: min over (iter<<34 | chain<<2 | kind); 1 negative objective, 2 no draw, 3 internal
 constexpr unsigned long long ERR_NONE = ~0ull;
 
-enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2, F_WALK_INLINE = 4, F_GLOBAL_REC = 8, F_PROPOSE_ONLY = 16 };  // F_GLOBAL_REC: rec_in is the all-gathered buffer (global chain ids)
+enum : int { F_CLOSE_PREV = 1, F_HAS_PENDING = 2, F_WALK_INLINE = 4, F_GLOBAL_REC = 8, F_PROPOSE_ONLY = 16, F_P2P_ARRIVE = 32 };  // F_P2P_ARRIVE: this launch counts the previous launch's pushes in (smm_p2p.hpp)  // F_GLOBAL_REC: rec_in is the all-gathered buffer (global chain ids)
 
 struct KParams {
     // problem
@@ -103,6 +103,7 @@ struct KParams {
     unsigned char* p2p_self;       // == p2p_win[p2p_rank] (a member of its own: no dynamic index into the kernel arguments)
     int p2p_G, p2p_rank;
     unsigned long long p2p_want;   // arrivals per source rank this launch waits for before it reads its window
+    uint32_t p2p_off[6];           // byte offsets inside a window: rec[0], rec[1], val[0], val[1], slot[0], slot[1] (p2p_layout)
 };
 
 // Order keys are computed from the HIGH WORD of the value (sign, exponent, 20 mantissa bits): for finite values >= 0 it is a

@@ -54,9 +54,12 @@ __device__ inline uint32_t lean_partner(const unsigned char* lds, const uint32_t
     return (i == g ? j : i) + 1u;
 }
 
+// (GUARD: called before the exact values are read on a key tie — the p2p form makes sure they have landed; a no-op elsewhere)
+struct WalkNoGuard { __device__ inline void operator()() const {} };
 // one pair, on its own (further words of a level wider than the workgroup)
-template <int US, bool WIDE = false>
-__device__ inline void lean_pair(const double* __restrict__ vsrc, const int vstride, const uint32_t pw, const uint32_t stamp, const double thr = 0.0) {
+template <int US, bool WIDE = false, class GUARD = WalkNoGuard>
+__device__ inline void lean_pair(const double* __restrict__ vsrc, const int vstride, const uint32_t pw, const uint32_t stamp, const double thr = 0.0,
+                                 const GUARD& guard = GUARD()) {
     uint32_t ai, aj;
     lean_decode<US>(pw, ai, aj);
     if constexpr (WIDE) {
@@ -72,6 +75,7 @@ __device__ inline void lean_pair(const double* __restrict__ vsrc, const int vstr
     u32x2_t si, sj;
     asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
     bool swap = si.x > sj.x;
+    if constexpr (!std::is_same<GUARD, WalkNoGuard>::value) { if (__ballot(si.x == sj.x) != 0ull) guard(); }
     if (si.x == sj.x) swap = vsrc[(size_t)(si.y & 0xffffu) * vstride] - vsrc[(size_t)(sj.y & 0xffffu) * vstride] > 0.0;
     if (swap) {
         const u32x2_t ni = {sj.x, (sj.y & 0xffffu) | stamp}, nj = {si.x, (si.y & 0xffffu) | stamp};
@@ -87,9 +91,9 @@ __device__ inline int lean_walk_tail(const uint32_t ov, const int nlev, const in
     const unsigned long long wide = __ballot(lane < nlev && nx - ov > 64u);
     return wide ? 64 - __builtin_clzll(wide) : 0;
 }
-template <int NT, int US, bool WIDE = false>
+template <int NT, int US, bool WIDE = false, class GUARD = WalkNoGuard>
 __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const int vstride, const uint32_t pbase, const uint32_t ov,
-                                        const int nlev, const int tid, const int ltail, const double thr = 0.0) {
+                                        const int nlev, const int tid, const int ltail, const double thr = 0.0, const GUARD& guard = GUARD()) {
     const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63);   // this wave's first word within a trip
     const uint32_t tid4p = pbase + 4u * (uint32_t)tid;
     const uint32_t tidst = ((uint32_t)tid + 1u) << 16;                           // this lane's stamp at position 0
@@ -124,6 +128,7 @@ __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const i
                 bool swap = si.x > sj.x;
                 const bool tie = si.x == sj.x;
                 if (__builtin_expect(__ballot(tie) != 0ull, 0)) {   // the keys do not decide: the exact values (dist_fun = -, AlgoBGP.jl:688)
+                    guard();
                     if (tie) swap = vsrc[(size_t)(si.y & 0xffffu) * vstride] - vsrc[(size_t)(sj.y & 0xffffu) * vstride] > 0.0;
                 }
                 if (swap) {   // swap_ev_ij!, :739-744; the stamp stands for set_exchanged!, :747-748
@@ -136,7 +141,7 @@ __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const i
                 for (uint32_t o = (uint32_t)NT; wbase + o < width; o += (uint32_t)NT) {
                     uint32_t pwx;
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pwx) : "v"(tid4p + 4u * (st + o)) : "memory");
-                    lean_pair<US, WIDE>(vsrc, vstride, pwx, ((st + o) << 16) + tidst, thr);
+                    lean_pair<US, WIDE, GUARD>(vsrc, vstride, pwx, ((st + o) << 16) + tidst, thr, guard);
                 }
             }
         } else if (wbase < st2 - st1) {   // idle in this level, not in the next: its word

@@ -212,6 +212,7 @@ struct Ctx {
     bool p2p_current = false;                  // the windows hold the records after iteration `iter`
     bool p2p_inline = false;                   // k_chain_iter_norm_p2p walks inline and pushes from its epilogue
     bool p2p_unwaited = false;                 // nobody has waited for the arrivals of the last push yet
+    bool p2p_owed = false;                     // the last chain kernel pushed from its epilogue and left the arrival to the next launch
     double* ext_vals_out = nullptr;            // p2p generic form: the accept step's values go into the window
 };
 
@@ -588,19 +589,20 @@ void launch_chain_iter_norm_p2p(Ctx* c, int t, int flags) {
         default: launch_chain_iter_norm_p2p_t<4>(c, P, t, flags, smem); break;
     }
 }
-// this rank's slice of parity b -> every rank's window; FROM_CTX: out of the context's own record array
-void launch_p2p_push(Ctx* c, int b, const double* rec_src) {
+// this rank's slice after iteration t -> every rank's window (parity t & 1); FROM_CTX: out of the context's own record array
+void launch_p2p_push(Ctx* c, int t, const double* rec_src) {
     KParams P = c->P;
-    if (rec_src) hipLaunchKernelGGL(k_p2p_push<true>, dim3(p2p_units(P.N)), dim3(256), 0, c->stream, P, b, rec_src);
-    else hipLaunchKernelGGL(k_p2p_push<false>, dim3(p2p_units(P.N)), dim3(256), 0, c->stream, P, b, (const double*)nullptr);
+    if (rec_src) hipLaunchKernelGGL(k_p2p_push<true>, dim3(p2p_units(P.N)), dim3(256), 0, c->stream, P, t, rec_src);
+    else hipLaunchKernelGGL(k_p2p_push<false>, dim3(p2p_units(P.N)), dim3(256), 0, c->stream, P, t, (const double*)nullptr);
     c->p2p_seq += 1;
     c->p2p_unwaited = true;
 }
 void launch_p2p_wait(Ctx* c) {
     KParams P = c->P;
     P.p2p_want = (unsigned long long)p2p_units(P.N) * c->p2p_seq;
-    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, c->stream, P);
+    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, c->stream, P, c->iter, c->p2p_owed ? p2p_units(P.N) : 0);
     c->p2p_unwaited = false;
+    c->p2p_owed = false;
 }
 // exchangeMoves! of iteration t from the values in this rank's window (complete: somebody has waited for the arrivals)
 void launch_resolve_window(Ctx* c, int t) {
@@ -1205,9 +1207,24 @@ int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathere
         const int t = c->iter + 1;
         const KParams& P = c->P;
         int flags = (c->prev_open ? F_CLOSE_PREV : 0);
+        // profiling mode 2: this call is one more iteration of the "step" smm_sync sums up (the kernels' own begin/end stamps)
+        const bool prof = c->profiling == 2;
+        const int it = c->pev_iters;
+        if (prof) {
+            while ((int)c->pev.size() < 4 * (it + 1)) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                c->pev.push_back(e);
+            }
+            c->pev_exch.resize((size_t)it + 1, 0);
+            c->pev_exch[it] = 0;
+            if (it == 0) HIPCHK(hipEventRecord(c->ev0, c->stream));
+        }
         if (c->rec_external) {
             if (c->pending_ext) {   // exchangeMoves! of iteration t-1 over the gathered records (before its plan window can move on)
+                if (prof && c->lean_resolve) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
                 launch_resolve(c, t - 1, (const double*)gathered_prev_dev);
+                c->kev0 = c->kev1 = nullptr;
                 flags |= F_HAS_PENDING;
             }
             flags |= F_GLOBAL_REC;
@@ -1217,8 +1234,17 @@ int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathere
         }
         ensure_windows(c, t);
         c->ext_rec_out = (double*)gathered_next_dev + (size_t)P.offset * P.RW;
+        if (prof) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
         launch_chain_iter(c, t, flags);
+        c->kev0 = c->kev1 = nullptr;
         c->ext_rec_in = nullptr; c->ext_rec_out = nullptr;
+        if (prof) {
+            HIPCHK(hipEventRecord(c->ev1, c->stream));
+            c->pev_iters = it + 1;
+            c->pending_timing = true;
+            c->timing.iters = it + 1;
+            c->timing.chain_evals = (int64_t)(it + 1) * P.N;
+        }
         HIPCHK(hipGetLastError());
         c->prev_open = true;
         c->pending = false;
@@ -1279,6 +1305,8 @@ int smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out) {
             for (int r = 0; r < P2P_MAXG; ++r) P.p2p_win[r] = nullptr;
             P.p2p_win[P.p2p_rank] = c->p2p_mine;
             P.p2p_self = c->p2p_mine;
+            for (int b = 0; b < 2; ++b) { P.p2p_off[b] = (uint32_t)L.rec[b]; P.p2p_off[2 + b] = (uint32_t)L.val[b]; P.p2p_off[4 + b] = (uint32_t)L.slot[b]; }
+            if (L.total >= ((size_t)1 << 32)) throw std::string("p2p window larger than 4 GiB");
             c->p2p_attached = 1u << P.p2p_rank;
             c->p2p_seq = 0;
             c->p2p_current = false;
@@ -1356,7 +1384,8 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         if (!c->p2p_current) {   // first publication: the state after iteration `iter`, its exchange settled, into every window
             flush(c);
-            launch_p2p_push(c, c->iter & 1, c->rec[c->cur]);
+            if (c->p2p_owed) launch_p2p_wait(c);   // (an uploaded state threw the last iterations away: their arrivals are still counted)
+            launch_p2p_push(c, c->iter, c->rec[c->cur]);
             c->p2p_current = true;
             c->pending_ext = false;
         }
@@ -1366,14 +1395,26 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
             const bool prof = c->profiling == 2;
             int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
             if (inl) {
-                if (c->pending_ext) flags |= F_HAS_PENDING | F_WALK_INLINE;
+                if (c->pending_ext) {
+                    flags |= F_HAS_PENDING;
+                    // the walk of iteration t-1 needs that iteration's plan: where the plan window is about to move on, the
+                    // exchange is resolved by the stand-alone kernel first (once per window of 256 iterations)
+                    if (t >= c->plan_t0 && t < c->plan_t0 + c->plan_w) flags |= F_WALK_INLINE;
+                    else {
+                        if (c->p2p_unwaited || c->p2p_owed) launch_p2p_wait(c);
+                        launch_resolve_window(c, t - 1);
+                    }
+                }
                 ensure_windows(c, t);
+                if (c->p2p_owed) flags |= F_P2P_ARRIVE;
                 if (prof) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
                 launch_chain_iter_norm_p2p(c, t, flags);
                 c->kev0 = c->kev1 = nullptr;
                 c->p2p_seq += 1;
                 c->p2p_unwaited = true;   // (the next inline kernel waits itself; anybody else launches k_p2p_wait)
+                c->p2p_owed = true;       // (... and counts this launch's pushes in)
             } else {
+                if (c->p2p_owed) launch_p2p_wait(c);   // (a chain kernel of the inline form ran before: its arrivals are still owed)
                 if (c->pending_ext) {   // exchangeMoves! of iteration t-1 (before its plan window can move on)
                     if (c->p2p_unwaited) launch_p2p_wait(c);
                     if (prof && c->lean_resolve) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
@@ -1389,7 +1430,7 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
                 launch_chain_iter(c, t, flags);
                 c->kev0 = c->kev1 = nullptr;
                 c->ext_rec_in = nullptr; c->ext_rec_out = nullptr; c->ext_vals_out = nullptr;
-                launch_p2p_push(c, t & 1, nullptr);
+                launch_p2p_push(c, t, nullptr);
             }
             c->prev_open = true;
             c->pending = false;
@@ -1420,7 +1461,7 @@ int smm_bgp_p2p_finish(void* ctx) {
         const KParams& P = c->P;
         const P2PLayout L = p2p_layout(P.Ng, P.RW);
         int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
-        if (c->p2p_unwaited) launch_p2p_wait(c);   // the donors' records of the last iteration must have landed
+        if (c->p2p_unwaited || c->p2p_owed) launch_p2p_wait(c);   // the donors' records of the last iteration must have landed
         if (c->pending_ext) {
             launch_resolve_window(c, c->iter);
             flags |= F_HAS_PENDING;

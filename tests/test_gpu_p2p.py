@@ -74,9 +74,10 @@ def assert_shards_equal_single(ctxs, single):
     assert (hs.exchanged != 0).any()
 
 
-@pytest.mark.parametrize("G,N,T,fe", [(1, 48, 20, None), (2, 64, 30, None), (4, 64, 30, 7), (2, 5000, 12, None), (4, 8192, 8, None), (8, 640, 40, 11)])
+@pytest.mark.parametrize("G,N,T,fe", [(1, 48, 20, None), (2, 64, 30, None), (4, 64, 30, 7), (2, 5000, 12, None), (4, 8192, 8, None), (8, 640, 40, 11), (2, 64, 300, None)])
 def test_p2p_inline_equals_single(S, O, G, N, T, fe):
     # objfunc_norm 2p/2m, min_improve == 0, N_global <= 8192: one launch per iteration and shard (k_chain_iter_norm_p2p)
+    # (300 iterations: across a look-ahead window of 256)
     prob, opts = cm.serial_normal(N=N, T=T, ns=64 if N > 100 else 300)
     single = S.hip_context(prob, opts)
     single.step(T)
