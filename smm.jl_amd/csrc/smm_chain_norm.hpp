@@ -239,19 +239,16 @@ __device__ inline bool exchange_walk_lean_wide(const KParams& P, const int tx, u
     return true;
 }
 
-// the lean walk of a SHARD (the p2p form, smm_p2p.hpp): the slots of all N_global <= 8192 chains come from this rank's window,
-// where every rank's accept step of iteration tx stored them.  Nobody polls first: plan and slots are requested in one batch and
-// every slot says which iteration it is from (p2p_tag); a wave that finds an older one among ITS slots waits for the arrival
-// counters and reads its slots again.  On a key tie the exact values are read: those carry no tag, so the walk's guard waits
-// for the counters first (rare).  false: timed out, the plan does not fit the form, or a NaN value.
-struct P2PTieGuard {
-    const KParams& P; int lane, t;
-    __device__ inline void operator()() const { if (p2p_wait_arrivals(P, lane) == 1 && lane == 0) report_error(P, 3, t, P.offset); }
-};
+// the lean walk of a SHARD (the inline p2p form, smm_p2p.hpp): the slots of all N_global <= 8192 chains come from this rank's
+// window, where every rank's accept step of iteration tx stored them.  Nobody polls anything first: plan and slots are requested
+// in one batch and every slot says which iteration it is from (p2p_tag); a lane that finds an older one looks again, past the
+// caches, until it is there.  On a key tie the exact values are read from their self-validating copies (P2PWalkValues).
+// false: timed out, the plan does not fit the form, or a NaN value.
+template <int NMAX>   // the largest population the staging loops serve: XLVL_MAX (4096) or XLDS_MAX (8192)
 __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, unsigned char* lds, const int tid, const int ts_tile) {
     constexpr int NT = NORM_WG;
-    constexpr int SR = XLDS_MAX / (4 * NT);                                       // rounds of four slots per lane
-    constexpr int PR = (XLDS_MAX + 64 * LV_MAXLEV + 4 * NT - 1) / (4 * NT);        // rounds of four pair words per lane
+    constexpr int SR = NMAX / (4 * NT);                                       // rounds of four slots per lane
+    constexpr int PR = (NMAX + 64 * LV_MAXLEV + 4 * NT - 1) / (4 * NT);        // rounds of four pair words per lane
     const int Ng = P.Ng;
     const int w = tx - P.plan_t0;
     const uint32_t* __restrict__ g_offp = P.lv_offp + (size_t)w * LV_OFFP;
@@ -263,15 +260,12 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
     const uint4* g_slots = (const uint4*)(mine + p2p_slot_off(P, tx & 1));
     const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
     uint4 s_[2 * SR];
-    auto load_slots = [&]() {
 #pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            const int q = tid + r * NT;
-            s_[2 * r] = make_uint4(0u, 0u, 0u, 0u); s_[2 * r + 1] = s_[2 * r];
-            if (4 * q < Ng) { s_[2 * r] = g_slots[2 * q]; s_[2 * r + 1] = g_slots[2 * q + 1]; }
-        }
-    };
-    load_slots();
+    for (int r = 0; r < SR; ++r) {
+        const int q = tid + r * NT;
+        s_[2 * r] = make_uint4(0u, 0u, 0u, 0u); s_[2 * r + 1] = s_[2 * r];
+        if (4 * q < Ng) { s_[2 * r] = g_slots[2 * q]; s_[2 * r + 1] = g_slots[2 * q + 1]; }
+    }
     const uint32_t wflags = *(const uint32_t*)(mine + 128 * (size_t)P2P_MAXG + 0 * (size_t)(tid & 1));
     uint4 p_[PR];
 #pragma unroll
@@ -280,27 +274,26 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
         p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
     }
     const uint32_t want_hi = p2p_tag(tx) << 16;
-    auto fresh = [&]() {
-        bool ok = true;
+    bool timed_out = false;
 #pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            const int g = 4 * (tid + r * NT);
-            if (g < Ng) ok = ok && (s_[2 * r].y & 0xffff0000u) == want_hi;
-            if (g + 1 < Ng) ok = ok && (s_[2 * r].w & 0xffff0000u) == want_hi;
-            if (g + 2 < Ng) ok = ok && (s_[2 * r + 1].y & 0xffff0000u) == want_hi;
-            if (g + 3 < Ng) ok = ok && (s_[2 * r + 1].w & 0xffff0000u) == want_hi;
+    for (int r = 0; r < SR; ++r) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int g = 4 * (tid + r * NT) + 2 * hh;   // the two slots of this 16-byte piece: g, g + 1 (Ng is what it is: the pad slots carry nothing)
+            uint4& q = s_[2 * r + hh];
+            auto ok = [&]() { return (g >= Ng || (q.y & 0xffff0000u) == want_hi) && (g + 1 >= Ng || (q.w & 0xffff0000u) == want_hi); };
+            if (__builtin_expect(!ok(), 0)) {   // somebody's stores are still on their way
+                const unsigned long long t0 = wall_clock64();
+                do {
+                    __builtin_amdgcn_s_sleep(1);
+                    q = p2p_load16_sys(g_slots + (g >> 1));
+                    if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { timed_out = true; break; }
+                } while (!ok());
+            }
         }
-        return __ballot(!ok) == 0ull;
-    };
-    int arrived = 0;
-    if (__builtin_expect(!fresh(), 0)) {   // somebody's stores are still on their way: the counters, then the slots once more
-        arrived = p2p_wait_arrivals(P, lane);
-        load_slots();
-        if (arrived == 0 && !fresh()) arrived = 1;
     }
+    if (timed_out) report_error(P, 3, tx + 1, P.offset);   // (everybody goes on to the barriers below; the failure is reported)
     const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
-    // (a wave that gives up must not leave the others at the barriers below: everybody goes on, the failure is reported)
-    if (arrived == 1 && lane == 0) report_error(P, 3, tx + 1, P.offset);
     const bool form_ok = __builtin_amdgcn_readlane((int)ov, 34) != 0 && __builtin_amdgcn_readfirstlane((int)wflags) == 0 && (uint32_t)(size_t)lds == 0u;
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
@@ -320,10 +313,9 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
     __syncthreads();
     if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
     if (!form_ok) return false;   // (wave-uniform AND the same in every wave: plan and flag are what they are for the whole launch)
-    const double* vals = (const double*)(mine + p2p_val_off(P, tx & 1));
-    const P2PTieGuard guard{P, lane, tx + 1};
-    if (P.lean_unit == 8) lean_walk_levels<NORM_WG, 0, false, P2PTieGuard>(vals, 1, pbase, ov, nlev, tid, ltail, 0.0, guard);
-    else lean_walk_levels<NORM_WG, 1, false, P2PTieGuard>(vals, 1, pbase, ov, nlev, tid, ltail, 0.0, guard);
+    const P2PWalkValues values{P, tx};
+    if (NMAX <= XLVL_MAX || P.lean_unit == 8) lean_walk_levels<NORM_WG, 0, false, P2PWalkValues>(nullptr, 1, pbase, ov, nlev, tid, ltail, 0.0, values);
+    else lean_walk_levels<NORM_WG, 1, false, P2PWalkValues>(nullptr, 1, pbase, ov, nlev, tid, ltail, 0.0, values);
     return true;
 }
 
@@ -338,7 +330,7 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
 // kernel the headline kernel spilled 8 scalar registers in its latency-bound prologue and took 0.3 us longer)
 // (P2P: a shard of the p2p form, smm_p2p.hpp — records, values and walk slots of ALL chains live in this rank's window, the accept
 // step stores its results into every rank's window and arrives; WALK then means "when the launch says so", F_WALK_INLINE)
-template <int NP, bool WALK, bool WIDE, bool LEAN, bool P2P = false>
+template <int NP, bool WALK, bool WIDE, bool LEAN, bool P2P = false, bool P2P_BIG = true>
 __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int t, const double* __restrict__ rec_in_arg,
                                                      double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -363,12 +355,9 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     const bool valid = ctl && c < N;
     const int gc = P.offset + c;
     const int goff = (flags & F_GLOBAL_REC) ? 0 : P.offset;   // rec_in indexed by global chain id (all-gathered buffer)?
-    const double* __restrict__ rec_in = P2P ? (const double*)(P.p2p_self + p2p_rec_off(P, (t - 1) & 1)) : rec_in_arg;
+    const double* __restrict__ rec_in = rec_in_arg;   // (P2P: the records come out of this rank's window, below)
     const bool walk_now = WALK && (!P2P || (flags & F_WALK_INLINE));
     TS_MARK(0);
-    if constexpr (P2P) {   // the previous launch's pushes are complete (stream order): count this tile's share in, everywhere
-        if ((flags & F_P2P_ARRIVE) && wave == 2) p2p_arrive<false>(P, lane);
-    }
 
     // ---- global reads that do not depend on the exchange, all issued before anything waits ----
     double za[NORM_ZU];
@@ -410,22 +399,13 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     if (!walk_now) __syncthreads();
 
     uint32_t kmeta = 0u;   // lean walk: src | stamp << 16 of the chain's slot (the partner is looked up while the record is on its way)
-    unsigned long long p2p_peek = ~0ull;   // p2p: this rank's arrival counter of source rank `lane`, requested now, looked at after the walk
-    if constexpr (P2P) {
-        if (walk_now && ctl && lane < P.p2p_G)
-            p2p_peek = __hip_atomic_load((const unsigned long long*)(P.p2p_self + 128 * (size_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
     if (walk_now) {
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716), by all lanes of the workgroup, while those loads are in flight
         if constexpr (LEAN) {
             bool lean;
-            if constexpr (P2P) lean = exchange_walk_lean_p2p(P, t - 1, (unsigned char*)smem, tid, tile);
+            if constexpr (P2P) lean = exchange_walk_lean_p2p<P2P_BIG ? XLDS_MAX : XLVL_MAX>(P, t - 1, (unsigned char*)smem, tid, tile);
             else if constexpr (WIDE) lean = exchange_walk_lean_wide(P, t - 1, (unsigned char*)smem, tid, tile);
             else lean = exchange_walk_lean(P, t - 1, (unsigned char*)smem, tid, tile);
-            if constexpr (P2P) {   // (asked again now that the walk is over: the answer travels while the slot is read and the partner looked up)
-                if (ctl && lane < P.p2p_G && p2p_peek < P.p2p_want)
-                    p2p_peek = __hip_atomic_load((const unsigned long long*)(P.p2p_self + 128 * (size_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
             if (!lean) {   // (cannot happen: the host launches k_chain_iter_norm_any wherever it can; loud if it does)
                 if (tid == 0) report_error(P, 3, t, gc);
             } else if (valid) {
@@ -480,18 +460,36 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
         {
             // its own record, or its donor's (swap_ev_ij!, :734-749): the one dependent memory level of the iteration
             double rc[RW];
-            if constexpr (P2P) {   // records carry no tag: the arrival counters say that they have landed (peeked at while the walk ran)
-                if (walk_now && __ballot(lane < P.p2p_G && p2p_peek < P.p2p_want) != 0ull) {
-                    if (p2p_wait_arrivals(P, lane) == 1 && lane == 0) report_error(P, 3, t, gc);
-                }
-            }
             if (valid) {
                 const int s = (int)(unsigned)(xr & 0xffffffffu) - goff;
-                const double2* g_rec = (const double2*)(rec_in + (size_t)s * RW);
+                if constexpr (P2P) {   // the self-validating record of iteration t-1 out of this rank's window (its own chain's, or the donor's)
+                    const uint4* g_ll = (const uint4*)(P.p2p_self + p2p_llrec_off(P, (t - 1) & 1) + (size_t)s * RW * 16);
+                    const uint32_t tag = p2p_tag(t - 1);
+                    uint4 q[RW];
 #pragma unroll
-                for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc[2 * i] = q.x; rc[2 * i + 1] = q.y; }
+                    for (int i = 0; i < RW; ++i) q[i] = g_ll[i];
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) ok = ok && p2p_ll_ok(q[i], tag);
+                    if (__builtin_expect(!ok, 0)) {   // still on its way: look again, past the caches
+                        const unsigned long long t0 = wall_clock64();
+                        do {
+                            __builtin_amdgcn_s_sleep(1);
+                            ok = true;
+#pragma unroll
+                            for (int i = 0; i < RW; ++i) { q[i] = p2p_load16_sys(g_ll + i); ok = ok && p2p_ll_ok(q[i], tag); }
+                            if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { report_error(P, 3, t, gc); break; }
+                        } while (!ok);
+                    }
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) rc[i] = p2p_ll_double(q[i]);
+                } else {
+                    const double2* g_rec = (const double2*)(rec_in + (size_t)s * RW);
+#pragma unroll
+                    for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc[2 * i] = q.x; rc[2 * i + 1] = q.y; }
+                }
                 if (WALK && LEAN && (kmeta >> 16))   // set_exchanged!, :747-748: from the pair word the swap stamped into the slot
-                    partner = (P2P && P.lean_unit != 8) ? (int)lean_partner<1>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc)
+                    partner = (P2P && P2P_BIG && P.lean_unit != 8) ? (int)lean_partner<1>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc)
                               : !WIDE ? (int)lean_partner<0>((const unsigned char*)smem, 8u * ((uint32_t)((P.Ng + 3) & ~3) + 4u), kmeta, (uint32_t)gc)
                               : P.lean_unit == 16 ? (int)lean_partner<0, 4>((const unsigned char*)smem, 16u * ((uint32_t)((P.Ng + 3) & ~3) + 1u), kmeta, (uint32_t)gc)
                                                   : (int)lean_partner<1, 4>((const unsigned char*)smem, 16u * ((uint32_t)((P.Ng + 3) & ~3) + 1u), kmeta, (uint32_t)gc);
@@ -645,10 +643,10 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_any(const KParam
 }
 
 // a shard of the p2p form: the lean key walk inline when the launch says so (N_global <= 8192), results into every rank's window
-template <int NP>
+template <int NP, bool BIG>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_p2p(const KParams P, const int t, const double* __restrict__ rec_in,
                                                                      double* __restrict__ rec_out, const int flags) {
-    chain_iter_norm_body<NP, true, false, true, true>(P, t, rec_in, rec_out, flags);
+    chain_iter_norm_body<NP, true, false, true, true, BIG>(P, t, rec_in, rec_out, flags);
 }
 
 // objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks
@@ -738,7 +736,9 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
             for (int p = 0; p < P2P_MAXG; ++p)
                 if (p < P.p2p_G) {
                     unsigned char* w = P.p2p_win[p];
-                    p2p_store8((double*)(w + p2p_val_off(P, pb)) + gc, __builtin_bit_cast(unsigned long long, v));
+                    const unsigned long long vb = __builtin_bit_cast(unsigned long long, v);
+                    const p2p_u32x4 qv = {(unsigned)vb, p2p_tag(t), (unsigned)(vb >> 32), p2p_tag(t)};
+                    p2p_store16u((uint4*)(w + p2p_llval_off(P, pb)) + gc, qv);
                     p2p_store8((uint2*)(w + p2p_slot_off(P, pb)) + gc, p2p_slot_word(v, (uint32_t)gc, t));
                     if (v != v) __hip_atomic_fetch_or((uint32_t*)(w + 128 * (size_t)P2P_MAXG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
@@ -770,7 +770,7 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
             if constexpr (P2P) {   // into every rank's window, global chain order
 #pragma unroll
                 for (int p = 0; p < P2P_MAXG; ++p)
-                    if (p < P.p2p_G && i < NPC) p2p_store16((double2*)(P.p2p_win[p] + p2p_rec_off(P, pb)) + (size_t)gc * NPC + i, v);
+                    if (p < P.p2p_G && i < NPC) p2p_store_ll(P.p2p_win[p] + p2p_llrec_off(P, pb) + ((size_t)gc * NPC + i) * 32, v, p2p_tag(t));
             } else {
                 if (i < NPC) ((double2*)(rec_out + (size_t)c * RW))[i] = v;
             }

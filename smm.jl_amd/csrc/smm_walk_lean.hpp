@@ -54,8 +54,14 @@ __device__ inline uint32_t lean_partner(const unsigned char* lds, const uint32_t
     return (i == g ? j : i) + 1u;
 }
 
-// (GUARD: called before the exact values are read on a key tie — the p2p form makes sure they have landed; a no-op elsewhere)
-struct WalkNoGuard { __device__ inline void operator()() const {} };
+// (GUARD: where the exact value of chain s comes from on a key tie — vsrc[s * vstride] by default; the p2p form reads a
+// self-validating copy out of its window, GUARD::value)
+struct WalkNoGuard {};
+template <class GUARD>
+__device__ inline double walk_value(const GUARD& g, const double* __restrict__ vsrc, const int vstride, const uint32_t s) {
+    if constexpr (std::is_same<GUARD, WalkNoGuard>::value) return vsrc[(size_t)s * vstride];
+    else return g.value(s);
+}
 // one pair, on its own (further words of a level wider than the workgroup)
 template <int US, bool WIDE = false, class GUARD = WalkNoGuard>
 __device__ inline void lean_pair(const double* __restrict__ vsrc, const int vstride, const uint32_t pw, const uint32_t stamp, const double thr = 0.0,
@@ -75,8 +81,7 @@ __device__ inline void lean_pair(const double* __restrict__ vsrc, const int vstr
     u32x2_t si, sj;
     asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
     bool swap = si.x > sj.x;
-    if constexpr (!std::is_same<GUARD, WalkNoGuard>::value) { if (__ballot(si.x == sj.x) != 0ull) guard(); }
-    if (si.x == sj.x) swap = vsrc[(size_t)(si.y & 0xffffu) * vstride] - vsrc[(size_t)(sj.y & 0xffffu) * vstride] > 0.0;
+    if (si.x == sj.x) swap = walk_value(guard, vsrc, vstride, si.y & 0xffffu) - walk_value(guard, vsrc, vstride, sj.y & 0xffffu) > 0.0;
     if (swap) {
         const u32x2_t ni = {sj.x, (sj.y & 0xffffu) | stamp}, nj = {si.x, (si.y & 0xffffu) | stamp};
         asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
@@ -128,8 +133,7 @@ __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const i
                 bool swap = si.x > sj.x;
                 const bool tie = si.x == sj.x;
                 if (__builtin_expect(__ballot(tie) != 0ull, 0)) {   // the keys do not decide: the exact values (dist_fun = -, AlgoBGP.jl:688)
-                    guard();
-                    if (tie) swap = vsrc[(size_t)(si.y & 0xffffu) * vstride] - vsrc[(size_t)(sj.y & 0xffffu) * vstride] > 0.0;
+                    if (tie) swap = walk_value(guard, vsrc, vstride, si.y & 0xffffu) - walk_value(guard, vsrc, vstride, sj.y & 0xffffu) > 0.0;
                 }
                 if (swap) {   // swap_ev_ij!, :739-744; the stamp stands for set_exchanged!, :747-748
                     const u32x2_t ni = {sj.x, (sj.y & 0xffffu) | stamp}, nj = {si.x, (si.y & 0xffffu) | stamp};

@@ -210,9 +210,9 @@ struct Ctx {
     unsigned p2p_attached = 0;                 // bit r: rank r's window is known
     unsigned long long p2p_seq = 0;            // pushes so far (every rank counts the same)
     bool p2p_current = false;                  // the windows hold the records after iteration `iter`
-    bool p2p_inline = false;                   // k_chain_iter_norm_p2p walks inline and pushes from its epilogue
+    bool p2p_inline = false;                   // the inline form is available: k_chain_iter_norm_p2p walks inline and pushes from its epilogue
+    bool p2p_mode_inline = false;              // ... and is what the windows currently hold (decided at every publication)
     bool p2p_unwaited = false;                 // nobody has waited for the arrivals of the last push yet
-    bool p2p_owed = false;                     // the last chain kernel pushed from its epilogue and left the arrival to the next launch
     double* ext_vals_out = nullptr;            // p2p generic form: the accept step's values go into the window
 };
 
@@ -566,13 +566,19 @@ struct DevBuf {
 
 
 // ---- the p2p form of the sharded iteration (smm_p2p.hpp, include/smmhip.h) ----
-template <int NP>
-void launch_chain_iter_norm_p2p_t(Ctx* c, const KParams& P, int t, int flags, size_t smem) {
+template <int NP, bool BIG>
+void launch_chain_iter_norm_p2p_tb(Ctx* c, const KParams& P, int t, int flags, size_t smem) {
     const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
     if (c->kev0)
-        hipExtLaunchKernelGGL((k_chain_iter_norm_p2p<NP>), grid, block, smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (double*)nullptr, flags);
+        hipExtLaunchKernelGGL((k_chain_iter_norm_p2p<NP, BIG>), grid, block, smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (double*)nullptr, flags);
     else
-        hipLaunchKernelGGL((k_chain_iter_norm_p2p<NP>), grid, block, smem, c->stream, P, t, (const double*)nullptr, (double*)nullptr, flags);
+        hipLaunchKernelGGL((k_chain_iter_norm_p2p<NP, BIG>), grid, block, smem, c->stream, P, t, (const double*)nullptr, (double*)nullptr, flags);
+}
+template <int NP>
+void launch_chain_iter_norm_p2p_t(Ctx* c, const KParams& P, int t, int flags, size_t smem) {
+    // (BIG: staging loops for up to 8192 chains — two shards of 4096; the small form serves populations up to 4096)
+    if (P.Ng > XLVL_MAX || P.plan_K > XLVL_MAX) launch_chain_iter_norm_p2p_tb<NP, true>(c, P, t, flags, smem);
+    else launch_chain_iter_norm_p2p_tb<NP, false>(c, P, t, flags, smem);
 }
 size_t p2p_walk_bytes(const Ctx* c) { return (lean_walk_bytes(c->P.Ng, c->P.plan_K) + 15) & ~(size_t)15; }
 void launch_chain_iter_norm_p2p(Ctx* c, int t, int flags) {
@@ -580,7 +586,6 @@ void launch_chain_iter_norm_p2p(Ctx* c, int t, int flags) {
     point_values(c, P, t - 1, t);
     const bool walk = (flags & F_WALK_INLINE) != 0;
     P.tile_off = walk ? (int)(p2p_walk_bytes(c) / sizeof(double)) : 0;
-    P.p2p_want = (unsigned long long)p2p_units(P.N) * c->p2p_seq;
     const size_t smem = (size_t)P.tile_off * sizeof(double) + norm_tile_doubles(P.np) * sizeof(double);
     switch (P.np) {
         case 1: launch_chain_iter_norm_p2p_t<1>(c, P, t, flags, smem); break;
@@ -589,20 +594,25 @@ void launch_chain_iter_norm_p2p(Ctx* c, int t, int flags) {
         default: launch_chain_iter_norm_p2p_t<4>(c, P, t, flags, smem); break;
     }
 }
-// this rank's slice after iteration t -> every rank's window (parity t & 1); FROM_CTX: out of the context's own record array
-void launch_p2p_push(Ctx* c, int t, const double* rec_src) {
+// this rank's slice after iteration t -> every rank's window (parity t & 1); rec_src: out of the context's own record array (a
+// publication), else out of its own window (generic form, after a chain kernel); ll: the self-validating form of the inline kernels
+void launch_p2p_push(Ctx* c, int t, const double* rec_src, bool ll) {
     KParams P = c->P;
-    if (rec_src) hipLaunchKernelGGL(k_p2p_push<true>, dim3(p2p_units(P.N)), dim3(256), 0, c->stream, P, t, rec_src);
-    else hipLaunchKernelGGL(k_p2p_push<false>, dim3(p2p_units(P.N)), dim3(256), 0, c->stream, P, t, (const double*)nullptr);
-    c->p2p_seq += 1;
-    c->p2p_unwaited = true;
+    const dim3 grid(p2p_units(P.N)), block(256);
+    if (ll) hipLaunchKernelGGL((k_p2p_push<true, true>), grid, block, 0, c->stream, P, t, rec_src);
+    else if (rec_src) hipLaunchKernelGGL((k_p2p_push<true, false>), grid, block, 0, c->stream, P, t, rec_src);
+    else hipLaunchKernelGGL((k_p2p_push<false, false>), grid, block, 0, c->stream, P, t, (const double*)nullptr);
+    if (!ll) { c->p2p_seq += 1; c->p2p_unwaited = true; }
 }
 void launch_p2p_wait(Ctx* c) {
     KParams P = c->P;
     P.p2p_want = (unsigned long long)p2p_units(P.N) * c->p2p_seq;
-    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, c->stream, P, c->iter, c->p2p_owed ? p2p_units(P.N) : 0);
+    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, c->stream, P, c->iter);
     c->p2p_unwaited = false;
-    c->p2p_owed = false;
+}
+// inline form: everybody's records and values after iteration t, out of their self-validating form into this rank's plain arrays
+void launch_p2p_unpack(Ctx* c, int t) {
+    hipLaunchKernelGGL(k_p2p_unpack, dim3((c->P.Ng + 255) / 256), dim3(256), 0, c->stream, c->P, t);
 }
 // exchangeMoves! of iteration t from the values in this rank's window (complete: somebody has waited for the arrivals)
 void launch_resolve_window(Ctx* c, int t) {
@@ -1044,10 +1054,14 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_eval_batch<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -1294,7 +1308,9 @@ int smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out) {
         const P2PLayout L = p2p_layout(P.Ng, P.RW);
         if (!c->p2p_mine) {
             // uncached device memory: what peers store is never served from a stale line of this device's caches, and what this
-            // device stores goes to memory (IPC-exportable like any device allocation)
+            // device stores goes to memory (IPC-exportable like any device allocation).  (Plain and fine-grained allocations
+            // pass the same tests at the same speed on one device — tools/exp/r3_p2p_mem.sh —: the self-validating words make the
+            // readers independent of it; uncached is the one whose semantics need no argument across devices.)
             void* w = nullptr;
             HIPCHK(hipExtMallocWithFlags(&w, L.total, hipDeviceMallocUncached));
             c->p2p_mine = (unsigned char*)w;
@@ -1305,7 +1321,10 @@ int smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out) {
             for (int r = 0; r < P2P_MAXG; ++r) P.p2p_win[r] = nullptr;
             P.p2p_win[P.p2p_rank] = c->p2p_mine;
             P.p2p_self = c->p2p_mine;
-            for (int b = 0; b < 2; ++b) { P.p2p_off[b] = (uint32_t)L.rec[b]; P.p2p_off[2 + b] = (uint32_t)L.val[b]; P.p2p_off[4 + b] = (uint32_t)L.slot[b]; }
+            for (int b = 0; b < 2; ++b) {
+                P.p2p_off[b] = (uint32_t)L.rec[b]; P.p2p_off[2 + b] = (uint32_t)L.val[b]; P.p2p_off[4 + b] = (uint32_t)L.slot[b];
+                P.p2p_off[6 + b] = (uint32_t)L.llrec[b]; P.p2p_off[8 + b] = (uint32_t)L.llval[b];
+            }
             if (L.total >= ((size_t)1 << 32)) throw std::string("p2p window larger than 4 GiB");
             c->p2p_attached = 1u << P.p2p_rank;
             c->p2p_seq = 0;
@@ -1384,37 +1403,31 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         if (!c->p2p_current) {   // first publication: the state after iteration `iter`, its exchange settled, into every window
             flush(c);
-            if (c->p2p_owed) launch_p2p_wait(c);   // (an uploaded state threw the last iterations away: their arrivals are still counted)
-            launch_p2p_push(c, c->iter, c->rec[c->cur]);
+            c->p2p_mode_inline = c->p2p_inline && !c->nan_values;
+            launch_p2p_push(c, c->iter, c->rec[c->cur], c->p2p_mode_inline);
             c->p2p_current = true;
             c->pending_ext = false;
         }
-        const bool inl = c->p2p_inline && !c->nan_values;
         for (int it = 0; it < n_iters; ++it) {
             const int t = c->iter + 1;
             const bool prof = c->profiling == 2;
             int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
-            if (inl) {
+            if (c->p2p_mode_inline) {
                 if (c->pending_ext) {
                     flags |= F_HAS_PENDING;
                     // the walk of iteration t-1 needs that iteration's plan: where the plan window is about to move on, the
                     // exchange is resolved by the stand-alone kernel first (once per window of 256 iterations)
                     if (t >= c->plan_t0 && t < c->plan_t0 + c->plan_w) flags |= F_WALK_INLINE;
                     else {
-                        if (c->p2p_unwaited || c->p2p_owed) launch_p2p_wait(c);
+                        launch_p2p_unpack(c, t - 1);
                         launch_resolve_window(c, t - 1);
                     }
                 }
                 ensure_windows(c, t);
-                if (c->p2p_owed) flags |= F_P2P_ARRIVE;
                 if (prof) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
                 launch_chain_iter_norm_p2p(c, t, flags);
                 c->kev0 = c->kev1 = nullptr;
-                c->p2p_seq += 1;
-                c->p2p_unwaited = true;   // (the next inline kernel waits itself; anybody else launches k_p2p_wait)
-                c->p2p_owed = true;       // (... and counts this launch's pushes in)
             } else {
-                if (c->p2p_owed) launch_p2p_wait(c);   // (a chain kernel of the inline form ran before: its arrivals are still owed)
                 if (c->pending_ext) {   // exchangeMoves! of iteration t-1 (before its plan window can move on)
                     if (c->p2p_unwaited) launch_p2p_wait(c);
                     if (prof && c->lean_resolve) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
@@ -1430,7 +1443,7 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
                 launch_chain_iter(c, t, flags);
                 c->kev0 = c->kev1 = nullptr;
                 c->ext_rec_in = nullptr; c->ext_rec_out = nullptr; c->ext_vals_out = nullptr;
-                launch_p2p_push(c, t, nullptr);
+                launch_p2p_push(c, t, nullptr, false);
             }
             c->prev_open = true;
             c->pending = false;
@@ -1461,7 +1474,9 @@ int smm_bgp_p2p_finish(void* ctx) {
         const KParams& P = c->P;
         const P2PLayout L = p2p_layout(P.Ng, P.RW);
         int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
-        if (c->p2p_unwaited || c->p2p_owed) launch_p2p_wait(c);   // the donors' records of the last iteration must have landed
+        // the donors' records of the last iteration must have landed, in plain form
+        if (c->p2p_mode_inline) launch_p2p_unpack(c, c->iter);
+        else if (c->p2p_unwaited) launch_p2p_wait(c);
         if (c->pending_ext) {
             launch_resolve_window(c, c->iter);
             flags |= F_HAS_PENDING;
