@@ -399,13 +399,16 @@ def main():
             roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "
                             "(FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)")
     # the same chain kernel without the exchange walk in its prologue (single shard, C2): what the fused launch consists of
-    if roof is not None and not sharded and args.workload == "c2" and not args.no_unfused and os.environ.get("SMMHIP_INLINE_WALK") != "0":
+    if roof is not None and not sharded and args.workload == "c2" and not args.no_unfused and os.path.exists(S._abi.HOOKS_LIB_PATH):
+        # (a seam of the TEST build of the library, libsmmhip_hooks.so: the shipped one has no switch for it)
         os.environ["SMMHIP_INLINE_WALK"] = "0"
         try:
+            S._abi.use_test_hooks(True)
             prob2, opts2 = cm.serial_normal(N=n_glob, T=2 * ITERS_PER_STEP, device=device)
             c2 = S.hip_context(prob2, opts2)
         finally:
             del os.environ["SMMHIP_INLINE_WALK"]
+            S._abi.use_test_hooks(False)
         c2.step(ITERS_PER_STEP)
         c2.set_profiling(2)
         c2.step(ITERS_PER_STEP)

@@ -93,7 +93,7 @@ function MAlgoBGPHip(m::MProb, opts::Dict)
     temps = N > 1 ? collect(range(1.0, stop = Float64(opts["maxtemp"]), length = N)) : [1.0]      # AlgoBGP.jl:508
     mi = chain_vector(opts, "min_improve", 0.5, N)                                                  # :522
     acc = chain_vector(opts, "acc_tuners", 2.0, N)                                                  # :523
-    dist_fun = get(opts, "dist_fun", -)                                                             # :537
+    dist_fun = get(opts, "hip_dist_fun", get(opts, "dist_fun", -))                                  # :537 (hip_dist_fun: the menu entry of a saved run, as_reference)
     dist_id = device_dist_fun(dist_fun)
     pnames = Symbol[Symbol(k) for k in keys(m.params_to_sample)]
     mnames = Symbol[Symbol(k) for k in keys(m.moments)]
@@ -244,7 +244,14 @@ The run as a plain `SMM.MAlgoBGP` (same MProb, opts, iteration and the synced ch
 file saved from the GPU path is read by the reference's own `readMalgo` (AlgoAbstract.jl:95-102) on any machine.
 """
 function as_reference(algo::MAlgoBGPHip)
-    ref = MAlgoBGP(algo.m, algo.opts)
+    # the reference stores opts["dist_fun"] in a field typed ::Function (AlgoBGP.jl:503,537): a menu entry (:absdiff, "reldiff", ...)
+    # would throw there, so the plain algo gets the host function and the menu entry moves to "hip_dist_fun" (read back on resume)
+    opts = copy(algo.opts)
+    if haskey(opts, "dist_fun") && !(opts["dist_fun"] isa Function)
+        opts["hip_dist_fun"] = opts["dist_fun"]
+        opts["dist_fun"] = getfield(algo, :dist_fun)
+    end
+    ref = MAlgoBGP(algo.m, opts)
     ref.chains = algo.chains
     ref.i = algo.i
     return ref

@@ -10,6 +10,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsmmhip.so")
+# the same sources with the test seams compiled in (-DSMM_TEST_HOOKS: forcing an exchange kernel, switching a fast path off, ...):
+# loaded by tests/ and tools/ only, never by the product path
+HOOKS_LIB_PATH = os.path.join(_HERE, "csrc", "libsmmhip_hooks.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -170,6 +173,30 @@ def load():
         if _lib.smm_abi_version() != 3:
             raise ImportError("libsmmhip.so ABI version mismatch")
     return _lib
+
+
+_hooks_lib = None
+
+
+def load_hooks():
+    """the test build (libsmmhip_hooks.so); tests/ and tools/ make it current with use_test_hooks()"""
+    global _hooks_lib
+    if _hooks_lib is None:
+        if not os.path.exists(HOOKS_LIB_PATH):
+            raise ImportError("libsmmhip_hooks.so not found at %s — `make -C smm.jl_amd/csrc all`" % HOOKS_LIB_PATH)
+        lib = bind(C.CDLL(HOOKS_LIB_PATH, mode=C.RTLD_GLOBAL))   # (GLOBAL like the shipped one: one HIP runtime per process; both are linked -Bsymbolic)
+        lib.smm_debug_has_test_hooks.restype = C.c_int
+        if lib.smm_abi_version() != 3 or lib.smm_debug_has_test_hooks() != 1:
+            raise ImportError("libsmmhip_hooks.so: wrong ABI version or built without -DSMM_TEST_HOOKS")
+        _hooks_lib = lib
+    return _hooks_lib
+
+
+def use_test_hooks(on=True):
+    """contexts created from now on come from the test build (on) or the shipped library (off); returns the library"""
+    global _lib
+    _lib = load_hooks() if on else None
+    return load()
 
 
 def dptr(a):

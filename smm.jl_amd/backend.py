@@ -76,6 +76,26 @@ class Tables:
         self.pairs = None if pairs is None else np.ascontiguousarray(pairs, dtype=np.int32)  # [T][K][2]
         self.Z = None if Z is None else A.f64(Z)                                   # [nm][ns]
 
+    def check(self, problem, opts):
+        """the C ABI reads T x ... entries out of these host arrays (include/smmhip.h, smm_tables_t): shapes that do not cover
+        opts.maxiter iterations of this shard would be a host over-read, so they are refused here"""
+        T, N, npar = opts.maxiter, opts.N, problem.np
+        if self.probs_acc is not None and self.probs_acc.shape != (T, N):
+            raise ValueError("Tables.probs_acc must be [maxiter][N] = %s, got %s" % ((T, N), self.probs_acc.shape))
+        if self.prop_normals is not None and (self.prop_normals.ndim != 4 or self.prop_normals.shape[0] != T or
+                                              self.prop_normals.shape[1] < 1 or self.prop_normals.shape[2:] != (npar, N)):
+            raise ValueError("Tables.prop_normals must be [maxiter][tries][np][N] = (%d, K, %d, %d), got %s"
+                             % (T, npar, N, self.prop_normals.shape))
+        if self.pairs is not None and (self.pairs.ndim != 3 or self.pairs.shape[0] != T or self.pairs.shape[2] != 2):
+            raise ValueError("Tables.pairs must be [maxiter][n_pairs][2] with maxiter = %d, got %s" % (T, self.pairs.shape))
+        if self.Z is not None and self.Z.shape != (problem.nm, problem.ns):
+            raise ValueError("Tables.Z must be [nm][ns] = %s, got %s" % ((problem.nm, problem.ns), self.Z.shape))
+
+    def covers_iterations(self):
+        """iterations the per-iteration tables were made for (None: nothing injected per iteration)"""
+        ts = [a.shape[0] for a in (self.probs_acc, self.prop_normals, self.pairs) if a is not None]
+        return min(ts) if ts else None
+
     def struct(self):
         t = A.smm_tables_t()
         t.probs_acc = A.dptr(self.probs_acc)
@@ -101,6 +121,8 @@ class BGPContext:
         self.tables = tables
         self._ctx = C.c_void_p()
         ps, os_ = problem.struct(), opts.struct(problem.np)
+        if tables is not None:
+            tables.check(problem, opts)
         ts = tables.struct() if tables is not None else None
         rc = self._fn("ctx_create")(C.byref(ps), C.byref(os_), C.byref(ts) if ts is not None else None,
                                     C.byref(self._ctx))

@@ -83,11 +83,11 @@ def optSlices(m, npoints, parallel=False, tol=1e-5, update=None, filename=None, 
     the parameter's current range, the others at the best point so far; the grid point with the smallest finite value becomes
     the best point (strict <, first wins); after a cycle the ranges shrink around the best point by the factor `update` (if
     given) and the cycle's moves dvec decide convergence (norm <= tol).  Returns {"best": {"p", "value"}, "history": rows,
-    "iterations": n}.  (The reference's trace file is JLD2; `filename`, if given, gets the same dict as .npz-friendly JSON.)
+    "iterations": n, "converged": bool}.  (The reference's trace file is JLD2; `filename`, if given, gets the same dict as .npz-friendly JSON.)
     `maxiter` bounds the cycles (the reference has no bound)."""
     ranges = OrderedDict((k, dict(v)) for k, v in m.params_to_sample.items())
     bestp = OrderedDict(m.initial_value)
-    dvec = OrderedDict((k, np.inf) for k in bestp)
+    dvec = OrderedDict((k, np.inf) for k in ranges)   # (the sampled parameters only: a fixed one never moves and would keep the norm at inf)
     dout = {"history": []}
     delta, it = np.inf, 0
     while delta > tol and it < maxiter:
@@ -117,6 +117,7 @@ def optSlices(m, npoints, parallel=False, tol=1e-5, update=None, filename=None, 
                     ranges[k]["ub"] = min(v + update * r, ranges[k]["ub"])
         delta = float(np.linalg.norm(list(dvec.values())))
     dout["iterations"] = it
+    dout["converged"] = bool(delta <= tol)   # (False: stopped by maxiter)
     if filename:
         import json
         with open(filename, "w") as f:

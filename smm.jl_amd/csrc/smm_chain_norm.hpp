@@ -25,6 +25,9 @@ constexpr int NORM_WG = 2 * WG;       // 1024 lanes
 #ifndef SMM_EXP_SETPRIO
 #define SMM_EXP_SETPRIO 1
 #endif
+#ifndef SMM_EXP_P2P_PLAIN_FIRST
+#define SMM_EXP_P2P_PLAIN_FIRST 0
+#endif
 #ifndef SMM_EXP_NORM_ZU
 #define SMM_EXP_NORM_ZU 4
 #endif
@@ -259,13 +262,6 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
     const unsigned char* mine = P.p2p_self;
     const uint4* g_slots = (const uint4*)(mine + p2p_slot_off(P, tx & 1));
     const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
-    uint4 s_[2 * SR];
-#pragma unroll
-    for (int r = 0; r < SR; ++r) {
-        const int q = tid + r * NT;
-        s_[2 * r] = make_uint4(0u, 0u, 0u, 0u); s_[2 * r + 1] = s_[2 * r];
-        if (4 * q < Ng) { s_[2 * r] = g_slots[2 * q]; s_[2 * r + 1] = g_slots[2 * q + 1]; }
-    }
     const uint32_t wflags = *(const uint32_t*)(mine + 128 * (size_t)P2P_MAXG + 0 * (size_t)(tid & 1));
     uint4 p_[PR];
 #pragma unroll
@@ -273,7 +269,19 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
         const int q4 = tid + r * NT;
         p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
     }
-    const uint32_t want_hi = p2p_tag(tx) << 16;
+    // the slots, past the caches (p2p_load16_sys), all in flight together with the plan words above
+    uint4 s_[2 * SR];
+    {
+        const int qc0 = min(tid, (Ng - 1) / 4), qc1 = min(tid + NT, (Ng - 1) / 4);   // (lanes past the end read the last piece: not used)
+#if SMM_EXP_P2P_PLAIN_FIRST
+        s_[0] = g_slots[2 * qc0]; s_[1] = g_slots[2 * qc0 + 1];
+        if constexpr (SR == 2) { s_[2] = g_slots[2 * qc1]; s_[3] = g_slots[2 * qc1 + 1]; }
+#else
+        if constexpr (SR == 1) p2p_load16x2_sys(g_slots + 2 * qc0, g_slots + 2 * qc0 + 1, s_[0], s_[1]);
+        else p2p_load16x4_sys(g_slots + 2 * qc0, g_slots + 2 * qc0 + 1, g_slots + 2 * qc1, g_slots + 2 * qc1 + 1, s_[0], s_[1], s_[2], s_[3]);
+#endif
+    }
+    const uint32_t want_hi = p2p_tag(P, tx) << 16;
     bool timed_out = false;
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
@@ -464,10 +472,17 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
                 const int s = (int)(unsigned)(xr & 0xffffffffu) - goff;
                 if constexpr (P2P) {   // the self-validating record of iteration t-1 out of this rank's window (its own chain's, or the donor's)
                     const uint4* g_ll = (const uint4*)(P.p2p_self + p2p_llrec_off(P, (t - 1) & 1) + (size_t)s * RW * 16);
-                    const uint32_t tag = p2p_tag(t - 1);
+                    const uint32_t tag = p2p_tag(P, t - 1);
                     uint4 q[RW];
+                    static_assert(RW % 2 == 0, "records are an even number of doubles");
+#if SMM_EXP_P2P_PLAIN_FIRST
 #pragma unroll
                     for (int i = 0; i < RW; ++i) q[i] = g_ll[i];
+#else
+#pragma unroll
+                    for (int i = 0; i + 4 <= RW; i += 4) p2p_load16x4_sys(g_ll + i, g_ll + i + 1, g_ll + i + 2, g_ll + i + 3, q[i], q[i + 1], q[i + 2], q[i + 3]);
+                    if constexpr (RW % 4 != 0) p2p_load16x2_sys(g_ll + RW - 2, g_ll + RW - 1, q[RW - 2], q[RW - 1]);
+#endif
                     bool ok = true;
 #pragma unroll
                     for (int i = 0; i < RW; ++i) ok = ok && p2p_ll_ok(q[i], tag);
@@ -737,9 +752,9 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
                 if (p < P.p2p_G) {
                     unsigned char* w = P.p2p_win[p];
                     const unsigned long long vb = __builtin_bit_cast(unsigned long long, v);
-                    const p2p_u32x4 qv = {(unsigned)vb, p2p_tag(t), (unsigned)(vb >> 32), p2p_tag(t)};
+                    const p2p_u32x4 qv = {(unsigned)vb, p2p_tag(P, t), (unsigned)(vb >> 32), p2p_tag(P, t)};
                     p2p_store16u((uint4*)(w + p2p_llval_off(P, pb)) + gc, qv);
-                    p2p_store8((uint2*)(w + p2p_slot_off(P, pb)) + gc, p2p_slot_word(v, (uint32_t)gc, t));
+                    p2p_store8((uint2*)(w + p2p_slot_off(P, pb)) + gc, p2p_slot_word(P, v, (uint32_t)gc, t));
                     if (v != v) __hip_atomic_fetch_or((uint32_t*)(w + 128 * (size_t)P2P_MAXG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
         } else {
@@ -770,7 +785,7 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
             if constexpr (P2P) {   // into every rank's window, global chain order
 #pragma unroll
                 for (int p = 0; p < P2P_MAXG; ++p)
-                    if (p < P.p2p_G && i < NPC) p2p_store_ll(P.p2p_win[p] + p2p_llrec_off(P, pb) + ((size_t)gc * NPC + i) * 32, v, p2p_tag(t));
+                    if (p < P.p2p_G && i < NPC) p2p_store_ll(P.p2p_win[p] + p2p_llrec_off(P, pb) + ((size_t)gc * NPC + i) * 32, v, p2p_tag(P, t));
             } else {
                 if (i < NPC) ((double2*)(rec_out + (size_t)c * RW))[i] = v;
             }

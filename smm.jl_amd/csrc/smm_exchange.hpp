@@ -1,5 +1,7 @@
 // stand-alone exchangeMoves! kernels: k_exch_resolve_lds / _lvl / _lvl_soa / _lvl_big / _any, k_exch_plan_big, k_exch_apply — part of libsmmhip (included by smmhip.hip inside its anonymous namespace; gfx950 device code).
 #pragma once
+#define XTS(i) do { if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + (i)] = wall_clock64(); } while (0)
+#ifdef SMM_TEST_HOOKS   // (the ticket kernel is a test reference: not in the shipped library)
 // ------------------------------------------------------------------------------------------
 // k_exch_resolve_lds: exchangeMoves! (AlgoBGP.jl:647-716) for N_global <= XLDS_MAX, one workgroup,
 // all state in LDS.  The reference walks the K sampled pairs in order and swaps the two chains'
@@ -23,7 +25,6 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
     const unsigned long long* __restrict__ plan = P.plan + (size_t)(t - P.plan_t0) * K;
     const double* __restrict__ plan_mi = P.plan_mi + (size_t)(t - P.plan_t0) * K;
 
-#define XTS(i) do { if (P.ts && tid == 0) P.ts[(size_t)8 * 60000 + (i)] = wall_clock64(); } while (0)
     XTS(0);
     // this thread's pairs (list positions tid, tid+1024, ...): plan words and thresholds up front
     constexpr int MAXPP = XLDS_MAX / XWG;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lds(const KParams P, const
     for (int g = tid; g < Ng; g += XWG) P.xres[g] = (unsigned long long)src[g] | ((unsigned long long)partner[g] << 32);
     XTS(4);
 }
+#endif
 
 // k_exch_resolve_lvl: the same result for N_global <= XLVL_MAX, executed level by level: the plan
 // groups the pair list by dependency level (k_exch_plan); the pairs of one level touch pairwise
@@ -1205,7 +1207,11 @@ __global__ __launch_bounds__(XWG) void k_a2a_index(const KParams P, const int t,
     __shared__ uint32_t wsum[XWG / 64];
     const int tid = threadIdx.x, p = blockIdx.x;
     const int N = P.N, me = P.offset / P.N;
-    if (*(const volatile unsigned long long*)P.err != ERR_NONE) return;
+    // (one read for the whole workgroup: lanes that saw different answers would part ways in front of the barriers below)
+    __shared__ int s_stop;
+    if (tid == 0) s_stop = *(const volatile unsigned long long*)P.err != ERR_NONE;
+    __syncthreads();
+    if (s_stop) return;
     for (int part = 0; part < 2; ++part) {
         uint32_t base = 0;
         for (int i0 = 0; i0 < N; i0 += XWG) {

@@ -53,18 +53,23 @@ __device__ inline size_t p2p_val_off(const KParams& P, const int b) { return b ?
 __device__ inline size_t p2p_slot_off(const KParams& P, const int b) { return b ? P.p2p_off[5] : P.p2p_off[4]; }
 __device__ inline size_t p2p_llrec_off(const KParams& P, const int b) { return b ? P.p2p_off[7] : P.p2p_off[6]; }
 __device__ inline size_t p2p_llval_off(const KParams& P, const int b) { return b ? P.p2p_off[9] : P.p2p_off[8]; }
-__host__ __device__ inline uint32_t p2p_tag(const int t) { return 0x8000u | ((uint32_t)t & 0x7fffu); }   // (never 0: a fresh window is zeroed)
-__device__ inline unsigned long long p2p_slot_word(const double v, const uint32_t gchain, const int t) {
-    return (unsigned long long)order_key32(v) | ((unsigned long long)(gchain | (p2p_tag(t) << 16)) << 32);
+// the tag of iteration t: never 0 (a fresh window is zeroed); different from the tag of iteration t-2, whose words the stores of
+// iteration t replace (same parity), and from every word an EARLIER PUBLICATION left behind — a run that was settled, rolled back
+// by an uploaded state and published again writes the same iteration numbers a second time, and a reader must not take the old
+// words for the new ones: the epoch (publications so far, the same on every rank) is part of the tag
+__host__ __device__ inline uint32_t p2p_tag_of(const int t, const uint32_t epoch) { return 0x8000u | ((epoch & 0x7ffu) << 4) | ((uint32_t)t & 0xfu); }
+__device__ inline uint32_t p2p_tag(const KParams& P, const int t) { return p2p_tag_of(t, P.p2p_epoch); }
+__device__ inline unsigned long long p2p_slot_word(const KParams& P, const double v, const uint32_t gchain, const int t) {
+    return (unsigned long long)order_key32(v) | ((unsigned long long)(gchain | (p2p_tag(P, t) << 16)) << 32);
 }
 // chains per arrival unit (generic form): the push kernel arrives once per workgroup of this share
 constexpr int P2P_UNIT = 16;
 __host__ __device__ inline int p2p_units(const int N) { return (N + P2P_UNIT - 1) / P2P_UNIT; }
 constexpr unsigned long long P2P_TIMEOUT_TICKS = 400000000ull;   // 4 s of the 100 MHz wall clock: a peer is gone, not late
 
-// Stores into a window are system-scope stores (sc0 sc1) into UNCACHED memory (hipDeviceMallocUncached): no level of any device's
-// cache hierarchy keeps a line of a window dirty, and "s_waitcnt vmcnt(0)" after them is the release (generic form).  A system-
-// scope release fence would write back the whole L2 per tile and launch: measured 50 us instead of 14 per launch.
+// Stores into a window are system-scope stores (sc0 sc1: written through, acknowledged once visible to every agent), so
+// "s_waitcnt vmcnt(0)" after them is the release (generic form).  A system-scope release fence would write back the whole L2 per
+// tile and launch: measured 50 us instead of 14 per launch.
 typedef unsigned int p2p_u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline void p2p_store16u(void* p, const p2p_u32x4 q) {
     // (s_nop 1: a VALU write of the data registers of a store of more than 8 bytes needs 2 wait states on gfx940+, and the
@@ -87,19 +92,35 @@ __device__ inline void p2p_store_ll(void* p, const double2 v, const uint32_t tag
     p2p_store16u(p, q0);
     p2p_store16u((unsigned char*)p + 16, q1);
 }
-// a load that no cache serves (system scope): what a reader uses when it looks AGAIN at a word whose tag was not yet the one it wants
+// A load that no cache serves (system scope): how a self-validating word is read — a line fetched earlier in the same launch,
+// before the word's new contents had landed, must not be served again.
 __device__ inline uint4 p2p_load16_sys(const void* p) {
     p2p_u32x4 q;
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(p) : "memory");
     return make_uint4(q.x, q.y, q.z, q.w);
+}
+// four / eight of them in flight together (one wait: an asm load's destination counts as written at the end of its statement)
+__device__ inline void p2p_load16x4_sys(const void* p0, const void* p1, const void* p2, const void* p3, uint4& a, uint4& b, uint4& c, uint4& d) {
+    p2p_u32x4 q0, q1, q2, q3;
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+    a = make_uint4(q0.x, q0.y, q0.z, q0.w); b = make_uint4(q1.x, q1.y, q1.z, q1.w);
+    c = make_uint4(q2.x, q2.y, q2.z, q2.w); d = make_uint4(q3.x, q3.y, q3.z, q3.w);
+}
+__device__ inline void p2p_load16x2_sys(const void* p0, const void* p1, uint4& a, uint4& b) {
+    p2p_u32x4 q0, q1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1) : "v"(p0), "v"(p1) : "memory");
+    a = make_uint4(q0.x, q0.y, q0.z, q0.w); b = make_uint4(q1.x, q1.y, q1.z, q1.w);
 }
 __device__ inline bool p2p_ll_ok(const uint4 q, const uint32_t tag) { return q.y == tag && q.w == tag; }
 __device__ inline double p2p_ll_double(const uint4 q) { return __hiloint2double((int)q.z, (int)q.x); }
 // the exact value of chain g after iteration t out of this rank's window (any lane on its own, e.g. the tie branch of the walk)
 __device__ inline double p2p_ll_value(const KParams& P, const int t, const uint32_t g) {
     const uint4* a = (const uint4*)(P.p2p_self + p2p_llval_off(P, t & 1)) + g;
-    const uint32_t tag = p2p_tag(t);
-    uint4 q = *a;
+    const uint32_t tag = p2p_tag(P, t);
+    uint4 q = p2p_load16_sys(a);   // (past the caches, like every read of a window: see p2p_load16_sys)
     if (!p2p_ll_ok(q, tag)) {
         const unsigned long long t0 = wall_clock64();
         do {
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(256) void k_p2p_push(const KParams P, const int t, 
     unsigned char* mine = P.p2p_self;
     const double* rs = FROM_CTX ? rec_src + (size_t)c0 * RW : (const double*)(mine + p2p_rec_off(P, b)) + (size_t)(P.offset + c0) * RW;
     const double* vs = (const double*)(mine + p2p_val_off(P, b)) + P.offset + c0;
-    const uint32_t tag = p2p_tag(t);
+    const uint32_t tag = p2p_tag(P, t);
 #pragma unroll
     for (int p = 0; p < P2P_MAXG; ++p) {
         if (p >= P.p2p_G) break;
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(256) void k_p2p_push(const KParams P, const int t, 
                 const p2p_u32x4 q = {(unsigned)vb, tag, (unsigned)(vb >> 32), tag};
                 p2p_store16u((uint4*)(w + p2p_llval_off(P, b)) + P.offset + c0 + tid, q);
             } else if (!own) p2p_store8((double*)(w + p2p_val_off(P, b)) + P.offset + c0 + tid, vb);
-            p2p_store8((uint2*)(w + p2p_slot_off(P, b)) + P.offset + c0 + tid, p2p_slot_word(v, (uint32_t)(P.offset + c0 + tid), t));
+            p2p_store8((uint2*)(w + p2p_slot_off(P, b)) + P.offset + c0 + tid, p2p_slot_word(P, v, (uint32_t)(P.offset + c0 + tid), t));
             if (v != v) { __hip_atomic_fetch_or((uint32_t*)(w + 128 * (size_t)P2P_MAXG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     }
@@ -198,14 +219,14 @@ __global__ __launch_bounds__(256) void k_p2p_unpack(const KParams P, const int t
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (g >= P.Ng) return;
     const int b = t & 1, RW = P.RW;
-    const uint32_t tag = p2p_tag(t);
+    const uint32_t tag = p2p_tag(P, t);
     unsigned char* mine = P.p2p_self;
     ((double*)(mine + p2p_val_off(P, b)))[g] = p2p_ll_value(P, t, (uint32_t)g);
     const uint4* src = (const uint4*)(mine + p2p_llrec_off(P, b) + (size_t)g * RW * 16);
     double* dst = (double*)(mine + p2p_rec_off(P, b)) + (size_t)g * RW;
     const unsigned long long t0 = wall_clock64();
     for (int i = 0; i < RW; ++i) {
-        uint4 q = src[i];
+        uint4 q = p2p_load16_sys(src + i);
         while (!p2p_ll_ok(q, tag)) {
             __builtin_amdgcn_s_sleep(1);
             q = p2p_load16_sys(src + i);

@@ -64,6 +64,16 @@ using namespace smm;
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_create_err;
 
+// Test seams.  The shipped library (libsmmhip.so) reads two environment variables, both diagnostics: SMMHIP_TS (phase stamps for
+// tools/) and SMMHIP_DBG (timing experiments; results invalid).  Everything that changes which kernel runs or how much it may
+// hold — forcing an exchange kernel, switching a fast path off, a tiny capacity, poisoned allocations — exists only in the build
+// the tests load next to it (libsmmhip_hooks.so, -DSMM_TEST_HOOKS): a stray variable cannot change what production runs.
+#ifdef SMM_TEST_HOOKS
+#define SMM_HOOK(name) getenv(name)
+#else
+#define SMM_HOOK(name) ((const char*)nullptr)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // user objectives: compiled with hiprtc (loaded lazily, the library does not link against it)
 // ------------------------------------------------------------------------------------------
@@ -174,6 +184,8 @@ struct Ctx {
     int32_t *a2a_send_idx = nullptr, *a2a_send_cnt = nullptr, *a2a_rowidx = nullptr;   // the values form of the sharded exchange
     int a2a_cap = 0, a2a_G = 0;
     bool a2a_open = false;
+    int xk = 0;                 // ExchKernel: the stand-alone exchange resolution of this context (choose_exchange)
+    bool exch_done = false;     // the three-phase / values forms: exchangeMoves! of iteration `iter` has been applied (cleared by the next local step)
     double* vals_buf[2] = {nullptr, nullptr};   // KParams::vals / vals_out, by iteration parity (point_values)
     uint2* slot8_buf[2] = {nullptr, nullptr};
     bool deep_plan = false;      // an injected pair list has an iteration of more than LV_MAXLEV dependency levels
@@ -231,7 +243,7 @@ T* dalloc(Ctx* c, size_t n) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
     c->allocs.push_back(p);
-    if (const char* f = getenv("SMMHIP_FILL"))   // test hook: every allocation starts as this byte (reads of memory nobody wrote show up)
+    if (const char* f = SMM_HOOK("SMMHIP_FILL"))   // test hook: every allocation starts as this byte (reads of memory nobody wrote show up)
         HIPCHK(hipMemset(p, atoi(f), (n ? n : 1) * sizeof(T)));
     return (T*)p;
 }
@@ -267,7 +279,9 @@ size_t tile_smem(const Ctx* c, int ct, int tpw = 1) {   // dynamic LDS of k_chai
                        : walk_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)c->P.plan_K * 4);
 }
 size_t plan_lds_bytes(int Ng, int K) { return (size_t)(Ng + 2) * 4 + (size_t)K * 8 + (size_t)K * 4 + 128 + 16; }
+#ifdef SMM_TEST_HOOKS
 size_t resolve_lds_bytes(int Ng) { return (size_t)Ng * 16 + 16; }
+#endif
 size_t resolve_lvl_soa_bytes(int Ng, int K) { return (size_t)Ng * 12 + (size_t)K * 4 + 16; }
 size_t resolve_lvl_bytes(int Ng, int K) { return (size_t)Ng * 16 + (size_t)K * 12 + 64 * 8 + 64; }
 
@@ -443,52 +457,88 @@ size_t resolve_lean_bytes(int Ng, int K, bool wide) { return std::max(wide ? lea
 void launch_resolve_p(Ctx* c, const KParams& P, int t, const double* gathered);
 void launch_resolve(Ctx* c, int t, const double* gathered) { launch_resolve_p(c, c->P, t, gathered); }
 // (P: the context's parameters, or a copy whose RW is the stride of the value column in `gathered`)
+// Which stand-alone kernel resolves exchangeMoves! (AlgoBGP.jl:647-716) — ONE decision, taken once per context (choose_exchange,
+// at the end of smm_ctx_create), from the population, the thresholds and dist_fun:
+//
+//   N_global        min_improve                      dist_fun   kernel                       slots / where
+//   <= 8192 (~7400) one value >= 0 for all chains    -          k_exch_resolve_lean          8-byte keys (0) or 16-byte values (> 0), LDS
+//   <= 4096         anything else                    any        k_exch_resolve_lvl<1024>     16-byte slots, LDS
+//   <= 8192         anything else                    any        k_exch_resolve_lvl_soa       split slots, LDS
+//   <= 32768        0 for all chains                 -          k_exch_keys + _rows          4-byte slots (17-bit keys), rows of 1024 pairs, LDS
+//   <= 32768        anything else                    -          k_exch_keys + _key           4-byte slots (16-bit keys, intervals), LDS
+//   <= 65535        anything else / other dist_fun   any        k_exch_resolve_lvl_big       16-byte slots, global memory
+//   above, or K > N_global                           any        k_exch_resolve_any           barrier rounds, global atomics
+//
+// (single shards of objfunc_norm up to 4096 chains do not get here in steady state: their chain kernel walks inline.)  The test
+// build can force an entry (SMM_TEST_HOOKS: SMMHIP_*_EXCHANGE, SMMHIP_KEY_WALK) and adds the ticket kernel k_exch_resolve_lds.
+enum ExchKernel { XK_LEAN, XK_LVL, XK_LVL_SOA, XK_TICKETS, XK_ROWS, XK_KEY, XK_LVL_BIG, XK_ANY };
+ExchKernel choose_exchange(const Ctx* c) {
+    if (c->lean_resolve) return XK_LEAN;
+    if (c->lvl_exchange) return XK_LVL;
+    if (c->lvl_soa_exchange) return XK_LVL_SOA;
+    if (c->lds_exchange) return XK_TICKETS;   // (test build only: SMMHIP_DATAFLOW_EXCHANGE)
+    if (c->key_exchange) return c->rows_exchange ? XK_ROWS : XK_KEY;
+    if (c->big_exchange) return XK_LVL_BIG;
+    return XK_ANY;
+}
 void launch_resolve_p(Ctx* c, const KParams& P_in, int t, const double* gathered) {
     KParams P = P_in;
     point_values(c, P, t, t);   // (single shard: the values the accept step of iteration t wrote)
-    if (c->lean_resolve)
+    switch ((ExchKernel)c->xk) {
+    case XK_LEAN:
         if (c->kev0)
             hipExtLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K, P.lean_wide != 0), c->stream, c->kev0, c->kev1, 0, P, t,
                                   gathered);
         else
             hipLaunchKernelGGL(k_exch_resolve_lean, dim3(1), dim3(XWG), resolve_lean_bytes(P.Ng, P.plan_K, P.lean_wide != 0), c->stream, P, t, gathered);
-    else if (c->lvl_exchange)
-        if (c->lvl_wg == 256)
-            hipLaunchKernelGGL(k_exch_resolve_lvl<256>, dim3(1), dim3(256), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
-        else if (c->lvl_wg == 512)
-            hipLaunchKernelGGL(k_exch_resolve_lvl<512>, dim3(1), dim3(512), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+        break;
+    case XK_LVL:
+#ifdef SMM_TEST_HOOKS
+        if (c->lvl_wg == 256) { hipLaunchKernelGGL(k_exch_resolve_lvl<256>, dim3(1), dim3(256), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered); break; }
+        if (c->lvl_wg == 512) { hipLaunchKernelGGL(k_exch_resolve_lvl<512>, dim3(1), dim3(512), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered); break; }
+#endif
+        if (c->kev0)
+            hipExtLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, c->kev0, c->kev1, 0, P, t, gathered);
         else
-            if (c->kev0)
-                hipExtLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, c->kev0,
-                                      c->kev1, 0, P, t, gathered);
-            else
-                hipLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
-    else if (c->lvl_soa_exchange)
+            hipLaunchKernelGGL(k_exch_resolve_lvl<1024>, dim3(1), dim3(1024), resolve_lvl_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
+        break;
+    case XK_LVL_SOA:
         hipLaunchKernelGGL(k_exch_resolve_lvl_soa<1024>, dim3(1), dim3(1024), resolve_lvl_soa_bytes(P.Ng, P.plan_K), c->stream, P, t, gathered);
-    else if (c->lds_exchange)
+        break;
+    case XK_TICKETS:
+#ifdef SMM_TEST_HOOKS
         hipLaunchKernelGGL(k_exch_resolve_lds, dim3(1), dim3(XWG), resolve_lds_bytes(P.Ng), c->stream, P, t, gathered);
-    else if (c->key_exchange) {
+#endif
+        break;
+    case XK_ROWS:
+    case XK_KEY: {
         // values and initial slots by the whole chip (gathered records: their value column; single shard: the compact array)
         const double* src = gathered ? gathered : (const double*)P.vals;
         double* vals = gathered ? P.xval : P.vals;
         hipLaunchKernelGGL(k_exch_keys, dim3((P.Ng + 255) / 256), dim3(256), 0, c->stream, src, gathered ? P.RW : 1, P.Ng, vals,
                            (uint32_t*)P.xsrc, c->rows_exchange ? c->slots17 : (uint32_t*)nullptr, c->nan_flags, t);
-        if (c->rows_exchange && P.Ng <= XKEY_PARTNER_MAX)
+        const bool plds = P.Ng <= XKEY_PARTNER_MAX;   // partners in LDS, else the ballot replay
+        if (c->xk == XK_ROWS && plds)
             hipLaunchKernelGGL(k_exch_resolve_rows<true>, dim3(1), dim3(XWG), resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap), c->stream, P, t,
                                (const double*)vals, (const uint32_t*)P.xsrc, (const uint32_t*)c->slots17, (const uint32_t*)c->nan_flags);
-        else if (c->rows_exchange)
+        else if (c->xk == XK_ROWS)
             hipLaunchKernelGGL(k_exch_resolve_rows<false>, dim3(1), dim3(XWG), resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap), c->stream, P, t,
                                (const double*)vals, (const uint32_t*)P.xsrc, (const uint32_t*)c->slots17, (const uint32_t*)c->nan_flags);
-        else if (P.Ng <= XKEY_PARTNER_MAX)
+        else if (plds)
             hipLaunchKernelGGL(k_exch_resolve_key<true>, dim3(1), dim3(XWG), resolve_key_bytes(P.Ng, P.plan_K), c->stream, P, t,
                                (const double*)vals, (const uint32_t*)P.xsrc);
         else
             hipLaunchKernelGGL(k_exch_resolve_key<false>, dim3(1), dim3(XWG), resolve_key_bytes(P.Ng, P.plan_K), c->stream, P, t,
                                (const double*)vals, (const uint32_t*)P.xsrc);
-    } else if (c->big_exchange)
+        break;
+    }
+    case XK_LVL_BIG:
         hipLaunchKernelGGL(k_exch_resolve_lvl_big, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
-    else
+        break;
+    case XK_ANY:
         hipLaunchKernelGGL(k_exch_resolve_any, dim3(1), dim3(XWG), 0, c->stream, P, t, gathered);
+        break;
+    }
 }
 
 // settle the open end of the last iteration (no-op when nothing is open)
@@ -540,9 +590,10 @@ int check_device_error(Ctx* c) {
     // The reference aborts inside the failing iteration (AlgoBGP.jl:341,409).  Here that iteration completes for all chains
     // and every later launch of the step sees the error word and stores nothing: the run stands at the failing iteration,
     // its exchange is never applied, and the context refuses to go on until smm_set_state.
-    if (kind != 3 && kind != 0 && it >= 1 && it <= c->iter) {
+    if (kind != 3 && it >= 1 && it <= c->iter) {   // (kind 0, a block of the values form overflowed: the exchange of iteration `it` was not applied either)
         c->iter = it;
         c->pending = false; c->prev_open = false; c->unresolved = false; c->pending_ext = false; c->rec_external = false;
+        c->a2a_open = false; c->p2p_current = false;
     }
     c->failed = rc;
     return rc;
@@ -626,6 +677,15 @@ void launch_resolve_window(Ctx* c, int t) {
 extern "C" {
 
 int smm_abi_version(void) { return SMMHIP_ABI_VERSION; }
+
+// 1 in the build the tests load for their seams (libsmmhip_hooks.so), 0 in the shipped library (not part of the public header)
+int smm_debug_has_test_hooks(void) {
+#ifdef SMM_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 static int register_user_source(const std::string& src, int n_sums, int lanes, int32_t* objective_id_out) {
     std::lock_guard<std::mutex> lock(g_user_mutex);
@@ -751,7 +811,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         c->obj = user_obj ? SMM_OBJ_USER : prob->objective_id;
         c->exchange_from = opts->exchange_from_iter;
         {
-            const char* e = getenv("SMMHIP_ANY_EXCHANGE");  // test hook: force the any-size resolution kernel
+            const char* e = SMM_HOOK("SMMHIP_ANY_EXCHANGE");  // test hook: force the any-size resolution kernel
             c->force_any_exchange = e && e[0] == '1';
             const char* d = getenv("SMMHIP_DBG");
             P.dbg = d ? atoi(d) : 0;
@@ -863,22 +923,22 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.plan_K = K;
         c->lds_exchange = Ng > 1 && Ng <= XLDS_MAX && K >= 1 && K <= Ng && !c->force_any_exchange;
         {
-            const char* e = getenv("SMMHIP_DATAFLOW_EXCHANGE");  // test hook: force the ticket (data-flow) resolution kernel
+            const char* e = SMM_HOOK("SMMHIP_DATAFLOW_EXCHANGE");  // test hook: force the ticket (data-flow) resolution kernel
             c->lvl_exchange = c->lds_exchange && Ng <= XLVL_MAX && !(e && e[0] == '1');
             c->lvl_soa_exchange = c->lds_exchange && !c->lvl_exchange && !(e && e[0] == '1');
-            const char* lw = getenv("SMMHIP_LVL_WG");  // tuning hook
+            const char* lw = SMM_HOOK("SMMHIP_LVL_WG");  // tuning hook
             if (lw) c->lvl_wg = atoi(lw);
-            const char* be = getenv("SMMHIP_BIG_EXCHANGE");  // test hook: force the global-memory level kernels
+            const char* be = SMM_HOOK("SMMHIP_BIG_EXCHANGE");  // test hook: force the global-memory level kernels
             const bool force_big = be && be[0] == '1';
             c->big_exchange = Ng > 1 && Ng <= 65535 && K >= 1 && K <= Ng && !c->force_any_exchange && (force_big || !c->lds_exchange);
             if (c->big_exchange) { c->lds_exchange = false; c->lvl_exchange = false; c->lvl_soa_exchange = false; }
-            const char* ke = getenv("SMMHIP_KEY_EXCHANGE");   // test hook: "0" keeps the global-memory walk
+            const char* ke = SMM_HOOK("SMMHIP_KEY_EXCHANGE");   // test hook: "0" keeps the global-memory walk
             c->key_exchange = c->big_exchange && Ng <= XKEY_MAX && K <= XKEY_MAX && !(ke && ke[0] == '0') && opts->dist_fun == SMM_DIST_MINUS;   // (the keys order value_i - value_j)
             // inline exchange walk: single shard, level plan available, and two tiles must still share a CU's 160 KB LDS
-            const char* iw = getenv("SMMHIP_INLINE_WALK");
+            const char* iw = SMM_HOOK("SMMHIP_INLINE_WALK");
             const int tile_ct = is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8);
             const size_t tile_b = (tile_smem_base(c, tile_ct) + 15) & ~(size_t)15;
-            const char* nf = getenv("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
+            const char* nf = SMM_HOOK("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
             c->norm_fast = is_sim(c->obj) && np == nm && np <= 4 && opts->batch_size == np && P.dbg == 0 && !opts->chol_L && !(nf && nf[0] == '0');
             // k_chain_iter_norm: pair list NOT overlaid; room for either walk (16-byte slots, 4-byte slots + value table)
             const bool wide_form = P.mi_uniform && P.mi_value != 0.0 && !(P.mi_value < 0.0);   // (the lean walk on 16-byte slots, below)
@@ -890,11 +950,11 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                            : walk_slot_bytes(Ng) + std::max(tile_b, (size_t)K * 4) <= (size_t)80 * 1024);
             P.tile_off = c->inline_walk ? (int)((c->norm_fast ? walk_b : walk_slot_bytes(Ng)) / sizeof(double)) : 0;
             // (the lean plan: the same conditions as further down, where its tables are allocated)
-            const char* kw0 = getenv("SMMHIP_KEY_WALK");
+            const char* kw0 = SMM_HOOK("SMMHIP_KEY_WALK");
             const bool lean_plan = P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && !(kw0 && kw0[0] == '0') &&
                                    (P.mi_value == 0.0 || resolve_lean_bytes(Ng, K, true) <= (size_t)160 * 1024);
             // two tiles per workgroup share one walk (the 2p/2m-style simulation tile of 8 chains only)
-            const char* tp = getenv("SMMHIP_TPW");
+            const char* tp = SMM_HOOK("SMMHIP_TPW");
             int n_cu = 256;
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
             // ... worth it only when two tiles would share a CU anyway (more tiles than CUs)
@@ -918,7 +978,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
                 c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
                 c->big_scratch = dalloc<uint32_t>(c, (size_t)c->win_cap * BigPlanScratch::words(Ng, K));
-                const char* kw = getenv("SMMHIP_KEY_WALK");   // test hook: "0" keeps k_exch_resolve_key
+                const char* kw = SMM_HOOK("SMMHIP_KEY_WALK");   // test hook: "0" keeps k_exch_resolve_key
                 if (c->key_exchange && P.mi_uniform && P.mi_value == 0.0 && !(kw && kw[0] == '0')) {
                     c->rows_exchange = true;
                     P.rows_cap = std::min(XROWS_MAX, (K + XWG - 1) / XWG + LV_MAXLEV);
@@ -937,7 +997,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
                 // the lean walk (smm_walk_lean.hpp): one min_improve for every chain — 0: 8-byte slots of order keys; > 0 (or NaN:
                 // nothing ever swaps): 16-byte slots of values, as far as the 160 KB of LDS reach (~7400 chains)
-                const char* kw = getenv("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walks on 16-byte / split slots
+                const char* kw = SMM_HOOK("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walks on 16-byte / split slots
                 const bool keys = P.mi_uniform && P.mi_value == 0.0;
                 const bool wide = P.mi_uniform && !keys && !(P.mi_value < 0.0) && resolve_lean_bytes(Ng, K, true) <= (size_t)160 * 1024;
                 if ((keys || wide) && K <= XLDS_MAX && !(kw && kw[0] == '0') && opts->dist_fun == SMM_DIST_MINUS) {
@@ -972,7 +1032,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.xres = dalloc<unsigned long long>(c, Ng);
         if (N > 0 && Ng % N == 0 && opts->chain_offset % N == 0) {   // equal shards: the values form of the sharded exchange is available
             c->a2a_G = Ng / N;
-            const char* ce = getenv("SMMHIP_A2A_CAP");   // test hook: a small capacity
+            const char* ce = SMM_HOOK("SMMHIP_A2A_CAP");   // test hook: a small capacity
             c->a2a_cap = ce ? std::max(1, atoi(ce)) : a2a_capacity(N, c->a2a_G);
             c->a2a_send_idx = dalloc<int32_t>(c, (size_t)c->a2a_G * c->a2a_cap);
             c->a2a_send_cnt = dalloc<int32_t>(c, (size_t)c->a2a_G);
@@ -1013,14 +1073,18 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (int)resolve_rows_bytes(XKEY_PARTNER_MAX, XKEY_PARTNER_MAX, XROWS_MAX)));
         }
         if (c->lds_exchange) {
+#ifdef SMM_TEST_HOOKS
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lds_bytes(XLDS_MAX)));
+#endif
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_plan, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)plan_lds_bytes(XLDS_MAX, XLDS_MAX)));
+#ifdef SMM_TEST_HOOKS
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<512>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));
+#endif
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl_soa<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lvl_soa_bytes(XLDS_MAX, XLDS_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1068,6 +1132,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             if (tile_smem(c, is_sim(c->obj) ? c->ct : (c->obj == SMM_OBJ_DENSE ? 16 : 8)) > (size_t)lim)
                 throw std::string("tile does not fit the 160 KiB LDS");
         }
+        c->xk = (int)choose_exchange(c);
         HIPCHK(hipDeviceSynchronize());
     } catch (const std::string& m) {
         g_create_err = m;
@@ -1161,7 +1226,7 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
                 c->pending = true;
             }
             if (c->profiling && !kscoped) { HIPCHK(hipEventRecord(c->pev[4 * it + 2], c->stream)); HIPCHK(hipEventRecord(c->pev[4 * it + 3], c->stream)); }
-            c->iter = t;
+            c->iter = t; c->exch_done = false;
         }
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         HIPCHK(hipGetLastError());
@@ -1186,6 +1251,7 @@ int smm_bgp_local_step(void* ctx) {
     if (!c) return SMM_ERR_INVALID_ARG;
     if (c->failed) return c->failed;
     if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
+    if (c->a2a_open) return fail(c, SMM_ERR_STATE, "smm_bgp_a2a_pack_dev without smm_bgp_a2a_apply_dev: the exchange of this iteration would be dropped");
     if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     try {
         HIPCHK(hipSetDevice(c->device));
@@ -1199,7 +1265,7 @@ int smm_bgp_local_step(void* ctx) {
         HIPCHK(hipGetLastError());
         c->prev_open = true;
         c->pending = false;
-        c->iter = t;
+        c->iter = t; c->exch_done = false;
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
@@ -1264,7 +1330,7 @@ int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathere
         c->pending = false;
         c->rec_external = true;
         c->pending_ext = exchange_active(c, t);
-        c->iter = t;
+        c->iter = t; c->exch_done = false;
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
@@ -1307,12 +1373,14 @@ int smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out) {
         KParams& P = c->P;
         const P2PLayout L = p2p_layout(P.Ng, P.RW);
         if (!c->p2p_mine) {
-            // uncached device memory: what peers store is never served from a stale line of this device's caches, and what this
-            // device stores goes to memory (IPC-exportable like any device allocation).  (Plain and fine-grained allocations
-            // pass the same tests at the same speed on one device — tools/exp/r3_p2p_mem.sh —: the self-validating words make the
-            // readers independent of it; uncached is the one whose semantics need no argument across devices.)
+            // Plain device memory — what the receive buffers of the collective libraries are.  (An UNCACHED allocation,
+            // hipDeviceMallocUncached, looked like the natural choice and was the first one: it passed every test of its own file and
+            // failed in the full suite, in both forms, whenever the process had run other contexts before — later kernels were served
+            // lines that an earlier allocation at the same address had left behind; the cache maintenance at kernel boundaries, which
+            // plain memory gets, does not seem to cover it.  Within a launch nothing relies on the caches: stores into a window are
+            // system-scope stores, self-validating words are re-read past the caches until their tag is the wanted one.)
             void* w = nullptr;
-            HIPCHK(hipExtMallocWithFlags(&w, L.total, hipDeviceMallocUncached));
+            HIPCHK(hipMalloc(&w, L.total));
             c->p2p_mine = (unsigned char*)w;
             HIPCHK(hipMemset(w, 0, L.total));
             HIPCHK(hipDeviceSynchronize());
@@ -1404,6 +1472,7 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
         if (!c->p2p_current) {   // first publication: the state after iteration `iter`, its exchange settled, into every window
             flush(c);
             c->p2p_mode_inline = c->p2p_inline && !c->nan_values;
+            c->P.p2p_epoch += 1;   // (a new generation of tags: words of an earlier publication are nobody's any more)
             launch_p2p_push(c, c->iter, c->rec[c->cur], c->p2p_mode_inline);
             c->p2p_current = true;
             c->pending_ext = false;
@@ -1449,7 +1518,7 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
             c->pending = false;
             c->rec_external = true;
             c->pending_ext = exchange_active(c, t);
-            c->iter = t;
+            c->iter = t; c->exch_done = false;
         }
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         HIPCHK(hipGetLastError());
@@ -1520,9 +1589,10 @@ int smm_bgp_exchange_dev(void* ctx, const void* gathered_dev) {
     if (!c || !gathered_dev) return SMM_ERR_INVALID_ARG;
     if (c->failed) return c->failed;
     if (c->iter < 1) return fail(c, SMM_ERR_STATE, "exchange before the first local step");
-    if (c->pending) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
+    if (c->pending || c->exch_done || c->a2a_open) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
     try {
         HIPCHK(hipSetDevice(c->device));
+        c->exch_done = true;
         if (exchange_active(c, c->iter)) {
             const KParams& P = c->P;
             launch_resolve(c, c->iter, (const double*)gathered_dev);
@@ -1565,7 +1635,7 @@ int smm_bgp_a2a_pack_dev(void* ctx, const void* vals_all_dev, void* send_dev) {
     if (c->failed) return c->failed;
     if (c->a2a_cap <= 0) return fail(c, SMM_ERR_STATE, "the values form needs equal shards (N_global a multiple of N, chain_offset a multiple of N)");
     if (c->iter < 1) return fail(c, SMM_ERR_STATE, "exchange before the first local step");
-    if (c->pending || c->a2a_open) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
+    if (c->pending || c->a2a_open || c->exch_done) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
     try {
         HIPCHK(hipSetDevice(c->device));
         if (exchange_active(c, c->iter)) {
@@ -1601,6 +1671,7 @@ int smm_bgp_a2a_apply_dev(void* ctx, const void* recv_dev) {
         }
         HIPCHK(hipGetLastError());
         c->a2a_open = false;
+        c->exch_done = true;
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
@@ -1814,6 +1885,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         c->prev_open = false;
         c->a2a_open = false;
         c->p2p_current = false;   // (the next smm_bgp_p2p_step publishes the uploaded state)
+        c->exch_done = false;
         if (P.walk_flags) HIPCHK(hipMemset(P.walk_flags, 0, 16));   // (the values the next exchange sees are written by the next accept step)
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);

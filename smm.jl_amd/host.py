@@ -526,12 +526,18 @@ def readMalgo(algo, filename):
 def restart(algo, extra_iter):
     """restart!(algo, extraIter), AlgoBGP.jl:804-884, with clean resume semantics (continue at i+1): the
     history capacity is extended by building a new device context and uploading the saved state."""
+    new_maxiter = int(algo.opts["maxiter"]) + int(extra_iter)
+    tb = algo._tables
+    if tb is not None and tb.covers_iterations() is not None and tb.covers_iterations() < new_maxiter:
+        # injected per-iteration randomness (parity runs) was made for the old maxiter: the extended run would read past it
+        raise ValueError("restart: the injected randomness tables cover %d iterations, the extended run needs %d — "
+                         "build the MAlgoBGP with tables for the whole run, or without tables" % (tb.covers_iterations(), new_maxiter))
     h, s = algo._ctx.history(0, algo.i), algo._ctx.state()
-    algo.opts["maxiter"] = int(algo.opts["maxiter"]) + int(extra_iter)
+    algo.opts["maxiter"] = new_maxiter
     bo = algo._bopts
-    bo.maxiter = algo.opts["maxiter"]
+    bo.maxiter = new_maxiter
     algo._ctx.close()
-    algo._ctx = hip_context(algo._prob, bo, algo._tables)   # (injected randomness tables cover the old maxiter only)
+    algo._ctx = hip_context(algo._prob, bo, tb)
     s.iter = algo.i
     algo._ctx.set_state(s, h)
     algo._invalidate()

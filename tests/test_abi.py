@@ -142,3 +142,20 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle" not in txt.lower().replace("# oracle", ""), os.path.join(dirpath, f)
     out = subprocess.check_output(["ldd", A.LIB_PATH]).decode()
     assert "smm_oracle" not in out
+
+
+def test_the_shipped_library_has_no_test_seams():
+    """VERDICT r2 #6 / ADVICE: the switches that force a kernel or shrink a capacity live in libsmmhip_hooks.so only.  The shipped
+    library reads two environment variables, both diagnostics (SMMHIP_TS, SMMHIP_DBG)."""
+    blob = open(A.LIB_PATH, "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"SMMHIP_[A-Z0-9_]+", blob)))
+    assert names == ["SMMHIP_DBG", "SMMHIP_TS"], names
+    lib = A.load()
+    lib.smm_debug_has_test_hooks.restype = C.c_int
+    assert lib.smm_debug_has_test_hooks() == 0
+    hooks = A.load_hooks()
+    assert hooks.smm_debug_has_test_hooks() == 1
+    for n in declared_symbols():
+        assert hasattr(hooks, n), "libsmmhip_hooks.so does not export %s" % n
+    seams = sorted(set(m.decode() for m in re.findall(rb"SMMHIP_[A-Z0-9_]+", open(A.HOOKS_LIB_PATH, "rb").read())))
+    assert "SMMHIP_INLINE_WALK" in seams and "SMMHIP_A2A_CAP" in seams

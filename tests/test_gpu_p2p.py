@@ -68,7 +68,10 @@ def assert_shards_equal_single(ctxs, single):
     for r, c in enumerate(ctxs):
         hr, st = c.history(), c.state()
         for f in A.HistoryBuffers.FIELDS:
-            assert np.array_equal(getattr(hr, f), getattr(hs, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+            a, b = getattr(hr, f), getattr(hs, f)[..., r * n:(r + 1) * n]
+            if not np.array_equal(a, b, equal_nan=True):
+                bad = np.argwhere(~((a == b) | ((a != a) & (b != b))))
+                raise AssertionError("history field %s of rank %d: %d entries differ, first at %s" % (f, r, len(bad), bad[0].tolist()))
         for f in A.StateBuffers.FIELDS:
             assert np.array_equal(getattr(st, f), getattr(ss, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
     assert (hs.exchanged != 0).any()

@@ -210,7 +210,7 @@ def test_three_phase_calls_after_step(S, O):
 
 @pytest.mark.parametrize("npar,N,T", [(2, 5, 30), (2, 16, 30), (2, 17, 25), (2, 100, 40), (2, 4096, 12), (1, 37, 30), (2, 5000, 8),
                                       (3, 50, 30), (4, 100, 30), (3, 4096, 10), (4, 6000, 8)])
-def test_norm_kernel_equals_general_kernel(S, O, npar, N, T, monkeypatch):
+def test_norm_kernel_equals_general_kernel(S, O, npar, N, T, monkeypatch, hooks):
     # k_chain_iter_norm (16-chain tiles, np == nm <= 2) against the general k_chain_iter on the same problem: bit-identical
     if npar == 2:
         prob, opts = cm.serial_normal(N=N, T=T, ns=1000 if N > 1000 else 10000, objective_id=A.SMM_OBJ_NORM_FAILBOX,
@@ -418,7 +418,7 @@ def test_c2_full_size_against_oracle(S, O):
 
 
 @pytest.mark.parametrize("N", [2, 3, 50, 1000])
-def test_any_size_exchange_kernel_matches(S, O, N, monkeypatch):
+def test_any_size_exchange_kernel_matches(S, O, N, monkeypatch, hooks):
     # the barrier-round resolution kernel (used above N_global = 8192) against the LDS data-flow one
     prob, opts = cm.serial_normal(N=N, T=30, ns=200)
     a, o = run_both(S, O, prob, opts, None)
@@ -430,7 +430,7 @@ def test_any_size_exchange_kernel_matches(S, O, N, monkeypatch):
 
 
 @pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096])
-def test_inline_walk_equals_resolve_kernel(S, O, N, monkeypatch):
+def test_inline_walk_equals_resolve_kernel(S, O, N, monkeypatch, hooks):
     # default single-shard path: the exchange walk runs in the prologue of the next chain kernel (every tile,
     # redundantly); against the stand-alone k_exch_resolve_lvl kernel and the oracle.  Non-uniform thresholds
     # (the plan's per-pair column instead of one scalar) and stepping in uneven pieces (an unresolved exchange
@@ -459,7 +459,7 @@ def test_inline_walk_equals_resolve_kernel(S, O, N, monkeypatch):
 
 @pytest.mark.parametrize("N", [9, 24, 50, 1000])
 @pytest.mark.parametrize("banana", [False, True])
-def test_two_tiles_per_workgroup_forced(S, O, N, banana, monkeypatch):
+def test_two_tiles_per_workgroup_forced(S, O, N, banana, monkeypatch, hooks):
     # two tiles per workgroup (one inline exchange walk per CU) is chosen above 2048 chains; force it at small and odd tile counts
     monkeypatch.setenv("SMMHIP_TPW", "2")
     if banana:
@@ -476,7 +476,7 @@ def test_two_tiles_per_workgroup_forced(S, O, N, banana, monkeypatch):
 
 
 @pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096, 6000])
-def test_dataflow_exchange_kernel_matches(S, O, N, monkeypatch):
+def test_dataflow_exchange_kernel_matches(S, O, N, monkeypatch, hooks):
     # the ticket (data-flow) resolution kernel against the level-synchronous ones (16-byte chain slots up to
     # N_global = 4096, split slots up to 8192: N = 6000)
     prob, opts = cm.serial_normal(N=N, T=12, ns=64)
@@ -489,7 +489,7 @@ def test_dataflow_exchange_kernel_matches(S, O, N, monkeypatch):
 
 
 @pytest.mark.parametrize("N", [2, 3, 50, 1000, 4096])
-def test_big_exchange_kernels_match(S, O, N, monkeypatch):
+def test_big_exchange_kernels_match(S, O, N, monkeypatch, hooks):
     # the global-memory level plan + walk (8192 < N_global <= 65535) forced at small sizes
     prob, opts = cm.serial_normal(N=N, T=12, ns=64)
     a, o = run_both(S, O, prob, opts, None)
@@ -593,7 +593,7 @@ def test_c3_fused_sharded_8x4096_real_workload(S, O):
     assert (ho.exchanged != 0).mean() > 0.05
 
 
-def test_exchange_worst_case_star_pairs(S, O):
+def test_exchange_worst_case_star_pairs(S, O, hooks):
     # injected pair list in which every pair touches chain 0: dependency depth == number of pairs
     N, T = 40, 6
     prob, opts = cm.serial_normal(N=N, T=T, ns=64, acc_tuners=np.ones(N), min_improve=0.0)
@@ -699,7 +699,7 @@ def test_c5_dense_4096_chains(S, O):
 @pytest.mark.parametrize("kind,npar,N,sig,smpl,bs", [("dense", 50, 100, 0.08, 100000, None), ("dense", 50, 37, 0.12, 100000, 25),
                                                       ("dense", 50, 16, 0.3, 40, None), ("norm", 18, 70, 0.12, 100000, None),
                                                       ("norm", 32, 9, 0.15, 100000, 16), ("dense", 64, 33, 0.06, 100000, None)])
-def test_many_parameters_many_tries(S, O, monkeypatch, kind, npar, N, sig, smpl, bs):
+def test_many_parameters_many_tries(S, O, monkeypatch, kind, npar, N, sig, smpl, bs, hooks):
     # proposals of 16 and more components whose tries run far past the pre-generated ones (sigma so wide that a try
     # seldom lands inside the box): the tile's lane segments share the open chains' further tries; same tries, same
     # order, same winner as the serial loop (mysample, AlgoBGP.jl:400-410) -- and the same hard error when smpl_iters
@@ -829,7 +829,7 @@ def test_cholesky_proposal_covariance(S):
 
 
 @pytest.mark.parametrize("N,mi", [(9000, 0.0), (20000, 0.3), (32768, 0.0), (12000, -0.05)])
-def test_key_exchange_kernel_equals_global_memory_walk(S, O, N, mi, monkeypatch):
+def test_key_exchange_kernel_equals_global_memory_walk(S, O, N, mi, monkeypatch, hooks):
     # k_exch_resolve_key (4-byte LDS slots: src + 16-bit order key, exact values only for undecided pairs) against the
     # global-memory level walk it replaces for 8192 < N_global <= 32768, and against the oracle; thresholds 0, > 0, < 0
     prob, opts = cm.serial_normal(N=N, T=8, ns=64, min_improve=mi)
@@ -846,7 +846,7 @@ def test_key_exchange_kernel_equals_global_memory_walk(S, O, N, mi, monkeypatch)
     cm.assert_history_equal(a.history(), o.history(), atol=1e-13)
 
 
-def test_key_exchange_kernel_ties_failures_and_small_populations(S, O, monkeypatch):
+def test_key_exchange_kernel_ties_failures_and_small_populations(S, O, monkeypatch, hooks):
     # forced for a small population (SMMHIP_BIG_EXCHANGE): equal values (iteration 1: every chain at the start value), the
     # failed-objective value -1.0 (negative order keys) and per-chain thresholds
     monkeypatch.setenv("SMMHIP_BIG_EXCHANGE", "1")
@@ -861,7 +861,7 @@ def test_key_exchange_kernel_ties_failures_and_small_populations(S, O, monkeypat
 
 
 @pytest.mark.parametrize("N,npar,failbox", [(4096, 2, False), (1000, 2, True), (333, 1, False), (17, 2, True)])
-def test_key_walk_equals_slot_walk(S, O, monkeypatch, N, npar, failbox):
+def test_key_walk_equals_slot_walk(S, O, monkeypatch, N, npar, failbox, hooks):
     # k_chain_iter_norm's lean exchange walk (8-byte slots: 32-bit order key of the value, src, level of the last swap; padded
     # level plan) against the same kernel on 16-byte slots (SMMHIP_KEY_WALK=0) and, for the small ones, the oracle; failbox:
     # the -1.0 of a failed objective (negative keys) and, at iteration 1, every chain at the same value (equal keys: the
@@ -914,7 +914,7 @@ def test_key_walk_deep_plan_falls_back(S, O):
 
 
 @pytest.mark.parametrize("nan", [False, True])
-def test_key_walk_special_values(S, O, monkeypatch, nan):
+def test_key_walk_special_values(S, O, monkeypatch, nan, hooks):
     # last accepted values that the order keys must not get wrong, planted through set_state: values that share the high word
     # of the double (equal keys: the exact values are read), -0.0 against +0.0 (equal), the -1.0 of a failed objective, Inf,
     # and (nan) NaN, which no key covers: the accept step raises the sticky flag and the launches walk on 16-byte slots
@@ -953,7 +953,7 @@ def test_key_walk_special_values(S, O, monkeypatch, nan):
 
 @pytest.mark.parametrize("N,npar,mi,failbox", [(4096, 2, 0.05, False), (1000, 2, 0.5, True), (333, 1, 1e-3, False), (17, 2, 0.05, True),
                                                (64, 2, np.inf, False), (64, 2, np.nan, False), (5, 3, 0.01, False), (2, 2, 0.0005, False)])
-def test_wide_walk_equals_slot_walk(S, O, monkeypatch, N, npar, mi, failbox):
+def test_wide_walk_equals_slot_walk(S, O, monkeypatch, N, npar, mi, failbox, hooks):
     # one min_improve > 0 for all chains (the reference's default is 0.5, AlgoBGP.jl:522; Examples.jl:90 uses 0.05): the lean
     # walk on 16-byte slots {value, src | stamp} (k_chain_iter_norm_wide) against the same run on the older walk
     # (SMMHIP_KEY_WALK=0) and, for the small ones, the oracle.  Inf / NaN thresholds: nothing ever swaps.
@@ -987,7 +987,7 @@ def test_wide_walk_equals_slot_walk(S, O, monkeypatch, N, npar, mi, failbox):
 
 
 @pytest.mark.parametrize("Ng,G", [(6000, 1), (7400, 2), (8192, 2)])
-def test_wide_walk_standalone_and_sharded(S, O, monkeypatch, Ng, G):
+def test_wide_walk_standalone_and_sharded(S, O, monkeypatch, Ng, G, hooks):
     # the same form as the kernel of its own (k_exch_resolve_lean): single shards too large for the inline walk, and shards of
     # a sharded run (the walk reads the gathered records); 8192 chains do not fit the LDS on 16-byte slots and keep the older
     # kernel — all against the run with SMMHIP_KEY_WALK=0
@@ -1163,7 +1163,7 @@ def test_values_form_of_the_sharded_exchange_equals_single(S, O, G, N, T, npar):
         cm.assert_state_equal(c.state(), _slice_state(single.state(), r * n, (r + 1) * n), rtol=0)
 
 
-def test_values_form_block_overflow_is_a_hard_error(S, monkeypatch):
+def test_values_form_block_overflow_is_a_hard_error(S, monkeypatch, hooks):
     # a (source, destination) block that needs more records than its capacity: sticky device error, reported at the next sync
     monkeypatch.setenv("SMMHIP_A2A_CAP", "1")
     prob, opts = cm.serial_normal(N=64, T=10, ns=64)
@@ -1172,7 +1172,7 @@ def test_values_form_block_overflow_is_a_hard_error(S, monkeypatch):
     assert e.value.code == A.SMM_ERR_EXCHANGE_CAPACITY
 
 
-def test_lean_walk_across_plan_windows(S, O, monkeypatch):
+def test_lean_walk_across_plan_windows(S, O, monkeypatch, hooks):
     # 1000 chains over 600 iterations: the look-ahead plan is rebuilt twice (windows of 256 iterations), every switch settles the
     # open exchange through the stand-alone kernel; stepping in uneven pieces; lean walk against the 16-byte walk and the oracle
     N, T = 1000, 600

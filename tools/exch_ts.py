@@ -5,6 +5,7 @@ os.environ["SMMHIP_TS"] = "1"; os.environ["SMMHIP_INLINE_WALK"] = "0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import smm_jl_amd as S, common as cm
+S._abi.use_test_hooks(True)   # (the SMMHIP_* seams below exist in the test build of the library only)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 prob, opts = cm.serial_normal(N=N, T=60, ns=64)
 c = S.hip_context(prob, opts)

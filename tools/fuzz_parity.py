@@ -9,6 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import smm_jl_amd as S  # noqa: E402
+S._abi.use_test_hooks(True)   # (the SMMHIP_* seams below exist in the test build of the library only)
 import common as cm  # noqa: E402
 from smm_jl_amd import _abi as A  # noqa: E402
 from oracle import oracle as O  # noqa: E402
