@@ -89,6 +89,10 @@ function reference_chains(m::MProb, opts::Dict, N::Int, temps::Vector{Float64}, 
 end
 
 function MAlgoBGPHip(m::MProb, opts::Dict)
+    # opts["animate"] (AlgoBGP.jl:621-624) makes the reference push a plot frame of its chains into algo.anim every iteration:
+    # that is a host-side per-iteration hook on objects this backend fills lazily; refused rather than silently ignored
+    get(opts, "animate", false) == true &&
+        throw(ArgumentError("opts[\"animate\"] is not supported by the GPU backend: run without it and plot the synced chains afterwards"))
     N = Int(opts["N"])
     temps = N > 1 ? collect(range(1.0, stop = Float64(opts["maxtemp"]), length = N)) : [1.0]      # AlgoBGP.jl:508
     mi = chain_vector(opts, "min_improve", 0.5, N)                                                  # :522

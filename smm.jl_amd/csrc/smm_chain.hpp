@@ -602,6 +602,78 @@ __device__ inline bool exchange_walk_tile_lean(const KParams& P, const int tx, u
     return true;
 }
 
+// The lean KEY walk in k_chain_iter, for single shards of 4096 < N <= 8192 chains (BASELINE config 4: banana, 8192 chains — one
+// launch per iteration instead of chain kernel + stand-alone resolution): 8-byte slots {order_key32(value), src | stamp << 16}
+// built from the chains' values exactly as k_exch_resolve_lean builds them, min_improve == 0, dist_fun = -.  The control wave of
+// every tile takes its chains' result (src | partner << 32) into xr.  false (uniform; nothing done): the plan has more than 31
+// levels or a value is NaN — the host does not launch this form where it knows of either; loud where it happens anyway.
+template <int NT>
+__device__ inline bool exchange_walk_tile_keys(const KParams& P, const int tx, unsigned char* lds, const int tid, const bool valid, const int gc,
+                                               unsigned long long& xr, const int ts_tile) {
+    const int Ng = P.Ng;
+    const int w = tx - P.plan_t0;
+    const uint32_t* __restrict__ g_offp = P.lv_offp + (size_t)w * LV_OFFP;
+    const uint4* __restrict__ g_pairs = (const uint4*)(P.lv_pairs_p + (size_t)w * P.plan_Kp);
+    const int lane = tid & 63;
+    const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
+    const uint32_t pbase = 8u * (Ng4 + 4u);               // LDS offset of the pair words
+    constexpr int PT = XLDS_MAX / NT;                     // chains per lane
+    constexpr int PR = (XLDS_MAX + 64 * LV_MAXLEV + 4 * NT - 1) / (4 * NT);   // rounds of 16-byte loads for the pair words
+    const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
+    double v_[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        v_[r] = g < Ng ? P.vals[g] : 0.0;
+    }
+    uint4 p_[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int q4 = tid + r * NT;
+        p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
+    bool nan = false;
+#pragma unroll
+    for (int r = 0; r < PT; ++r) nan = nan || v_[r] != v_[r];
+    const bool fits = __builtin_amdgcn_readlane((int)ov, 34) != 0 && (uint32_t)(size_t)lds == 0u;
+    // (one answer for the whole workgroup, through a spare slot behind the dummy pair's: __syncthreads_or would put a static
+    // LDS word into every instantiation of the kernel, and the dynamic 160 KB are all there is)
+    uint32_t* s_nan = (uint32_t*)(lds + 8u * (Ng4 + 2u));
+    if (tid == 0) *s_nan = 0u;
+    __syncthreads();
+    if (nan) *s_nan = 1u;
+    __syncthreads();
+    const bool has_nan = *s_nan != 0u;
+    __syncthreads();
+    if (has_nan || !fits) return false;
+    uint2* slot = (uint2*)lds;
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int g = tid + r * NT;
+        if (g < Ng) slot[g] = make_uint2(order_key32(v_[r]), (uint32_t)g);
+    }
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int q4 = tid + r * NT;
+        if (4 * q4 < P.plan_Kp) ((uint4*)(lds + pbase))[q4] = p_[r];
+    }
+    if (tid == 0) { slot[Ng4] = make_uint2(1u, 0u); slot[Ng4 + 1] = make_uint2(2u, 0u); }   // the dummy pair's slots: keys 1 < 2, "no swap"
+    const int ltail = lean_walk_tail(ov, nlev, lane);
+    __syncthreads();
+    if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
+    if (P.lean_unit == 8) lean_walk_levels<NT, 0>(P.vals, 1, pbase, ov, nlev, tid, ltail);
+    else lean_walk_levels<NT, 1>(P.vals, 1, pbase, ov, nlev, tid, ltail);
+    __syncthreads();   // (the narrow tail was wave 0's alone; the control waves of other tiles read now)
+    if (valid) {
+        const uint32_t meta = slot[gc].y;
+        const uint32_t partner = P.lean_unit == 8 ? lean_partner<0>(lds, pbase, meta, (uint32_t)gc) : lean_partner<1>(lds, pbase, meta, (uint32_t)gc);
+        xr = (unsigned long long)(meta & 0xffffu) | ((unsigned long long)partner << 32);
+    }
+    __syncthreads();   // (from here on the tile's blocks may overwrite the pair list)
+    return true;
+}
+
 // The same walk with the level loop written for latency: a level is ONE LDS round trip (both 16-byte slots of a pair with a
 // ds_read_b128 each), the compare, the two 16-byte writes of a swap and the barrier; the next level's pair word is fetched
 // ahead; nothing else is in the loop (thresholds: a scalar when min_improve is uniform — the loop is instantiated twice).
@@ -852,7 +924,10 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         if (IW && (flags & F_WALK_INLINE)) {
             // exchangeMoves! of iteration t-1, by all lanes of the tile, while the level-1 blocks are in flight
             // (the tile's own LDS blocks overlay the walk's pair list: nothing of the tile is written before this returns)
-            if (!(P.gen_lean && exchange_walk_tile_lean<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, tile))) {
+            if (P.gen_lean == 2) {   // 4096 < N <= 8192: the key walk (no other form fits the LDS at this size)
+                if (!exchange_walk_tile_keys<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, tile) && threadIdx.x == 0)
+                    report_error(P, 3, t, gc);
+            } else if (!(P.gen_lean && exchange_walk_tile_lean<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, tile))) {
                 exchange_walk_tile<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, tile);
                 if (valid) {
                     const XSlot sv = ((const XSlot*)smem)[gc];

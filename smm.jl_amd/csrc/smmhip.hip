@@ -191,6 +191,7 @@ struct Ctx {
     bool deep_plan = false;      // an injected pair list has an iteration of more than LV_MAXLEV dependency levels
     bool nan_values = false;     // the uploaded state holds NaN values (smm_set_state)
     bool gen_lean = false;       // k_chain_iter walks inline on the lean form (16-byte slots) when the plan fits it
+    bool gen_keys = false;       // ... on the lean KEY form (8-byte slots): single shards of 4096 < N <= 8192 chains without a simulation (two 16-chain tiles per workgroup)
     bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
@@ -275,6 +276,7 @@ size_t tile_smem(const Ctx* c, int ct, int tpw = 1) {   // dynamic LDS of k_chai
     const size_t base = tile_smem_base(c, ct);           // walk its chain slots in front and its pair list under the tiles
     const size_t tiles = (size_t)tpw * ((base + 15) & ~(size_t)15);
     if (!c->inline_walk) return tiles;
+    if (c->gen_keys) return (size_t)(((c->P.Ng + 3) & ~3) + 4) * 8 + std::max(tiles, (size_t)lean_walk_Kp(c->P.plan_K) * 4);
     return c->gen_lean ? tile_lean_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)lean_walk_Kp(c->P.plan_K) * 4)
                        : walk_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)c->P.plan_K * 4);
 }
@@ -442,6 +444,8 @@ void launch_chain_iter(Ctx* c, int t, int flags) {
         else launch_chain_iter_ct<1, 8>(c, t, flags);
     } else if (c->obj == SMM_OBJ_DENSE) {
         launch_chain_iter_ct<2, 16>(c, t, flags);
+    } else if (c->gen_keys) {
+        launch_chain_iter_ct<0, 16, 2>(c, t, flags);
     } else if (tile_smem_base(c, 64) <= (size_t)60 * 1024 && !c->inline_walk) {
         launch_chain_iter_ct<0, 64>(c, t, flags);
     } else if (c->tpw == 2) {
@@ -966,6 +970,16 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             c->gen_lean = c->inline_walk && !c->norm_fast && lean_plan &&
                           tile_lean_slot_bytes(Ng) + std::max((size_t)c->tpw * tile_b, (size_t)lean_walk_Kp(K) * 4) <= (size_t)(c->tpw == 2 ? 160 : 80) * 1024;
             if (c->gen_lean) { P.tile_off = (int)(tile_lean_slot_bytes(Ng) / sizeof(double)); P.gen_lean = 1; }
+            // single shards of 4096 < N <= 8192 chains without a simulation (banana, BASELINE config 4): the key walk inline, two
+            // 16-chain tiles per workgroup of 1024 lanes (256 workgroups at 8192 chains: one per CU, one launch per iteration)
+            {
+                const size_t tile16 = (tile_smem_base(c, 16) + 15) & ~(size_t)15;
+                const size_t slots = (size_t)(((Ng + 3) & ~3) + 4) * 8;
+                c->gen_keys = !c->inline_walk && !(iw && iw[0] == '0') && obj_kind(c->obj) == 0 && c->obj != SMM_OBJ_USER && N == Ng && Ng > XLVL_MAX &&
+                              Ng <= XLDS_MAX && K <= XLDS_MAX && c->lds_exchange && P.mi_uniform && P.mi_value == 0.0 && opts->dist_fun == SMM_DIST_MINUS &&
+                              !(kw0 && kw0[0] == '0') && slots + std::max(2 * tile16, (size_t)lean_walk_Kp(K) * 4) <= (size_t)160 * 1024;
+                if (c->gen_keys) { c->inline_walk = true; c->tpw = 2; P.gen_lean = 2; P.tile_off = (int)(slots / sizeof(double)); }
+            }
         }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
             const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 : 0);
@@ -1099,6 +1113,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<1, 8, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<2, 16, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter<0, 8, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -1216,7 +1231,7 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
             if (c->profiling) c->pev_exch[it] = 0;
             c->unresolved = false;
             if (exchange_active(c, t)) {
-                if (c->inline_walk) {
+                if (c->inline_walk && !(c->gen_keys && (c->deep_plan || c->nan_values))) {   // (the key form has no second walk to fall back to)
                     c->unresolved = true;   // resolved in the prologue of the next chain kernel (or by resolve_now)
                 } else {
                     if (kscoped) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }

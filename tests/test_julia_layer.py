@@ -5,6 +5,8 @@ the glue has the reference's field names and defines the methods SMM.jl dispatch
 files is balanced (a coarse syntax check)."""
 import os
 import re
+
+import pytest
 import subprocess
 import tempfile
 
@@ -159,3 +161,37 @@ def test_block_structure_is_balanced():
             elif tok in openers and depth == 0:
                 blocks += 1
         assert depth == 0 and blocks == 0, (path, depth, blocks)
+
+
+REF = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference sources are only present in the build container")
+def test_every_smm_symbol_the_glue_uses_exists_in_the_reference():
+    """the glue has never met a Julia parser (no julia binary in the image), so at least every name it takes from SMM must exist
+    there: exported by src/SMM.jl:31-57, or defined (function / struct / const / one-line method) somewhere under src/"""
+    glue = strip_julia(open(GLUE).read())
+    imports = re.search(r"import SMM:((?:[^\n]*,\s*\n)*[^\n]*)", glue).group(1)
+    names = {n.strip() for n in imports.replace("\n", " ").split(",") if n.strip()}
+    names |= set(re.findall(r"\bSMM\.([A-Za-z_]\w*!?)", glue))
+    assert {"computeNextIteration!", "BGPChain", "extendBGPChain!", "restart!", "objfunc_norm"} <= names
+    src = ""
+    for root, _, files in os.walk(REF):
+        for f in files:
+            if f.endswith(".jl"):
+                src += open(os.path.join(root, f), errors="replace").read() + "\n"
+    exported = set(re.findall(r"[A-Za-z_]\w*!?", " ".join(re.findall(r"^export\s+((?:[^\n]*,\s*\n)*[^\n]*)", src, re.M))))
+    missing = []
+    for n in sorted(names):
+        e = re.escape(n)
+        defined = re.search(r"(?m)^\s*(?:function\s+(?:SMM\.)?%s\s*[\({]|(?:mutable\s+)?struct\s+%s\b|abstract\s+type\s+%s\b|const\s+%s\b|%s\([^)]*\)\s*=)" % (e, e, e, e, e), src)
+        via_using = n == "DataFrame" and re.search(r"(?m)^using DataFrames\b", src)     # (a binding SMM has through `using DataFrames`, src/SMM.jl:9)
+        if not (n in exported or defined or via_using):
+            missing.append(n)
+    assert not missing, "names the glue takes from SMM that the reference neither exports nor defines: %s" % missing
+
+
+def test_glue_refuses_animate():
+    # AlgoBGP.jl:621-624: the reference's per-iteration animation hook cannot be served by lazily filled chains
+    glue = open(GLUE).read()
+    assert re.search(r'get\(opts, "animate", false\) == true\s*&&\s*\n?\s*throw\(ArgumentError', glue)
