@@ -48,7 +48,7 @@ WORKLOADS = {
                kernel="k_chain_iter_norm<2, false>",
                label="serialNormal objfunc_norm 2p/2m, ns=10000, 32768 chains = 8 temperature levels x 4096 (BASELINE configs[2])"),
     # ~80 flop vs (2*10 + 10 + 8) * 8 = 304 B per chain evaluation: an HBM / latency stream
-    "c4": dict(chains=8192, total=False, flop=80, bytes=304, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", kernel="k_chain_iter<0, 64",
+    "c4": dict(chains=8192, total=False, flop=80, bytes=304, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", kernel="k_chain_iter<0, 16, 2, true>",
                label="banana / Rosenbrock 10 params / 10 moments, 8192 chains (BASELINE configs[3])"),
     # 2*256*256 + 2*256*50 flop per chain evaluation on FP64 MFMA
     "c5": dict(chains=4096, total=False, flop=2 * 256 * 256 + 2 * 256 * 50, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma", peak=PEAK_FP64_MFMA_TFLOPS,
@@ -74,16 +74,27 @@ def newest_profile(pattern):
     return files[-1] if files else None
 
 
-def pmc_traffic(kernel):
+def profile_tag(workload):
+    """file name infix of the committed profiles of a workload: r03_pmc_summary.txt (C2), r03_c4_pmc_summary.txt, ..."""
+    return "" if workload in ("c2", "c3") else workload + "_"
+
+
+def pmc_traffic(kernel, workload="c2"):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are KB per launch; gfx950's FETCH_SIZE tallies wide coalesced reads at half their size (MI355X_MICROARCH.md, HBM)
     so it is doubled.  Counters cannot be read from inside the timed process, so the number comes from the profile file; `stale`
     says whether that profile was taken from other device sources than this build (the summary carries the source hash)."""
     import re
-    f = newest_profile("r*_pmc_summary.txt")
+    f = newest_profile("r[0-9][0-9]_%spmc_summary.txt" % profile_tag(workload))
     if not f:
         return None, None, None
     fetch = write = src_hash = None
+    if workload not in ("c2", "c3"):   # (the C4 / C5 summaries carry no hash line of their own: the C2 bundle of the same round does)
+        import re as _re
+        f0 = f.replace("_%spmc" % profile_tag(workload), "_pmc")
+        if os.path.exists(f0):
+            m0 = _re.search(r"kernel_source_sha16=([0-9a-f]+)", open(f0).read())
+            src_hash = m0.group(1) if m0 else None
     for line in open(f):
         m = re.match(r"#\s*kernel_source_sha16=([0-9a-f]+)", line)
         if m:
@@ -99,11 +110,11 @@ def pmc_traffic(kernel):
     return (2.0 * fetch + write) * 1024.0, os.path.relpath(f, ROOT), (src_hash != kernel_source_hash())
 
 
-def rocprof_kernel_us(kernel):
+def rocprof_kernel_us(kernel, workload="c2"):
     """average duration of the dominant kernel in the newest committed rocprofv3 --kernel-trace --stats summary (profiles/), with
     the staleness of that file against this build's device sources (a `# kernel_source_sha16=` line next to it)"""
     import csv
-    f = newest_profile("r*_kernel_stats.csv")
+    f = newest_profile("r[0-9][0-9]_%skernel_stats.csv" % profile_tag(workload))
     if not f:
         return None, None, None
     us = None
@@ -112,7 +123,7 @@ def rocprof_kernel_us(kernel):
         if kernel in name and "AverageNs" in row:
             us = float(row["AverageNs"]) / 1e3
             break
-    tag = f.replace("_kernel_stats.csv", "_pmc_summary.txt")
+    tag = f.replace("_%skernel_stats.csv" % profile_tag(workload), "_pmc_summary.txt")
     stale = None
     if os.path.exists(tag):
         import re
@@ -378,8 +389,8 @@ def main():
         hbm = n_loc * W["bytes"] / (k_us * 1e-6) / 1e9
         kernel = W["kernel"] if not sharded else ("k_chain_iter_norm_p2p<2>" if (protocol == "p2p" and args.workload in ("c2", "c3") and n_glob <= 8192)
                                                   else W["kernel"].replace("true", "false"))
-        traffic, traffic_src, traffic_stale = pmc_traffic(kernel)
-        prof_us, prof_src, prof_stale = rocprof_kernel_us(kernel)
+        traffic, traffic_src, traffic_stale = pmc_traffic(kernel, args.workload)
+        prof_us, prof_src, prof_stale = rocprof_kernel_us(kernel, args.workload)
         roof = {"bound": W["bound"], "kernel": kernel, "achieved": ach, "peak": W["peak"], "unit": W["unit"], "frac": ach / W["peak"],
                 "frac_rocprof": (work / (prof_us * 1e-6) / (1e12 if W["bound"] != "hbm" else 1e9) / W["peak"]) if prof_us else None,
                 "rocprof_kernel_us": prof_us, "rocprof_source": prof_src, "rocprof_stale": prof_stale,
