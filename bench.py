@@ -397,12 +397,13 @@ def main():
                 "traffic": traffic, "traffic_stale": traffic_stale,
                 "traffic_note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from %s; algorithmic: %d B"
                                 % (traffic_src, n_loc * W["bytes"]),
-                "avg_kernel_us": k_us, "avg_exchange_us": x_us, "iteration_us": step_us,
-                "other_us": max(0.0, step_us - k_us - x_us),
+                "avg_kernel_us": k_us, "avg_exchange_us": x_us, "profiled_iteration_us": step_us,
+                "profiled_other_us": max(0.0, step_us - k_us - x_us),
                 "timing_note": "rank 0, one profiled step: avg_kernel_us = the chain kernel's own start/stop events (dispatch duration, what "
                                "rocprofv3 reports; used for 'achieved' and 'frac'), avg_exchange_us = the stand-alone exchange resolution "
-                               "where there is one, iteration_us = the step's events / 200, other_us = the rest (launch boundaries, push / "
-                               "collective).  frac_rocprof = the same work over the committed rocprofv3 average (the profiler lowers the clock)",
+                               "where there is one, profiled_iteration_us = the PROFILED step's events / 200 (start/stop events on every kernel slow the "
+                               "stream down: the unprofiled figure is ms_per_step / iters_per_step), profiled_other_us = its rest (launch boundaries, "
+                               "event handling, push / collective).  frac_rocprof = the same work over the committed rocprofv3 average (the profiler lowers the clock)",
                 "algorithmic_per_launch": {"flop": n_loc * W["flop"], "hbm_bytes": n_loc * W["bytes"]},
                 "hbm": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
                         "note": "algorithmic %d B per chain-eval" % W["bytes"]}}

@@ -10,7 +10,7 @@ for f in sh_p2p sd2 sd4; do python - $o/$f.json $f <<'P'
 import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r=d.get("roofline") or {}
-    print("%-10s %8.1f M/s  iter %.2f us  kernel %s exch %s other %s frac %s  proto %s" % (sys.argv[2], d["value"]/1e6, d["ms_per_step"]*1e3/200, r.get("avg_kernel_us"), r.get("avg_exchange_us"), r.get("other_us"), r.get("frac"), d["config"].get("protocol")))
+    print("%-10s %8.1f M/s  iter %.2f us  kernel %s exch %s other %s frac %s  proto %s" % (sys.argv[2], d["value"]/1e6, d["ms_per_step"]*1e3/200, r.get("avg_kernel_us"), r.get("avg_exchange_us"), r.get("profiled_other_us"), r.get("frac"), d["config"].get("protocol")))
 except Exception as e:
     print(sys.argv[2], "FAILED", e)
 P
