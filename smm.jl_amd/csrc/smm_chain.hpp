@@ -617,14 +617,16 @@ __device__ inline bool exchange_walk_tile_keys(const KParams& P, const int tx, u
     const int lane = tid & 63;
     const uint32_t Ng4 = (uint32_t)((Ng + 3) & ~3);
     const uint32_t pbase = 8u * (Ng4 + 4u);               // LDS offset of the pair words
-    constexpr int PT = XLDS_MAX / NT;                     // chains per lane
     constexpr int PR = (XLDS_MAX + 64 * LV_MAXLEV + 4 * NT - 1) / (4 * NT);   // rounds of 16-byte loads for the pair words
     const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
-    double v_[PT];
+    // the chains' slots as the accept step wrote them ({order_key32(value), chain}; a NaN value set the sticky flag): two per 16 bytes
+    constexpr int SR = XLDS_MAX / (2 * NT);               // 16-byte pieces per lane
+    const uint32_t wflags = P.walk_flags[tid & 3];        // (word 0 is looked at; a per-lane address keeps it a vector load among the others)
+    uint4 s_[SR];
 #pragma unroll
-    for (int r = 0; r < PT; ++r) {
-        const int g = tid + r * NT;
-        v_[r] = g < Ng ? P.vals[g] : 0.0;
+    for (int r = 0; r < SR; ++r) {
+        const int q = tid + r * NT;
+        s_[r] = 2 * q < Ng ? ((const uint4*)P.slot8)[q] : make_uint4(0u, 0u, 0u, 0u);
     }
     uint4 p_[PR];
 #pragma unroll
@@ -633,25 +635,12 @@ __device__ inline bool exchange_walk_tile_keys(const KParams& P, const int tx, u
         p_[r] = 4 * q4 < P.plan_Kp ? g_pairs[q4] : make_uint4(0u, 0u, 0u, 0u);
     }
     const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
-    bool nan = false;
-#pragma unroll
-    for (int r = 0; r < PT; ++r) nan = nan || v_[r] != v_[r];
-    const bool fits = __builtin_amdgcn_readlane((int)ov, 34) != 0 && (uint32_t)(size_t)lds == 0u;
-    // (one answer for the whole workgroup, through a spare slot behind the dummy pair's: __syncthreads_or would put a static
-    // LDS word into every instantiation of the kernel, and the dynamic 160 KB are all there is)
-    uint32_t* s_nan = (uint32_t*)(lds + 8u * (Ng4 + 2u));
-    if (tid == 0) *s_nan = 0u;
-    __syncthreads();
-    if (nan) *s_nan = 1u;
-    __syncthreads();
-    const bool has_nan = *s_nan != 0u;
-    __syncthreads();
-    if (has_nan || !fits) return false;
+    if (__builtin_amdgcn_readlane((int)ov, 34) == 0 || __builtin_amdgcn_readlane((int)wflags, 0) != 0 || (uint32_t)(size_t)lds != 0u) return false;
     uint2* slot = (uint2*)lds;
 #pragma unroll
-    for (int r = 0; r < PT; ++r) {
-        const int g = tid + r * NT;
-        if (g < Ng) slot[g] = make_uint2(order_key32(v_[r]), (uint32_t)g);
+    for (int r = 0; r < SR; ++r) {
+        const int q = tid + r * NT;
+        if (2 * q < Ng) ((uint4*)lds)[q] = s_[r];
     }
 #pragma unroll
     for (int r = 0; r < PR; ++r) {
@@ -1289,7 +1278,12 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         // parameter and moment arrays (and the history row's parameters) by all lanes of the chain below
         if (acc) { ro[0] = value; ro[1] = prob; ro[2] = (double)status; }
         else { ro[0] = rc[0]; ro[1] = rc[1]; ro[2] = rc[2]; }
-        P.vals_out[c] = acc ? value : old;
+        const double vnew = acc ? value : old;
+        P.vals_out[c] = vnew;
+        if (P.slot8_out) {   // the chain's slot at the start of the next inline key walk (exchange_walk_tile_keys)
+            P.slot8_out[c] = make_uint2(order_key32(vnew), (uint32_t)gc);
+            if (vnew != vnew) atomicOr(P.walk_flags, 1u);
+        }
     }
     __builtin_amdgcn_wave_barrier();
     if constexpr (KIND == 2) {

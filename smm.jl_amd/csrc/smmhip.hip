@@ -979,6 +979,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                               Ng <= XLDS_MAX && K <= XLDS_MAX && c->lds_exchange && P.mi_uniform && P.mi_value == 0.0 && opts->dist_fun == SMM_DIST_MINUS &&
                               !(kw0 && kw0[0] == '0') && slots + std::max(2 * tile16, (size_t)lean_walk_Kp(K) * 4) <= (size_t)160 * 1024;
                 if (c->gen_keys) { c->inline_walk = true; c->tpw = 2; P.gen_lean = 2; P.tile_off = (int)(slots / sizeof(double)); }
+                // (its slots are written by the accept step, like the headline kernel's: allocated further down, with the lean plan)
             }
         }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
@@ -1021,7 +1022,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                     c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->win_cap * P.plan_Kp);
                     c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->win_cap * LV_OFFP);
                     c->lean_resolve = true;
-                    if (keys && c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) {   // ... in the prologue of k_chain_iter_norm
+                    if (keys && ((c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) || c->gen_keys)) {   // ... in the prologue of k_chain_iter_norm, or of k_chain_iter (key form)
                         for (int b = 0; b < 2; ++b) c->slot8_buf[b] = dalloc<uint2>(c, (size_t)N + 4);
                         P.slot8 = c->slot8_buf[0];
                         P.walk_flags = dalloc<uint32_t>(c, 4);
