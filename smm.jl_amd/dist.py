@@ -102,10 +102,20 @@ class ShardedBGP:
             if self.world > 1:
                 handles = [None] * self.world
                 dist.all_gather_object(handles, handle, group=group)
-                for r, h in enumerate(handles):
-                    if r != self.rank:
-                        engine.p2p_attach(r, handle=h)
-                dist.barrier(group=group)   # every window is mapped everywhere before anybody stores into one
+                err = None
+                try:
+                    for r, h in enumerate(handles):
+                        if r != self.rank:
+                            engine.p2p_attach(r, handle=h)
+                except Exception as e:   # noqa: BLE001 -- reported below, on EVERY rank
+                    err = e
+                # every window is mapped everywhere before anybody stores into one — and if one rank could not map one, all ranks
+                # raise together (a rank that left alone would leave the others at a collective it never joins)
+                be = str(dist.get_backend(group))
+                flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=engine.device if "nccl" in be else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if not bool(flag.item()):
+                    raise RuntimeError("p2p: a rank could not map a peer's window%s" % (": %s" % err if err else " (another rank)"))
             self.fused = False
             return
         if protocol == "values":
