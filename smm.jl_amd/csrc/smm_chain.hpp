@@ -1280,6 +1280,10 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         else { ro[0] = rc[0]; ro[1] = rc[1]; ro[2] = rc[2]; }
         const double vnew = acc ? value : old;
         P.vals_out[c] = vnew;
+        if (P.slots17_out) {   // the chain's initial slots of k_exch_resolve_rows / _key (what k_exch_keys would make of vals[c])
+            P.slots17_out[c] = (uint32_t)gc | (order_key17(vnew) << 15);
+            if (vnew != vnew) atomicOr(P.nan_flags_out, 1u);
+        }
         if (P.slot8_out) {   // the chain's slot at the start of the next inline key walk (exchange_walk_tile_keys)
             P.slot8_out[c] = make_uint2(order_key32(vnew), (uint32_t)gc);
             if (vnew != vnew) atomicOr(P.walk_flags, 1u);

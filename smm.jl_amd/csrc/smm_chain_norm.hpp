@@ -327,7 +327,7 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
     return true;
 }
 
-template <int NP, bool P2P>
+template <int NP, bool P2P, bool BIG>
 __device__ inline void epilogue_norm(const KParams& P, const int t, double* __restrict__ rec_out, const double* s_theta, const double* s_part,
                                      const double* s_park, const int tile, const int tid);
 
@@ -638,7 +638,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     }
     if (P.ts && tid2 == 0) P.ts[(size_t)tile * 8 + 3] = wall_clock64();
     // Epilogue by the control wave: everything it needs comes from LDS (parked by the prologue)
-    epilogue_norm<NP, P2P>(P, t, rec_out, s_theta, s_part, s_park, tile, tid2);
+    epilogue_norm<NP, P2P, !WALK>(P, t, rec_out, s_theta, s_part, s_park, tile, tid2);
 }
 template <int NP, bool WALK>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P, const int t, const double* __restrict__ rec_in,
@@ -665,7 +665,9 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_p2p(const KParam
 }
 
 // objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks
-template <int NP, bool P2P>
+// (BIG: the kernel without an inline walk — the one large populations run: their stand-alone resolution takes its initial slots
+// from the accept step when the host says so, KParams::slots17_out)
+template <int NP, bool P2P, bool BIG>
 __device__ inline void epilogue_norm(const KParams& P, const int t, double* __restrict__ rec_out, const double* s_theta,
                                      const double* s_part, const double* s_park, const int tile, const int tid) {
     using L = NormLayout<NP>;
@@ -759,6 +761,12 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
                 }
         } else {
             P.vals_out[c] = v;
+            if constexpr (BIG) {
+                if (P.slots17_out) {   // the chain's initial slots of k_exch_resolve_rows / _key (what k_exch_keys would make of vals[c])
+                    P.slots17_out[c] = (uint32_t)gc | (order_key17(v) << 15);
+                    if (v != v) atomicOr(P.nan_flags_out, 1u);
+                }
+            }
             if (P.slot8_out) {   // the chain's slot at the start of the next exchange walk (exchange_walk_lean)
                 P.slot8_out[c] = make_uint2(order_key32(v), (uint32_t)gc);
                 if (v != v) atomicOr(P.walk_flags, 1u);

@@ -817,7 +817,9 @@ __device__ inline void resolve_key_body(const KParams& P, const int t, const dou
     uint32_t q0 = pn < (uint32_t)K ? g_pairs[pn] : 0u;
     uint32_t q1 = pn + XWG < (uint32_t)K ? g_pairs[pn + XWG] : 0u;
     uint32_t q2 = pn + 2 * XWG < (uint32_t)K ? g_pairs[pn + 2 * XWG] : 0u;
-    {
+    if (slots0 == nullptr) {   // nobody made the initial slots (the accept step wrote the rows walk's only, and this is its rare fallback): from the values
+        for (int g = tid; g < Ng; g += XWG) state[g] = (uint32_t)g | (order_key16(vals[g]) << 16);
+    } else {
         typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
         const u32x4s_t* __restrict__ s4 = (const u32x4s_t*)slots0;     // the initial slots, made by k_exch_keys: 16 bytes per lane
         u32x4s_t* d4 = (u32x4s_t*)state;
@@ -983,7 +985,7 @@ __host__ __device__ inline size_t resolve_rows_bytes(int Ng, int K, int rows_cap
 template <bool PLDS>   // PLDS: the last partner of every chain in a 2-byte LDS array of its own, written by the swap (N_global <= XKEY_PARTNER_MAX)
 __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, const int t, const double* __restrict__ vals,
                                                            const uint32_t* __restrict__ slots16, const uint32_t* __restrict__ slots17,
-                                                           const uint32_t* __restrict__ nan_flags) {
+                                                           uint32_t* __restrict__ nan_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -993,6 +995,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
     XTS(0);
     const int nrows = (int)info[0];
     const unsigned long long endmask = (unsigned long long)info[1] | ((unsigned long long)info[2] << 32);
+    if (tid == 0) nan_flags[(t + 1) & 1] = 0u;   // (the next iteration's word: its accept step or k_exch_keys raises it)
     if (info[3] == 0u || nan_flags[t & 1] != 0u) {
 #ifndef SMM_EXP_NO_FALLBACK   // (inspection builds: the rows walk's own code without the fallback's)
         resolve_key_body<PLDS>(P, t, vals, slots16, xsm);

@@ -87,6 +87,10 @@ struct KParams {
     uint2* slot8;              // [N] the chain's initial slot of the lean walk: {order_key32(vals[c]), c} (k_chain_iter_norm, or null)
     uint2* slot8_out;          // (like vals_out)
     uint32_t* walk_flags;      // bit 0 (sticky): a NaN value entered vals[]: order keys do not cover it, the 16-byte walk runs
+    // single shards of 8192 < N <= 32768 chains: the initial slots of k_exch_resolve_rows / _key, written by the accept step itself
+    // (no k_exch_keys pre-pass between chain kernel and resolution): key17 << 15 | chain and the NaN word of the iteration's parity
+    // (null: the pre-pass makes them; the 16-bit slots of the rows walk's rare fallback are then made by the fallback itself)
+    uint32_t* slots17_out; uint32_t* nan_flags_out;
     // scratch of the any-size exchange kernel
     int32_t *xsrc, *xpartner, *xnext, *xpairs;
     double* xval;

@@ -174,7 +174,8 @@ struct Ctx {
     bool pending = false;      // exchange of iteration `iter` resolved but not applied
     bool prev_open = false;    // accept-rate counters of iteration `iter` not closed yet
     // look-ahead windows
-    int win_cap = 0;           // iterations per window
+    int win_cap = 0;           // iterations per window of pre-generated randomness
+    int plan_cap = 0;          // iterations per window of exchange plans
     double* win_rb = nullptr;
     unsigned long long* win_plan = nullptr;
     double* win_plan_mi = nullptr;
@@ -184,6 +185,7 @@ struct Ctx {
     int32_t *a2a_send_idx = nullptr, *a2a_send_cnt = nullptr, *a2a_rowidx = nullptr;   // the values form of the sharded exchange
     int a2a_cap = 0, a2a_G = 0;
     bool a2a_open = false;
+    int slots_iter = -1;        // single shard, rows exchange: the accept step of this iteration wrote the resolution's initial slots (no pre-pass)
     int xk = 0;                 // ExchKernel: the stand-alone exchange resolution of this context (choose_exchange)
     bool exch_done = false;     // the three-phase / values forms: exchangeMoves! of iteration `iter` has been applied (cleared by the next local step)
     double* vals_buf[2] = {nullptr, nullptr};   // KParams::vals / vals_out, by iteration parity (point_values)
@@ -304,7 +306,7 @@ void ensure_windows(Ctx* c, int t) {
         P.rb = c->win_rb; P.rb_t0 = t;
     }
     if (c->big_exchange && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
-        const int W = std::min(c->win_cap, P.T - t + 1);
+        const int W = std::min(c->plan_cap, P.T - t + 1);
         hipLaunchKernelGGL(k_exch_plan_big, dim3(W), dim3(XWG), 0, c->stream, P, t, c->big_scratch, c->win_lv_pairs, c->win_lv_mi,
                            c->win_lv_off, c->win_lv_rows, c->win_lv_rowinfo);
         c->plan_t0 = t; c->plan_w = W;
@@ -313,7 +315,7 @@ void ensure_windows(Ctx* c, int t) {
         P.lv_pairs = c->win_lv_pairs; P.lv_mi = c->win_lv_mi; P.lv_off = c->win_lv_off;
     }
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
-        const int W = std::min(c->win_cap, P.T - t + 1);
+        const int W = std::min(c->plan_cap, P.T - t + 1);
         hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
                            c->win_plan_mi, c->win_lv_pairs, c->win_lv_mi, c->win_lv_off, c->win_lv_pairs_p, c->win_lv_offp);
         c->plan_t0 = t; c->plan_w = W;
@@ -426,6 +428,11 @@ void launch_user_kernel(Ctx* c, const double* theta, int n, double* simM, double
 void launch_chain_iter(Ctx* c, int t, int flags) {
     point_values(c, c->P, t - 1, t);   // the inline walk reads what the accept step of t-1 wrote; this accept step writes the other array
     if (c->ext_vals_out) { c->P.vals_out = c->ext_vals_out; c->P.slot8_out = nullptr; }
+    // large single shards (k_exch_resolve_rows): the accept step writes the resolution's initial slots itself
+    const bool own_slots = c->rows_exchange && c->P.N == c->P.Ng && !c->ext_rec_out && !c->ext_vals_out && c->obj != SMM_OBJ_USER;
+    c->P.slots17_out = own_slots ? c->slots17 : nullptr;
+    c->P.nan_flags_out = own_slots ? c->nan_flags + (t & 1) : nullptr;
+    if (own_slots) c->slots_iter = t;
     if (c->obj == SMM_OBJ_USER) {
         // proposal launch (stores nothing but the proposals) -> the user's kernel -> accept launch (repeats the
         // deterministic prologue, takes value / moments / status from the user's kernel)
@@ -519,15 +526,17 @@ void launch_resolve_p(Ctx* c, const KParams& P_in, int t, const double* gathered
         // values and initial slots by the whole chip (gathered records: their value column; single shard: the compact array)
         const double* src = gathered ? gathered : (const double*)P.vals;
         double* vals = gathered ? P.xval : P.vals;
-        hipLaunchKernelGGL(k_exch_keys, dim3((P.Ng + 255) / 256), dim3(256), 0, c->stream, src, gathered ? P.RW : 1, P.Ng, vals,
-                           (uint32_t*)P.xsrc, c->rows_exchange ? c->slots17 : (uint32_t*)nullptr, c->nan_flags, t);
+        if (gathered || c->slots_iter != t)   // (a single shard's accept step of iteration t has made the slots already)
+            hipLaunchKernelGGL(k_exch_keys, dim3((P.Ng + 255) / 256), dim3(256), 0, c->stream, src, gathered ? P.RW : 1, P.Ng, vals,
+                               (uint32_t*)P.xsrc, c->rows_exchange ? c->slots17 : (uint32_t*)nullptr, c->nan_flags, t);
         const bool plds = P.Ng <= XKEY_PARTNER_MAX;   // partners in LDS, else the ballot replay
+        const uint32_t* slots16 = (gathered || c->slots_iter != t) ? (const uint32_t*)P.xsrc : (const uint32_t*)nullptr;
         if (c->xk == XK_ROWS && plds)
             hipLaunchKernelGGL(k_exch_resolve_rows<true>, dim3(1), dim3(XWG), resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap), c->stream, P, t,
-                               (const double*)vals, (const uint32_t*)P.xsrc, (const uint32_t*)c->slots17, (const uint32_t*)c->nan_flags);
+                               (const double*)vals, slots16, (const uint32_t*)c->slots17, c->nan_flags);
         else if (c->xk == XK_ROWS)
             hipLaunchKernelGGL(k_exch_resolve_rows<false>, dim3(1), dim3(XWG), resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap), c->stream, P, t,
-                               (const double*)vals, (const uint32_t*)P.xsrc, (const uint32_t*)c->slots17, (const uint32_t*)c->nan_flags);
+                               (const double*)vals, slots16, (const uint32_t*)c->slots17, c->nan_flags);
         else if (plds)
             hipLaunchKernelGGL(k_exch_resolve_key<true>, dim3(1), dim3(XWG), resolve_key_bytes(P.Ng, P.plan_K), c->stream, P, t,
                                (const double*)vals, (const uint32_t*)P.xsrc);
@@ -984,32 +993,43 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         }
         {   // look-ahead window: as many iterations as ~192 MiB of tables allow, at most 256
             const size_t per_iter = (size_t)P.RBW * N * 8 + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 : 0);
-            c->win_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)192 << 20) / per_iter));
+            (void)per_iter;
+            // Two windows with budgets of their own (288 GB of HBM: a few hundred MiB of look-ahead tables are nothing), at most 256
+            // iterations each.  The plan kernels are launched with one workgroup per iteration of the window: a short window leaves
+            // the chip idle while they run — at 32768 chains k_exch_plan_big needs 1.7 ms per launch, which with the 26 iterations the
+            // former common budget of 192 MiB allowed was 63 us per iteration, more than the exchange itself (round 3, rocprofv3).
+            const bool pregen = !(c->norm_fast && !(tab && tab->prop_normals) && !(tab && tab->probs_acc));   // (k_chain_iter_norm draws in the kernel)
+            const size_t rb_iter = (size_t)P.RBW * N * 8;
+            const size_t plan_iter = (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
+                                     (size_t)lean_walk_Kp(K) * 4 + 1024;
+            c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
             c->win_cap = std::min(c->win_cap, T);
+            c->plan_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)1536 << 20) / plan_iter));
+            c->plan_cap = std::min(c->plan_cap, T);
             c->win_rb = dalloc<double>(c, (size_t)c->win_cap * N * P.RBW);
             HIPCHK(hipMemset(c->win_rb, 0, (size_t)c->win_cap * N * P.RBW * 8));
             if (c->big_exchange) {
-                c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->win_cap * K);
-                c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
-                c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
-                c->big_scratch = dalloc<uint32_t>(c, (size_t)c->win_cap * BigPlanScratch::words(Ng, K));
+                c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * K);
+                c->win_lv_mi = dalloc<double>(c, (size_t)c->plan_cap * K);
+                c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->plan_cap * (K + 2));
+                c->big_scratch = dalloc<uint32_t>(c, (size_t)c->plan_cap * BigPlanScratch::words(Ng, K));
                 const char* kw = SMM_HOOK("SMMHIP_KEY_WALK");   // test hook: "0" keeps k_exch_resolve_key
                 if (c->key_exchange && P.mi_uniform && P.mi_value == 0.0 && !(kw && kw[0] == '0')) {
                     c->rows_exchange = true;
                     P.rows_cap = std::min(XROWS_MAX, (K + XWG - 1) / XWG + LV_MAXLEV);
-                    c->win_lv_rows = dalloc<uint32_t>(c, (size_t)c->win_cap * P.rows_cap * XWG);
-                    c->win_lv_rowinfo = dalloc<uint32_t>(c, (size_t)c->win_cap * 4);
+                    c->win_lv_rows = dalloc<uint32_t>(c, (size_t)c->plan_cap * P.rows_cap * XWG);
+                    c->win_lv_rowinfo = dalloc<uint32_t>(c, (size_t)c->plan_cap * 4);
                     c->slots17 = dalloc<uint32_t>(c, (size_t)Ng + 4);
                     c->nan_flags = dalloc<uint32_t>(c, 4);
                     HIPCHK(hipMemset(c->nan_flags, 0, 16));
                 }
             }
             if (c->lds_exchange) {
-                c->win_plan = dalloc<unsigned long long>(c, (size_t)c->win_cap * K);
-                c->win_plan_mi = dalloc<double>(c, (size_t)c->win_cap * K);
-                c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->win_cap * K);
-                c->win_lv_mi = dalloc<double>(c, (size_t)c->win_cap * K);
-                c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->win_cap * (K + 2));
+                c->win_plan = dalloc<unsigned long long>(c, (size_t)c->plan_cap * K);
+                c->win_plan_mi = dalloc<double>(c, (size_t)c->plan_cap * K);
+                c->win_lv_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * K);
+                c->win_lv_mi = dalloc<double>(c, (size_t)c->plan_cap * K);
+                c->win_lv_off = dalloc<uint32_t>(c, (size_t)c->plan_cap * (K + 2));
                 // the lean walk (smm_walk_lean.hpp): one min_improve for every chain — 0: 8-byte slots of order keys; > 0 (or NaN:
                 // nothing ever swaps): 16-byte slots of values, as far as the 160 KB of LDS reach (~7400 chains)
                 const char* kw = SMM_HOOK("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walks on 16-byte / split slots
@@ -1019,8 +1039,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                     P.lean_wide = wide ? 1 : 0;
                     P.plan_Kp = lean_walk_Kp(K);
                     P.lean_unit = wide ? lean_wide_unit(Ng) : lean_walk_unit(Ng);
-                    c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->win_cap * P.plan_Kp);
-                    c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->win_cap * LV_OFFP);
+                    c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->plan_cap * P.plan_Kp);
+                    c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->plan_cap * LV_OFFP);
                     c->lean_resolve = true;
                     if (keys && ((c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) || c->gen_keys)) {   // ... in the prologue of k_chain_iter_norm, or of k_chain_iter (key form)
                         for (int b = 0; b < 2; ++b) c->slot8_buf[b] = dalloc<uint2>(c, (size_t)N + 4);
@@ -1902,6 +1922,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         c->a2a_open = false;
         c->p2p_current = false;   // (the next smm_bgp_p2p_step publishes the uploaded state)
         c->exch_done = false;
+        c->slots_iter = -1;
         if (P.walk_flags) HIPCHK(hipMemset(P.walk_flags, 0, 16));   // (the values the next exchange sees are written by the next accept step)
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);

@@ -612,6 +612,21 @@ def test_exchange_worst_case_star_pairs(S, O, hooks):
             cm.assert_history_equal(h.history(), b.history(), exact_floats=True)
 
 
+def test_rows_fallback_with_slots_from_the_accept_step(S, O):
+    # a single shard of more than 8192 chains takes the initial slots of k_exch_resolve_rows from its accept step (no k_exch_keys
+    # pre-pass); where an iteration's plan does not fit the rows form — here: an injected pair list 40 levels deep — the kernel falls
+    # back to the key walk, whose 16-bit slots it then makes itself
+    N, T = 9000, 5
+    prob, opts = cm.serial_normal(N=N, T=T, ns=32, min_improve=0.0)
+    tab = cm.random_tables(prob, opts, tries=24)
+    tab.pairs[1::2, :40, 0] = 0                       # odd iterations: forty pairs through chain 0, one after the other
+    tab.pairs[1::2, :40, 1] = 1 + np.arange(40)[None, :] * 3
+    h, o = run_both(S, O, prob, opts, tab)
+    assert (h.history().exchanged != 0).sum() > 0
+    cm.assert_history_equal(h.history(), o.history(), rtol=1e-12)
+    cm.assert_state_equal(h.state(), o.state(), rtol=1e-12)
+
+
 def test_n_global_between_4096_and_8192(S, O):
     prob, opts = cm.serial_normal(N=5000, T=6, ns=32)
     h, o = make_pair(S, O, prob, opts, threads=8)
