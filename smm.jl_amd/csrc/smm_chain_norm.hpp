@@ -31,6 +31,9 @@ constexpr int NORM_WG = 2 * WG;       // 1024 lanes
 #ifndef SMM_EXP_NORM_ZU
 #define SMM_EXP_NORM_ZU 4
 #endif
+#ifndef SMM_EXP_DMA_STAGE
+#define SMM_EXP_DMA_STAGE 1
+#endif
 constexpr int NORM_ZU = SMM_EXP_NORM_ZU;   // shock rows per chunk (the 16 means sit in SGPRs: 16 accumulators + two chunk buffers = 64 VGPRs)
 
 template <int ZK>
@@ -161,6 +164,14 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
     }
 }
 
+// one LDS-DMA instruction: 16 bytes per lane from gsrc (per lane) to LDS byte address lds_dst (wave-uniform) + 16 * lane.
+// hipcc does not count it: whoever reads the data waits for vmcnt(0) itself (cdna_hip_programming.md, "LDS-DMA recipe").
+__device__ inline void lds_dma16(const void* gsrc, const uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // (the lean exchange walk itself: smm_walk_lean.hpp)
 // false (nothing done): this iteration's plan does not fit the form (more than 31 levels), a NaN value is among the chains',
 // or the dynamic LDS does not start at address 0 — the caller runs the 16-byte walk.  The result is in LDS (slots at lds);
@@ -179,6 +190,30 @@ __device__ inline bool exchange_walk_lean(const KParams& P, const int tx, unsign
     // (everything is requested before anything is looked at: a load issued behind the first wait is a round trip of its own)
     const uint32_t wflags = P.walk_flags[tid & 3];   // (word 0 is looked at; a per-lane address keeps it a vector load among the others)
     const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
+#if SMM_EXP_DMA_STAGE
+    // (round 3, VERDICT r2 #4a) slots and pair list straight into LDS by LDS-DMA, no VGPR hop, no ds_write pass: staging 1.67 ->
+    // 1.59 us, kernel -0.03..0.1 us (A/B on one box: small, never negative).  A wave's share
+    // is contiguous in memory and in LDS alike (the image is lane-linear): two instructions for its 256 chains' slots, two for its
+    // pair words.  Whole 1 KB pieces only: populations that are a multiple of 128 chains (others take the register path below).
+    if ((Ng & 127) == 0 && (uint32_t)(size_t)lds == 0u) {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint4* gs = (const uint4*)P.slot8;
+        if (wv * 256 < Ng) lds_dma16(gs + wv * 128 + lane, (uint32_t)(wv * 2048));
+        if (wv * 256 + 128 < Ng) lds_dma16(gs + wv * 128 + 64 + lane, (uint32_t)(wv * 2048 + 1024));
+        if (4 * (wv * 64) < P.plan_Kp) lds_dma16(g_pairs + tid, pbase + (uint32_t)(wv * 1024));
+        if (4 * (wv * 64 + NT) < P.plan_Kp) lds_dma16(g_pairs + tid + NT, pbase + (uint32_t)((wv + 16) * 1024));
+        const int nlev_d = __builtin_amdgcn_readlane((int)ov, 33);
+        const bool bad = __builtin_amdgcn_readlane((int)ov, 34) == 0 || __builtin_amdgcn_readlane((int)wflags, 0) != 0;
+        const int ltail_d = lean_walk_tail(ov, nlev_d, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) ((uint4*)lds)[2 * (Ng4 / 4)] = make_uint4(1u, 0u, 2u, 0u);   // the two dummy slots: keys 1 < 2, "no swap"
+        __syncthreads();
+        if (bad) return false;
+        if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
+        lean_walk_levels<NORM_WG, 0>(P.vals, 1, pbase, ov, nlev_d, tid, ltail_d);
+        return true;
+    }
+#endif
     uint4 s0 = make_uint4(0u, 0u, 0u, 0u), s1 = s0;
     if (4 * tid < Ng) { s0 = ((const uint4*)P.slot8)[2 * tid]; s1 = ((const uint4*)P.slot8)[2 * tid + 1]; }
     uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0;

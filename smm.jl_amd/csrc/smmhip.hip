@@ -1039,11 +1039,11 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                     P.lean_wide = wide ? 1 : 0;
                     P.plan_Kp = lean_walk_Kp(K);
                     P.lean_unit = wide ? lean_wide_unit(Ng) : lean_walk_unit(Ng);
-                    c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->plan_cap * P.plan_Kp);
+                    c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->plan_cap * P.plan_Kp + 512);   // (+512: whole 1 KB pieces may be read past the last iteration's words)
                     c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->plan_cap * LV_OFFP);
                     c->lean_resolve = true;
                     if (keys && ((c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) || c->gen_keys)) {   // ... in the prologue of k_chain_iter_norm, or of k_chain_iter (key form)
-                        for (int b = 0; b < 2; ++b) c->slot8_buf[b] = dalloc<uint2>(c, (size_t)N + 4);
+                        for (int b = 0; b < 2; ++b) c->slot8_buf[b] = dalloc<uint2>(c, (size_t)N + 4 + 128);
                         P.slot8 = c->slot8_buf[0];
                         P.walk_flags = dalloc<uint32_t>(c, 4);
                         HIPCHK(hipMemset(P.walk_flags, 0, 16));
