@@ -76,7 +76,7 @@ def newest_profile(pattern):
 
 def profile_tag(workload):
     """file name infix of the committed profiles of a workload: r03_pmc_summary.txt (C2), r03_c4_pmc_summary.txt, ..."""
-    return "" if workload in ("c2", "c3") else workload + "_"
+    return "" if workload == "c2" else workload + "_"   # (no committed profile of c3: its lines carry no rocprof / traffic figures)
 
 
 def pmc_traffic(kernel, workload="c2"):
@@ -89,7 +89,7 @@ def pmc_traffic(kernel, workload="c2"):
     if not f:
         return None, None, None
     fetch = write = src_hash = None
-    if workload not in ("c2", "c3"):   # (the C4 / C5 summaries carry no hash line of their own: the C2 bundle of the same round does)
+    if workload != "c2":   # (the C4 / C5 summaries carry no hash line of their own: the C2 bundle of the same round does)
         import re as _re
         f0 = f.replace("_%spmc" % profile_tag(workload), "_pmc")
         if os.path.exists(f0):
