@@ -24,8 +24,10 @@ def test_plain_command_launches_two_ranks():
 
 def test_under_a_launcher_it_is_one_rank():
     # the driver's form: python -m torch.distributed.run ... bench.py --gpus N: no second level of launching
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-                        "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-launch"],
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-launch"],
                        capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

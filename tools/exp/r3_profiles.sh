@@ -12,7 +12,8 @@ for cfg in "single shard (no sharding)|$B" \
            "1 rank, RCCL all-gather of records|SMM_BENCH_FORCE_SHARDED=1 $B --protocol records" \
            "1 rank, RCCL values + all-to-all|SMM_BENCH_FORCE_SHARDED=1 $B --protocol values" \
            "2 PROCESSES on the one GPU x 2048 chains, p2p over HIP IPC|$B --gpus 2 --same-device" \
-           "4 PROCESSES on the one GPU x 1024 chains, p2p over HIP IPC|$B --gpus 4 --same-device"; do
+           "4 PROCESSES on the one GPU x 1024 chains, p2p over HIP IPC|$B --gpus 4 --same-device" \
+           "8 PROCESSES on the one GPU x 512 chains, p2p over HIP IPC|$B --gpus 8 --same-device"; do
   name=${cfg%%|*}; cmd=${cfg#*|}
   eval "timeout 200 env $cmd" 2>/dev/null | python -c "
 import json,sys
