@@ -275,17 +275,19 @@ int  smm_bgp_sharded_finish(void* ctx, const void* gathered_dev);
 /* The p2p form of the sharded iteration: NO collective call at all.  The xGMI fabric of an MI355X node is point-to-point, so
  * the all-gather of the last-accepted records is done by the chains' accept step itself: every rank owns a WINDOW of device
  * memory that all other ranks map (HIP IPC between processes; plain device pointers between contexts of one process), a
- * chain's accept step stores its record, value and walk slot into every rank's window and counts itself in with one atomic
- * per tile; the next iteration's kernel waits on the counters of its own window.  An iteration of a shard is ONE launch
- * (objfunc_norm, np == nm <= 4, min_improve == 0, N_global <= 8192; else chain kernel + push kernel + resolve kernel) and the
- * host enqueues nothing else.  Same results as every other form (bit-identical to the single shard).
+ * chain's accept step stores its record, value and walk slot into every rank's window, and the next iteration's kernel reads
+ * its own window.  Where the single shard needs one launch per iteration so does a shard (objfunc_norm, np == nm <= 4,
+ * min_improve == 0, N_global <= 8192): every word in a window carries the iteration it belongs to, a reader that finds an older
+ * one looks again (nobody waits for an acknowledgement, nothing is counted); everywhere else: chain kernel + push kernel (stores,
+ * then one arrival count per 16 chains and rank) + wait + resolve kernel.  The host enqueues nothing else.  Same results as every
+ * other form (bit-identical to the single shard).  smm.jl_amd/csrc/smm_p2p.hpp has the protocol.
  *   smm_bgp_p2p_init(ctx, handle_out, window_out): allocates this rank's window (rank = chain_offset / N, equal shards, at most
  *        8 ranks); handle_out (SMM_P2P_HANDLE_BYTES bytes, may be NULL) receives its hipIpcMemHandle_t for the other
  *        PROCESSES, window_out (may be NULL) its device pointer for other contexts of THIS process.
  *   smm_bgp_p2p_attach(ctx, rank, handle, window): rank's window, by IPC handle or by device pointer (exactly one non-NULL).
  *   smm_bgp_p2p_step(ctx, n): enqueues n iterations and returns (smm_sync waits).  All ranks call it with the same n, in the
- *        same order relative to each other's p2p calls (the arrival counters count pushes).  A rank whose peers never arrive
- *        gives up after ~4 s per launch and reports SMM_ERR_HIP at the next smm_sync.
+ *        same order relative to each other's p2p calls (publications and pushes are counted).  A rank whose peers' stores never
+ *        arrive gives up after ~4 s and reports SMM_ERR_HIP at the next smm_sync.
  *   smm_bgp_p2p_finish(ctx): settles the last iteration into the context (required before smm_get_history / smm_get_state /
  *        the other stepping forms).  Callers must not destroy a context while a peer may still be stepping. */
 #define SMM_P2P_HANDLE_BYTES 64
