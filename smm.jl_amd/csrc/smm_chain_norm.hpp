@@ -699,6 +699,14 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_p2p(const KParam
     chain_iter_norm_body<NP, true, false, true, true, BIG>(P, t, rec_in, rec_out, flags);
 }
 
+// a shard of the rows form (8192 < N_global <= 32768): no walk in this kernel at all — k_exch_resolve_rows<., true> has resolved the
+// exchange from the window's 4-byte slots, which this kernel's accept step stores
+template <int NP>
+__global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_p2p_rows(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                          double* __restrict__ rec_out, const int flags) {
+    chain_iter_norm_body<NP, false, false, true, true, true>(P, t, rec_in, rec_out, flags);
+}
+
 // objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks
 // (BIG: the kernel without an inline walk — the one large populations run: their stand-alone resolution takes its initial slots
 // from the accept step when the host says so, KParams::slots17_out)
@@ -791,7 +799,8 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
                     const unsigned long long vb = __builtin_bit_cast(unsigned long long, v);
                     const p2p_u32x4 qv = {(unsigned)vb, p2p_tag(P, t), (unsigned)(vb >> 32), p2p_tag(P, t)};
                     p2p_store16u((uint4*)(w + p2p_llval_off(P, pb)) + gc, qv);
-                    p2p_store8((uint2*)(w + p2p_slot_off(P, pb)) + gc, p2p_slot_word(P, v, (uint32_t)gc, t));
+                    if constexpr (BIG) p2p_store4((uint32_t*)(w + p2p_slot4_off(P, pb)) + gc, p2p_slot4_word(P, v, t));   // (rows form: the kernel without the walk)
+                    else p2p_store8((uint2*)(w + p2p_slot_off(P, pb)) + gc, p2p_slot_word(P, v, (uint32_t)gc, t));
                     if (v != v) __hip_atomic_fetch_or((uint32_t*)(w + 128 * (size_t)P2P_MAXG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
         } else {

@@ -415,13 +415,22 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_lean(const KParams P, cons
 // critical (runs ahead of the dependent loop, one window at a time).
 // ------------------------------------------------------------------------------------------
 struct BigPlanScratch {  // per workgroup
-    uint32_t *cnt, *ep, *pi, *pj, *ri, *rj, *prei, *prej, *lvl, *nl;
-    __host__ __device__ static size_t words(int Ng, int K) { return (size_t)(Ng + 4) + (size_t)K * 10; }
-    __device__ void carve(uint32_t* base, int Ng, int K) {
-        cnt = base; ep = cnt + Ng + 4; pi = ep + 2 * K; pj = pi + K; ri = pj + K; rj = ri + K;
-        prei = rj + K; prej = prei + K; lvl = prej + K; nl = lvl + K;
-    }
+    uint32_t *cnt, *pw, *lvl;
+    __host__ __device__ static size_t words(int Ng, int K) { return (size_t)(Ng + 4) + (size_t)K * 2; }
+    __device__ void carve(uint32_t* base, int Ng, int K) { cnt = base; pw = cnt + Ng + 4; lvl = pw + K; }
 };
+// its LDS: the level every chain was last met at (16 bits: there are at most K <= 65535 levels), the pair counts of the first
+// PLANBIG_HIST levels, a claim table of H words (H a power of two: what is left of 156 KiB, at most 16384)
+constexpr int PLANBIG_HIST = 1024;
+__host__ __device__ inline uint32_t plan_big_claims(int Ng) {
+    const size_t left = (size_t)156 * 1024 - (((size_t)Ng * 2 + 15) & ~(size_t)15) - (size_t)PLANBIG_HIST * 4;
+    uint32_t H = 16384;
+    while ((size_t)H * 4 > left) H >>= 1;
+    return H;
+}
+__host__ __device__ inline size_t plan_big_lds_bytes(int Ng) {
+    return (((size_t)Ng * 2 + 15) & ~(size_t)15) + (size_t)PLANBIG_HIST * 4 + (size_t)plan_big_claims(Ng) * 4;
+}
 
 __device__ inline uint32_t block_excl_scan_step(uint32_t v, uint32_t* wsum, int tid, uint32_t& total) {
     // exclusive scan of one value per thread over the 1024-thread block
@@ -456,89 +465,79 @@ __device__ inline void block_excl_scan(uint32_t* a, int n, uint32_t* wsum, int t
     }
 }
 
+// The levels (pair q's level = 1 + the later of the levels its two chains were last met at) are found in list order, a batch of
+// XWG consecutive pairs at a time, a lane per pair: a pair may take its level once no EARLIER pair of the batch that shares a chain
+// with it is still waiting — every waiting pair puts its batch position into the claim slots of its two chains (LDS atomic min; the
+// slots are hashed, a false conflict only costs a round), and whoever holds both of its slots is ready.  The earliest waiting pair
+// always is, and a batch of 1024 random pairs out of 32768 chains is done in 3-4 rounds: O(K) work and ~100 barriers per iteration,
+// where the Jacobi sweeps over predecessor links this replaces cost depth x K global accesses (1.7 ms per iteration at 32768).
 __global__ __launch_bounds__(XWG) void k_exch_plan_big(const KParams P, const int t0, uint32_t* __restrict__ scratch,
                                                        uint32_t* __restrict__ lv_pairs, double* __restrict__ lv_mi,
                                                        uint32_t* __restrict__ lv_off, uint32_t* __restrict__ lv_rows,
                                                        uint32_t* __restrict__ lv_rowinfo) {
+    extern __shared__ __align__(16) unsigned char pb_smem[];
     __shared__ uint32_t wsum[XWG / 64];
-    __shared__ uint32_t s_nlev;
+    __shared__ uint32_t s_nlev, s_pend[2];
     const int tid = threadIdx.x;
     const int t = t0 + blockIdx.x;
     const int Ng = P.Ng, K = P.plan_K;
     BigPlanScratch S;
     S.carve(scratch + (size_t)blockIdx.x * BigPlanScratch::words(Ng, K), Ng, K);
+    uint16_t* last = (uint16_t*)pb_smem;
+    uint32_t* hist = (uint32_t*)(pb_smem + (((size_t)Ng * 2 + 15) & ~(size_t)15));
+    uint32_t* claim = hist + PLANBIG_HIST;
+    const uint32_t Hm = plan_big_claims(Ng) - 1u;
     for (int c = tid; c < Ng + 4; c += XWG) S.cnt[c] = 0;
-    if (P.pairtab) {
-        for (int q = tid; q < K; q += XWG) {
-            S.pi[q] = (uint32_t)P.pairtab[((size_t)(t - 1) * K + q) * 2];
-            S.pj[q] = (uint32_t)P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
+    for (int c = tid; c < (Ng + 1) / 2; c += XWG) ((uint32_t*)last)[c] = 0u;
+    for (int c = tid; c < PLANBIG_HIST; c += XWG) hist[c] = 0u;
+    for (uint32_t c = tid; c <= Hm; c += XWG) claim[c] = 0xffffffffu;
+    if (tid == 0) { s_nlev = 0; s_pend[0] = 0; s_pend[1] = 0; }
+    PairPerm pp;
+    if (!P.pairtab) pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
+    __syncthreads();
+    uint32_t mx = 0, rnd = 0;
+    for (int q0 = 0; q0 < K; q0 += XWG) {
+        const int q = q0 + tid;
+        bool pend = q < K;
+        uint32_t i = 0, j = 0;
+        if (pend) {
+            if (P.pairtab) {
+                i = (uint32_t)P.pairtab[((size_t)(t - 1) * K + q) * 2];
+                j = (uint32_t)P.pairtab[((size_t)(t - 1) * K + q) * 2 + 1];
+            } else {
+                int32_t a, b;
+                pair_unrank(pp.eval((uint64_t)q), a, b);
+                i = (uint32_t)a; j = (uint32_t)b;
+            }
+            S.pw[q] = i | (j << 16);
         }
-    } else {
-        PairPerm pp;
-        pp.init(P.seed, (uint32_t)t, (uint64_t)Ng * (uint64_t)(Ng - 1) / 2);
-        for (int q = tid; q < K; q += XWG) {
-            int32_t i, j;
-            pair_unrank(pp.eval((uint64_t)q), i, j);
-            S.pi[q] = (uint32_t)i;
-            S.pj[q] = (uint32_t)j;
+        const uint32_t hi = i & Hm, hj = j & Hm;
+        for (;;) {
+            if (pend) { atomicMin(&claim[hi], (uint32_t)tid); atomicMin(&claim[hj], (uint32_t)tid); }
+            __syncthreads();
+            if (pend && claim[hi] == (uint32_t)tid && claim[hj] == (uint32_t)tid) {
+                const uint32_t a = last[i], b = last[j];
+                const uint32_t lv = 1u + (a > b ? a : b);
+                last[i] = (uint16_t)lv; last[j] = (uint16_t)lv;
+                const uint32_t r = lv < (uint32_t)PLANBIG_HIST ? atomicAdd(&hist[lv], 1u) : atomicAdd(&S.cnt[lv], 1u);
+                S.lvl[q] = lv | (r << 16);       // r: its place among the pairs of its level (any order: they share no chain)
+                mx = lv > mx ? lv : mx;
+                claim[hi] = 0xffffffffu; claim[hj] = 0xffffffffu;
+                pend = false;
+            }
+            if (pend) s_pend[rnd & 1] = 1u;
+            if (tid == 0) s_pend[(rnd + 1) & 1] = 0u;   // (last read before this round's first barrier)
+            __syncthreads();
+            const bool more = s_pend[rnd & 1] != 0u;
+            ++rnd;
+            if (!more) break;
         }
     }
-    __syncthreads();
-    for (int q = tid; q < K; q += XWG) { atomicAdd(&S.cnt[S.pi[q]], 1u); atomicAdd(&S.cnt[S.pj[q]], 1u); }
-    __syncthreads();
-    block_excl_scan(S.cnt, Ng, wsum, tid);  // bucket starts
-    for (int q = tid; q < K; q += XWG) {   // scatter (arbitrary order inside a bucket)
-        S.ep[atomicAdd(&S.cnt[S.pi[q]], 1u)] = (uint32_t)q;
-        S.ep[atomicAdd(&S.cnt[S.pj[q]], 1u)] = (uint32_t)q;
-    }
-    __syncthreads();  // cnt[c] == end of bucket c
-    for (int q = tid; q < K; q += XWG) {   // ranks
-        const uint32_t i = S.pi[q], j = S.pj[q];
-        uint32_t b = i ? S.cnt[i - 1] : 0u, e = S.cnt[i], ri = 0, rj = 0;
-        for (uint32_t x = b; x < e; ++x) ri += (S.ep[x] < (uint32_t)q) ? 1u : 0u;
-        b = j ? S.cnt[j - 1] : 0u; e = S.cnt[j];
-        for (uint32_t x = b; x < e; ++x) rj += (S.ep[x] < (uint32_t)q) ? 1u : 0u;
-        S.ri[q] = ri; S.rj[q] = rj;
-    }
-    __syncthreads();
-    for (int q = tid; q < K; q += XWG) {   // buckets in rank order
-        const uint32_t i = S.pi[q], j = S.pj[q];
-        S.ep[(i ? S.cnt[i - 1] : 0u) + S.ri[q]] = (uint32_t)q;
-        S.ep[(j ? S.cnt[j - 1] : 0u) + S.rj[q]] = (uint32_t)q;
-    }
-    __syncthreads();
-    for (int q = tid; q < K; q += XWG) {   // predecessors
-        const uint32_t i = S.pi[q], j = S.pj[q];
-        S.prei[q] = S.ri[q] ? S.ep[(i ? S.cnt[i - 1] : 0u) + S.ri[q] - 1] : 0xffffffffu;
-        S.prej[q] = S.rj[q] ? S.ep[(j ? S.cnt[j - 1] : 0u) + S.rj[q] - 1] : 0xffffffffu;
-        S.lvl[q] = 0;
-    }
-    __syncthreads();
-    int changed = 1;
-    while (changed) {  // Jacobi sweeps
-        for (int q = tid; q < K; q += XWG) {
-            const uint32_t pa = S.prei[q], pb = S.prej[q];
-            const uint32_t a = pa != 0xffffffffu ? S.lvl[pa] : 0u, b = pb != 0xffffffffu ? S.lvl[pb] : 0u;
-            const bool known = (pa == 0xffffffffu || a) && (pb == 0xffffffffu || b);
-            S.nl[q] = known ? 1u + (a > b ? a : b) : 0u;
-        }
-        __syncthreads();
-        int mine = 0;
-        for (int q = tid; q < K; q += XWG)
-            if (S.nl[q] != S.lvl[q]) { S.lvl[q] = S.nl[q]; mine = 1; }
-        changed = __syncthreads_or(mine);
-    }
-    // counting sort by level (cnt is free now)
-    for (int c = tid; c < Ng + 4; c += XWG) S.cnt[c] = 0;
-    if (tid == 0) s_nlev = 0;
-    __syncthreads();
-    {
-        uint32_t mx = 0;
-        for (int q = tid; q < K; q += XWG) { atomicAdd(&S.cnt[S.lvl[q]], 1u); mx = S.lvl[q] > mx ? S.lvl[q] : mx; }
-        atomicMax(&s_nlev, mx);
-    }
+    atomicMax(&s_nlev, mx);
     __syncthreads();
     const int nlev = (int)s_nlev;
+    for (int l = tid; l < PLANBIG_HIST && l <= nlev; l += XWG) S.cnt[l] = hist[l];
+    __syncthreads();
     block_excl_scan(S.cnt, nlev + 1, wsum, tid);  // cnt[l] = pairs in levels < l (1-based l)
     uint32_t* o_off = lv_off + (size_t)blockIdx.x * (K + 2);
     for (int l = tid; l < nlev; l += XWG) o_off[l] = (l + 2 <= nlev) ? S.cnt[l + 2] : (uint32_t)K;
@@ -575,13 +574,15 @@ __global__ __launch_bounds__(XWG) void k_exch_plan_big(const KParams P, const in
     __syncthreads();
     uint32_t* o_pairs = lv_pairs + (size_t)blockIdx.x * K;
     double* o_mi = lv_mi + (size_t)blockIdx.x * K;
+    for (int l = tid; l < PLANBIG_HIST && l <= nlev; l += XWG) hist[l] = S.cnt[l];   // (first position of level l)
+    __syncthreads();
     for (int q = tid; q < K; q += XWG) {
-        const uint32_t lv = S.lvl[q];
-        const uint32_t pos = atomicAdd(&S.cnt[lv], 1u);
-        const uint32_t i = S.pi[q], j = S.pj[q];
-        o_pairs[pos] = i | (j << 16);
-        o_mi[pos] = P.min_improve_g[i];
-        if (rows_ok) o_rows[s_rs[lv] * (uint32_t)XWG + (pos - s_ls[lv])] = i | (j << 16);
+        const uint32_t lr = S.lvl[q], lv = lr & 0xffffu, r = lr >> 16;
+        const uint32_t pos = (lv < (uint32_t)PLANBIG_HIST ? hist[lv] : S.cnt[lv]) + r;
+        const uint32_t w = S.pw[q];
+        o_pairs[pos] = w;
+        o_mi[pos] = P.min_improve_g[w & 0xffffu];
+        if (rows_ok) o_rows[s_rs[lv] * (uint32_t)XWG + r] = w;
     }
 }
 
@@ -982,7 +983,12 @@ __host__ __device__ inline size_t resolve_rows_bytes(int Ng, int K, int rows_cap
     const size_t b = resolve_key_bytes(Ng, K);
     return a > b ? a : b;
 }
-template <bool PLDS>   // PLDS: the last partner of every chain in a 2-byte LDS array of its own, written by the swap (N_global <= XKEY_PARTNER_MAX)
+// WIN (the p2p form of a sharded run, smm_p2p.hpp): the initial slots are the tagged 8-byte slots every rank's accept step has
+// stored into THIS rank's window — read past the caches and validated word by word (a slot that has not landed yet is read
+// again), so that nobody waits for anybody in a kernel of its own and no pre-pass makes keys; exact values (ties, the
+// fallback) are the window's self-validating values.  A value whose key says "negative, infinite or NaN" sends the whole
+// iteration to the fallback (k_exch_resolve_key's body on the exact values, unpacked here).
+template <bool PLDS, bool WIN = false>   // PLDS: the last partner of every chain in a 2-byte LDS array of its own, written by the swap (N_global <= XKEY_PARTNER_MAX)
 __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, const int t, const double* __restrict__ vals,
                                                            const uint32_t* __restrict__ slots16, const uint32_t* __restrict__ slots17,
                                                            uint32_t* __restrict__ nan_flags) {
@@ -995,12 +1001,18 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
     XTS(0);
     const int nrows = (int)info[0];
     const unsigned long long endmask = (unsigned long long)info[1] | ((unsigned long long)info[2] << 32);
-    if (tid == 0) nan_flags[(t + 1) & 1] = 0u;   // (the next iteration's word: its accept step or k_exch_keys raises it)
-    if (info[3] == 0u || nan_flags[t & 1] != 0u) {
-#ifndef SMM_EXP_NO_FALLBACK   // (inspection builds: the rows walk's own code without the fallback's)
-        resolve_key_body<PLDS>(P, t, vals, slots16, xsm);
-#endif
+    if ((uint32_t)(size_t)xsm != 0u) {   // the walk's LDS addresses count from 0: a static __shared__ object in this kernel breaks it (loud)
+        if (tid == 0) report_error(P, 3, t + 1, 0);
         return;
+    }
+    if constexpr (!WIN) {
+        if (tid == 0) nan_flags[(t + 1) & 1] = 0u;   // (the next iteration's word: its accept step or k_exch_keys raises it)
+        if (info[3] == 0u || nan_flags[t & 1] != 0u) {
+#ifndef SMM_EXP_NO_FALLBACK   // (inspection builds: the rows walk's own code without the fallback's)
+            resolve_key_body<PLDS>(P, t, vals, slots16, xsm);
+#endif
+            return;
+        }
     }
     uint32_t* slot = (uint32_t*)xsm;
     const uint32_t sl_words = ((uint32_t)Ng + 2u + 3u) & ~3u;
@@ -1022,8 +1034,70 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
         asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(q) : "v"(lane_off), "s"(rows_rsrc), "s"(min(rr, rl) * (XWG * 4)) : "memory");
     };
     uint32_t q0, q1, q2;
+    if constexpr (WIN) {
+        // the tagged 4-byte slots (order_key17(value) << 15 | tag15, smm_p2p.hpp) of this rank's window, four per 16-byte piece: all of
+        // a lane's pieces requested together, then looked at one by one
+        constexpr int PP = PT / 4;
+        const uint4* g_slots = (const uint4*)(P.p2p_self + p2p_slot4_off(P, t & 1));
+        const uint32_t want = p2p_tag15(P, t);
+        const int last_piece = (Ng - 1) / 4;
+        p2p_u32x4 s_[PP];
+#pragma unroll
+        for (int r = 0; r < PP; ++r) {
+            const uint4* a = g_slots + min(tid + r * XWG, last_piece);   // (lanes past the end read the last piece: not used)
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(s_[r]) : "v"(a) : "memory");
+        }
+        static_assert(PP == 8, "the wait below names eight pieces");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(s_[0]), "+v"(s_[1]), "+v"(s_[2]), "+v"(s_[3]), "+v"(s_[4]), "+v"(s_[5]), "+v"(s_[6]), "+v"(s_[7]) :: "memory");
+        bool odd = false;
+        auto slot17 = [&](const uint32_t w4, const uint32_t g) -> uint32_t {   // key17 << 15 | chain; the last bucket may be a NaN
+            if ((w4 >> 15) == XKEY17_TOP) odd = true;
+            return (w4 & ~0x7fffu) | g;
+        };
+#pragma unroll
+        for (int r = 0; r < PP; ++r) {
+            const int pc = tid + r * XWG, g = 4 * pc;
+            if (g < Ng) {
+                p2p_u32x4 q = s_[r];
+                auto ok = [&]() {
+                    return (q.x & 0x7fffu) == want && (g + 1 >= Ng || (q.y & 0x7fffu) == want) && (g + 2 >= Ng || (q.z & 0x7fffu) == want) &&
+                           (g + 3 >= Ng || (q.w & 0x7fffu) == want);
+                };
+                if (__builtin_expect(!ok(), 0)) {   // somebody's stores are still on their way
+                    const unsigned long long t0 = wall_clock64();
+                    do {
+                        __builtin_amdgcn_s_sleep(1);
+                        const uint4 q4 = p2p_load16_sys(g_slots + pc);
+                        q = p2p_u32x4{q4.x, q4.y, q4.z, q4.w};
+                        if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { report_error(P, 3, t + 1, g); odd = true; break; }
+                    } while (!ok());
+                }
+                const p2p_u32x4 w4 = {slot17(q.x, (uint32_t)g), g + 1 < Ng ? slot17(q.y, (uint32_t)g + 1u) : 0u,
+                                      g + 2 < Ng ? slot17(q.z, (uint32_t)g + 2u) : 0u, g + 3 < Ng ? slot17(q.w, (uint32_t)g + 3u) : 0u};
+                ((p2p_u32x4*)xsm)[pc] = w4;
+            }
+        }
+        // (no static LDS in this kernel: the walk addresses the dynamic block from 0.  Every wave leaves its verdict in the words
+        // behind the slots, which nothing uses before the walk)
+        uint32_t* oddw = (uint32_t*)(xsm + 4u * ((((uint32_t)Ng + 2u + 3u) & ~3u)));
+        const bool wave_odd = __ballot(odd) != 0ull;
+        if (lane == 0) oddw[wave] = wave_odd ? 1u : 0u;
+        __syncthreads();
+        uint32_t any_odd = 0u;
+#pragma unroll
+        for (int wv = 0; wv < XWG / 64; ++wv) any_odd |= oddw[wv];
+        __syncthreads();   // (read by everybody before the fallback or the walk reuse the words)
+        if (info[3] == 0u || any_odd != 0u) {
+            // the fallback on exact values: unpacked into the window's plain value array (this workgroup is its only reader)
+            double* pv = (double*)(P.p2p_self + p2p_val_off(P, t & 1));
+            for (int g = tid; g < Ng; g += XWG) pv[g] = p2p_ll_value(P, t, (uint32_t)g);
+            __syncthreads();
+            resolve_key_body<PLDS>(P, t, pv, nullptr, xsm);
+            return;
+        }
+    }
     fetch(q0, 0); fetch(q1, 1); fetch(q2, 2);
-    {
+    if constexpr (!WIN) {
         typedef unsigned int u32x4s_t __attribute__((ext_vector_type(4)));
         const u32x4s_t* __restrict__ s4 = (const u32x4s_t*)slots17;     // made by k_exch_keys: 16 bytes per lane and round
         constexpr int P4 = PT / 4;
@@ -1052,7 +1126,10 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
         bool swap = si > sj;
         const bool tie = (si ^ sj) < 0x8000u;
         if (__builtin_expect(__ballot(tie) != 0ull, 0)) {   // the keys do not decide: the exact values (dist_fun = -, AlgoBGP.jl:688)
-            if (tie) swap = vals[si & 0x7fffu] - vals[sj & 0x7fffu] > 0.0;
+            if (tie) {
+                if constexpr (WIN) swap = p2p_ll_value(P, t, si & 0x7fffu) - p2p_ll_value(P, t, sj & 0x7fffu) > 0.0;
+                else swap = vals[si & 0x7fffu] - vals[sj & 0x7fffu] > 0.0;
+            }
         }
         if (swap) {   // swap_ev_ij!, :739-744
             asm volatile("ds_write_b32 %0, %2\n\tds_write_b32 %1, %3" :: "v"(ai), "v"(aj), "v"(sj), "v"(si) : "memory");

@@ -31,9 +31,10 @@
 //   nan                u32                    a NaN value entered the population (order keys do not cover it: sticky)
 //   rec [2][Ng][RW], val [2][Ng + 4]          plain records / values
 //   slot[2][Ng + 4]    uint2                  tagged walk slots
+//   slot4[2][Ng + 4]   u32                    tagged 17-bit keys (rows form: 8192 < N_global <= 32768)
 //   llrec[2][Ng][2 RW], llval[2][Ng] uint4    self-validating records / values
 // ------------------------------------------------------------------------------------------
-struct P2PLayout { size_t arrived, nan, rec[2], val[2], slot[2], llrec[2], llval[2], total; };
+struct P2PLayout { size_t arrived, nan, rec[2], val[2], slot[2], llrec[2], llval[2], slot4[2], total; };
 __host__ __device__ inline P2PLayout p2p_layout(const int Ng, const int RW) {
     P2PLayout L;
     L.arrived = 0;
@@ -44,6 +45,7 @@ __host__ __device__ inline P2PLayout p2p_layout(const int Ng, const int RW) {
     for (int b = 0; b < 2; ++b) { L.slot[b] = o; o += ((size_t)(Ng + 4) * 8 + 127) & ~(size_t)127; }
     for (int b = 0; b < 2; ++b) { L.llrec[b] = o; o += ((size_t)Ng * RW * 16 + 127) & ~(size_t)127; }
     for (int b = 0; b < 2; ++b) { L.llval[b] = o; o += ((size_t)(Ng + 4) * 16 + 127) & ~(size_t)127; }
+    for (int b = 0; b < 2; ++b) { L.slot4[b] = o; o += ((size_t)(Ng + 4) * 4 + 127) & ~(size_t)127; }
     L.total = o;
     return L;
 }
@@ -53,6 +55,7 @@ __device__ inline size_t p2p_val_off(const KParams& P, const int b) { return b ?
 __device__ inline size_t p2p_slot_off(const KParams& P, const int b) { return b ? P.p2p_off[5] : P.p2p_off[4]; }
 __device__ inline size_t p2p_llrec_off(const KParams& P, const int b) { return b ? P.p2p_off[7] : P.p2p_off[6]; }
 __device__ inline size_t p2p_llval_off(const KParams& P, const int b) { return b ? P.p2p_off[9] : P.p2p_off[8]; }
+__device__ inline size_t p2p_slot4_off(const KParams& P, const int b) { return b ? P.p2p_off[11] : P.p2p_off[10]; }
 // the tag of iteration t: never 0 (a fresh window is zeroed); different from the tag of iteration t-2, whose words the stores of
 // iteration t replace (same parity), and from every word an EARLIER PUBLICATION left behind — a run that was settled, rolled back
 // by an uploaded state and published again writes the same iteration numbers a second time, and a reader must not take the old
@@ -62,6 +65,14 @@ __device__ inline uint32_t p2p_tag(const KParams& P, const int t) { return p2p_t
 __device__ inline unsigned long long p2p_slot_word(const KParams& P, const double v, const uint32_t gchain, const int t) {
     return (unsigned long long)order_key32(v) | ((unsigned long long)(gchain | (p2p_tag(P, t) << 16)) << 32);
 }
+// The rows form (8192 < N_global <= 32768; k_exch_resolve_rows<., true>) keeps a chain's walk slot in FOUR bytes: the 17-bit order key of
+// its value (smm_params.hpp; the last bucket also says "NaN": the reader then resolves that iteration on the exact values) over a
+// 15-bit tag — half the bytes the one resolving workgroup has to fetch past the caches.  The chain is the word's position.
+__device__ inline uint32_t p2p_tag15(const KParams& P, const int t) { return 0x4000u | ((P.p2p_epoch & 0x3ffu) << 4) | ((uint32_t)t & 0xfu); }
+__device__ inline uint32_t p2p_slot4_word(const KParams& P, const double v, const int t) {
+    return ((v != v ? XKEY17_TOP : order_key17(v)) << 15) | p2p_tag15(P, t);
+}
+__device__ inline void p2p_store4(void* p, const uint32_t v) { __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // chains per arrival unit (generic form): the push kernel arrives once per workgroup of this share
 constexpr int P2P_UNIT = 16;
 __host__ __device__ inline int p2p_units(const int N) { return (N + P2P_UNIT - 1) / P2P_UNIT; }
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(256) void k_p2p_push(const KParams P, const int t, 
                 p2p_store16u((uint4*)(w + p2p_llval_off(P, b)) + P.offset + c0 + tid, q);
             } else if (!own) p2p_store8((double*)(w + p2p_val_off(P, b)) + P.offset + c0 + tid, vb);
             p2p_store8((uint2*)(w + p2p_slot_off(P, b)) + P.offset + c0 + tid, p2p_slot_word(P, v, (uint32_t)(P.offset + c0 + tid), t));
+            if (LL) p2p_store4((uint32_t*)(w + p2p_slot4_off(P, b)) + P.offset + c0 + tid, p2p_slot4_word(P, v, t));
             if (v != v) { __hip_atomic_fetch_or((uint32_t*)(w + 128 * (size_t)P2P_MAXG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     }

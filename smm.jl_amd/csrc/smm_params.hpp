@@ -108,7 +108,7 @@ struct KParams {
     int p2p_G, p2p_rank;
     uint32_t p2p_epoch;            // publications so far (the same on every rank): part of every tag
     unsigned long long p2p_want;   // arrivals per source rank this launch waits for before it reads its window
-    uint32_t p2p_off[10];          // byte offsets inside a window: rec[0], rec[1], val[0], val[1], slot[0], slot[1], llrec[0], llrec[1], llval[0], llval[1] (p2p_layout)
+    uint32_t p2p_off[12];          // byte offsets inside a window: rec[0], rec[1], val[0], val[1], slot[0], slot[1], llrec[0], llrec[1], llval[0], llval[1], slot4[0], slot4[1] (p2p_layout)
 };
 
 // Order keys are computed from the HIGH WORD of the value (sign, exponent, 20 mantissa bits): for finite values >= 0 it is a

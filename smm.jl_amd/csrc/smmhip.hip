@@ -226,6 +226,7 @@ struct Ctx {
     unsigned long long p2p_seq = 0;            // pushes so far (every rank counts the same)
     bool p2p_current = false;                  // the windows hold the records after iteration `iter`
     bool p2p_inline = false;                   // the inline form is available: k_chain_iter_norm_p2p walks inline and pushes from its epilogue
+    bool p2p_rows = false;                     // the same kernel without the walk + k_exch_resolve_rows<., true> on the window's slots
     bool p2p_mode_inline = false;              // ... and is what the windows currently hold (decided at every publication)
     bool p2p_unwaited = false;                 // nobody has waited for the arrivals of the last push yet
     double* ext_vals_out = nullptr;            // p2p generic form: the accept step's values go into the window
@@ -307,7 +308,7 @@ void ensure_windows(Ctx* c, int t) {
     }
     if (c->big_exchange && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->plan_cap, P.T - t + 1);
-        hipLaunchKernelGGL(k_exch_plan_big, dim3(W), dim3(XWG), 0, c->stream, P, t, c->big_scratch, c->win_lv_pairs, c->win_lv_mi,
+        hipLaunchKernelGGL(k_exch_plan_big, dim3(W), dim3(XWG), plan_big_lds_bytes(P.Ng), c->stream, P, t, c->big_scratch, c->win_lv_pairs, c->win_lv_mi,
                            c->win_lv_off, c->win_lv_rows, c->win_lv_rowinfo);
         c->plan_t0 = t; c->plan_w = W;
         P.plan_t0 = t;
@@ -584,7 +585,7 @@ int check_device_error(Ctx* c) {
     char b[256];
     int rc;
     if (kind == 3) {
-        snprintf(b, sizeof b, "internal error: the exchange of iteration %d could not be resolved in the form chosen for it", it);
+        snprintf(b, sizeof b, "internal error: the exchange of iteration %d could not be resolved in the form chosen for it (chain %d)", it, chain + 1);
         rc = SMM_ERR_HIP;
     } else if (kind == 0) {
         snprintf(b, sizeof b, "values form of the sharded exchange: more than %d records between one pair of ranks (chain %d, iteration %d): "
@@ -645,12 +646,29 @@ void launch_chain_iter_norm_p2p_t(Ctx* c, const KParams& P, int t, int flags, si
     else launch_chain_iter_norm_p2p_tb<NP, false>(c, P, t, flags, smem);
 }
 size_t p2p_walk_bytes(const Ctx* c) { return (lean_walk_bytes(c->P.Ng, c->P.plan_K) + 15) & ~(size_t)15; }
+template <int NP>
+void launch_chain_iter_norm_p2p_rows_t(Ctx* c, const KParams& P, int t, int flags, size_t smem) {
+    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
+    if (c->kev0)
+        hipExtLaunchKernelGGL((k_chain_iter_norm_p2p_rows<NP>), grid, block, smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (double*)nullptr, flags);
+    else
+        hipLaunchKernelGGL((k_chain_iter_norm_p2p_rows<NP>), grid, block, smem, c->stream, P, t, (const double*)nullptr, (double*)nullptr, flags);
+}
 void launch_chain_iter_norm_p2p(Ctx* c, int t, int flags) {
     KParams P = c->P;
     point_values(c, P, t - 1, t);
     const bool walk = (flags & F_WALK_INLINE) != 0;
     P.tile_off = walk ? (int)(p2p_walk_bytes(c) / sizeof(double)) : 0;
     const size_t smem = (size_t)P.tile_off * sizeof(double) + norm_tile_doubles(P.np) * sizeof(double);
+    if (c->p2p_rows) {   // the kernel without a walk; its accept step stores the 4-byte slots of k_exch_resolve_rows<., true>
+        switch (P.np) {
+            case 1: launch_chain_iter_norm_p2p_rows_t<1>(c, P, t, flags, smem); break;
+            case 2: launch_chain_iter_norm_p2p_rows_t<2>(c, P, t, flags, smem); break;
+            case 3: launch_chain_iter_norm_p2p_rows_t<3>(c, P, t, flags, smem); break;
+            default: launch_chain_iter_norm_p2p_rows_t<4>(c, P, t, flags, smem); break;
+        }
+        return;
+    }
     switch (P.np) {
         case 1: launch_chain_iter_norm_p2p_t<1>(c, P, t, flags, smem); break;
         case 2: launch_chain_iter_norm_p2p_t<2>(c, P, t, flags, smem); break;
@@ -684,6 +702,19 @@ void launch_resolve_window(Ctx* c, int t) {
     KParams P1 = c->P;
     P1.RW = 1;   // (the resolve kernels read value s at gathered[s * RW])
     launch_resolve_p(c, P1, t, (const double*)(c->p2p_mine + L.val[t & 1]));
+}
+// the same straight from the tagged slots and self-validating values of the window (p2p form of large norm populations): no wait,
+// no unpacking, no key pre-pass in front of k_exch_resolve_rows
+void launch_resolve_rows_window(Ctx* c, int t) {
+    const KParams& P = c->P;
+    const size_t smem = resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap);
+    if (P.Ng <= XKEY_PARTNER_MAX) {
+        if (c->kev0) hipExtLaunchKernelGGL((k_exch_resolve_rows<true, true>), dim3(1), dim3(XWG), smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        else hipLaunchKernelGGL((k_exch_resolve_rows<true, true>), dim3(1), dim3(XWG), smem, c->stream, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    } else {
+        if (c->kev0) hipExtLaunchKernelGGL((k_exch_resolve_rows<false, true>), dim3(1), dim3(XWG), smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        else hipLaunchKernelGGL((k_exch_resolve_rows<false, true>), dim3(1), dim3(XWG), smem, c->stream, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    }
 }
 }  // namespace
 
@@ -1096,6 +1127,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const unsigned long long e = ERR_NONE;
             HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
         }
+        if (c->big_exchange)
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_plan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_big_lds_bytes(65535)));
         if (c->key_exchange)
         {
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_key<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1105,6 +1138,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_rows_bytes(XKEY_MAX, XKEY_MAX, XROWS_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_rows_bytes(XKEY_PARTNER_MAX, XKEY_PARTNER_MAX, XROWS_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)resolve_rows_bytes(XKEY_MAX, XKEY_MAX, XROWS_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_rows_bytes(XKEY_PARTNER_MAX, XKEY_PARTNER_MAX, XROWS_MAX)));
         }
         if (c->lds_exchange) {
@@ -1154,6 +1191,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -1428,6 +1469,7 @@ int smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out) {
             for (int b = 0; b < 2; ++b) {
                 P.p2p_off[b] = (uint32_t)L.rec[b]; P.p2p_off[2 + b] = (uint32_t)L.val[b]; P.p2p_off[4 + b] = (uint32_t)L.slot[b];
                 P.p2p_off[6 + b] = (uint32_t)L.llrec[b]; P.p2p_off[8 + b] = (uint32_t)L.llval[b];
+                P.p2p_off[10 + b] = (uint32_t)L.slot4[b];
             }
             if (L.total >= ((size_t)1 << 32)) throw std::string("p2p window larger than 4 GiB");
             c->p2p_attached = 1u << P.p2p_rank;
@@ -1437,6 +1479,10 @@ int smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out) {
             // single shard has it too: objfunc_norm with np == nm <= 4, min_improve == 0, N_global <= 8192
             c->p2p_inline = c->norm_fast && c->win_lv_pairs_p && !P.lean_wide && P.Ng <= XLDS_MAX && P.plan_K <= XLDS_MAX && !c->deep_plan &&
                             P.dist_fun == SMM_DIST_MINUS && p2p_walk_bytes(c) + norm_tile_doubles(P.np) * 8 <= (size_t)160 * 1024;
+            // two launches per iteration for the large norm populations (8192 < N_global <= 32768, min_improve == 0: BASELINE
+            // configs[2], 4 and 8 shards of 4096): k_exch_resolve_rows reads the window's tagged slots itself, the chain kernel
+            // pushes from its epilogue like the inline form's
+            c->p2p_rows = c->norm_fast && !c->p2p_inline && c->xk == XK_ROWS;
         }
         if (ipc_handle_out) {
             hipIpcMemHandle_t h;
@@ -1507,7 +1553,7 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         if (!c->p2p_current) {   // first publication: the state after iteration `iter`, its exchange settled, into every window
             flush(c);
-            c->p2p_mode_inline = c->p2p_inline && !c->nan_values;
+            c->p2p_mode_inline = (c->p2p_inline || c->p2p_rows) && !c->nan_values;
             c->P.p2p_epoch += 1;   // (a new generation of tags: words of an earlier publication are nobody's any more)
             launch_p2p_push(c, c->iter, c->rec[c->cur], c->p2p_mode_inline);
             c->p2p_current = true;
@@ -1522,7 +1568,26 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
                     flags |= F_HAS_PENDING;
                     // the walk of iteration t-1 needs that iteration's plan: where the plan window is about to move on, the
                     // exchange is resolved by the stand-alone kernel first (once per window of 256 iterations)
-                    if (t >= c->plan_t0 && t < c->plan_t0 + c->plan_w) flags |= F_WALK_INLINE;
+                    if (c->p2p_rows) {
+                        if (prof) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
+                        launch_resolve_rows_window(c, t - 1);
+                        c->kev0 = c->kev1 = nullptr;
+#ifdef SMM_TEST_HOOKS
+                        if (SMM_HOOK("SMMHIP_ROWS_WIN_CHECK")) {   // the same exchange through the unpacked values and the plain kernels
+                            std::vector<unsigned long long> a((size_t)P.Ng), b((size_t)P.Ng);
+                            HIPCHK(hipStreamSynchronize(c->stream));
+                            HIPCHK(hipMemcpy(a.data(), P.xres, a.size() * 8, hipMemcpyDeviceToHost));
+                            launch_p2p_unpack(c, t - 1);
+                            launch_resolve_window(c, t - 1);
+                            HIPCHK(hipStreamSynchronize(c->stream));
+                            HIPCHK(hipMemcpy(b.data(), P.xres, b.size() * 8, hipMemcpyDeviceToHost));
+                            int bad = 0;
+                            for (int g = 0; g < P.Ng; ++g)
+                                if (a[g] != b[g] && bad++ < 8) fprintf(stderr, "rows window check: iteration %d chain %d: %llx != %llx\n", t - 1, g, a[g], b[g]);
+                            fprintf(stderr, "rows window check: iteration %d: %d of %d differ\n", t - 1, bad, P.Ng);
+                        }
+#endif
+                    } else if (t >= c->plan_t0 && t < c->plan_t0 + c->plan_w) flags |= F_WALK_INLINE;
                     else {
                         launch_p2p_unpack(c, t - 1);
                         launch_resolve_window(c, t - 1);

@@ -93,6 +93,24 @@ def test_p2p_inline_equals_single(S, O, G, N, T, fe):
         cm.assert_history_equal(single.history(), o.history())
 
 
+@pytest.mark.parametrize("G,N,T,fe,failbox", [(4, 16384, 8, None, False), (8, 32768, 6, 4, False), (2, 20000, 6, None, False), (3, 9000, 8, 3, False),
+                                              (4, 16384, 6, None, True), (2, 10000, 300, None, False)])
+def test_p2p_rows_equals_single(S, G, N, T, fe, failbox):
+    # objfunc_norm, min_improve == 0, 8192 < N_global <= 32768 (BASELINE configs[2]: 8 shards of 4096): two launches per iteration and
+    # shard — k_exch_resolve_rows<., true> on the tagged slots of the window, k_chain_iter_norm_p2p without the walk.  failbox: the
+    # first iteration leaves the value -1 with every chain that starts inside the box (a key that orders nothing: the iteration's
+    # exchange is resolved by the fallback on the exact values, unpacked inside the kernel)
+    kw = dict(objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[0.1, 0.3]) if failbox else {}
+    prob, opts = cm.serial_normal(N=N, T=T, ns=64, **kw)
+    single = S.hip_context(prob, opts)
+    single.step(T)
+    if failbox:
+        assert (single.history().value[0] == -1.0).all()
+    ctxs = p2p_contexts(S, prob, opts, G)
+    p2p_run_lockstep(ctxs, T, finish_every=fe)
+    assert_shards_equal_single(ctxs, single)
+
+
 @pytest.mark.parametrize("case", ["norm_16384", "norm_mi", "general_np6", "banana", "dense"])
 def test_p2p_generic_equals_single(S, case):
     # everything the inline form does not cover: chain kernel into the own window + push kernel + resolve from the window
@@ -199,10 +217,11 @@ put("result", pickle.dumps(({{f: getattr(h, f) for f in h.FIELDS}}, {{f: getattr
 """
 
 
-@pytest.mark.parametrize("G,N,ns", [(2, 2048, 1000), (4, 1024, 1000), (2, 512, 64)])
+@pytest.mark.parametrize("G,N,ns", [(2, 2048, 1000), (4, 1024, 1000), (2, 512, 64), (2, 16384, 64)])
 def test_p2p_processes_over_hip_ipc(S, tmp_path, G, N, ns):
     # G processes on the one GPU, 16 chains per workgroup: at most 256 workgroups in all, so that waiting kernels cannot keep
-    # the kernels they wait for from starting
+    # the kernels they wait for from starting.  (16384: the rows form — its chain kernels wait only for records whose slots have
+    # arrived, the one waiting workgroup is k_exch_resolve_rows')
     import pickle
     T = 40
     prob, opts = cm.serial_normal(N=N, T=T, ns=ns)
