@@ -387,8 +387,10 @@ def main():
         work = n_loc * (W["flop"] if W["bound"] != "hbm" else W["bytes"])
         ach = work / (k_us * 1e-6) / (1e12 if W["bound"] != "hbm" else 1e9)
         hbm = n_loc * W["bytes"] / (k_us * 1e-6) / 1e9
-        kernel = W["kernel"] if not sharded else ("k_chain_iter_norm_p2p<2>" if (protocol == "p2p" and args.workload in ("c2", "c3") and n_glob <= 8192)
-                                                  else W["kernel"].replace("true", "false"))
+        norm_p2p = sharded and protocol == "p2p" and args.workload in ("c2", "c3")
+        kernel = (W["kernel"] if not sharded else "k_chain_iter_norm_p2p<2>" if norm_p2p and n_glob <= 8192      # the walk inline
+                  else "k_chain_iter_norm_p2p_rows<2>" if norm_p2p and n_glob <= 32768                       # + k_exch_resolve_rows<., true>
+                  else W["kernel"].replace("true", "false"))
         traffic, traffic_src, traffic_stale = pmc_traffic(kernel, args.workload)
         prof_us, prof_src, prof_stale = rocprof_kernel_us(kernel, args.workload)
         roof = {"bound": W["bound"], "kernel": kernel, "achieved": ach, "peak": W["peak"], "unit": W["unit"], "frac": ach / W["peak"],
