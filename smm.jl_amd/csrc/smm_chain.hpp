@@ -602,6 +602,8 @@ __device__ inline bool exchange_walk_tile_lean(const KParams& P, const int tx, u
     return true;
 }
 
+#include "smm_cone.hpp"
+
 // The lean KEY walk in k_chain_iter, for single shards of 4096 < N <= 8192 chains (BASELINE config 4: banana, 8192 chains — one
 // launch per iteration instead of chain kernel + stand-alone resolution): 8-byte slots {order_key32(value), src | stamp << 16}
 // built from the chains' values exactly as k_exch_resolve_lean builds them, min_improve == 0, dist_fun = -.  The control wave of
@@ -914,7 +916,13 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             // exchangeMoves! of iteration t-1, by all lanes of the tile, while the level-1 blocks are in flight
             // (the tile's own LDS blocks overlay the walk's pair list: nothing of the tile is written before this returns)
             if (P.gen_lean == 2) {   // 4096 < N <= 8192: the key walk (no other form fits the LDS at this size)
-                if (!exchange_walk_tile_keys<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, tile) && threadIdx.x == 0)
+                bool done = false;
+                if constexpr (WG * TPW == 1024) {   // the workgroup's cone, where the plan kernel made one (smm_cone.hpp)
+                    if (P.cone_ok)
+                        done = P.lean_unit == 8 ? exchange_walk_tile_cone<1024, 0>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, (int)blockIdx.x, tile)
+                                                : exchange_walk_tile_cone<1024, 1>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, (int)blockIdx.x, tile);
+                }
+                if (!done && !exchange_walk_tile_keys<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, tile) && threadIdx.x == 0)
                     report_error(P, 3, t, gc);
             } else if (!(P.gen_lean && exchange_walk_tile_lean<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr, tile))) {
                 exchange_walk_tile<WG * TPW>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, tile);

@@ -149,14 +149,17 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
     }
     __syncthreads();
     int prei[MAXPP], prej[MAXPP];
+    bool lasti[MAXPP], lastj[MAXPP];   // the pair is the last one of its chain i / j (the cones start there, at the end of the kernel)
 #pragma unroll
     for (int m = 0; m < MAXPP; ++m) {
         const int q = tid + m * XWG;
-        prei[m] = -1; prej[m] = -1;
+        prei[m] = -1; prej[m] = -1; lasti[m] = false; lastj[m] = false;
         if (q < K) {
             const uint32_t i = pi[q], j = pj[q];
             if (rri[m]) prei[m] = (int)ep[(i ? cnt[i - 1] : 0u) + rri[m] - 1];
             if (rrj[m]) prej[m] = (int)ep[(j ? cnt[j - 1] : 0u) + rrj[m] - 1];
+            lasti[m] = (i ? cnt[i - 1] : 0u) + rri[m] + 1u == cnt[i];
+            lastj[m] = (j ? cnt[j - 1] : 0u) + rrj[m] + 1u == cnt[j];
         }
     }
     __syncthreads();  // cnt / ep are free from here on
@@ -266,9 +269,11 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
     __syncthreads();
     uint32_t* o_pairs = lv_pairs + (size_t)blockIdx.x * K;
     double* o_mi = lv_mi + (size_t)blockIdx.x * K;
+    uint16_t ci[MAXPP], cj[MAXPP], lvq[MAXPP];
 #pragma unroll
     for (int m = 0; m < MAXPP; ++m) {
         const int q = tid + m * XWG;
+        ci[m] = 0; cj[m] = 0; lvq[m] = 0;
         if (q < K) {
             const uint32_t lv = lvl[q];
             const uint32_t pos = atomicAdd(&lhist[lv], 1u);
@@ -276,6 +281,123 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
             o_pairs[pos] = i | (j << 16);
             o_mi[pos] = P.min_improve_g[i];
             if (lean) o_pp[s_pst[lv] + (pos - s_lst[lv])] = (sc8 * i) | ((sc8 * j) << 16);
+            ci[m] = (uint16_t)i; cj[m] = (uint16_t)j; lvq[m] = (uint16_t)lv;
         }
     }
+    // ---- the cones (smm_cone.hpp): for every workgroup of the chain kernel the pairs its chains' outcome depends on ----
+    // A pair is in a workgroup's cone when it is the last pair of one of its chains, or the predecessor (on either chain) of a pair of
+    // the cone: one bit per workgroup and pair, seeded at the chains' last pairs and OR-ed into the predecessors level by level from
+    // the last level down.  Then, per workgroup: its pairs counted by level, a level's pairs laid out in sub-levels of 64 words (the
+    // consumer pads the last one with dummy pairs itself: a byte per sub-level says how many words count), the pairs scattered.  No
+    // pass has a barrier per level except the propagation, and every thread's pairs are spread over the whole list (q = tid + 1024 m):
+    // the pairs of the first levels, which are in hundreds of cones, are not one thread's.  As many workgroups per pass as their bits
+    // fit the LDS next to the counters (8192 pairs: 128).
+    if (P.cone_ok == nullptr) return;
+    const int tiles = P.cone_tiles;
+    uint32_t* o_ok = (uint32_t*)P.cone_ok + blockIdx.x;
+    if (!lean) {   // (a deep plan: the walk's own fallback serves the iteration)
+        if (tid == 0) *o_ok = 0u;
+        return;
+    }
+    const int LS = nlev + 1;
+    int wpp = (int)(((size_t)150 * 1024) / ((size_t)K * 4 + (size_t)32 * LS * 4));   // words of bits per pair and pass
+    if (wpp > (tiles + 31) / 32) wpp = (tiles + 31) / 32;
+    if (wpp < 1) { if (tid == 0) *o_ok = 0u; return; }
+    __shared__ uint32_t s_bad;
+    if (tid == 0) s_bad = 0u;
+    uint32_t* need = (uint32_t*)xsm;                 // [K][wpp]
+    uint32_t* lcnt = need + (size_t)K * wpp;         // [32 wpp][LS]: pairs of (workgroup, level); then: where the level's words start
+    uint32_t* o_hdr = (uint32_t*)P.cone_hdr + (size_t)blockIdx.x * tiles * CONE_HDRW;
+    uint32_t* o_cp = (uint32_t*)P.cone_pairs + (size_t)blockIdx.x * tiles * (CONE_LEVELS * 64);
+    const uint32_t ct = (uint32_t)P.cone_ct;
+    for (int b0 = 0; b0 < tiles; b0 += 32 * wpp) {   // workgroups b0 .. b0 + 32 wpp - 1
+        const int nb = min(32 * wpp, tiles - b0);
+        __syncthreads();   // (first pass: everything in LDS is dead — pairs and levels are in registers)
+        for (int x = tid; x < K * wpp + 32 * wpp * LS; x += XWG) need[x] = 0u;
+        __syncthreads();
+        auto seed = [&](const uint32_t c, const int q) {
+            const uint32_t b = (c - (uint32_t)P.offset) / ct - (uint32_t)b0;   // (single shard: offset 0, whole tiles)
+            if (b < (uint32_t)nb) atomicOr(&need[(size_t)q * wpp + (b >> 5)], 1u << (b & 31u));
+        };
+#pragma unroll
+        for (int m = 0; m < MAXPP; ++m) {
+            const int q = tid + m * XWG;
+            if (q < K) {
+                if (lasti[m]) seed(ci[m], q);
+                if (lastj[m]) seed(cj[m], q);
+            }
+        }
+        __syncthreads();
+        for (int l = nlev; l >= 2; --l) {
+#pragma unroll
+            for (int m = 0; m < MAXPP; ++m) {
+                const int q = tid + m * XWG;
+                if (q < K && lvq[m] == l)
+                    for (int w = 0; w < wpp; ++w) {
+                        const uint32_t v = need[(size_t)q * wpp + w];
+                        if (v) {
+                            if (prei[m] >= 0) atomicOr(&need[(size_t)prei[m] * wpp + w], v);
+                            if (prej[m] >= 0) atomicOr(&need[(size_t)prej[m] * wpp + w], v);
+                        }
+                    }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int m = 0; m < MAXPP; ++m) {   // count
+            const int q = tid + m * XWG;
+            if (q < K)
+                for (int w = 0; w < wpp; ++w) {
+                    uint32_t bits = need[(size_t)q * wpp + w];
+                    while (bits) {
+                        const uint32_t b = (uint32_t)w * 32u + (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        atomicAdd(&lcnt[b * LS + lvq[m]], 1u);
+                    }
+                }
+        }
+        __syncthreads();
+        for (int b = tid; b < nb; b += XWG) {   // sub-levels: counts out, starting words in
+            uint32_t sub = 0;
+            uint32_t hw[CONE_HDRW];
+#pragma unroll
+            for (int x = 0; x < CONE_HDRW; ++x) hw[x] = 0u;
+            for (int l = 1; l <= nlev; ++l) {
+                const uint32_t n = lcnt[b * LS + l];
+                lcnt[b * LS + l] = sub * 64u;
+                for (uint32_t x = 0; x < n; x += 64u, ++sub)
+                    if (sub < (uint32_t)CONE_LEVELS) {
+                        const uint32_t cnt_s = n - x < 64u ? n - x : 64u;
+#pragma unroll
+                        for (int y = 0; y < CONE_LEVELS / 4; ++y)
+                            if ((int)(sub >> 2) == y) hw[1 + y] |= cnt_s << (8u * (sub & 3u));
+                    }
+            }
+            hw[0] = sub < (uint32_t)CONE_LEVELS ? sub : (uint32_t)CONE_LEVELS;
+            if (sub > (uint32_t)CONE_LEVELS) atomicOr(&s_bad, 1u);
+#pragma unroll
+            for (int x = 0; x < CONE_HDRW; ++x) o_hdr[(size_t)(b0 + b) * CONE_HDRW + x] = hw[x];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MAXPP; ++m) {   // scatter
+            const int q = tid + m * XWG;
+            if (q < K) {
+                const uint32_t word = (sc8 * ci[m]) | ((sc8 * cj[m]) << 16);
+                for (int w = 0; w < wpp; ++w) {
+                    uint32_t bits = need[(size_t)q * wpp + w];
+                    while (bits) {
+                        const uint32_t b = (uint32_t)w * 32u + (uint32_t)__builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        const uint32_t dst = atomicAdd(&lcnt[b * LS + lvq[m]], 1u);
+                        if (dst < (uint32_t)(CONE_LEVELS * 64)) o_cp[(size_t)(b0 + b) * (CONE_LEVELS * 64) + dst] = word;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) *o_ok = s_bad ? 0u : 1u;
 }
+// LDS of the cone passes (k_exch_plan's request is the larger of this and its own)
+__host__ __device__ inline size_t plan_cone_bytes() { return (size_t)152 * 1024; }

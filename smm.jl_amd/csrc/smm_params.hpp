@@ -75,6 +75,11 @@ struct KParams {
     const uint32_t* lv_rowinfo;      // [W][4]: rows; bit r of words 1 (low) and 2 (high): row r is the last of its level; 1 when the plan fits the form
     int rows_cap;
     int plan_t0, plan_K;
+    // ... and the cones of the inline key walk's workgroups (smm_cone.hpp; k_chain_iter's key form, 4096 < N <= 8192; null otherwise):
+    const uint32_t* cone_ok;         // [W]: 1 when every workgroup's cone of the iteration fits CONE_LEVELS sub-levels
+    const uint32_t* cone_hdr;        // [W][tiles][CONE_HDRW]: word 0 = sub-levels; from word 1: the pairs of sub-level s, one byte each
+    const uint32_t* cone_pairs;      // [W][tiles][CONE_LEVELS * 64]: sub-level s = words 64 s .. 64 s + (its count) - 1, as lv_pairs_p words
+    int cone_tiles, cone_ct;         // workgroups, chains per workgroup
     // state
     double* cs;                // [N][CSW]
     unsigned long long* xres;  // [Ng]
@@ -140,6 +145,7 @@ __host__ __device__ inline double dist_fun_eval(const int kind, const double a, 
     return d / fabs(a);
 }
 constexpr int LV_OFFP = 40, LV_MAXLEV = 31;
+constexpr int CONE_LEVELS = 32, CONE_HDRW = 1 + CONE_LEVELS / 4;   // a workgroup's cone: at most 32 sub-levels of 64 pairs (smm_cone.hpp)
 // 32-bit order key of a chain value: for any two non-NaN doubles, key(a) > key(b) implies a > b and key(a) < key(b) implies a < b
 // (the high word of the double, made monotone across the sign; -0.0 counts as +0.0); equal keys decide nothing.
 __host__ __device__ inline uint32_t order_key32(const double v) {

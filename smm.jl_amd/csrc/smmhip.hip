@@ -226,6 +226,7 @@ struct Ctx {
     unsigned long long p2p_seq = 0;            // pushes so far (every rank counts the same)
     bool p2p_current = false;                  // the windows hold the records after iteration `iter`
     bool p2p_inline = false;                   // the inline form is available: k_chain_iter_norm_p2p walks inline and pushes from its epilogue
+    bool cone = false;                         // the key form of k_chain_iter walks its workgroups' cones (smm_cone.hpp)
     bool p2p_rows = false;                     // the same kernel without the walk + k_exch_resolve_rows<., true> on the window's slots
     bool p2p_mode_inline = false;              // ... and is what the windows currently hold (decided at every publication)
     bool p2p_unwaited = false;                 // nobody has waited for the arrivals of the last push yet
@@ -317,7 +318,7 @@ void ensure_windows(Ctx* c, int t) {
     }
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->plan_cap, P.T - t + 1);
-        hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
+        hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), c->cone ? std::max(plan_lds_bytes(P.Ng, P.plan_K), plan_cone_bytes()) : plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
                            c->win_plan_mi, c->win_lv_pairs, c->win_lv_mi, c->win_lv_off, c->win_lv_pairs_p, c->win_lv_offp);
         c->plan_t0 = t; c->plan_w = W;
         P.plan = c->win_plan; P.plan_mi = c->win_plan_mi; P.plan_t0 = t;
@@ -1031,8 +1032,11 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             // former common budget of 192 MiB allowed was 63 us per iteration, more than the exchange itself (round 3, rocprofv3).
             const bool pregen = !(c->norm_fast && !(tab && tab->prop_normals) && !(tab && tab->probs_acc));   // (k_chain_iter_norm draws in the kernel)
             const size_t rb_iter = (size_t)P.RBW * N * 8;
+            // the workgroups' cones of the inline key walk (smm_cone.hpp): where k_chain_iter walks 8192 chains' keys in every workgroup
+            const char* nc = SMM_HOOK("SMMHIP_NO_CONE");   // test hook: every workgroup walks the whole list
+            const bool want_cone = c->gen_keys && c->tpw == 2 && N % 32 == 0 && N / 32 <= 256 && !(nc && nc[0] == '1');
             const size_t plan_iter = (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
-                                     (size_t)lean_walk_Kp(K) * 4 + 1024;
+                                     (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / 32) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
             c->win_cap = std::min(c->win_cap, T);
             c->plan_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)1536 << 20) / plan_iter));
@@ -1078,6 +1082,15 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                         P.slot8 = c->slot8_buf[0];
                         P.walk_flags = dalloc<uint32_t>(c, 4);
                         HIPCHK(hipMemset(P.walk_flags, 0, 16));
+                        if (want_cone) {
+                            const size_t tiles = (size_t)N / 32;
+                            c->cone = true;
+                            P.cone_tiles = (int)tiles; P.cone_ct = 32;
+                            P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
+                            P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
+                            P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64));
+                            HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
+                        }
                     }
                 }
             }
@@ -1150,7 +1163,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (int)resolve_lds_bytes(XLDS_MAX)));
 #endif
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_plan, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)plan_lds_bytes(XLDS_MAX, XLDS_MAX)));
+                                       (int)std::max(plan_lds_bytes(XLDS_MAX, XLDS_MAX), plan_cone_bytes())));
 #ifdef SMM_TEST_HOOKS
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_lvl<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_lvl_bytes(XLVL_MAX, XLVL_MAX)));

@@ -111,6 +111,24 @@ def test_p2p_rows_equals_single(S, G, N, T, fe, failbox):
     assert_shards_equal_single(ctxs, single)
 
 
+def test_p2p_rows_with_a_deep_plan_and_injected_tables(S):
+    # rows form with injected randomness and a pair list that does not fit the rows plan in the odd iterations (forty pairs through
+    # chain 0, one after the other): those iterations take the fallback inside k_exch_resolve_rows<., true>, the others the rows walk
+    G, N, T = 3, 9000, 6
+    prob, opts = cm.serial_normal(N=N, T=T, ns=32, min_improve=0.0)
+    tab = cm.random_tables(prob, opts, tries=24)
+    tab.pairs[1::2, :40, 0] = 0
+    tab.pairs[1::2, :40, 1] = 1 + np.arange(40)[None, :] * 3
+    single = S.hip_context(prob, opts, tab)
+    single.step(T)
+    n = N // G
+    tabs = [S.Tables(probs_acc=tab.probs_acc[:, r * n:(r + 1) * n], prop_normals=tab.prop_normals[..., r * n:(r + 1) * n], pairs=tab.pairs, Z=tab.Z)
+            for r in range(G)]
+    ctxs = p2p_contexts(S, prob, opts, G, tabs)
+    p2p_run_lockstep(ctxs, T)
+    assert_shards_equal_single(ctxs, single)
+
+
 @pytest.mark.parametrize("case", ["norm_16384", "norm_mi", "general_np6", "banana", "dense"])
 def test_p2p_generic_equals_single(S, case):
     # everything the inline form does not cover: chain kernel into the own window + push kernel + resolve from the window

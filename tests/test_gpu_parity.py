@@ -649,6 +649,69 @@ def test_c4_banana_8192_chains(S, O):
     assert (hh.exchanged != 0).mean() > 0.01 and (np.diff(hh.best_val, axis=0) <= 0).all()
 
 
+def banana10(S, N, T, mi=0.0, seed=3):
+    # (started away from the optimum: the hotter chains, with their larger steps, get ahead of the colder ones, so that
+    # `value_i - value_j > 0` — the exchange test at min_improve == 0 — is true for many pairs)
+    npar = 10
+    prob = S.Problem(init=np.full(npar, 1.2), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1,
+                     objective_id=A.SMM_OBJ_BANANA)
+    opts = S.BGPOpts(N=N, maxiter=T, sigma=0.02 * cm.temps(N, 5), acc_tuner=np.geomspace(20, 1, N), min_improve=mi * np.ones(N), seed=seed)
+    return prob, opts
+
+
+@pytest.mark.parametrize("N,T", [(8192, 40), (5024, 30), (6000, 30), (4128, 300)])
+def test_c4_key_form_against_oracle(S, O, N, T):
+    # BASELINE config 4 as bench.py runs it (min_improve == 0): ONE launch per iteration, k_chain_iter<0, 16, 2, true> with the key walk
+    # in its prologue — every workgroup walks its own cone of the pair list (smm_cone.hpp) where the population is whole
+    # workgroups of 32 chains (8192, 5024, 4128; 6000 is not: the whole list in every workgroup); 300 iterations cross a window
+    prob, opts = banana10(S, N, T)
+    h, o = run_both(S, O, prob, opts, None)
+    hh = h.history()
+    cm.assert_history_equal(hh, o.history(), atol=1e-12)   # (parameters pass through 0: lb + x (ub - lb) cancels)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-12)
+    assert (hh.exchanged != 0).mean() > 0.01
+
+
+def test_c4_cones_equal_the_whole_walk(S, monkeypatch, hooks):
+    prob, opts = banana10(S, 8192, 30)
+    a = S.hip_context(prob, opts)
+    a.step(30)
+    monkeypatch.setenv("SMMHIP_NO_CONE", "1")
+    b = S.hip_context(prob, opts)
+    b.step(30)
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+
+
+def test_c4_a_cone_that_does_not_fit_falls_back(S, O):
+    # a pair list of 31 levels in which the cone of workgroup 0 is 32, 64, 100, 100, ... pairs wide going back from the last level:
+    # about 60 sub-levels of 64, more than the 32 a cone may have — the plan kernel says so (cone_ok = 0) and every workgroup of that
+    # iteration walks the whole list.  Even iterations carry the random list (cones).
+    N, T = 8192, 6
+    prob, opts = banana10(S, N, T)
+    tab = cm.random_tables(prob, opts, tries=24)
+    levels, fresh, frontier = [], 32, list(range(32))
+    for back in range(31):   # from the last level backwards
+        lv = []
+        for c in frontier[:100]:
+            lv.append((c, fresh)); fresh += 1
+        frontier = frontier + [p[1] for p in lv]
+        levels.append(lv)
+    pairs = [p for lv in reversed(levels) for p in lv]
+    rest = list(range(fresh, N))   # the other chains among themselves, round after round (a few levels deep, no chain of the cone)
+    half, rnd = len(rest) // 2, 0
+    while len(pairs) < N:
+        for x in range(half):
+            if len(pairs) < N:
+                pairs.append((rest[x], rest[half + (x + rnd) % half]))
+        rnd += 1
+    pt = np.array(pairs[:N], np.int32)
+    pt = np.stack([pt.min(1), pt.max(1)], 1)
+    tab.pairs[1::2] = pt[None]
+    h, o = run_both(S, O, prob, opts, tab)
+    assert (h.history().exchanged != 0).any()
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-12)
+
+
 def test_window_boundaries(S, O):
     # look-ahead tables are produced window by window (256 iterations): cross two boundaries
     prob, opts = cm.serial_normal(N=40, T=600, ns=64)

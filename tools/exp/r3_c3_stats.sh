@@ -17,5 +17,5 @@ for mode in single p2p; do
   f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1)
   cp $f $out/kernel_stats_$mode.csv
   echo "== $mode"; top $f
-  python $GRAFT_REPO_ROOT/bench.py --workload c3 $X --no-cpu-baseline --no-unfused 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('value %.4g  us/iter %.2f' % (d['value'], d['ms_per_step']*1e3/200))"
+  python $GRAFT_REPO_ROOT/bench.py --workload c3 $X --no-cpu-baseline --no-unfused 2>/dev/null | grep "^{" | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('value %.4g  us/iter %.2f' % (d['value'], d['ms_per_step']*1e3/200))"
 done

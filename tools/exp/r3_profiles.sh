@@ -13,7 +13,12 @@ for cfg in "single shard (no sharding)|$B" \
            "1 rank, RCCL values + all-to-all|SMM_BENCH_FORCE_SHARDED=1 $B --protocol values" \
            "2 PROCESSES on the one GPU x 2048 chains, p2p over HIP IPC|$B --gpus 2 --same-device" \
            "4 PROCESSES on the one GPU x 1024 chains, p2p over HIP IPC|$B --gpus 4 --same-device" \
-           "8 PROCESSES on the one GPU x 512 chains, p2p over HIP IPC|$B --gpus 8 --same-device"; do
+           "8 PROCESSES on the one GPU x 512 chains, p2p over HIP IPC|$B --gpus 8 --same-device" \
+           "16384 chains, single shard (what 4 GPUs hold)|$B --chains 16384" \
+           "16384 chains, 1 rank, p2p rows form (SMM_BENCH_FORCE_SHARDED=1)|SMM_BENCH_FORCE_SHARDED=1 $B --chains 16384 --protocol p2p" \
+           "C3 32768 chains, single shard|$B --workload c3" \
+           "C3 32768 chains, 1 rank, p2p rows form (SMM_BENCH_FORCE_SHARDED=1)|SMM_BENCH_FORCE_SHARDED=1 $B --workload c3 --protocol p2p" \
+           "C3 32768 chains, 1 rank, RCCL all-gather of records|SMM_BENCH_FORCE_SHARDED=1 $B --workload c3 --protocol records"; do
   name=${cfg%%|*}; cmd=${cfg#*|}
   eval "timeout 200 env $cmd" 2>/dev/null | python -c "
 import json,sys
@@ -28,6 +33,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt2 && SMM_BENCH_FORCE_SHARDED=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --protocol p2p > /dev/null 2>&1
 cp $(find /tmp/kt2 -name "*kernel_stats.csv" | head -1) $out/p2p_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
+bash tools/exp/r3_c3_stats.sh > $out/c3_kernel_stats.txt 2>&1
 python tools/exch_time.py > $out/exch_time.txt 2>&1
 python tools/dbg_ts.py 2>&1 | grep -v "^\[W\|amdgpu" > $out/phase_stamps.txt
 python tools/exp/ts_p2p.py 2>&1 | grep -v "^\[W\|amdgpu" >> $out/phase_stamps.txt
