@@ -302,8 +302,8 @@ void ensure_windows(Ctx* c, int t) {
     if (pregen && !(t >= c->rng_t0 && t < c->rng_t0 + c->rng_w)) {
         const int W = std::min(c->win_cap, P.T - t + 1);
         const size_t Q = (size_t)(P.np + 1) / 2;
-        const size_t total = (size_t)W * P.rb_tries * Q * P.N;
-        hipLaunchKernelGGL(k_pregen_rng, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, P, t, W, c->win_rb);
+        const size_t per_iter = (size_t)P.rb_tries * Q * P.N;   // (< 2^31: checked at creation)
+        hipLaunchKernelGGL(k_pregen_rng, dim3((unsigned)((per_iter + 255) / 256), (unsigned)W), dim3(256), 0, c->stream, P, t, W, c->win_rb);
         c->rng_t0 = t; c->rng_w = W;
         P.rb = c->win_rb; P.rb_t0 = t;
     }
@@ -945,6 +945,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         } else {
             P.rb_tries = np <= 8 ? 8 : (np <= 32 ? 4 : 2);
         }
+        if ((size_t)P.rb_tries * (size_t)((np + 1) / 2) * (size_t)N >= ((size_t)1 << 31))   // (k_pregen_rng indexes one iteration's pieces in 32 bits)
+            throw std::string("injected proposal normals: tries x parameters x chains of one iteration must stay below 2^31 pieces");
         if (tab && tab->pairs && tab->n_pairs > 0) {
             P.n_pairs_tab = tab->n_pairs;
             P.pairtab = dupload(c, tab->pairs, (size_t)T * tab->n_pairs * 2);
