@@ -79,7 +79,7 @@ __device__ inline double quad_bcast_dyn(double v, int lane, int q) {   // q: wav
 
 // the simulation for a tile of 16 chains: half h (512 lanes, l = lane of the half) sums the draws of the moments
 // k = h, h+2, ...; lane l takes the draws l, l+512, ... in that order (numerical contract).  s_part [NP][8][16].
-template <int NP>
+template <int NP, int HALVES = 2>   // HALVES: halves of 512 lanes in the workgroup — two (moments h, h + 2, ...) or one (every moment, one after the other)
 __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const double* s_theta, double* s_part, const int h, const int wih,
                                        double (&zc)[NORM_ZU]) {
     constexpr int ZU = NORM_ZU;
@@ -94,7 +94,7 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
     const int last_draws = ns - (nch - 1) * (ZU * WG);
     const bool ragged = last_draws < ZU * WG;
 #pragma clang loop unroll(disable)
-    for (int k = h; k < NP; k += 2) {
+    for (int k = h; k < NP; k += HALVES) {
         double acc[CT], mu[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -132,7 +132,7 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
                 }
             }
         };
-        const int knext = (k + 2 < NP) ? k + 2 : k;   // last moment of the half: a harmless reload
+        const int knext = (k + HALVES < NP) ? k + HALVES : k;   // last moment of the half: a harmless reload
         double zn[ZU];
         int ch = 0;
 #pragma clang loop unroll(disable)
@@ -373,7 +373,7 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
 // kernel the headline kernel spilled 8 scalar registers in its latency-bound prologue and took 0.3 us longer)
 // (P2P: a shard of the p2p form, smm_p2p.hpp — records, values and walk slots of ALL chains live in this rank's window, the accept
 // step stores its results into every rank's window and arrives; WALK then means "when the launch says so", F_WALK_INLINE)
-template <int NP, bool WALK, bool WIDE, bool LEAN, bool P2P = false, bool P2P_BIG = true>
+template <int NP, bool WALK, bool WIDE, bool LEAN, bool P2P = false, bool P2P_BIG = true, int HALVES = 2>
 __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int t, const double* __restrict__ rec_in_arg,
                                                      double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -658,7 +658,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     TS_MARK(2);
 
     // ---- simulation: every lane, ns draws x its half's moments x 16 chains ----
-    if (simw) simulate_tile16<NP>(P, zb, s_theta, s_part, h, wave & 7, za);
+    if (simw) simulate_tile16<NP, HALVES>(P, zb, s_theta, s_part, h, wave & 7, za);
     // No workgroup barrier: only the control wave consumes the partial sums.  Every wave announces its partials with one
     // LDS add and is done; the control wave waits for the announcements of the waves that had a moment.
     // (lane ids are derived anew from mbcnt and the scalar wave id: no register of the prologue stays live across the simulation)
@@ -667,7 +667,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
     if (simw && (tid2 & 63) == 0) __hip_atomic_fetch_add(s_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (tid2 >= 64) return;
     {
-        const unsigned want = (unsigned)(8 * (NP < 2 ? NP : 2));
+        const unsigned want = (unsigned)(8 * (NP < HALVES ? NP : HALVES));
         while (__hip_atomic_load(s_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
@@ -679,6 +679,14 @@ template <int NP, bool WALK>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm(const KParams P, const int t, const double* __restrict__ rec_in,
                                                                  double* __restrict__ rec_out, const int flags) {
     chain_iter_norm_body<NP, WALK, false, true>(P, t, rec_in, rec_out, flags);
+}
+// the kernel without the walk on workgroups of ONE half (512 lanes: the tile's moments one after the other, each over the same 512
+// lanes in the same order — the numerical contract does not change): two workgroups share a CU, and one's serial prologue and
+// epilogue (3.6 of a tile's 10.9 us) run under the other's simulation.  For shards of more than one round of tiles (> 4096 chains).
+template <int NP>
+__global__ __launch_bounds__(NORM_WG / 2, 4) void k_chain_iter_norm_narrow(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                           double* __restrict__ rec_out, const int flags) {
+    chain_iter_norm_body<NP, false, false, true, false, true, 1>(P, t, rec_in, rec_out, flags);
 }
 template <int NP>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_wide(const KParams P, const int t, const double* __restrict__ rec_in,

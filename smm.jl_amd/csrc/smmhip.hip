@@ -226,6 +226,7 @@ struct Ctx {
     unsigned long long p2p_seq = 0;            // pushes so far (every rank counts the same)
     bool p2p_current = false;                  // the windows hold the records after iteration `iter`
     bool p2p_inline = false;                   // the inline form is available: k_chain_iter_norm_p2p walks inline and pushes from its epilogue
+    bool norm_narrow = false;                  // k_chain_iter_norm_narrow instead of k_chain_iter_norm<., false>: shards of more than one round of tiles
     bool cone = false;                         // the key form of k_chain_iter walks its workgroups' cones (smm_cone.hpp)
     bool p2p_rows = false;                     // the same kernel without the walk + k_exch_resolve_rows<., true> on the window's slots
     bool p2p_mode_inline = false;              // ... and is what the windows currently hold (decided at every publication)
@@ -358,6 +359,17 @@ void launch_chain_iter_norm_t(Ctx* c, int t, int flags) {
         hipLaunchKernelGGL((k_chain_iter_norm<NP, WALK>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
 }
 template <int NP>
+void launch_chain_iter_norm_narrow_t(Ctx* c, int t, int flags) {
+    const KParams& P = c->P;
+    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG / 2);
+    const double* rin = c->ext_rec_in ? c->ext_rec_in : (const double*)c->rec[c->cur];
+    double* rout = c->ext_rec_out ? c->ext_rec_out : c->rec[c->cur ^ 1];
+    if (c->kev0)
+        hipExtLaunchKernelGGL((k_chain_iter_norm_narrow<NP>), grid, block, norm_smem(c), c->stream, c->kev0, c->kev1, 0, P, t, rin, rout, flags);
+    else
+        hipLaunchKernelGGL((k_chain_iter_norm_narrow<NP>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
+}
+template <int NP>
 void launch_chain_iter_norm_wide_t(Ctx* c, int t, int flags) {
     const KParams& P = c->P;
     const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
@@ -399,6 +411,15 @@ void launch_chain_iter_norm(Ctx* c, int t, int flags) {
             case 2: launch_chain_iter_norm_wide_t<2>(c, t, flags); break;
             case 3: launch_chain_iter_norm_wide_t<3>(c, t, flags); break;
             default: launch_chain_iter_norm_wide_t<4>(c, t, flags); break;
+        }
+        return;
+    }
+    if (!walk && c->norm_narrow) {   // more than one round of tiles: two half-size workgroups per CU (k_chain_iter_norm_narrow)
+        switch (c->P.np) {
+            case 1: launch_chain_iter_norm_narrow_t<1>(c, t, flags); break;
+            case 2: launch_chain_iter_norm_narrow_t<2>(c, t, flags); break;
+            case 3: launch_chain_iter_norm_narrow_t<3>(c, t, flags); break;
+            default: launch_chain_iter_norm_narrow_t<4>(c, t, flags); break;
         }
         return;
     }
@@ -987,6 +1008,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const size_t tile_b = (tile_smem_base(c, tile_ct) + 15) & ~(size_t)15;
             const char* nf = SMM_HOOK("SMMHIP_NORM_FAST");   // test hook: "0" keeps the general kernel for objfunc_norm
             c->norm_fast = is_sim(c->obj) && np == nm && np <= 4 && opts->batch_size == np && P.dbg == 0 && !opts->chol_L && !(nf && nf[0] == '0');
+            {   // more tiles than CUs: the walk-free kernel on half-size workgroups, two to a CU (k_chain_iter_norm_narrow)
+                int cus = 256;
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+                const char* nn = SMM_HOOK("SMMHIP_NORM_NARROW");   // test hook: "0" never, "1" always
+                c->norm_narrow = c->norm_fast && ((N + NORM_CT - 1) / NORM_CT > cus || (nn && nn[0] == '1')) && !(nn && nn[0] == '0');
+            }
             // k_chain_iter_norm: pair list NOT overlaid; room for either walk (16-byte slots, 4-byte slots + value table)
             const bool wide_form = P.mi_uniform && P.mi_value != 0.0 && !(P.mi_value < 0.0);   // (the lean walk on 16-byte slots, below)
             const size_t walk_b = std::max(walk_slot_bytes(Ng) + (((size_t)K * 4 + 15) & ~(size_t)15),
@@ -1198,6 +1225,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));

@@ -649,6 +649,22 @@ def test_c4_banana_8192_chains(S, O):
     assert (hh.exchanged != 0).mean() > 0.01 and (np.diff(hh.best_val, axis=0) <= 0).all()
 
 
+@pytest.mark.parametrize("npar,N", [(2, 37), (2, 1000), (1, 50), (3, 200), (4, 64)])
+def test_narrow_norm_kernel_forced(S, O, monkeypatch, hooks, npar, N):
+    # k_chain_iter_norm_narrow (workgroups of one half of 512 lanes, the tile's moments one after the other: what shards of more
+    # than one round of tiles run, e.g. C3's 32768 chains on one GPU) forced at small and ragged populations, every np
+    monkeypatch.setenv("SMMHIP_NORM_NARROW", "1")
+    monkeypatch.setenv("SMMHIP_INLINE_WALK", "0")   # (the narrow kernel is the one without the walk)
+    if npar == 2:
+        prob, opts = cm.serial_normal(N=N, T=30, ns=300)
+    else:
+        prob, opts = cm.general_normal(npar, N, 30, ns=300, batch_size=npar)
+    h, o = run_both(S, O, prob, opts, None)
+    cm.assert_history_equal(h.history(), o.history())
+    cm.assert_state_equal(h.state(), o.state())
+    assert (h.history().exchanged != 0).any()
+
+
 def banana10(S, N, T, mi=0.0, seed=3):
     # (started away from the optimum: the hotter chains, with their larger steps, get ahead of the colder ones, so that
     # `value_i - value_j > 0` — the exchange test at min_improve == 0 — is true for many pairs)
