@@ -715,6 +715,13 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_p2p_rows(const K
     chain_iter_norm_body<NP, false, false, true, true, true>(P, t, rec_in, rec_out, flags);
 }
 
+// ... on half-size workgroups, two to a CU, where the shard is more than one round of tiles (like k_chain_iter_norm_narrow)
+template <int NP>
+__global__ __launch_bounds__(NORM_WG / 2, 4) void k_chain_iter_norm_p2p_rows_narrow(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                                    double* __restrict__ rec_out, const int flags) {
+    chain_iter_norm_body<NP, false, false, true, true, true, 1>(P, t, rec_in, rec_out, flags);
+}
+
 // objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) and the result blocks
 // (BIG: the kernel without an inline walk — the one large populations run: their stand-alone resolution takes its initial slots
 // from the accept step when the host says so, KParams::slots17_out)

@@ -978,8 +978,10 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_key(const KParams P, const
 // LDS: slots u32[Ng + 2 (+ pad)] | swap ballots u64[rows_cap][16].
 // ------------------------------------------------------------------------------------------
 constexpr int XROWS_MAX = 63;
-__host__ __device__ inline size_t resolve_rows_bytes(int Ng, int K, int rows_cap) {
-    const size_t a = (((size_t)Ng + 2 + 3) & ~(size_t)3) * 4 + (Ng <= XKEY_PARTNER_MAX ? ((size_t)Ng + 4) * 2 : (size_t)rows_cap * 16 * 8);
+// (n_own > 0: the OWN form's partner array over the shard's chains instead of the ballots)
+__host__ __device__ inline size_t resolve_rows_bytes(int Ng, int K, int rows_cap, int n_own = 0) {
+    const size_t a = (((size_t)Ng + 2 + 3) & ~(size_t)3) * 4 +
+                     (Ng <= XKEY_PARTNER_MAX ? ((size_t)Ng + 4) * 2 : std::max((size_t)rows_cap * 16 * 8, ((size_t)n_own + 4) * 2));
     const size_t b = resolve_key_bytes(Ng, K);
     return a > b ? a : b;
 }
@@ -988,7 +990,10 @@ __host__ __device__ inline size_t resolve_rows_bytes(int Ng, int K, int rows_cap
 // again), so that nobody waits for anybody in a kernel of its own and no pre-pass makes keys; exact values (ties, the
 // fallback) are the window's self-validating values.  A value whose key says "negative, infinite or NaN" sends the whole
 // iteration to the fallback (k_exch_resolve_key's body on the exact values, unpacked here).
-template <bool PLDS, bool WIN = false>   // PLDS: the last partner of every chain in a 2-byte LDS array of its own, written by the swap (N_global <= XKEY_PARTNER_MAX)
+// OWN (a shard of a population too large for PLDS, e.g. 4096 of 32768 chains): a rank needs the last partner of ITS chains only — a
+// 2-byte array over them fits next to the slots, the swap writes it for the endpoints in the shard's range, and the second pass over
+// the rows (a third of the kernel) is gone.
+template <bool PLDS, bool WIN = false, bool OWN = false>   // PLDS: the last partner of every chain in a 2-byte LDS array of its own, written by the swap (N_global <= XKEY_PARTNER_MAX)
 __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, const int t, const double* __restrict__ vals,
                                                            const uint32_t* __restrict__ slots16, const uint32_t* __restrict__ slots17,
                                                            uint32_t* __restrict__ nan_flags) {
@@ -1115,8 +1120,12 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
     }
     __syncthreads();
     if (tid == 0) { slot[Ng] = 1u << 15; slot[Ng + 1] = 2u << 15; }   // the dummy pair's slots: keys 1 < 2, "no swap" (behind the staged words)
+    static_assert(!(PLDS && OWN), "one partner array or the other");
     if constexpr (PLDS)
         for (int g = tid; g < (Ng + 1) / 2; g += XWG) ((uint32_t*)partner)[g] = 0u;
+    if constexpr (OWN)
+        for (int g = tid; g < (P.N + 1) / 2; g += XWG) ((uint32_t*)partner)[g] = 0u;
+    const uint32_t own0 = (uint32_t)P.offset, ownN = (uint32_t)P.N;
     __syncthreads();
     XTS(1);
     auto row = [&](const uint32_t pw, const int r) {
@@ -1137,8 +1146,13 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
                 const uint32_t pi = pbase + (ai >> 1), pj = pbase + (aj >> 1);
                 asm volatile("ds_write_b16 %0, %2\n\tds_write_b16 %1, %3" :: "v"(pi), "v"(pj), "v"((pw >> 16) + 1u), "v"((pw & 0xffffu) + 1u) : "memory");
             }
+            if constexpr (OWN) {    // ... for the endpoints that are this shard's
+                const uint32_t ci = (pw & 0xffffu) - own0, cj = (pw >> 16) - own0;
+                if (ci < ownN) partner[ci] = (uint16_t)((pw >> 16) + 1u);
+                if (cj < ownN) partner[cj] = (uint16_t)((pw & 0xffffu) + 1u);
+            }
         }
-        if constexpr (!PLDS) {
+        if constexpr (!PLDS && !OWN) {
             const unsigned long long m = __ballot(swap);
             if (lane == 0) bits[r * 16 + wave] = m;
         }
@@ -1194,6 +1208,17 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
             if (4 * g4 < Ng) {
                 const uint2 pp = ((const uint2*)partner)[g4];   // four 2-byte entries (the array is padded)
                 put4(g4, src4[r], pp.x & 0xffffu, pp.x >> 16, pp.y & 0xffffu, pp.y >> 16);
+            }
+        }
+    } else if constexpr (OWN) {
+        XTS(3);
+        auto own_partner = [&](const uint32_t g) -> uint32_t { return g - own0 < ownN ? (uint32_t)partner[g - own0] : 0u; };   // (other shards' chains: nobody here asks)
+#pragma unroll
+        for (int r = 0; r < PT4; ++r) {
+            const int g4 = tid + r * XWG;
+            if (4 * g4 < Ng) {
+                const uint32_t g = 4u * (uint32_t)g4;
+                put4(g4, src4[r], own_partner(g), own_partner(g + 1u), own_partner(g + 2u), own_partner(g + 3u));
             }
         }
     } else {

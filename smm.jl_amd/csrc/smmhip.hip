@@ -670,8 +670,13 @@ void launch_chain_iter_norm_p2p_t(Ctx* c, const KParams& P, int t, int flags, si
 size_t p2p_walk_bytes(const Ctx* c) { return (lean_walk_bytes(c->P.Ng, c->P.plan_K) + 15) & ~(size_t)15; }
 template <int NP>
 void launch_chain_iter_norm_p2p_rows_t(Ctx* c, const KParams& P, int t, int flags, size_t smem) {
-    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
-    if (c->kev0)
+    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(c->norm_narrow ? NORM_WG / 2 : NORM_WG);
+    if (c->norm_narrow) {   // a shard of more than one round of tiles
+        if (c->kev0)
+            hipExtLaunchKernelGGL((k_chain_iter_norm_p2p_rows_narrow<NP>), grid, block, smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (double*)nullptr, flags);
+        else
+            hipLaunchKernelGGL((k_chain_iter_norm_p2p_rows_narrow<NP>), grid, block, smem, c->stream, P, t, (const double*)nullptr, (double*)nullptr, flags);
+    } else if (c->kev0)
         hipExtLaunchKernelGGL((k_chain_iter_norm_p2p_rows<NP>), grid, block, smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (double*)nullptr, flags);
     else
         hipLaunchKernelGGL((k_chain_iter_norm_p2p_rows<NP>), grid, block, smem, c->stream, P, t, (const double*)nullptr, (double*)nullptr, flags);
@@ -729,6 +734,14 @@ void launch_resolve_window(Ctx* c, int t) {
 // no unpacking, no key pre-pass in front of k_exch_resolve_rows
 void launch_resolve_rows_window(Ctx* c, int t) {
     const KParams& P = c->P;
+    // a shard of a population past XKEY_PARTNER_MAX: partners of its own chains only, written by the swaps (no second pass over the rows)
+    const bool own = P.Ng > XKEY_PARTNER_MAX && P.N < P.Ng && resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap, P.N) <= (size_t)158 * 1024;
+    if (own) {
+        const size_t sm = resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap, P.N);
+        if (c->kev0) hipExtLaunchKernelGGL((k_exch_resolve_rows<false, true, true>), dim3(1), dim3(XWG), sm, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        else hipLaunchKernelGGL((k_exch_resolve_rows<false, true, true>), dim3(1), dim3(XWG), sm, c->stream, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        return;
+    }
     const size_t smem = resolve_rows_bytes(P.Ng, P.plan_K, P.rows_cap);
     if (P.Ng <= XKEY_PARTNER_MAX) {
         if (c->kev0) hipExtLaunchKernelGGL((k_exch_resolve_rows<true, true>), dim3(1), dim3(XWG), smem, c->stream, c->kev0, c->kev1, 0, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
@@ -1183,6 +1196,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (int)resolve_rows_bytes(XKEY_PARTNER_MAX, XKEY_PARTNER_MAX, XROWS_MAX)));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_rows_bytes(XKEY_MAX, XKEY_MAX, XROWS_MAX)));
+            HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_resolve_rows<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)resolve_rows_bytes(XKEY_PARTNER_MAX, XKEY_PARTNER_MAX, XROWS_MAX)));
         }
@@ -1237,6 +1251,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_any<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows_narrow<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows_narrow<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows_narrow<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows_narrow<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_p2p_rows<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
