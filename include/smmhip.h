@@ -278,9 +278,11 @@ int  smm_bgp_sharded_finish(void* ctx, const void* gathered_dev);
  * chain's accept step stores its record, value and walk slot into every rank's window, and the next iteration's kernel reads
  * its own window.  Where the single shard needs one launch per iteration so does a shard (objfunc_norm, np == nm <= 4,
  * min_improve == 0, N_global <= 8192): every word in a window carries the iteration it belongs to, a reader that finds an older
- * one looks again (nobody waits for an acknowledgement, nothing is counted); everywhere else: chain kernel + push kernel (stores,
- * then one arrival count per 16 chains and rank) + wait + resolve kernel.  The host enqueues nothing else.  Same results as every
- * other form (bit-identical to the single shard).  smm.jl_amd/csrc/smm_p2p.hpp has the protocol.
+ * one looks again (nobody waits for an acknowledgement, nothing is counted); the same objectives at 8192 < N_global <= 32768 (four
+ * and eight shards of 4096): two launches, the exchange resolution reading the tagged words of its window itself and the chain kernel
+ * pushing from its accept step; everywhere else: chain kernel + push kernel (stores, then one arrival count per 16 chains and rank)
+ * + wait + resolve kernel.  The host enqueues nothing else.  Same results as every other form (bit-identical to the single shard).
+ * smm.jl_amd/csrc/smm_p2p.hpp has the protocol.
  *   smm_bgp_p2p_init(ctx, handle_out, window_out): allocates this rank's window (rank = chain_offset / N, equal shards, at most
  *        8 ranks); handle_out (SMM_P2P_HANDLE_BYTES bytes, may be NULL) receives its hipIpcMemHandle_t for the other
  *        PROCESSES, window_out (may be NULL) its device pointer for other contexts of THIS process.

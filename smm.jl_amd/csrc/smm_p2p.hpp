@@ -9,7 +9,7 @@
 // slot straight into every rank's window — fire-and-forget stores over the links.  The next iteration's kernel reads its own
 // window.  No host-enqueued collective, no RCCL kernel, no extra launch.
 //
-// Two forms share the windows:
+// Three forms share the windows:
 //   * INLINE (k_chain_iter_norm_p2p: objfunc_norm, np == nm <= 4, min_improve == 0, N_global <= 8192): ONE launch per iteration
 //     and NOBODY WAITS FOR AN ACKNOWLEDGEMENT.  Everything a reader takes out of a window says which iteration it is from:
 //       slot   uint2  {order_key32(value), chain | tag << 16}                 (the walk strips the tag while staging)
@@ -18,6 +18,11 @@
 //     8-byte stores are single-copy atomic, so a word with the right tag IS that iteration's word (the LL protocol of the
 //     collective libraries).  A reader that finds an older tag looks again with loads that no cache serves (sc0 sc1).
 //     The writer stores and ends: no s_waitcnt for the acknowledgements of remote stores in the tail of every launch, no atomic.
+//   * ROWS (k_chain_iter_norm_p2p_rows + k_exch_resolve_rows<., true>: the same objectives at 8192 < N_global <= 32768 — four and
+//     eight shards of 4096): TWO launches per iteration, still nobody waiting in a kernel of its own.  The accept step stores a
+//     4-byte slot4 word per chain, order_key17(value) << 15 | tag15 (the chain is the word's position); the one resolving workgroup
+//     reads them past the caches, validates word by word, walks, and falls back — inside the launch — to the exact values where a
+//     key says "NaN" or the plan does not fit the rows.  The chain kernel has no walk at all and reads the resolution's result.
 //   * GENERIC (every other objective / population): the chain kernel writes plain records and values into its OWN window, a push
 //     kernel copies them to every other window and counts itself in (one atomic per unit and rank, after the acknowledgements);
 //     k_p2p_wait waits on this rank's counters in front of the stand-alone exchange resolution.

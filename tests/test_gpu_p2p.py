@@ -94,12 +94,13 @@ def test_p2p_inline_equals_single(S, O, G, N, T, fe):
 
 
 @pytest.mark.parametrize("G,N,T,fe,failbox", [(4, 16384, 8, None, False), (8, 32768, 6, 4, False), (2, 20000, 6, None, False), (3, 9000, 8, 3, False),
-                                              (4, 16384, 6, None, True), (2, 10000, 300, None, False)])
+                                              (4, 16384, 6, None, True), (8, 32768, 5, None, True), (2, 10000, 300, None, False)])
 def test_p2p_rows_equals_single(S, G, N, T, fe, failbox):
     # objfunc_norm, min_improve == 0, 8192 < N_global <= 32768 (BASELINE configs[2]: 8 shards of 4096): two launches per iteration and
     # shard — k_exch_resolve_rows<., true> on the tagged slots of the window, k_chain_iter_norm_p2p without the walk.  failbox: the
     # first iteration leaves the value -1 with every chain that starts inside the box (a key that orders nothing: the iteration's
     # exchange is resolved by the fallback on the exact values, unpacked inside the kernel)
+    # (8 x 4096 of 32768: the form that keeps the partners of the rank's own chains only, k_exch_resolve_rows<false, true, true>)
     kw = dict(objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[0.1, 0.3]) if failbox else {}
     prob, opts = cm.serial_normal(N=N, T=T, ns=64, **kw)
     single = S.hip_context(prob, opts)
