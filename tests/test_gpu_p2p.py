@@ -236,10 +236,10 @@ put("result", pickle.dumps(({{f: getattr(h, f) for f in h.FIELDS}}, {{f: getattr
 """
 
 
-@pytest.mark.parametrize("G,N,ns", [(2, 2048, 1000), (4, 1024, 1000), (2, 512, 64), (2, 16384, 64)])
+@pytest.mark.parametrize("G,N,ns", [(2, 2048, 1000), (4, 1024, 1000), (2, 512, 64), (2, 16384, 64), (4, 16384, 64), (8, 32768, 64)])
 def test_p2p_processes_over_hip_ipc(S, tmp_path, G, N, ns):
     # G processes on the one GPU, 16 chains per workgroup: at most 256 workgroups in all, so that waiting kernels cannot keep
-    # the kernels they wait for from starting.  (16384: the rows form — its chain kernels wait only for records whose slots have
+    # the kernels they wait for from starting.  (16384, and 32768 — BASELINE configs[2] as eight processes: the rows form — its chain kernels wait only for records whose slots have
     # arrived, the one waiting workgroup is k_exch_resolve_rows')
     import pickle
     T = 40

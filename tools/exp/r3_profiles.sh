@@ -14,6 +14,9 @@ for cfg in "single shard (no sharding)|$B" \
            "2 PROCESSES on the one GPU x 2048 chains, p2p over HIP IPC|$B --gpus 2 --same-device" \
            "4 PROCESSES on the one GPU x 1024 chains, p2p over HIP IPC|$B --gpus 4 --same-device" \
            "8 PROCESSES on the one GPU x 512 chains, p2p over HIP IPC|$B --gpus 8 --same-device" \
+           "2 PROCESSES on the one GPU x 8192 chains (rows form), p2p over HIP IPC|$B --gpus 2 --same-device --chains 8192" \
+           "4 PROCESSES on the one GPU x 4096 chains (rows form), p2p over HIP IPC|$B --gpus 4 --same-device --chains 4096" \
+           "C3 as 8 PROCESSES on the one GPU x 4096 chains (rows form; time-sliced)|$B --gpus 8 --same-device --workload c3" \
            "16384 chains, single shard (what 4 GPUs hold)|$B --chains 16384" \
            "16384 chains, 1 rank, p2p rows form (SMM_BENCH_FORCE_SHARDED=1)|SMM_BENCH_FORCE_SHARDED=1 $B --chains 16384 --protocol p2p" \
            "C3 32768 chains, single shard|$B --workload c3" \
