@@ -612,6 +612,23 @@ def test_exchange_worst_case_star_pairs(S, O, hooks):
             cm.assert_history_equal(h.history(), b.history(), exact_floats=True)
 
 
+def test_big_plan_with_more_levels_than_its_lds_histogram(S, monkeypatch, hooks):
+    # k_exch_plan_big counts the pairs of the first 1024 levels in LDS and the rest in global memory: an injected list in which every
+    # pair touches chain 0 (1500 pairs, 1500 levels) through the global-memory level plan and walk, against the default kernels
+    N, T = 1500, 5
+    prob, opts = cm.serial_normal(N=N, T=T, ns=64, acc_tuners=np.ones(N), min_improve=0.0)
+    tab = cm.random_tables(prob, opts)
+    tab.pairs[:, :, 0] = 0
+    tab.pairs[:, :, 1] = 1 + (np.arange(N)[None, :] * 7 + np.arange(T)[:, None]) % (N - 1)
+    a = S.hip_context(prob, opts, tab)
+    a.step(T)
+    monkeypatch.setenv("SMMHIP_BIG_EXCHANGE", "1")
+    b = S.hip_context(prob, opts, tab)
+    b.step(T)
+    assert (a.history().exchanged != 0).any()
+    cm.assert_history_equal(a.history(), b.history(), exact_floats=True)
+
+
 def test_rows_fallback_with_slots_from_the_accept_step(S, O):
     # a single shard of more than 8192 chains takes the initial slots of k_exch_resolve_rows from its accept step (no k_exch_keys
     # pre-pass); where an iteration's plan does not fit the rows form — here: an injected pair list 40 levels deep — the kernel falls
