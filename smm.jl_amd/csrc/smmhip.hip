@@ -977,7 +977,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             P.rb_tries = tab->prop_tries; P.user_n = 1;
             P.user_ntab = dupload(c, tab->prop_normals, TN * (size_t)tab->prop_tries * np);
         } else {
-            P.rb_tries = np <= 8 ? 8 : (np <= 32 ? 4 : 2);
+            // tries of mysample whose normals are made ahead of time (k_pregen_rng); later ones come from the generator inside the chain
+            // kernel, ~1.4 us per try and tile.  Past 8 parameters: two (C4, 10 parameters: four cost 9 % — 398 -> 433 M chain-evals/s
+            // with two, 447 with one; a first try outside the support is rare, a second one rarer)
+            P.rb_tries = np <= 8 ? 8 : 2;
         }
         if ((size_t)P.rb_tries * (size_t)((np + 1) / 2) * (size_t)N >= ((size_t)1 << 31))   // (k_pregen_rng indexes one iteration's pieces in 32 bits)
             throw std::string("injected proposal normals: tries x parameters x chains of one iteration must stay below 2^31 pieces");

@@ -6,7 +6,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     import smm_jl_amd
     smm_jl_amd._abi.LIB_PATH = os.path.join(ROOT, "smm.jl_amd", "csrc", sys.argv[2])
-    sys.argv = ["bench.py", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-unfused"]
+    sys.argv = ["bench.py", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-unfused"] + os.environ.get("BENCH_AB_ARGS", "").split()
     import runpy
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
     sys.exit(0)
