@@ -847,7 +847,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     int partner = 0;
     // a hard error raised by an earlier iteration (AlgoBGP.jl:341,409 abort the run): later launches store nothing
     unsigned long long err_word = ERR_NONE;
-    if (ctl || KIND == 2) err_word = *(const volatile unsigned long long*)P.err;   // (dense kind: every wave — they meet at barriers behind the exit below)
+    if (ctl || KIND == 2 || (KIND == 0 && blockDim.x != 64)) err_word = *(const volatile unsigned long long*)P.err;   // (every wave that takes part in the shared epilogue: they meet at barriers behind the exit below)
     // wave 1: problem constants, requested now and written to LDS after the walk
     // (objectives without a simulation are launched with the control wave only, 64 lanes per tile: it loads the constants itself)
     const bool slim = KIND == 0 && blockDim.x == 64;
@@ -1218,10 +1218,13 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
     const bool sumsq = KIND != 0 && P.obj != SMM_OBJ_USER && P.obj != SMM_OBJ_BANANA;
     // (the dense kind has all its waves here: the terms, and below the copies and the stores of the long blocks, are shared by the
     // tile's 512 lanes, 32 per chain — the control wave alone: 7.3 + 3.5 us per iteration at 50 parameters and 50 moments)
+    // (so do objectives without a simulation wherever the tile was launched with all its waves — the key form of C4: its other waves
+    // have nothing to do after the walk: 403 -> 410 M chain-evals/s)
     constexpr int LPC2 = WG / CT;   // lanes per chain when every wave of the tile takes part
     const int cc2 = tid / LPC2, r2 = tid % LPC2;
-    const bool valid2 = KIND == 2 && tile * CT + cc2 < N;
-    if constexpr (KIND == 2) {
+    const bool coop_epi = KIND == 2 || (KIND == 0 && !slim);
+    const bool valid2 = coop_epi && tile * CT + cc2 < N;
+    if (coop_epi) {
         if (valid2 && sumsq) {
             double* smk = S.h + cc2 * HW + H_PARAMS + np;
             double* vkk = S.rout + cc2 * RW;          // (the proposal's scratch: free again)
@@ -1298,7 +1301,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if constexpr (KIND == 2) {
+    if (coop_epi) {
         __syncthreads();   // the accept step's results (history head, record head, state block) are every wave's now
         if (valid2) {      // (a chain's 32 lanes sit in one wave: its copies are in place before its stores read them)
             const int c2 = tile * CT + cc2;
