@@ -37,7 +37,7 @@ rm -rf /tmp/kt2 && SMM_BENCH_FORCE_SHARDED=1 timeout 300 rocprofv3 --kernel-trac
 cp $(find /tmp/kt2 -name "*kernel_stats.csv" | head -1) $out/p2p_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
 bash tools/exp/r3_c3_stats.sh > $out/c3_kernel_stats.txt 2>&1
-{ echo "# tools/exp/rows_own_time.sh: what each rank of 8 (32768 chains) and of 4 (16384) launches per iteration, measured by running the shards as contexts of one"
+{ echo "# tools/exp/rows_own_time.sh: what each rank of 8 (32768 chains), of 4 (16384) and of 2 (8192: the inline form, one launch) launches per iteration, measured by running the shards as contexts of one"
   echo "# process on ONE GPU, one context at a time (rocprofv3 --kernel-trace --stats; objfunc_norm 2p/2m, ns = 10000, 40 iterations)"
   bash tools/exp/rows_own_time.sh 2>&1 | grep -v "^W2026"; } > $out/c3_per_rank.txt
 cd $GRAFT_REPO_ROOT

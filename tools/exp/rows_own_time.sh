@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
-for cfg in "8 32768" "4 16384"; do
+for cfg in "8 32768" "4 16384" "2 8192"; do
 rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/tools/exp/rows_own_time.py $cfg > /tmp/o.txt 2>&1
 tail -1 /tmp/o.txt
 python - <<'PY'
