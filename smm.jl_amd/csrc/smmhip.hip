@@ -503,6 +503,9 @@ void launch_resolve(Ctx* c, int t, const double* gathered) { launch_resolve_p(c,
 //   <= 65535        anything else / other dist_fun   any        k_exch_resolve_lvl_big       16-byte slots, global memory
 //   above, or K > N_global                           any        k_exch_resolve_any           barrier rounds, global atomics
 //
+// (the p2p form of a sharded run launches k_exch_resolve_rows itself where this table says _rows — launch_resolve_rows_window:
+//  <., true> reads the tagged slots of its window instead of a key pre-pass, <false, true, true> keeps the partners of the rank's
+//  own chains only; every other p2p population resolves from the window's plain values through this table.)
 // (single shards of objfunc_norm up to 4096 chains do not get here in steady state: their chain kernel walks inline.)  The test
 // build can force an entry (SMM_TEST_HOOKS: SMMHIP_*_EXCHANGE, SMMHIP_KEY_WALK) and adds the ticket kernel k_exch_resolve_lds.
 enum ExchKernel { XK_LEAN, XK_LVL, XK_LVL_SOA, XK_TICKETS, XK_ROWS, XK_KEY, XK_LVL_BIG, XK_ANY };
