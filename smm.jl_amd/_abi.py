@@ -138,6 +138,8 @@ SYMBOLS = [
     ("smm_get_timing", C.c_int, [C.c_void_p, C.POINTER(smm_timing_t)]),
     ("smm_get_Z", C.c_int, [C.c_void_p, c_double_p]),
     ("smm_set_profiling", C.c_int, [C.c_void_p, C.c_int32]),
+    ("smm_set_persistent", C.c_int, [C.c_void_p, C.c_int32]),
+    ("smm_get_persistent", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 ]
 
 

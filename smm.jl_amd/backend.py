@@ -261,6 +261,16 @@ class BGPContext:
         """0/False off; 1/True event brackets; 2 per-kernel begin/end timestamps (see include/smmhip.h)"""
         self._check(self._fn("set_profiling")(self._ctx, int(on)))
 
+    def set_persistent(self, on=True):
+        """the persistent form of step() (one launch per look-ahead window; include/smmhip.h): on by default where a context qualifies"""
+        self._check(self._fn("set_persistent")(self._ctx, int(bool(on))))
+
+    def persistent_info(self):
+        """(would the next step take the persistent form, launches of it so far, repairs so far)"""
+        a, l, r = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._fn("get_persistent")(self._ctx, C.byref(a), C.byref(l), C.byref(r)))
+        return bool(a.value), int(l.value), int(r.value)
+
     def Z(self):
         z = np.empty((self.nm, self.problem.ns))
         self._check(self._fn("get_Z")(self._ctx, A.dptr(z)))

@@ -40,7 +40,7 @@ __device__ inline bool exchange_walk_tile_cone(const KParams& P, const int tx, u
     const int c_own = wg * P.cone_ct + tid;
     if (tid < P.cone_ct) own = P.slot8[c_own];
     if (okw == 0u || wflags != 0u || (uint32_t)(size_t)lds != 0u) return false;
-    const int nsub = __builtin_amdgcn_readlane((int)hv, 0);
+    const int nsub = __builtin_amdgcn_readlane((int)hv, 0) & 0xffff;   // (high half: the persistent kernel's gather count)
     uint2* slot = (uint2*)lds;
     const uint32_t dummy = ((8u >> US) * Ng4) | (((8u >> US) * (Ng4 + 1u)) << 16);   // the two slots behind the chains': keys 1 < 2, "no swap"
 #pragma unroll

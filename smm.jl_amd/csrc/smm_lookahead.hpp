@@ -303,20 +303,22 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         return;
     }
     const int LS = nlev + 1;
-    int wpp = (int)(((size_t)150 * 1024) / ((size_t)K * 4 + (size_t)32 * LS * 4));   // words of bits per pair and pass
+    int wpp = (int)(((size_t)150 * 1024) / ((size_t)K * 4 + (size_t)32 * LS * 4 + 32 * 4));   // words of bits per pair and pass
     if (wpp > (tiles + 31) / 32) wpp = (tiles + 31) / 32;
     if (wpp < 1) { if (tid == 0) *o_ok = 0u; return; }
     __shared__ uint32_t s_bad;
     if (tid == 0) s_bad = 0u;
     uint32_t* need = (uint32_t*)xsm;                 // [K][wpp]
     uint32_t* lcnt = need + (size_t)K * wpp;         // [32 wpp][LS]: pairs of (workgroup, level); then: where the level's words start
+    uint32_t* gcnt = lcnt + (size_t)32 * wpp * LS;   // [32 wpp]: chains of other workgroups in the cone (the persistent kernel's gather list)
+    uint16_t* o_gl = P.cone_gather ? P.cone_gather + (size_t)blockIdx.x * tiles * CONE_GCAP : nullptr;
     uint32_t* o_hdr = (uint32_t*)P.cone_hdr + (size_t)blockIdx.x * tiles * CONE_HDRW;
     uint32_t* o_cp = (uint32_t*)P.cone_pairs + (size_t)blockIdx.x * tiles * (CONE_LEVELS * 64);
     const uint32_t ct = (uint32_t)P.cone_ct;
     for (int b0 = 0; b0 < tiles; b0 += 32 * wpp) {   // workgroups b0 .. b0 + 32 wpp - 1
         const int nb = min(32 * wpp, tiles - b0);
         __syncthreads();   // (first pass: everything in LDS is dead — pairs and levels are in registers)
-        for (int x = tid; x < K * wpp + 32 * wpp * LS; x += XWG) need[x] = 0u;
+        for (int x = tid; x < K * wpp + 32 * wpp * LS + 32 * wpp; x += XWG) need[x] = 0u;
         __syncthreads();
         auto seed = [&](const uint32_t c, const int q) {
             const uint32_t b = (c - (uint32_t)P.offset) / ct - (uint32_t)b0;   // (single shard: offset 0, whole tiles)
@@ -394,8 +396,28 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
                         bits &= bits - 1u;
                         const uint32_t dst = atomicAdd(&lcnt[b * LS + lvq[m]], 1u);
                         if (dst < (uint32_t)(CONE_LEVELS * 64)) o_cp[(size_t)(b0 + b) * (CONE_LEVELS * 64) + dst] = word;
+                        // a chain is in the cones its FIRST pair is in (the bits are monotone along a chain: an earlier pair of the
+                        // chain carries every bit of a later one) — that is where its initial slot is needed
+                        if (o_gl) {
+                            if (rri[m] == 0 && ((uint32_t)ci[m] - (uint32_t)P.offset) / ct != (uint32_t)b0 + b) {
+                                const uint32_t g = atomicAdd(&gcnt[b], 1u);
+                                if (g < (uint32_t)CONE_GCAP) o_gl[(size_t)(b0 + b) * CONE_GCAP + g] = ci[m];
+                            }
+                            if (rrj[m] == 0 && ((uint32_t)cj[m] - (uint32_t)P.offset) / ct != (uint32_t)b0 + b) {
+                                const uint32_t g = atomicAdd(&gcnt[b], 1u);
+                                if (g < (uint32_t)CONE_GCAP) o_gl[(size_t)(b0 + b) * CONE_GCAP + g] = cj[m];
+                            }
+                        }
                     }
                 }
+            }
+        }
+        if (o_gl) {
+            __syncthreads();
+            for (int b = tid; b < nb; b += XWG) {
+                const uint32_t g = gcnt[b];
+                if (g > (uint32_t)CONE_GCAP) atomicOr(&s_bad, 1u);
+                o_hdr[(size_t)(b0 + b) * CONE_HDRW] |= (g < (uint32_t)CONE_GCAP ? g : (uint32_t)CONE_GCAP) << 16;
             }
         }
     }

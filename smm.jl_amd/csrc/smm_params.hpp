@@ -80,6 +80,16 @@ struct KParams {
     const uint32_t* cone_hdr;        // [W][tiles][CONE_HDRW]: word 0 = sub-levels; from word 1: the pairs of sub-level s, one byte each
     const uint32_t* cone_pairs;      // [W][tiles][CONE_LEVELS * 64]: sub-level s = words 64 s .. 64 s + (its count) - 1, as lv_pairs_p words
     int cone_tiles, cone_ct;         // workgroups, chains per workgroup
+    uint16_t* cone_gather;           // [W][tiles][CONE_GCAP] (k_chain_persist_norm; null otherwise): the chains of OTHER workgroups whose initial slots the
+                                     //          cone needs; their number is in the high half of the header's word 0
+    // ... the ring of k_chain_persist_norm (smm_chain_persist.hpp; null otherwise): tagged walk slots and self-validating records of the
+    // last PR_K iterations, the tiles' progress words, the launch's abort word
+    uint2* pr_slot;                  // [PR_K][Ng + 4]
+    uint4* pr_rec;                   // [PR_K][Ng][RW]
+    uint32_t* pr_progress;           // [tiles]
+    uint32_t* pr_ctl;                // [0]: == pr_epoch when a tile of this launch gave up waiting
+    uint32_t pr_epoch;               // launches of the persistent kernel so far (never 0): part of every tag
+    int exch_from;                   // first iteration with an exchange (AlgoBGP.jl:637)
     // state
     double* cs;                // [N][CSW]
     unsigned long long* xres;  // [Ng]
@@ -146,6 +156,7 @@ __host__ __device__ inline double dist_fun_eval(const int kind, const double a, 
 }
 constexpr int LV_OFFP = 40, LV_MAXLEV = 31;
 constexpr int CONE_LEVELS = 32, CONE_HDRW = 1 + CONE_LEVELS / 4;   // a workgroup's cone: at most 32 sub-levels of 64 pairs (smm_cone.hpp)
+constexpr int CONE_GCAP = 512;   // ... and at most this many chains of other workgroups (the persistent kernel's gather list, 1 KB)
 // 32-bit order key of a chain value: for any two non-NaN doubles, key(a) > key(b) implies a > b and key(a) < key(b) implies a < b
 // (the high word of the double, made monotone across the sign; -0.0 counts as +0.0); equal keys decide nothing.
 __host__ __device__ inline uint32_t order_key32(const double v) {

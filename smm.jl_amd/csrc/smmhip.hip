@@ -56,6 +56,7 @@ using namespace smm;
 #include "smm_chain.hpp"
 #include "smm_p2p.hpp"
 #include "smm_chain_norm.hpp"
+#include "smm_chain_persist.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
 
@@ -232,6 +233,22 @@ struct Ctx {
     bool p2p_mode_inline = false;              // ... and is what the windows currently hold (decided at every publication)
     bool p2p_unwaited = false;                 // nobody has waited for the arrivals of the last push yet
     double* ext_vals_out = nullptr;            // p2p generic form: the accept step's values go into the window
+    // the persistent chain kernel (smm_chain_persist.hpp): one launch for a run of iterations
+    bool persist = false;                      // this context can run it (objfunc_norm np <= 2, single shard of at most one tile per CU, key walk)
+    int persist_on = 1;                        // smm_set_persistent
+    bool persist_broken = false;               // a launch gave up waiting (tiles not resident together?): the form is off for this context
+    uint32_t pr_epoch = 0;                     // launches so far
+    int persist_launches = 0, persist_repairs = 0;
+    bool in_repair = false;
+    // ... and what persist_repair restores when a launch of it ends with the error word set: the state before the FIRST such launch
+    // since the last check of the error word
+    bool snap_valid = false;
+    int snap_iter = 0, snap_cur = 0, snap_slots_iter = -1;
+    bool snap_pending = false, snap_prev_open = false, snap_unresolved = false, snap_exch_done = false;
+    double *snap_cs = nullptr, *snap_rec = nullptr, *snap_vals[2] = {nullptr, nullptr}, *hist_fill = nullptr;
+    uint2* snap_slot8[2] = {nullptr, nullptr};
+    unsigned long long* snap_xres = nullptr;
+    uint32_t snap_walk_flags[4] = {0, 0, 0, 0};
 };
 
 #define HIPCHK(call)                                                                                  \
@@ -319,7 +336,7 @@ void ensure_windows(Ctx* c, int t) {
     }
     if (c->lds_exchange && P.Ng > 1 && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->plan_cap, P.T - t + 1);
-        hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), c->cone ? std::max(plan_lds_bytes(P.Ng, P.plan_K), plan_cone_bytes()) : plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
+        hipLaunchKernelGGL(k_exch_plan, dim3(W), dim3(XWG), (c->cone || c->persist) ? std::max(plan_lds_bytes(P.Ng, P.plan_K), plan_cone_bytes()) : plan_lds_bytes(P.Ng, P.plan_K), c->stream, P, t, c->win_plan,
                            c->win_plan_mi, c->win_lv_pairs, c->win_lv_mi, c->win_lv_off, c->win_lv_pairs_p, c->win_lv_offp);
         c->plan_t0 = t; c->plan_w = W;
         P.plan = c->win_plan; P.plan_mi = c->win_plan_mi; P.plan_t0 = t;
@@ -601,10 +618,19 @@ void flush(Ctx* c) {
     c->prev_open = false;
 }
 
+void persist_repair(Ctx* c);
 int check_device_error(Ctx* c) {
     if (c->failed) return c->failed;   // err holds the message of the first failure
     unsigned long long e = ERR_NONE;
     HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
+    if (e != ERR_NONE && c->snap_valid && !c->in_repair) {
+        // launches of the persistent kernel ran since the last check: their tiles do not stop at the failing iteration.  Back to the
+        // state before the first of them, and the same iterations again on the one-launch-per-iteration path, which does.
+        if ((e & 3) == 3) c->persist_broken = true;   // (a tile gave up waiting, or a cone did not fit: not this form again)
+        persist_repair(c);
+        HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
+    }
+    if (!c->in_repair) c->snap_valid = false;
     if (e == ERR_NONE) return SMM_OK;
     const int kind = (int)(e & 3), chain = (int)((e >> 2) & 0xffffffffu), it = (int)(e >> 34);
     char b[256];
@@ -754,6 +780,179 @@ void launch_resolve_rows_window(Ctx* c, int t) {
         else hipLaunchKernelGGL((k_exch_resolve_rows<false, true>), dim3(1), dim3(XWG), smem, c->stream, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     }
 }
+// ---- the persistent chain kernel (smm_chain_persist.hpp) ----
+template <int NP>
+void launch_chain_persist_t(Ctx* c, const PersistArgs& A) {
+    const dim3 grid((A.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
+    const size_t smem = persist_smem_bytes(A.Ng, NP);
+    if (c->kev0)
+        hipExtLaunchKernelGGL((k_chain_persist_norm<NP>), grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
+    else
+        hipLaunchKernelGGL((k_chain_persist_norm<NP>), grid, block, smem, c->stream, A);
+}
+// can the iterations from c->iter + 1 on run as one launch of it?  At least two (a single iteration is the ordinary kernel's), behind
+// an iteration some chain kernel has completed (the launch continues from the plain state blocks: no first iteration, no uploaded
+// state, no exchange applied by the three-phase calls), and an exchange left to "the next chain kernel" must have its plan in the
+// current window together with this iteration's.
+bool persist_usable(const Ctx* c, int n_left) {
+    if (!(c->persist && c->persist_on && !c->persist_broken && !c->in_repair && !c->nan_values && n_left >= 2 && !c->ext_rec_in && !c->ext_rec_out &&
+          !c->ext_vals_out && !c->rec_external && c->P.N == c->P.Ng))
+        return false;
+    if (c->iter < 1 || !c->prev_open || c->exch_done || (c->pending && !c->unresolved)) return false;
+    const int t0 = c->iter + 1;
+    if (c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) return false;
+    return true;
+}
+// the state a failed launch of the persistent kernel is rolled back to (device copies on the stream, before anything of the step runs)
+void persist_snapshot(Ctx* c) {
+    const KParams& P = c->P;
+    const size_t N = P.N;
+    HIPCHK(hipMemcpyAsync(c->snap_cs, P.cs, N * CSW * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->snap_rec, c->rec[c->cur], N * P.RW * 8, hipMemcpyDeviceToDevice, c->stream));
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(hipMemcpyAsync(c->snap_vals[b], c->vals_buf[b], (N + 4) * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (c->slot8_buf[b]) HIPCHK(hipMemcpyAsync(c->snap_slot8[b], c->slot8_buf[b], (N + 4 + 128) * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(c->snap_xres, P.xres, (size_t)P.Ng * 8, hipMemcpyDeviceToDevice, c->stream));
+    c->snap_iter = c->iter; c->snap_cur = c->cur; c->snap_slots_iter = c->slots_iter;
+    c->snap_pending = c->pending; c->snap_prev_open = c->prev_open; c->snap_unresolved = c->unresolved; c->snap_exch_done = c->exch_done;
+    c->snap_valid = true;
+}
+// iterations c->iter + 1 .. as ONE launch, as far as the look-ahead windows reach; returns how many it covers (0: not this time)
+int launch_chain_persist(Ctx* c, int n_left) {
+    const int t0 = c->iter + 1;
+    if (!c->unresolved) ensure_windows(c, t0);   // (with an exchange pending the window holds its plan and this iteration's: persist_usable)
+    const bool pregen = !(c->norm_fast && !c->P.user_ntab && !c->P.user_utab);
+    if (pregen && !(t0 >= c->rng_t0 && t0 < c->rng_t0 + c->rng_w)) ensure_windows(c, t0);
+    int t1 = std::min(c->iter + n_left, c->plan_t0 + c->plan_w - 1);
+    if (pregen) t1 = std::min(t1, c->rng_t0 + c->rng_w - 1);
+    t1 = std::min(t1, t0 + PR_MAX_ITERS - 1);
+    if (t1 - t0 + 1 < 2) return 0;
+    if (!c->snap_valid) persist_snapshot(c);
+    ++c->pr_epoch;
+    if ((c->pr_epoch & 0x7fu) == 0u) {   // the slot tags' epoch bits start over: nothing older may look current
+        HIPCHK(hipMemsetAsync(c->P.pr_slot, 0, persist_ring_slot_bytes(c->P.Ng), c->stream));
+        HIPCHK(hipMemsetAsync(c->P.pr_rec, 0, persist_ring_rec_bytes(c->P.Ng, c->P.RW), c->stream));
+    }
+    KParams& P = c->P;
+    P.pr_epoch = c->pr_epoch;
+    point_values(c, P, t0 - 1, t1);   // (nothing is read from the value arrays: the last iteration writes them)
+    PersistArgs A{};
+    A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
+    A.pr_slot = P.pr_slot; A.pr_rec = P.pr_rec; A.pr_progress = P.pr_progress; A.pr_ctl = P.pr_ctl;
+    A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
+    A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
+    A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp;
+    A.rb = pregen ? P.rb : nullptr;
+    A.N = P.N; A.Ng = P.Ng; A.ns = P.ns; A.zstride = P.zstride; A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from;
+    A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
+    A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
+    A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
+    A.walk_first = c->unresolved ? 1 : 0;
+    A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed;
+    if (P.np == 1) launch_chain_persist_t<1>(c, A); else launch_chain_persist_t<2>(c, A);
+    c->cur ^= 1;
+    ++c->persist_launches;
+    return t1 - t0 + 1;
+}
+
+// n_iters iterations onto the stream (smm_bgp_step_async, and persist_repair with the persistent kernel off)
+void enqueue_iterations(Ctx* c, int n_iters) {
+    int slot = 0;   // profiling: events of this launch
+    for (int it = 0; it < n_iters;) {
+        const int t = c->iter + 1;
+        int n = 0;
+        if (persist_usable(c, n_iters - it)) {
+            if (c->profiling == 1) HIPCHK(hipEventRecord(c->pev[4 * slot], c->stream));
+            if (c->profiling == 2) { c->kev0 = c->pev[4 * slot]; c->kev1 = c->pev[4 * slot + 1]; }
+            n = launch_chain_persist(c, n_iters - it);
+            c->kev0 = c->kev1 = nullptr;
+        }
+        if (n > 0) {
+            if (c->profiling == 1) { for (int e = 1; e < 4; ++e) HIPCHK(hipEventRecord(c->pev[4 * slot + e], c->stream)); }
+            if (c->profiling) c->pev_exch[slot] = 0;
+            ++slot;
+            const int t1 = c->iter + n;
+            c->prev_open = true;
+            c->pending = false; c->unresolved = false;
+            if (exchange_active(c, t1)) { c->unresolved = true; c->pending = true; }   // resolved in the prologue of the next chain kernel (or by resolve_now)
+            c->iter = t1; c->exch_done = false;
+            it += n;
+            continue;
+        }
+        // an exchange left to this chain kernel needs its plan: resolve it now if the plan window is about to move on
+        if (c->unresolved && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) resolve_now(c);
+        ensure_windows(c, t);
+        const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0) | (c->unresolved ? F_WALK_INLINE : 0);
+        const bool kscoped = c->profiling == 2 && c->lvl_exchange && c->lvl_wg == 1024;
+        if (c->profiling && !kscoped) HIPCHK(hipEventRecord(c->pev[4 * slot], c->stream));
+        if (kscoped) { c->kev0 = c->pev[4 * slot]; c->kev1 = c->pev[4 * slot + 1]; }
+        launch_chain_iter(c, t, flags);
+        c->kev0 = c->kev1 = nullptr;
+        if (c->profiling && !kscoped) HIPCHK(hipEventRecord(c->pev[4 * slot + 1], c->stream));
+        c->prev_open = true;
+        c->pending = false;
+        if (c->profiling) c->pev_exch[slot] = 0;
+        c->unresolved = false;
+        if (exchange_active(c, t)) {
+            if (c->inline_walk && !(c->gen_keys && (c->deep_plan || c->nan_values))) {   // (the key form has no second walk to fall back to)
+                c->unresolved = true;   // resolved in the prologue of the next chain kernel (or by resolve_now)
+            } else {
+                if (kscoped) { c->kev0 = c->pev[4 * slot + 2]; c->kev1 = c->pev[4 * slot + 3]; c->pev_exch[slot] = 1; }
+                launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange || c->key_exchange) ? nullptr : c->rec[c->cur]);
+                c->kev0 = c->kev1 = nullptr;
+            }
+            c->pending = true;
+        }
+        if (c->profiling && !kscoped) { HIPCHK(hipEventRecord(c->pev[4 * slot + 2], c->stream)); HIPCHK(hipEventRecord(c->pev[4 * slot + 3], c->stream)); }
+        c->iter = t; c->exch_done = false;
+        ++slot; ++it;
+    }
+    if (c->profiling) c->pev_iters = slot;
+}
+
+// A launch of the persistent kernel ended with the error word set (a hard error of the algorithm, AlgoBGP.jl:341,409 — or a tile gave
+// up waiting).  Its tiles do not stop at the failing iteration, so: the state of before (persist_snapshot), the history rows of the
+// iterations since filled as the constructor fills them, the error word cleared, and the same iterations again, one launch each —
+// that path stops at the failing iteration with the documented state (include/smmhip.h), or runs through if the failure was the form's.
+void persist_repair(Ctx* c) {
+    KParams& P = c->P;
+    const size_t N = P.N;
+    const int n = c->iter - c->snap_iter;
+    c->in_repair = true;
+    ++c->persist_repairs;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(P.cs, c->snap_cs, N * CSW * 8, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(c->rec[c->snap_cur], c->snap_rec, N * P.RW * 8, hipMemcpyDeviceToDevice));
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(hipMemcpy(c->vals_buf[b], c->snap_vals[b], (N + 4) * 8, hipMemcpyDeviceToDevice));
+        if (c->slot8_buf[b]) HIPCHK(hipMemcpy(c->slot8_buf[b], c->snap_slot8[b], (N + 4 + 128) * 8, hipMemcpyDeviceToDevice));
+    }
+    HIPCHK(hipMemcpy(P.xres, c->snap_xres, (size_t)P.Ng * 8, hipMemcpyDeviceToDevice));
+    // (an exchanged chain's row of iteration snap_iter may have been rewritten by the first launch's prologue: the replay rewrites it identically)
+    for (int t = c->snap_iter; t < c->iter; ++t)
+        HIPCHK(hipMemcpy(P.hrec + (size_t)t * N * P.HW, c->hist_fill, N * P.HW * 8, hipMemcpyDeviceToDevice));
+    const unsigned long long e = ERR_NONE;
+    HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
+    c->iter = c->snap_iter; c->cur = c->snap_cur; c->slots_iter = c->snap_slots_iter;
+    c->pending = c->snap_pending; c->prev_open = c->snap_prev_open; c->unresolved = c->snap_unresolved; c->exch_done = c->snap_exch_done;
+    c->plan_w = 0; c->rng_w = 0;   // (the windows are rebuilt: cheap, and nothing assumes where the failed run left them)
+    const int prof = c->profiling;
+    c->profiling = 0;
+    enqueue_iterations(c, n);
+    c->profiling = prof;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->in_repair = false;
+    c->snap_valid = false;
+}
+// calls that read or change the run's state other than by stepping: first make sure that what stands there is final (see persist_repair)
+void settle_persist(Ctx* c) {
+    if (!c->snap_valid) return;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)check_device_error(c);
+}
+
 }  // namespace
 
 extern "C" {
@@ -892,6 +1091,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         KParams& P = c->P;
         c->obj = user_obj ? SMM_OBJ_USER : prob->objective_id;
         c->exchange_from = opts->exchange_from_iter;
+        P.exch_from = opts->exchange_from_iter;
         {
             const char* e = SMM_HOOK("SMMHIP_ANY_EXCHANGE");  // test hook: force the any-size resolution kernel
             c->force_any_exchange = e && e[0] == '1';
@@ -1083,8 +1283,19 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             // the workgroups' cones of the inline key walk (smm_cone.hpp): where k_chain_iter walks 8192 chains' keys in every workgroup
             const char* nc = SMM_HOOK("SMMHIP_NO_CONE");   // test hook: every workgroup walks the whole list
             const bool want_cone = c->gen_keys && c->tpw == 2 && N % 32 == 0 && N / 32 <= 256 && !(nc && nc[0] == '1');
+            // the persistent chain kernel (smm_chain_persist.hpp): objfunc_norm with at most two moments (the lane's shocks of ONE moment
+            // stay in registers), a single shard of at most one 16-chain tile per CU, the key walk's conditions (one threshold 0, `-`),
+            // a pair list the lean plan holds
+            const char* pe = SMM_HOOK("SMMHIP_PERSIST");   // test hook: "0" never
+            int n_cus = 256;
+            (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            const bool want_persist = c->norm_fast && np <= 2 && ns <= WG * PR_ZR && N == Ng && Ng >= 2 && c->inline_walk && P.mi_uniform && P.mi_value == 0.0 &&
+                                      opts->dist_fun == SMM_DIST_MINUS && K <= XLVL_MAX && Ng <= XLVL_MAX && !c->deep_plan && (N + NORM_CT - 1) / NORM_CT <= n_cus &&
+                                      persist_smem_bytes(Ng, np) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
+            const size_t persist_tiles = (size_t)(N + NORM_CT - 1) / NORM_CT;
             const size_t plan_iter = (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
-                                     (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / 32) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0);
+                                     (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / 32) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
+                                     (want_persist ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
             c->win_cap = std::min(c->win_cap, T);
             c->plan_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)1536 << 20) / plan_iter));
@@ -1139,6 +1350,24 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                             P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64));
                             HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
                         }
+                        if (want_persist && lean_walk_unit(Ng) == 8 && c->norm_fast) {
+                            const size_t tiles = persist_tiles;
+                            P.cone_tiles = (int)tiles; P.cone_ct = NORM_CT;
+                            P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
+                            P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
+                            P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);   // (+: whole 1 KB pieces are fetched)
+                            P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP + 512);
+                            HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
+                            P.pr_slot = (uint2*)dalloc<unsigned char>(c, persist_ring_slot_bytes(Ng));
+                            P.pr_rec = (uint4*)dalloc<unsigned char>(c, persist_ring_rec_bytes(Ng, P.RW));
+                            P.pr_progress = dalloc<uint32_t>(c, tiles);
+                            P.pr_ctl = dalloc<uint32_t>(c, 4);
+                            HIPCHK(hipMemset(P.pr_slot, 0, persist_ring_slot_bytes(Ng)));
+                            HIPCHK(hipMemset(P.pr_rec, 0, persist_ring_rec_bytes(Ng, P.RW)));
+                            HIPCHK(hipMemset(P.pr_progress, 0, tiles * 4));
+                            HIPCHK(hipMemset(P.pr_ctl, 0, 16));
+                            c->persist = true;
+                        }
                     }
                 }
             }
@@ -1187,6 +1416,25 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         {
             const unsigned long long e = ERR_NONE;
             HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
+        }
+        if (c->persist) {
+            // all tiles of the persistent kernel must be resident together (they wait for each other): one per CU
+            const size_t smem = persist_smem_bytes(Ng, np);
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_persist_norm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_persist_norm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            int per_cu = 0, cus = 0;
+            if (np == 1) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_persist_norm<1>, NORM_WG, smem));
+            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_persist_norm<2>, NORM_WG, smem));
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            if ((N + NORM_CT - 1) / NORM_CT > per_cu * cus) c->persist = false;
+        }
+        if (c->persist) {
+            c->snap_cs = dalloc<double>(c, (size_t)N * CSW);
+            c->snap_rec = dalloc<double>(c, (size_t)N * P.RW);
+            for (int b = 0; b < 2; ++b) { c->snap_vals[b] = dalloc<double>(c, (size_t)N + 4); c->snap_slot8[b] = dalloc<uint2>(c, (size_t)N + 4 + 128); }
+            c->snap_xres = dalloc<unsigned long long>(c, Ng);
+            c->hist_fill = dalloc<double>(c, (size_t)N * P.HW);
+            HIPCHK(hipMemcpy(c->hist_fill, P.hrec, (size_t)N * P.HW * 8, hipMemcpyDeviceToDevice));   // (a row of the constructor's fill)
         }
         if (c->big_exchange)
             HIPCHK(hipFuncSetAttribute((const void*)k_exch_plan_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_big_lds_bytes(65535)));
@@ -1346,38 +1594,9 @@ int smm_bgp_step_async(void* ctx, int32_t n_iters) {
         }
         c->pev_iters = 0;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
-        for (int it = 0; it < n_iters; ++it) {
-            const int t = c->iter + 1;
-            // an exchange left to this chain kernel needs its plan: resolve it now if the plan window is about to move on
-            if (c->unresolved && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) resolve_now(c);
-            ensure_windows(c, t);
-            const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0) | (c->unresolved ? F_WALK_INLINE : 0);
-            const bool kscoped = c->profiling == 2 && c->lvl_exchange && c->lvl_wg == 1024;
-            if (c->profiling && !kscoped) HIPCHK(hipEventRecord(c->pev[4 * it], c->stream));
-            if (kscoped) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
-            launch_chain_iter(c, t, flags);
-            c->kev0 = c->kev1 = nullptr;
-            if (c->profiling && !kscoped) HIPCHK(hipEventRecord(c->pev[4 * it + 1], c->stream));
-            c->prev_open = true;
-            c->pending = false;
-            if (c->profiling) c->pev_exch[it] = 0;
-            c->unresolved = false;
-            if (exchange_active(c, t)) {
-                if (c->inline_walk && !(c->gen_keys && (c->deep_plan || c->nan_values))) {   // (the key form has no second walk to fall back to)
-                    c->unresolved = true;   // resolved in the prologue of the next chain kernel (or by resolve_now)
-                } else {
-                    if (kscoped) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
-                    launch_resolve(c, t, (c->lvl_exchange || c->lds_exchange || c->key_exchange) ? nullptr : c->rec[c->cur]);
-                    c->kev0 = c->kev1 = nullptr;
-                }
-                c->pending = true;
-            }
-            if (c->profiling && !kscoped) { HIPCHK(hipEventRecord(c->pev[4 * it + 2], c->stream)); HIPCHK(hipEventRecord(c->pev[4 * it + 3], c->stream)); }
-            c->iter = t; c->exch_done = false;
-        }
+        enqueue_iterations(c, n_iters);
         HIPCHK(hipEventRecord(c->ev1, c->stream));
         HIPCHK(hipGetLastError());
-        if (c->profiling) c->pev_iters = n_iters;
         c->pending_timing = true;
         c->timing.iters = n_iters;
         c->timing.chain_evals = (int64_t)n_iters * c->P.N;
@@ -1402,6 +1621,8 @@ int smm_bgp_local_step(void* ctx) {
     if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         const int t = c->iter + 1;
         // smm_bgp_step leaves the exchange of its last iteration to the next chain kernel (inline walk): the three-phase
         // form reads P.xres, so resolve it now (local_step after step read an unresolved xres)
@@ -1431,6 +1652,8 @@ int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathere
     if (c->unresolved) return fail(c, SMM_ERR_STATE, "mixing smm_bgp_step and smm_bgp_sharded_step without a flush");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         const int t = c->iter + 1;
         const KParams& P = c->P;
         int flags = (c->prev_open ? F_CLOSE_PREV : 0);
@@ -1493,6 +1716,8 @@ int smm_bgp_sharded_finish(void* ctx, const void* gathered_dev) {
     if (!gathered_dev) return SMM_ERR_INVALID_ARG;
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         const KParams& P = c->P;
         int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
         if (c->pending_ext) {
@@ -1609,6 +1834,8 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
     if (c->a2a_open) return fail(c, SMM_ERR_STATE, "smm_bgp_a2a_apply_dev comes first");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         KParams& P = c->P;
         const P2PLayout L = p2p_layout(P.Ng, P.RW);
         if (c->profiling == 2) {
@@ -1711,6 +1938,8 @@ int smm_bgp_p2p_finish(void* ctx) {
     if (!c->p2p_current || !c->rec_external) return SMM_OK;
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         const KParams& P = c->P;
         const P2PLayout L = p2p_layout(P.Ng, P.RW);
         int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
@@ -1744,6 +1973,8 @@ int smm_bgp_export_records_dev(void* ctx, void* rec_dev) {
     if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         // after smm_bgp_step the exchange of the last iteration is still pending (resolved or not): the exported records must
         // be the ones AFTER that exchange, as the three-phase protocol defines them
         if (c->pending || c->unresolved) flush(c);
@@ -1763,6 +1994,8 @@ int smm_bgp_exchange_dev(void* ctx, const void* gathered_dev) {
     if (c->pending || c->exch_done || c->a2a_open) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         c->exch_done = true;
         if (exchange_active(c, c->iter)) {
             const KParams& P = c->P;
@@ -1792,6 +2025,8 @@ int smm_bgp_export_values_dev(void* ctx, void* vals_dev) {
     if (c->iter < 1) return fail(c, SMM_ERR_STATE, "no iteration yet");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         if (c->pending || c->unresolved) flush(c);
         HIPCHK(hipMemcpyAsync(vals_dev, c->vals_buf[c->iter & 1], (size_t)c->P.N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     } catch (const std::string& m) {
@@ -1809,6 +2044,8 @@ int smm_bgp_a2a_pack_dev(void* ctx, const void* vals_all_dev, void* send_dev) {
     if (c->pending || c->a2a_open || c->exch_done) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         if (exchange_active(c, c->iter)) {
             KParams P1 = c->P;
             P1.RW = 1;   // (the resolve kernels read value s at gathered[s * RW])
@@ -1835,6 +2072,8 @@ int smm_bgp_a2a_apply_dev(void* ctx, const void* recv_dev) {
     if (!c->a2a_open) return fail(c, SMM_ERR_STATE, "smm_bgp_a2a_pack_dev comes first");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
+        if (c->failed) return c->failed;
         if (exchange_active(c, c->iter)) {
             const KParams& P = c->P;
             hipLaunchKernelGGL(k_a2a_apply, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter, (const double*)recv_dev,
@@ -1930,6 +2169,7 @@ int smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out) {
     if (!c || !out || t0 < 0 || t1 < t0 || t1 > c->P.T) return SMM_ERR_INVALID_ARG;
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
         flush(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         const KParams& P = c->P;
@@ -1965,6 +2205,7 @@ int smm_get_state(void* ctx, smm_state_t* s) {
     if (!c || !s) return SMM_ERR_INVALID_ARG;
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
         flush(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         const KParams& P = c->P;
@@ -2009,6 +2250,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         return fail(c, SMM_ERR_INVALID_ARG, "smm_set_state needs every field of smm_history_t");
     try {
         HIPCHK(hipSetDevice(c->device));
+        settle_persist(c);
         HIPCHK(hipStreamSynchronize(c->stream));
         KParams& P = c->P;
         const size_t N = P.N, RW = P.RW, HW = P.HW, np = P.np, nm = P.nm;
@@ -2069,6 +2311,22 @@ int smm_get_timing(void* ctx, smm_timing_t* out) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !out) return SMM_ERR_INVALID_ARG;
     *out = c->timing;
+    return SMM_OK;
+}
+
+int smm_set_persistent(void* ctx, int32_t on) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return SMM_ERR_INVALID_ARG;
+    c->persist_on = on ? 1 : 0;
+    return SMM_OK;
+}
+
+int smm_get_persistent(void* ctx, int32_t* available, int32_t* launches, int32_t* repairs) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return SMM_ERR_INVALID_ARG;
+    if (available) *available = (c->persist && c->persist_on && !c->persist_broken) ? 1 : 0;
+    if (launches) *launches = c->persist_launches;
+    if (repairs) *repairs = c->persist_repairs;
     return SMM_OK;
 }
 
