@@ -44,17 +44,21 @@
 constexpr int PR_K = 8;          // iterations in the ring
 constexpr int PR_ZR = 20;        // shocks per lane held in registers: ns <= 512 * PR_ZR
 constexpr int PR_MAX_ITERS = 4000;   // iterations per launch (12 bits of the tags count them)
+#ifndef SMM_EXP_PR_DELAY
+#define SMM_EXP_PR_DELAY 8
+#endif
+constexpr int PR_GATHER_DELAY = SMM_EXP_PR_DELAY;   // s_sleep units (64 clocks) between this tile's publication and the gather's first look
 constexpr int PR_STW = 12;       // doubles of chain state in front of the record in a tile's LDS line
 
 // LDS of a tile: [walk slots: 8 bytes per chain of the population + 4] [pair lists x 2] [gather lists x 2] [headers x 4] and, as doubles:
-// theta[16][NP] part[NP][8][16] lines[16][LW] rng[2][64][1 + 2 NP] hrow[16][HW] xrow[16][HW] z0[PR_ZR][64] const[16] misc[16]
+// theta[16][NP] part[NP][8][16] lines[16][LW] rng[2][64][1 + 2 NP] hrow[16][HW] xrow[16][HW] z0[PR_ZR][64] const[16] misc[16] donor[2][64] (uint4) gth[Ng4][NP]
 __host__ __device__ inline int persist_line(int np) { return PR_STW + ((3 + 2 * np + 1) & ~1); }
 __host__ __device__ inline size_t persist_smem_bytes(int Ng, int np) {
     const size_t slots = (size_t)(((Ng + 3) & ~3) + 4) * 8;
     const size_t lists = 2 * (size_t)CONE_LEVELS * 64 * 4 + 2 * (size_t)CONE_GCAP * 2 + 4 * 16 * 4;
     const size_t hw = (size_t)((H_PARAMS + 2 * np + 1) & ~1);
     const size_t dbl = (size_t)NORM_CT * np + (size_t)np * 8 * NORM_CT + (size_t)NORM_CT * persist_line(np) + 2 * 64 * (size_t)(1 + 2 * np) +
-                       2 * NORM_CT * hw + (size_t)PR_ZR * 64 + 16 + 16;   // (PersistLds)
+                       2 * NORM_CT * hw + (size_t)PR_ZR * 64 + 16 + 16 + 2 * 64 * 2 + (size_t)((Ng + 3) & ~3) * np;   // (PersistLds)
     return slots + lists + dbl * 8;
 }
 __host__ __device__ inline size_t persist_ring_slot_bytes(int Ng) { return (size_t)PR_K * (((size_t)Ng + 4) * 8); }
@@ -65,12 +69,55 @@ __device__ inline uint32_t pr_tag16(const uint32_t epoch, const int rel) { retur
 __device__ inline uint32_t pr_tag32(const uint32_t epoch, const int rel) { return 0x80000000u | ((epoch & 0x7ffffu) << 12) | ((uint32_t)rel & 0xfffu); }
 __device__ inline uint32_t pr_progress_word(const uint32_t epoch, const int rel) { return (epoch << 12) | (uint32_t)rel; }
 
+// The ring is written with write-through stores and read past the caches.  Scope: the tiles are workgroups of ONE device, so the
+// agent scope (sc1) is enough; SMM_EXP_PR_SYS=1 makes it the system scope (sc0 sc1) of the p2p windows, for comparison.
+#ifndef SMM_EXP_PR_SYS
+#define SMM_EXP_PR_SYS 0
+#endif
+#if SMM_EXP_PR_SYS
+#define PR_SC "sc0 sc1"
+#else
+#define PR_SC "sc1"
+#endif
 __device__ inline unsigned long long pr_load8_sys(const void* p) {
     unsigned long long v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off " PR_SC "\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-__device__ inline uint32_t pr_load4_sys(const void* p) { return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline uint32_t pr_load4_sys(const void* p) { return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint4 pr_load16_sys(const void* p) {
+    p2p_u32x4 q;
+    asm volatile("global_load_dwordx4 %0, %1, off " PR_SC "\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(p) : "memory");
+    return make_uint4(q.x, q.y, q.z, q.w);
+}
+__device__ inline void pr_load16x2_sys(const void* p0, const void* p1, uint4& a, uint4& b) {
+    p2p_u32x4 q0, q1;
+    asm volatile("global_load_dwordx4 %0, %2, off " PR_SC "\n\tglobal_load_dwordx4 %1, %3, off " PR_SC "\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1) : "v"(p0), "v"(p1) : "memory");
+    a = make_uint4(q0.x, q0.y, q0.z, q0.w); b = make_uint4(q1.x, q1.y, q1.z, q1.w);
+}
+__device__ inline void pr_store8(void* p, const unsigned long long v) {
+    asm volatile("global_store_dwordx2 %0, %1, off " PR_SC :: "v"(p), "v"(v) : "memory");
+}
+// one LDS-DMA instruction past the caches: 16 bytes per active lane from gsrc (per lane) to LDS byte address lds_dst (wave-uniform) + 16 * lane
+__device__ inline void pr_dma16(const void* gsrc, const uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off " PR_SC "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// 16 bytes of payload as 32 self-validating bytes at p (smm_p2p.hpp's granules; s_nop: the store-data hazard of inline asm stores)
+__device__ inline void pr_store_ll(void* p, const double2 v, const uint32_t tag) {
+    const unsigned long long a = __builtin_bit_cast(unsigned long long, v.x), b = __builtin_bit_cast(unsigned long long, v.y);
+    const p2p_u32x4 q0 = {(unsigned)a, tag, (unsigned)(a >> 32), tag}, q1 = {(unsigned)b, tag, (unsigned)(b >> 32), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off " PR_SC "\n\tglobal_store_dwordx4 %2, %3, off " PR_SC "\n\ts_nop 1"
+                 :: "v"(p), "v"(q0), "v"((unsigned char*)p + 16), "v"(q1) : "memory");
+}
+
+// The ring holds a record's doubles in its own order — parameters first, so that the gather fetches them together with the walk
+// slot: theta[NP], value, prob, status, sim_moments[NP], pad — one uint4 {lo, tag, hi, tag} per double.
+template <int NP> __device__ constexpr int pr_ring_index(const int classic) {   // classic: value, prob, status, theta[NP], sim_moments[NP], pad
+    return classic < 3 ? NP + classic : classic < 3 + NP ? classic - 3 : classic;
+}
 
 // what the kernel needs, and nothing else (the whole KParams block as a kernel argument cost the control wave hundreds of scalar
 // spills: every field the loop touches is loop-invariant and wants a register)
@@ -117,9 +164,30 @@ __device__ __attribute__((noinline)) unsigned long long pr_wait_slot(const PrWai
     } while ((((uint32_t)(v >> 32)) & 0xffff0000u) != want);
     return v;
 }
+// ... a slot and two self-validating pieces of the same chain's record (the gather): all three are looked at again together
+struct PrGather { unsigned long long v; uint4 q0, q1; };
+__device__ __attribute__((noinline)) PrGather pr_wait_gather(const PrWait W, const unsigned long long* ps, const uint4* p0, const uint4* p1, const uint32_t want,
+                                                             const uint32_t tag, const int t, const int g) {
+    PrGather o;
+    o.v = 0ull; o.q0 = make_uint4(0u, 0u, 0u, 0u); o.q1 = o.q0;
+    if (*W.s_abort) return o;
+    const unsigned long long w0 = wall_clock64();
+    unsigned spins = 0;
+    for (;;) {
+        __builtin_amdgcn_s_sleep(2);
+        unsigned long long v;
+        p2p_u32x4 q0, q1;
+        asm volatile("global_load_dwordx2 %0, %3, off " PR_SC "\n\tglobal_load_dwordx4 %1, %4, off " PR_SC "\n\tglobal_load_dwordx4 %2, %5, off " PR_SC "\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v), "=&v"(q0), "=&v"(q1) : "v"(ps), "v"(p0), "v"(p1) : "memory");
+        o.v = v; o.q0 = make_uint4(q0.x, q0.y, q0.z, q0.w); o.q1 = make_uint4(q1.x, q1.y, q1.z, q1.w);
+        if ((((uint32_t)(v >> 32)) & 0xffff0000u) == want && p2p_ll_ok(o.q0, tag) && p2p_ll_ok(o.q1, tag)) break;
+        if ((++spins & 63u) == 0u && pr_give_up(W, w0)) { pr_abort(W, t, g); break; }
+    }
+    return o;
+}
 // ... two self-validating pieces of a record
 struct PrLL2 { uint4 q0, q1; };
-__device__ __attribute__((noinline)) PrLL2 pr_wait_ll2(const PrWait W, const uint4* p, const uint32_t tag, const int t, const int g) {
+__device__ __attribute__((noinline)) PrLL2 pr_wait_ll2(const PrWait W, const uint4* p0, const uint4* p1, const uint32_t tag, const int t, const int g) {
     PrLL2 o;
     o.q0 = make_uint4(0u, 0u, 0u, 0u); o.q1 = o.q0;
     if (*W.s_abort) return o;
@@ -128,7 +196,7 @@ __device__ __attribute__((noinline)) PrLL2 pr_wait_ll2(const PrWait W, const uin
     unsigned spins = 0;
     do {
         __builtin_amdgcn_s_sleep(1);
-        p2p_load16x2_sys(p, p + 1, q0, q1);
+        pr_load16x2_sys(p0, p1, q0, q1);
         if ((++spins & 63u) == 0u && pr_give_up(W, w0)) { pr_abort(W, t, g); break; }
     } while (!(p2p_ll_ok(q0, tag) && p2p_ll_ok(q1, tag)));
     o.q0 = q0; o.q1 = q1;
@@ -137,25 +205,25 @@ __device__ __attribute__((noinline)) PrLL2 pr_wait_ll2(const PrWait W, const uin
 // the exact value of chain s after the last iteration (a key tie in the walk): double 0 of its record — self-validating in the ring,
 // plain in the launch's input records (first iteration).  Out of line, arguments by value (an object with an out-of-line member would
 // be built in scratch memory every iteration).
-__device__ __attribute__((noinline)) double pr_tie_value(const PrWait W, const uint4* ring, const double* plain, const uint32_t tag, const int RW, const int t,
+__device__ __attribute__((noinline)) double pr_tie_value(const PrWait W, const uint4* ring, const double* plain, const uint32_t tag, const int RW, const int NPV, const int t,
                                                          const uint32_t s) {
     if (plain) return plain[(size_t)s * RW];
-    const uint4* a = ring + (size_t)s * RW;
-    uint4 q = p2p_load16_sys(a);
+    const uint4* a = ring + (size_t)s * RW + NPV;   // (the ring's order: the value behind the parameters)
+    uint4 q = pr_load16_sys(a);
     if (!p2p_ll_ok(q, tag)) {
         const unsigned long long w0 = wall_clock64();
         unsigned spins = 0;
         do {
             __builtin_amdgcn_s_sleep(1);
-            q = p2p_load16_sys(a);
+            q = pr_load16_sys(a);
             if ((++spins & 63u) == 0u && pr_give_up(W, w0)) { pr_abort(W, t, (int)s); break; }
         } while (!p2p_ll_ok(q, tag));
     }
     return p2p_ll_double(q);
 }
 struct PersistWalkValues {   // GUARD of the lean walk (smm_walk_lean.hpp)
-    PrWait W; const uint4* ring; const double* plain; uint32_t tag; int RW; int t;
-    __device__ __forceinline__ double value(const uint32_t s) const { return pr_tie_value(W, ring, plain, tag, RW, t, s); }
+    PrWait W; const uint4* ring; const double* plain; uint32_t tag; int RW; int NPV; int t;
+    __device__ __forceinline__ double value(const uint32_t s) const { return pr_tie_value(W, ring, plain, tag, RW, NPV, t, s); }
 };
 
 // exp() out of line: inlined, its polynomial's nine 64-bit coefficients are hoisted out of the iteration loop into registers, spilled
@@ -255,9 +323,10 @@ struct PersistLds {   // where things are in a tile's LDS (byte offsets from its
     static constexpr int CT = NORM_CT, RW = L::RW, HW = L::HW, LW = PR_STW + RW, RNGW = 1 + 2 * NP;
     uint32_t pbase, gbase, hbase;
     uint2* slots; uint32_t* s_hdr;
-    double *s_theta, *s_part, *s_st, *s_rng, *s_hrow, *s_xrow, *s_z0, *s_const;
+    double *s_theta, *s_part, *s_st, *s_rng, *s_hrow, *s_xrow, *s_z0, *s_const, *s_gth;
+    uint4* s_donor;
     unsigned long long* s_ts;
-    unsigned* s_arrived; int* s_minprog; unsigned* s_abort; unsigned* s_xmask; int* s_glready;
+    unsigned* s_arrived; int* s_minprog; unsigned* s_abort; unsigned* s_xmask; int* s_glready; int* s_pub;
     __device__ inline PersistLds(unsigned char* lds, const int Ng4) {
         pbase = 8u * (uint32_t)(Ng4 + 4);
         gbase = pbase + 2u * CONE_LEVELS * 64 * 4;
@@ -272,12 +341,15 @@ struct PersistLds {   // where things are in a tile's LDS (byte offsets from its
         s_xrow = s_hrow + CT * HW;
         s_z0 = s_xrow + CT * HW;
         s_const = s_z0 + PR_ZR * 64;          // lb[NP] ub[NP] mom[NP] w[NP] failbox[2] ns
-        s_ts = (unsigned long long*)(s_const + 16);
+        s_ts = (unsigned long long*)(s_const + 16);   // [8] + 8 words of flags = 16 doubles
         s_arrived = (unsigned*)(s_ts + 8);
         s_minprog = (int*)(s_arrived + 1);
         s_abort = s_arrived + 2;
         s_xmask = s_arrived + 3;              // bit cl: chain cl's row of the last iteration is rewritten (s_xrow)
         s_glready = (int*)(s_arrived + 4);    // the exchange whose gather list has landed
+        s_pub = (int*)(s_arrived + 5);        // the iteration this tile has published (the others publish at about the same time)
+        s_donor = (uint4*)(s_const + 16 + 16);   // [2][64]: the donors' records as they land (LDS-DMA of the control wave: lane L -> entries L and 64 + L)
+        s_gth = s_const + 16 + 16 + 2 * 64 * 2;   // [Ng4][NP]: the parameters of the gathered chains' last accepted records (the donors' come from here)
     }
 };
 
@@ -380,7 +452,10 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
             double2* st2 = (double2*)(Y.s_st + cl * LW);
             for (int i = r; i < 6; i += 4) st2[i] = g_cs[i];
             for (int i = r; i < NPC; i += 4) st2[PR_STW / 2 + i] = g_rec[i];
-            if (r == 0) Y.slots[c] = make_uint2(order_key32(g_rec[0].x), (uint32_t)c);   // the tile's own slots of the first walk
+            if (r == 0) {
+                Y.slots[c] = make_uint2(order_key32(g_rec[0].x), (uint32_t)c);   // the tile's own slots of the first walk
+                for (int k = 0; k < NP; ++k) Y.s_gth[c * NP + k] = A.rec_in[(size_t)c * RW + 3 + k];   // (a donor may be a chain of the same tile)
+            }
         }
 #pragma unroll
         for (int u = 0; u < PR_ZR; ++u) Y.s_z0[u * 64 + lane] = (lane + u * WG < A.ns) ? A.Z[lane + (size_t)u * WG] : 0.0;   // (wave 0: half 0, lanes 0..63)
@@ -393,7 +468,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
         Y.s_const[4 * NP] = A.failbox ? A.objp[0] : 1.0; Y.s_const[4 * NP + 1] = A.failbox ? A.objp[1] : 0.0;   // (an empty interval: no "exception")
         Y.s_const[4 * NP + 2] = (double)A.ns;
         Y.slots[Ng4] = make_uint2(1u, 0u); Y.slots[Ng4 + 1] = make_uint2(2u, 0u);
-        *Y.s_arrived = 0u; *Y.s_minprog = 0; *Y.s_abort = 0u; *Y.s_xmask = 0u; *Y.s_glready = t0 - 1;
+        *Y.s_arrived = 0u; *Y.s_minprog = 0; *Y.s_abort = 0u; *Y.s_xmask = 0u; *Y.s_glready = t0 - 1; *Y.s_pub = t0 - 1;
     }
     if (tid >= 192 && tid < 200) Y.s_ts[tid - 192] = 0ull;
     // headers of the pending exchange t0 - 1 (walked by the first iteration) and of exchange t0
@@ -441,7 +516,10 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
             const uint16_t* gl = (const uint16_t*)(lds + Y.gbase) + ((t0 - 1) & 1) * CONE_GCAP;
             for (int e = tid - 256; e < ngat; e += 256) {
                 const int g = (int)gl[e];
-                Y.slots[g] = make_uint2(order_key32(A.rec_in[(size_t)g * RW]), (uint32_t)g);
+                const double* gr = A.rec_in + (size_t)g * RW;
+                Y.slots[g] = make_uint2(order_key32(gr[0]), (uint32_t)g);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) Y.s_gth[g * NP + k] = gr[3 + k];
             }
         }
     }
@@ -506,14 +584,16 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
             uint32_t nhdr = 0u;
             const bool want_hdr = wave == 3 && lane < CONE_HDRW && t + 1 < t1 && exch_on(t + 1);
             if (wave == 3) {
-                if (t > t0) store_rows(Y.s_hrow, t - 1, 0xffffu);   // the last iteration's history rows (complete since the barrier)
+                if (t > t0) {   // the last iteration's history rows, and the rows of iteration t-2 of the chains it found exchanged (set_eval! of swap_ev_ij!): complete since the barrier
+                    store_rows(Y.s_hrow, t - 1, 0xffffu);
+                    store_rows(Y.s_xrow, t - 2, *Y.s_xmask);
+                }
                 if (want_hdr) nhdr = A.cone_hdr[((size_t)(t + 1 - A.plan_t0) * tiles + tile) * CONE_HDRW + lane];
             }
             // the lists of the NEXT exchange (t), landing under the simulation (not by the gathering waves: the DMA would sit in front of
             // the gather's loads in their memory queue)
             if (t < t1 && exch_on(t)) request_lists(t);
             PR_BARRIER();   // BB: the proposals are in LDS
-            if (wave == 3) store_rows(Y.s_xrow, t - 1, *Y.s_xmask);   // the rows of the chains this prologue found exchanged (set_eval! of swap_ev_ij!)
             // ---- simulation: every lane, its resident shocks x 16 chains ----
             if (simw) {
                 if (nfull == PR_ZR - 1) persist_simulate<NP, true>(z, nfull, extra, Y.s_theta, Y.s_part, h, wih);
@@ -544,26 +624,42 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
                 // ---- gather for the NEXT iteration's walk: the cone's initial slots out of the ring, past the caches, under the control
                 // wave's accept step; every word says which iteration it is from, a lane that finds an older one looks again ----
                 while (__hip_atomic_load(Y.s_glready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(1);
+                // (no point in looking before anybody can have published: the tiles run in step, so this tile's own publication is the
+                // clock — and failed looks are not free: thousands of lanes re-reading scattered words load every CU's memory queue)
+                while (__hip_atomic_load(Y.s_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(PR_GATHER_DELAY);
                 const int ngat = (int)(Y.s_hdr[(t & 3) * 16] >> 16);
                 const unsigned long long* rs = (const unsigned long long*)A.pr_slot + (size_t)(rel % PR_K) * (A.Ng + 4);
                 const uint32_t want = pr_tag16(epoch, rel) << 16;
                 const uint16_t* gl = (const uint16_t*)(lds + Y.gbase) + (t & 1) * CONE_GCAP;
+                const uint4* rr = (const uint4*)A.pr_rec + (size_t)(rel % PR_K) * A.Ng * RW;
+                const uint32_t tag = pr_tag32(epoch, rel);
                 for (int e = tid - 256; e < ngat; e += 256) {
                     const int g = (int)gl[e];
-                    unsigned long long v = pr_load8_sys(rs + g);
-                    if (__builtin_expect((((uint32_t)(v >> 32)) & 0xffff0000u) != want, 0)) v = pr_wait_slot(W, rs + g, want, t + 1, g);
+                    // the slot and the record's parameters (the ring's first NP doubles), requested together
+                    unsigned long long v;
+                    p2p_u32x4 q0, q1;
+                    asm volatile("global_load_dwordx2 %0, %3, off " PR_SC "\n\tglobal_load_dwordx4 %1, %4, off " PR_SC "\n\tglobal_load_dwordx4 %2, %5, off " PR_SC "\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(v), "=&v"(q0), "=&v"(q1) : "v"(rs + g), "v"(rr + (size_t)g * RW), "v"(rr + (size_t)g * RW + (NP - 1)) : "memory");
+                    uint4 u0 = make_uint4(q0.x, q0.y, q0.z, q0.w), u1 = make_uint4(q1.x, q1.y, q1.z, q1.w);
+                    if (__builtin_expect((((uint32_t)(v >> 32)) & 0xffff0000u) != want || !(p2p_ll_ok(u0, tag) && p2p_ll_ok(u1, tag)), 0)) {
+                        const PrGather w3 = pr_wait_gather(W, rs + g, rr + (size_t)g * RW, rr + (size_t)g * RW + (NP - 1), want, tag, t + 1, g);
+                        v = w3.v; u0 = w3.q0; u1 = w3.q1;
+                    }
                     Y.slots[g] = make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xffffu);
+                    Y.s_gth[g * NP] = p2p_ll_double(u0);
+                    if constexpr (NP > 1) Y.s_gth[g * NP + 1] = p2p_ll_double(u1);
                 }
             }
         }
         PR_BARRIER();   // the last epilogue is done
-        if (wave == 3) store_rows(Y.s_hrow, t1, 0xffffu);
+        if (wave == 3) { store_rows(Y.s_hrow, t1, 0xffffu); store_rows(Y.s_xrow, t1 - 1, *Y.s_xmask); }
         if (wave == 1) {   // the result blocks where the next launch (of any form) expects them: out of the chains' lines
             const int cl = lane >> 2, r = lane & 3, c = tile * CT + cl;
             if (c < N) {
                 const double2* st2 = (const double2*)(Y.s_st + cl * LW);
                 double2* g_cs = (double2*)(A.cs + (size_t)c * CSW);
-                for (int i = r; i < 6; i += 4) g_cs[i] = st2[i];
+                for (int i = r; i < 6; i += 4) g_cs[i] = i == 2 ? make_double2(st2[2].x, 0.0) : st2[i];   // (the WASX field carried the record's source during the launch)
                 for (int i = r; i < NPC; i += 4) ((double2*)(A.rec_out + (size_t)c * RW))[i] = st2[PR_STW / 2 + i];
                 if (r == 0) {
                     const double v = Y.s_st[cl * LW + PR_STW];
@@ -576,11 +672,15 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
     }
 
     // =========================================================================================================================
-    // the CONTROL wave: four lanes per chain with identical state (lane r of a quad evaluates proposal try r)
+    // the CONTROL wave: four lanes per chain with identical state (lane r of a quad evaluates proposal try r).
+    // Per iteration, on the critical path between two publications: the walk, the proposal (parameters of the chain's own record or,
+    // for an exchanged chain, of its donor's — gathered with the slots), its share of the simulation, the objective and the accept
+    // step up to the publication.  Everything else — the donor's whole record (requested behind the walk, looked at only here),
+    // settling iteration t-1, counters, sigma, best values, the chain's line, the history rows — runs BEHIND the publication, in the
+    // shadow of the time its stores need to become visible to the other tiles.
+    // (every section derives its lane ids anew — mbcnt needs no input register — so that nothing lane-dependent stays live across the
+    // register-hungry simulation: the compiler spilled such values to scratch memory, and scratch reloads are memory operations)
     // =========================================================================================================================
-    // (every section of an iteration derives its lane ids anew — mbcnt needs no input register — so that nothing lane-dependent stays
-    // live across the register-hungry simulation: the compiler spilled such values to scratch memory, and a scratch reload behind the
-    // publication waits for the write-through stores' acknowledgements, ~2 us)
     const int nfull0 = A.ns / WG;
     for (int t = t0; t <= t1; ++t) {
         const int rel = t - t0 + 1;
@@ -588,139 +688,89 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
         const bool exch = first ? A.walk_first != 0 : exch_on(t - 1);
         PR_BARRIER();   // BA
         {
-        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const int cl = lane >> 2, r = lane & 3;
-        const int c = tile * CT + cl;                         // (single shard: global == local chain id)
-        const bool valid = c < N;
-        double* st = Y.s_st + cl * LW;
-        unsigned long long ts1 = 0;
-        if (A.ts && lane == 0) { ts1 = wall_clock64(); if (!first) Y.s_ts[0] += ts1 - Y.s_ts[7]; }   // (the wait for the gather at the barrier)
-        // ---- the walk over the cone's sub-levels: this wave alone, no barriers (its LDS operations complete in order) ----
-        uint32_t src = (uint32_t)c;
-        int partner = 0;
-        const uint32_t lbase = Y.pbase + (uint32_t)((t - 1) & 1) * (CONE_LEVELS * 64 * 4);
-        if (exch) {
-            const int nsub = (int)(Y.s_hdr[((t - 1) & 3) * 16] & 0xffffu);
-            const PersistWalkValues values{W, (const uint4*)A.pr_rec + (size_t)((rel - 1) % PR_K) * A.Ng * RW, first ? A.rec_in : nullptr, pr_tag32(epoch, rel - 1), RW, t};
-            lean_walk_levels<64, 0, false, PersistWalkValues>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, 0.0, values);
-            if (valid) {
-                const uint32_t kmeta = Y.slots[c].y;
-                src = kmeta & 0xffffu;
-                if (kmeta >> 16) partner = (int)lean_partner<0>(lds, lbase, kmeta, (uint32_t)c);   // set_exchanged!, :747-748
-            }
-        }
-        unsigned long long ts2 = 0;
-        if (A.ts && lane == 0) ts2 = wall_clock64();
-        // ---- the record the chain continues from: its own (LDS) or its donor's (swap_ev_ij!, :734-749) ----
-        double rc[RW];
-#pragma unroll
-        for (int f = 0; f < RW; ++f) rc[f] = st[PR_STW + f];
-        if (valid && src != (uint32_t)c) {
-            if (__builtin_expect(first, 0)) {   // the launch's input records (plain)
-                const double2* g_rec = (const double2*)(A.rec_in + (size_t)src * RW);
-#pragma unroll
-                for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc[2 * i] = q.x; rc[2 * i + 1] = q.y; }
-            } else {   // the donor's self-validating record of the last iteration out of the ring: lane r fetches the piece r
-                const uint4* g_ll = (const uint4*)A.pr_rec + ((size_t)((rel - 1) % PR_K) * A.Ng + src) * RW;
-                const uint32_t tag = pr_tag32(epoch, rel - 1);
-                static_assert(NPC <= 4, "one 16-byte piece of the record per lane of the quad");
-                uint4 q0 = make_uint4(0u, tag, 0u, tag), q1 = q0;
-                if (r < NPC) {
-                    p2p_load16x2_sys(g_ll + 2 * r, g_ll + 2 * r + 1, q0, q1);
-                    if (__builtin_expect(!(p2p_ll_ok(q0, tag) && p2p_ll_ok(q1, tag)), 0)) { const PrLL2 w2 = pr_wait_ll2(W, g_ll + 2 * r, tag, t, c); q0 = w2.q0; q1 = w2.q1; }
+            const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int cl = lane >> 2, r = lane & 3;
+            const int c = tile * CT + cl;                         // (single shard: global == local chain id)
+            const bool valid = c < N;
+            double* st = Y.s_st + cl * LW;
+            unsigned long long ts1 = 0;
+            if (A.ts && lane == 0) { ts1 = wall_clock64(); if (!first) Y.s_ts[0] += ts1 - Y.s_ts[7]; }   // (the wait for the gather at the barrier)
+            // ---- the walk over the cone's sub-levels: this wave alone, no barriers (its LDS operations complete in order) ----
+            uint32_t src = (uint32_t)c;
+            int partner = 0;
+            const uint32_t lbase = Y.pbase + (uint32_t)((t - 1) & 1) * (CONE_LEVELS * 64 * 4);
+            if (exch) {
+                const int nsub = (int)(Y.s_hdr[((t - 1) & 3) * 16] & 0xffffu);
+                const PersistWalkValues values{W, (const uint4*)A.pr_rec + (size_t)((rel - 1) % PR_K) * A.Ng * RW, first ? A.rec_in : nullptr, pr_tag32(epoch, rel - 1), RW, NP, t};
+                lean_walk_levels<64, 0, false, PersistWalkValues>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, 0.0, values);
+                if (valid) {
+                    const uint32_t kmeta = Y.slots[c].y;
+                    src = kmeta & 0xffffu;
+                    if (kmeta >> 16) partner = (int)lean_partner<0>(lds, lbase, kmeta, (uint32_t)c);   // set_exchanged!, :747-748
                 }
-                const double d0 = p2p_ll_double(q0), d1 = p2p_ll_double(q1);   // doubles 2r, 2r + 1 of the record
-                rc[0] = quad_bcast<0>(d0); rc[1] = quad_bcast<0>(d1);
-                rc[2] = quad_bcast<1>(d0); rc[3] = quad_bcast<1>(d1);
-                if constexpr (RW > 4) { rc[4] = quad_bcast<2>(d0); rc[5] = quad_bcast<2>(d1); }
-                if constexpr (RW > 6) { rc[6] = quad_bcast<3>(d0); rc[7] = quad_bcast<3>(d1); }
             }
-        }
-        // every read of the ring's last entry is done: say so (the publication of iteration rel + PR_K - 1 waits for it)
-        if (lane == 0) __hip_atomic_store(A.pr_progress + tile, pr_progress_word(epoch, rel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        unsigned long long ts3 = 0;
-        if (A.ts && lane == 0) ts3 = wall_clock64();
-        // ---- settle iteration t-1 (as k_chain_iter_norm's prologue; F_CLOSE_PREV always: the host starts this kernel behind a closed iteration) ----
-        const double sigma = st[CS_SIGMA];
-        int nn = (int)st[CS_NNOEX], na = (int)st[CS_NACC];
-        double bp = st[CS_BEST], bpid = st[CS_BESTID];
-        if (partner != 0) {
-            // set_eval!(ci, ej) of swap_ev_ij! as a history record: the chain's record of iteration t-1 is the donor's last
-            // accepted one (accepted = true, the donor's prob/status), curr = donor value, best against iteration t-2 (:231-243)
-            const double value = rc[0];
-            if (value < st[CS_BESTP]) { bp = value; bpid = (double)(t - 1); }
-            else { bp = st[CS_BESTP]; bpid = st[CS_BESTPID]; }
-            if (r == 0) {   // (the row goes out through LDS: wave 3 stores it behind the barrier)
-                double* hx = Y.s_xrow + cl * HW;
-                hx[H_VALUE] = value; hx[H_PROB] = rc[1]; hx[H_CURR] = value; hx[H_BEST] = bp; hx[H_BESTID] = bpid;
-                hx[H_EXCH] = (double)partner; hx[H_ACC] = 1.0; hx[H_STATUS] = rc[2];
-#pragma unroll
-                for (int k = 0; k < 2 * NP; ++k) hx[H_PARAMS + k] = rc[3 + k];
-                if (HW > H_PARAMS + 2 * NP) hx[HW - 1] = 0.0;
+            const bool donor = valid && src != (uint32_t)c;
+            // the donor's whole record (swap_ev_ij!, :734-749), requested now and looked at behind the simulation
+            // (by LDS-DMA: lane r of the quad brings the record's doubles r and 4 + r — ring order, a uint4 each — to entries lane and 64 + lane)
+            if (donor && !first) {
+                const uint4* g_ll = (const uint4*)A.pr_rec + ((size_t)((rel - 1) % PR_K) * A.Ng + src) * RW;
+                const uint32_t dbase = (uint32_t)((unsigned char*)Y.s_donor - lds);
+                pr_dma16(g_ll + r, dbase);
+                if (4 + r < RW) pr_dma16(g_ll + 4 + r, dbase + 64 * 16);
             }
-        } else if (valid) { nn += 1; na += (int)st[CS_LACC]; }   // set_acceptRate!, :253-257 (exchanged iterations do not count)
-        {
-            const unsigned long long xm = __ballot(partner != 0 && r == 0);
-            if (lane == 0) {
-                unsigned m = 0u;
-#pragma unroll
-                for (int q = 0; q < CT; ++q) m |= (unsigned)((xm >> (4 * q)) & 1ull) << q;
-                *Y.s_xmask = m;
-            }
-        }
-        // ---- proposal: lane r evaluates try r; the chain's first try inside the unit box wins (mysample, :400-410) ----
-        double mu01[NP], th[NP];
-        const double* o = Y.s_rng + ((t & 1) * 64 + lane) * RNGW;
-        const double u = o[0];
-        bool found = !valid;
-        {
-            double x[NP];
-            bool ok = valid;
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const double lbk = Y.s_const[k], ubk = Y.s_const[NP + k];
-                th[k] = valid ? rc[3 + k] : 0.0;
-                mu01[k] = (rc[3 + k] - lbk) / (ubk - lbk);   // mapto_01, mprob.jl:248
-                const double step = sigma * o[1 + k];          // MvNormal(mu01, sigma): x = mu + sigma*z
-                x[k] = mu01[k] + step;
-                if (!(x[k] >= 0.0 && x[k] <= 1.0)) ok = false;   // inclusive bounds, :405
-            }
-            if (r >= A.smpl_iters || (A.user_n && r >= A.rb_tries)) ok = false;
-            const unsigned long long m = __ballot(ok);
-            const unsigned quad = (unsigned)(m >> (lane & ~3)) & 0xfu;
-            if (quad) {
-                const int rwin = __builtin_ctz(quad);
+            unsigned long long ts2 = 0;
+            if (A.ts && lane == 0) ts2 = wall_clock64();
+            // ---- proposal: lane r evaluates try r; the chain's first try inside the unit box wins (mysample, :400-410) ----
+            double mu01[NP], th[NP], th_old[NP];
+            const double sigma = st[CS_SIGMA];
+            const double* o = Y.s_rng + ((t & 1) * 64 + lane) * RNGW;
+            bool found = !valid;
+            {
+                double x[NP];
+                bool ok = valid;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    const double lbk = Y.s_const[k];
-                    const double sc = x[k] * (Y.s_const[NP + k] - lbk);
-                    const double thk = sc + lbk;   // mapto_ab, mprob.jl:271
-                    th[k] = quad_bcast_dyn(thk, lane, rwin);
+                    const double lbk = Y.s_const[k], ubk = Y.s_const[NP + k];
+                    th_old[k] = donor ? Y.s_gth[src * NP + k] : st[PR_STW + 3 + k];   // the record the chain continues from: its own, or its donor's
+                    th[k] = valid ? th_old[k] : 0.0;
+                    mu01[k] = (th_old[k] - lbk) / (ubk - lbk);   // mapto_01, mprob.jl:248
+                    const double step = sigma * o[1 + k];          // MvNormal(mu01, sigma): x = mu + sigma*z
+                    x[k] = mu01[k] + step;
+                    if (!(x[k] >= 0.0 && x[k] <= 1.0)) ok = false;   // inclusive bounds, :405
                 }
-                found = true;
+                if (r >= A.smpl_iters || (A.user_n && r >= A.rb_tries)) ok = false;
+                const unsigned long long m = __ballot(ok);
+                const unsigned quad = (unsigned)(m >> (lane & ~3)) & 0xfu;
+                if (quad) {
+                    const int rwin = __builtin_ctz(quad);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        const double lbk = Y.s_const[k];
+                        const double sc = x[k] * (Y.s_const[NP + k] - lbk);
+                        const double thk = sc + lbk;   // mapto_ab, mprob.jl:271
+                        th[k] = quad_bcast_dyn(thk, lane, rwin);
+                    }
+                    found = true;
+                }
             }
-        }
-        if (__builtin_expect(__any(!found), 0)) {
-            const PrTries TR{A.rb, A.seed, A.rb_t0, A.N, A.RBW, A.rb_tries, A.user_n, A.smpl_iters};
-            const PrTh<NP> lt = persist_late_tries<NP>(TR, o, t, c, valid, lane, found, sigma, mu01[0], mu01[NP - 1], Y.s_const, th[0], th[NP - 1]);
+            if (__builtin_expect(__any(!found), 0)) {
+                const PrTries TR{A.rb, A.seed, A.rb_t0, A.N, A.RBW, A.rb_tries, A.user_n, A.smpl_iters};
+                const PrTh<NP> lt = persist_late_tries<NP>(TR, o, t, c, valid, lane, found, sigma, mu01[0], mu01[NP - 1], Y.s_const, th[0], th[NP - 1]);
 #pragma unroll
-            for (int k = 0; k < NP; ++k) th[k] = lt.th[k];
-            found = lt.found;
-            if (!found && r == 0) pr_report(A.err, 2, t, c);   // :409
-        }
-        // park what the epilogue needs in the chain's line (nothing of it stays in registers across the simulation)
-        if (r == 0) {
-            st[CS_NNOEX] = (double)nn; st[CS_NACC] = (double)na; st[CS_BEST] = bp; st[CS_BESTID] = bpid; st[CS_PARTNER] = (double)partner;
-            st[CS_WASX] = u;   // (free between prologue and epilogue: the MH uniform travels in it)
+                for (int k = 0; k < NP; ++k) th[k] = lt.th[k];
+                found = lt.found;
+                if (!found && r == 0) pr_report(A.err, 2, t, c);   // :409
+            }
+            if (r == 0) {
 #pragma unroll
-            for (int f = 0; f < RW; ++f) st[PR_STW + f] = rc[f];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) Y.s_theta[cl * NP + k] = th[k];
-        }
-        if (A.ts && lane == 0) {
-            const unsigned long long ts4 = wall_clock64();
-            Y.s_ts[1] += ts2 - ts1; Y.s_ts[2] += ts3 - ts2; Y.s_ts[3] += ts4 - ts3; Y.s_ts[6] = ts4;
-        }
+                for (int k = 0; k < NP; ++k) Y.s_theta[cl * NP + k] = th[k];
+                st[CS_PARTNER] = (double)partner;
+                st[CS_WASX] = (double)src;   // (free during the launch: where the record comes from, for the section behind the simulation)
+            }
+            if (A.ts && lane == 0) {
+                const unsigned long long ts4 = wall_clock64();
+                Y.s_ts[1] += ts2 - ts1; Y.s_ts[3] += ts4 - ts2; Y.s_ts[6] = ts4;
+            }
         }
         PR_BARRIER();   // BB
         // ---- this wave's share of the simulation: its shocks come out of LDS (they must not occupy registers during the serial parts) ----
@@ -743,12 +793,49 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
         double* st = Y.s_st + cl * LW;
         unsigned long long ts5 = 0;
         if (A.ts && lane == 0) ts5 = wall_clock64();
-        // ---- objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392), set_eval! (:220-245) ----
         if (valid) {
-            const double sig = st[CS_SIGMA], atun = st[CS_ATUN], uu = st[CS_WASX], bp2 = st[CS_BEST], bpid2 = st[CS_BESTID];
-            double rc2[RW], th2[NP], sm[NP];
+            // ---- the record the chain continues from (classic order: value, prob, status, theta, sim_moments) ----
+            const int src = (int)st[CS_WASX];
+            const bool donor = src != c;
+            double rc2[RW];
 #pragma unroll
             for (int f = 0; f < RW; ++f) rc2[f] = st[PR_STW + f];
+            if (donor) {
+                if (__builtin_expect(first, 0)) {   // the launch's input records (plain)
+                    const double2* g_rec = (const double2*)(A.rec_in + (size_t)src * RW);
+#pragma unroll
+                    for (int i = 0; i < NPC; ++i) { const double2 q = g_rec[i]; rc2[2 * i] = q.x; rc2[2 * i + 1] = q.y; }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed
+                    const uint32_t tag = pr_tag32(epoch, rel - 1);
+                    double rr[8];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) rr[f] = 0.0;
+                    bool ok = true;
+#pragma unroll
+                    for (int f = 0; f < RW; ++f) {
+                        const uint4 q = Y.s_donor[(f >> 2) * 64 + 4 * cl + (f & 3)];
+                        ok = ok && p2p_ll_ok(q, tag);
+                        rr[f] = p2p_ll_double(q);
+                    }
+                    if (__builtin_expect(!ok, 0)) {   // (cannot be: the gather has validated this chain's slot and parameters; late stores of the SAME publication?)
+                        const uint4* g_ll = (const uint4*)A.pr_rec + ((size_t)((rel - 1) % PR_K) * A.Ng + src) * RW;
+#pragma unroll
+                        for (int f = 0; f < RW; f += 2) {
+                            const PrLL2 w2 = pr_wait_ll2(W, g_ll + f, g_ll + f + 1, tag, t, c);
+                            rr[f] = p2p_ll_double(w2.q0); rr[f + 1] = p2p_ll_double(w2.q1);
+                        }
+                    }
+#pragma unroll
+                    for (int f = 0; f < RW; ++f) rc2[f] = rr[pr_ring_index<NP>(f)];
+                }
+            }
+            // every read of the ring's last entry is done: say so (the publication of iteration rel + PR_K - 1 waits for it)
+            if (lane == 0) __hip_atomic_store(A.pr_progress + tile, pr_progress_word(epoch, rel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ---- objective value (ObjExamples.jl:79-110), doAcceptReject! (:324-392) ----
+            const double atun = st[CS_ATUN];
+            const double uu = Y.s_rng[((t & 1) * 64 + lane) * RNGW];
+            double th2[NP], sm[NP];
 #pragma unroll
             for (int k = 0; k < NP; ++k) th2[k] = Y.s_theta[cl * NP + k];
             double value;
@@ -805,31 +892,59 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
                 if (__builtin_expect(rel >= PR_K && __hip_atomic_load(Y.s_minprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rel - PR_K + 1, 0))
                     pr_wait_progress(W, A.pr_progress, Y.s_minprog, rel - PR_K + 1, tiles, lane, t, c);
                 if (r == 0)
-                    p2p_store8((uint2*)A.pr_slot + (size_t)(rel % PR_K) * (A.Ng + 4) + c,
-                               (unsigned long long)order_key32(v) | ((unsigned long long)((uint32_t)c | (pr_tag16(epoch, rel) << 16)) << 32));
+                    pr_store8((uint2*)A.pr_slot + (size_t)(rel % PR_K) * (A.Ng + 4) + c,
+                              (unsigned long long)order_key32(v) | ((unsigned long long)((uint32_t)c | (pr_tag16(epoch, rel) << 16)) << 32));
                 unsigned char* g_ll = (unsigned char*)A.pr_rec + ((size_t)(rel % PR_K) * A.Ng + c) * RW * 16;
-                const double2 pv = sel4(r, make_double2(nr[0], nr[1]), make_double2(nr[2 % RW], nr[3 % RW]),
-                                        make_double2(nr[4 % RW], nr[5 % RW]), make_double2(nr[6 % RW], nr[7 % RW]));
-                if (r < NPC) p2p_store_ll(g_ll + (size_t)r * 32, pv, pr_tag32(epoch, rel));
+                double ro[8];   // the ring's order
+#pragma unroll
+                for (int f = 0; f < 8; ++f) ro[f] = 0.0;
+#pragma unroll
+                for (int f = 0; f < RW; ++f) ro[pr_ring_index<NP>(f)] = nr[f];
+                const double2 pv = sel4(r, make_double2(ro[0], ro[1]), make_double2(ro[2], ro[3]), make_double2(ro[4], ro[5]), make_double2(ro[6], ro[7]));
+                if (r < NPC) pr_store_ll(g_ll + (size_t)r * 32, pv, pr_tag32(epoch, rel));
+                if (lane == 0) __hip_atomic_store(Y.s_pub, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            // ---- the rest of doAcceptReject! and set_eval! ----
-            const int nn2 = (int)st[CS_NNOEX], na2 = (int)st[CS_NACC];
+            if (A.ts && lane == 0) { const unsigned long long ts6 = wall_clock64(); Y.s_ts[4] += ts5 - Y.s_ts[6]; Y.s_ts[5] += ts6 - ts5; Y.s_ts[6] = ts6; }
+            // ================= behind the publication =================
+            // ---- settle iteration t-1 (as k_chain_iter_norm's prologue; F_CLOSE_PREV always: the host starts this kernel behind a closed iteration) ----
+            const int partner = (int)st[CS_PARTNER];
+            const double sig = st[CS_SIGMA];
+            int nn = (int)st[CS_NNOEX], na = (int)st[CS_NACC];
+            double bp = st[CS_BEST], bpid = st[CS_BESTID];
+            if (partner != 0) {
+                // set_eval!(ci, ej) of swap_ev_ij! as a history record: the chain's record of iteration t-1 is the donor's last
+                // accepted one (accepted = true, the donor's prob/status), curr = donor value, best against iteration t-2 (:231-243)
+                const double dv = rc2[0];
+                if (dv < st[CS_BESTP]) { bp = dv; bpid = (double)(t - 1); }
+                else { bp = st[CS_BESTP]; bpid = st[CS_BESTPID]; }
+                if (r == 0) {   // (the row goes out through LDS: wave 3 stores it behind the next barrier)
+                    double* hx = Y.s_xrow + cl * HW;
+                    hx[H_VALUE] = dv; hx[H_PROB] = rc2[1]; hx[H_CURR] = dv; hx[H_BEST] = bp; hx[H_BESTID] = bpid;
+                    hx[H_EXCH] = (double)partner; hx[H_ACC] = 1.0; hx[H_STATUS] = rc2[2];
+#pragma unroll
+                    for (int k = 0; k < 2 * NP; ++k) hx[H_PARAMS + k] = rc2[3 + k];
+                    if (HW > H_PARAMS + 2 * NP) hx[HW - 1] = 0.0;
+                }
+            } else { nn += 1; na += (int)st[CS_LACC]; }   // set_acceptRate!, :253-257 (exchanged iterations do not count)
+            // ---- the rest of doAcceptReject! and set_eval! (:220-245) for iteration t ----
             double nsig = sig;
             const bool upd = (t % A.sigma_update_steps) == 0;
             if (upd || t == t1) {   // (the rate is looked at where sigma is adapted, and by whoever reads the state after the launch)
-                const double rate = (double)(na2 + (acc ? 1 : 0)) / (double)(nn2 + 1);   // set_acceptRate!, :253-257
+                const double rate = (double)(na + (acc ? 1 : 0)) / (double)(nn + 1);   // set_acceptRate!, :253-257
                 if (upd) nsig = (rate > 0.234) ? sig * (1.0 + A.sigma_adjust_by) : sig * (1.0 - A.sigma_adjust_by);   // :381-390
                 if (r == 0) st[CS_RATE] = rate;
             }
-            double bestv, bestid;   // set_eval!, :220-245
+            double bestv, bestid;
             const double currv = acc ? value : old;
-            if (value < bp2) { bestv = value; bestid = (double)t; }
-            else { bestv = bp2; bestid = bpid2; }
+            if (value < bp) { bestv = value; bestid = (double)t; }
+            else { bestv = bp; bestid = bpid; }
             if (r == 0) {
                 Y.slots[c] = make_uint2(order_key32(v), (uint32_t)c);   // the tile's own slots of the next walk
+#pragma unroll
+                for (int k = 0; k < NP; ++k) Y.s_gth[c * NP + k] = nr[3 + k];   // (... and parameters: a donor may be a chain of the same tile)
                 // ---- the chain's line for the next iteration ----
-                st[CS_SIGMA] = nsig; st[CS_LACC] = accd; st[CS_WASX] = 0.0;
-                st[CS_BEST] = bestv; st[CS_BESTID] = bestid; st[CS_BESTP] = bp2; st[CS_BESTPID] = bpid2;
+                st[CS_SIGMA] = nsig; st[CS_NNOEX] = (double)nn; st[CS_NACC] = (double)na; st[CS_LACC] = accd;
+                st[CS_BEST] = bestv; st[CS_BESTID] = bestid; st[CS_BESTP] = bp; st[CS_BESTPID] = bpid;
 #pragma unroll
                 for (int f = 0; f < RW; ++f) st[PR_STW + f] = nr[f];
                 // ---- the history row, through LDS (wave 3 stores it behind the next barrier) ----
@@ -841,8 +956,20 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
                 if (HW > H_PARAMS + 2 * NP) hv[HW - 1] = 0.0;
             }
         }
-        if (A.ts && lane == 0) { const unsigned long long ts6 = wall_clock64(); Y.s_ts[4] += ts5 - Y.s_ts[6]; Y.s_ts[5] += ts6 - ts5; Y.s_ts[7] = ts6; }
+        {   // which chains' rows of iteration t-1 are rewritten (s_xrow)
+            const unsigned long long xm = __ballot(valid && r == 0 && (int)st[CS_PARTNER] != 0);
+            if (lane == 0) {
+                unsigned m = 0u;
+#pragma unroll
+                for (int q = 0; q < CT; ++q) m |= (unsigned)((xm >> (4 * q)) & 1ull) << q;
+                *Y.s_xmask = m;
+            }
+        }
+        if (A.ts && lane == 0) { const unsigned long long ts7 = wall_clock64(); Y.s_ts[2] += ts7 - Y.s_ts[6]; Y.s_ts[7] = ts7; }
     }
     PR_BARRIER();   // the last epilogue is done (the workers store the last history rows and the result blocks)
-    if (A.ts && lane < 7) A.ts[(size_t)tile * 8 + lane] = lane < 6 ? Y.s_ts[lane] : (unsigned long long)(t1 - t0 + 1);
+    {
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (A.ts && lane < 7) A.ts[(size_t)tile * 8 + lane] = lane < 6 ? Y.s_ts[lane] : (unsigned long long)(t1 - t0 + 1);
+    }
 }
