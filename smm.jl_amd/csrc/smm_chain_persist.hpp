@@ -130,6 +130,8 @@ struct PersistArgs {
     const double* rb;                 // randomness blocks of injected tables (null: drawn in the kernel)
     int N, Ng, ns, zstride, plan_t0, exch_from, sigma_update_steps, smpl_iters, t0, t1;
     int rb_t0, RBW, rb_tries, user_n, failbox;
+    int ring_k;                       // entries of the ring in use (a power of two <= PR_K)
+    int slow_tile, slow_ticks;        // test build: this tile's control wave idles so many wall-clock ticks before it publishes (skew)
     int walk_first;                   // the exchange of iteration t0 - 1 is still to be applied: the first iteration walks it on the launch's input records
     uint32_t epoch;
     double sigma_adjust_by;
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
     const uint32_t epoch = A.epoch;
     const int t0 = A.t0, t1 = A.t1;
     const PrWait W{A.err, A.pr_ctl, Y.s_abort, A.epoch};
+    const int rmask = A.ring_k - 1;   // (the ring's depth: PR_K; the test build can make it smaller)
     const bool exch_any = A.Ng > 1;
     auto exch_on = [&](const int tx) { return exch_any && tx >= A.exch_from; };   // AlgoBGP.jl:637
 
@@ -629,10 +632,10 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
                 while (__hip_atomic_load(Y.s_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_s_sleep(PR_GATHER_DELAY);
                 const int ngat = (int)(Y.s_hdr[(t & 3) * 16] >> 16);
-                const unsigned long long* rs = (const unsigned long long*)A.pr_slot + (size_t)(rel % PR_K) * (A.Ng + 4);
+                const unsigned long long* rs = (const unsigned long long*)A.pr_slot + (size_t)(rel & rmask) * (A.Ng + 4);
                 const uint32_t want = pr_tag16(epoch, rel) << 16;
                 const uint16_t* gl = (const uint16_t*)(lds + Y.gbase) + (t & 1) * CONE_GCAP;
-                const uint4* rr = (const uint4*)A.pr_rec + (size_t)(rel % PR_K) * A.Ng * RW;
+                const uint4* rr = (const uint4*)A.pr_rec + (size_t)(rel & rmask) * A.Ng * RW;
                 const uint32_t tag = pr_tag32(epoch, rel);
                 for (int e = tid - 256; e < ngat; e += 256) {
                     const int g = (int)gl[e];
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
             const uint32_t lbase = Y.pbase + (uint32_t)((t - 1) & 1) * (CONE_LEVELS * 64 * 4);
             if (exch) {
                 const int nsub = (int)(Y.s_hdr[((t - 1) & 3) * 16] & 0xffffu);
-                const PersistWalkValues values{W, (const uint4*)A.pr_rec + (size_t)((rel - 1) % PR_K) * A.Ng * RW, first ? A.rec_in : nullptr, pr_tag32(epoch, rel - 1), RW, NP, t};
+                const PersistWalkValues values{W, (const uint4*)A.pr_rec + (size_t)((rel - 1) & rmask) * A.Ng * RW, first ? A.rec_in : nullptr, pr_tag32(epoch, rel - 1), RW, NP, t};
                 lean_walk_levels<64, 0, false, PersistWalkValues>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, 0.0, values);
                 if (valid) {
                     const uint32_t kmeta = Y.slots[c].y;
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
             // the donor's whole record (swap_ev_ij!, :734-749), requested now and looked at behind the simulation
             // (by LDS-DMA: lane r of the quad brings the record's doubles r and 4 + r — ring order, a uint4 each — to entries lane and 64 + lane)
             if (donor && !first) {
-                const uint4* g_ll = (const uint4*)A.pr_rec + ((size_t)((rel - 1) % PR_K) * A.Ng + src) * RW;
+                const uint4* g_ll = (const uint4*)A.pr_rec + ((size_t)((rel - 1) & rmask) * A.Ng + src) * RW;
                 const uint32_t dbase = (uint32_t)((unsigned char*)Y.s_donor - lds);
                 pr_dma16(g_ll + r, dbase);
                 if (4 + r < RW) pr_dma16(g_ll + 4 + r, dbase + 64 * 16);
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
                         rr[f] = p2p_ll_double(q);
                     }
                     if (__builtin_expect(!ok, 0)) {   // (cannot be: the gather has validated this chain's slot and parameters; late stores of the SAME publication?)
-                        const uint4* g_ll = (const uint4*)A.pr_rec + ((size_t)((rel - 1) % PR_K) * A.Ng + src) * RW;
+                        const uint4* g_ll = (const uint4*)A.pr_rec + ((size_t)((rel - 1) & rmask) * A.Ng + src) * RW;
 #pragma unroll
                         for (int f = 0; f < RW; f += 2) {
                             const PrLL2 w2 = pr_wait_ll2(W, g_ll + f, g_ll + f + 1, tag, t, c);
@@ -889,12 +892,15 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
             // ---- publish: the walk slot and the self-validating record of iteration t into the ring (write-through stores) ----
             if (t < t1) {
                 // entry rel mod PR_K still holds iteration rel - PR_K: has everybody read it?  (always, in practice)
-                if (__builtin_expect(rel >= PR_K && __hip_atomic_load(Y.s_minprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rel - PR_K + 1, 0))
-                    pr_wait_progress(W, A.pr_progress, Y.s_minprog, rel - PR_K + 1, tiles, lane, t, c);
+                if (__builtin_expect(rel > rmask && __hip_atomic_load(Y.s_minprog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < rel - rmask, 0))
+                    pr_wait_progress(W, A.pr_progress, Y.s_minprog, rel - rmask, tiles, lane, t, c);
+#ifdef SMM_TEST_HOOKS
+                if (tile == A.slow_tile) { const unsigned long long w0 = wall_clock64(); while (wall_clock64() - w0 < (unsigned long long)A.slow_ticks) __builtin_amdgcn_s_sleep(8); }
+#endif
                 if (r == 0)
-                    pr_store8((uint2*)A.pr_slot + (size_t)(rel % PR_K) * (A.Ng + 4) + c,
+                    pr_store8((uint2*)A.pr_slot + (size_t)(rel & rmask) * (A.Ng + 4) + c,
                               (unsigned long long)order_key32(v) | ((unsigned long long)((uint32_t)c | (pr_tag16(epoch, rel) << 16)) << 32));
-                unsigned char* g_ll = (unsigned char*)A.pr_rec + ((size_t)(rel % PR_K) * A.Ng + c) * RW * 16;
+                unsigned char* g_ll = (unsigned char*)A.pr_rec + ((size_t)(rel & rmask) * A.Ng + c) * RW * 16;
                 double ro[8];   // the ring's order
 #pragma unroll
                 for (int f = 0; f < 8; ++f) ro[f] = 0.0;

@@ -239,6 +239,7 @@ struct Ctx {
     bool persist_broken = false;               // a launch gave up waiting (tiles not resident together?): the form is off for this context
     uint32_t pr_epoch = 0;                     // launches so far
     int persist_launches = 0, persist_repairs = 0;
+    int pr_ring_k = PR_K, pr_slow_tile = -1, pr_slow_ticks = 0;   // (test build: SMMHIP_PR_RING, SMMHIP_PR_SLOW_TILE, SMMHIP_PR_SLOW_US)
     bool in_repair = false;
     // ... and what persist_repair restores when a launch of it ends with the error word set: the state before the FIRST such launch
     // since the last check of the error word
@@ -849,6 +850,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
     A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
     A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
     A.walk_first = c->unresolved ? 1 : 0;
+    A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
     A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed;
     if (P.np == 1) launch_chain_persist_t<1>(c, A); else launch_chain_persist_t<2>(c, A);
     c->cur ^= 1;
@@ -1367,6 +1369,9 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                             HIPCHK(hipMemset(P.pr_progress, 0, tiles * 4));
                             HIPCHK(hipMemset(P.pr_ctl, 0, 16));
                             c->persist = true;
+                            if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
+                            if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
+                            if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                         }
                     }
                 }
