@@ -42,7 +42,7 @@ PEAK_HBM_GBS = 8000.0
 WORKLOADS = {
     # 2*nm*ns FP64 adds + ~100 for proposal/objective/accept; 128 B of HBM traffic (state read 40 B + history record 88 B)
     "c2": dict(chains=4096, total=False, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
-               kernel="k_chain_iter_norm<2, true>",
+               kernel="k_chain_persist_norm<2>",
                label="serialNormal objfunc_norm 2 params / 2 moments, ns=10000 (BASELINE configs[1])"),
     "c3": dict(chains=32768, total=True, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
                kernel="k_chain_iter_norm_narrow<2>",
@@ -79,16 +79,32 @@ def profile_tag(workload):
     return "" if workload == "c2" else workload + "_"   # (no committed profile of c3: its lines carry no rocprof / traffic figures)
 
 
+CHAIN_KERNELS_C2 = ("k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>")   # the persistent launches + the single iterations at window boundaries
+
+
+def _profile_iterations(summary_path, which):
+    import re
+    if not summary_path or not os.path.exists(summary_path):
+        return None
+    m = re.search(r"iterations_%s=(\d+)" % which, open(summary_path).read())
+    return int(m.group(1)) if m else None
+
+
 def pmc_traffic(kernel, workload="c2"):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
     WRITE_SIZE are KB per launch; gfx950's FETCH_SIZE tallies wide coalesced reads at half their size (MI355X_MICROARCH.md, HBM)
     so it is doubled.  Counters cannot be read from inside the timed process, so the number comes from the profile file; `stale`
-    says whether that profile was taken from other device sources than this build (the summary carries the source hash)."""
+    says whether that profile was taken from other device sources than this build (the summary carries the source hash).
+    The persistent chain kernel (C2) covers many iterations per launch: its figure is per ITERATION — the totals over all chain
+    kernels of the profiled command / its iterations."""
     import re
     f = newest_profile("r[0-9][0-9]_%spmc_summary.txt" % profile_tag(workload))
     if not f:
         return None, None, None
     fetch = write = src_hash = None
+    per_iter = kernel.startswith("k_chain_persist")
+    iters = _profile_iterations(f, "pmc") if per_iter else None
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
     if workload != "c2":   # (the C4 / C5 summaries carry no hash line of their own: the C2 bundle of the same round does)
         import re as _re
         f0 = f.replace("_%spmc" % profile_tag(workload), "_pmc")
@@ -99,12 +115,21 @@ def pmc_traffic(kernel, workload="c2"):
         m = re.match(r"#\s*kernel_source_sha16=([0-9a-f]+)", line)
         if m:
             src_hash = m.group(1)
-        if kernel in line:
+        if per_iter:
+            if any(k in line for k in CHAIN_KERNELS_C2):
+                m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+launches=\s*\d+\s+mean_per_launch=\s*[0-9.]+\s+total=\s*([0-9.]+)", line)
+                if m:
+                    tot[m.group(1)] += float(m.group(2))
+        elif kernel in line:
             m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+launches=\s*\d+\s+mean_per_launch=\s*([0-9.]+)", line)
             if m and m.group(1) == "FETCH_SIZE" and fetch is None:
                 fetch = float(m.group(2))
             elif m and m.group(1) == "WRITE_SIZE" and write is None:
                 write = float(m.group(2))
+    if per_iter:
+        if not iters or tot["FETCH_SIZE"] == 0.0:
+            return None, None, None
+        fetch, write = tot["FETCH_SIZE"] / iters, tot["WRITE_SIZE"] / iters
     if fetch is None or write is None:
         return None, None, None
     return (2.0 * fetch + write) * 1024.0, os.path.relpath(f, ROOT), (src_hash != kernel_source_hash())
@@ -112,18 +137,27 @@ def pmc_traffic(kernel, workload="c2"):
 
 def rocprof_kernel_us(kernel, workload="c2"):
     """average duration of the dominant kernel in the newest committed rocprofv3 --kernel-trace --stats summary (profiles/), with
-    the staleness of that file against this build's device sources (a `# kernel_source_sha16=` line next to it)"""
+    the staleness of that file against this build's device sources (a `# kernel_source_sha16=` line next to it).  The persistent
+    chain kernel: per ITERATION — the total duration of all chain kernels of the profiled command / its iterations."""
     import csv
     f = newest_profile("r[0-9][0-9]_%skernel_stats.csv" % profile_tag(workload))
     if not f:
         return None, None, None
+    tag = f.replace("_%skernel_stats.csv" % profile_tag(workload), "_pmc_summary.txt")
     us = None
+    per_iter = kernel.startswith("k_chain_persist")
+    total_ns = 0.0
     for row in csv.DictReader(l for l in open(f) if not l.startswith("#")):
         name = row.get("Name") or row.get("KernelName") or ""
-        if kernel in name and "AverageNs" in row:
+        if per_iter:
+            if any(k in name for k in CHAIN_KERNELS_C2) and "TotalDurationNs" in row:
+                total_ns += float(row["TotalDurationNs"])
+        elif kernel in name and "AverageNs" in row:
             us = float(row["AverageNs"]) / 1e3
             break
-    tag = f.replace("_%skernel_stats.csv" % profile_tag(workload), "_pmc_summary.txt")
+    if per_iter:
+        iters = _profile_iterations(tag, "kernel_trace")
+        us = total_ns / 1e3 / iters if iters and total_ns else None
     stale = None
     if os.path.exists(tag):
         import re
@@ -397,10 +431,14 @@ def main():
                 "frac_rocprof": (work / (prof_us * 1e-6) / (1e12 if W["bound"] != "hbm" else 1e9) / W["peak"]) if prof_us else None,
                 "rocprof_kernel_us": prof_us, "rocprof_source": prof_src, "rocprof_stale": prof_stale,
                 "traffic": traffic, "traffic_stale": traffic_stale,
-                "traffic_note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from %s; algorithmic: %d B"
-                                % (traffic_src, n_loc * W["bytes"]),
+                "traffic_note": ("HBM bytes per %s = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from %s; algorithmic: %d B"
+                                 % ("ITERATION (all chain kernels of the profiled command / its iterations)" if kernel.startswith("k_chain_persist") else "launch",
+                                    traffic_src, n_loc * W["bytes"])),
                 "avg_kernel_us": k_us, "avg_exchange_us": x_us, "profiled_iteration_us": step_us,
                 "profiled_other_us": max(0.0, step_us - k_us - x_us),
+                "unit_of_work": ("one ITERATION of all chains: the persistent kernel covers up to a look-ahead window of iterations per launch, so every per-launch "
+                                 "figure of this object (achieved, traffic, avg_kernel_us, rocprof_kernel_us) is the launches' total / the iterations they cover"
+                                 if kernel.startswith("k_chain_persist") else "one launch = one iteration of all chains"),
                 "timing_note": "rank 0, one profiled step: avg_kernel_us = the chain kernel's own start/stop events (dispatch duration, what "
                                "rocprofv3 reports; used for 'achieved' and 'frac'), avg_exchange_us = the stand-alone exchange resolution "
                                "where there is one, profiled_iteration_us = the PROFILED step's events / 200 (start/stop events on every kernel slow the "
@@ -412,6 +450,25 @@ def main():
         if args.workload in ("c2", "c3"):
             roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "
                             "(FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)")
+    # the one-launch-per-iteration path on the same problem (what the persistent kernel replaced): smm_set_persistent(0)
+    if roof is not None and not sharded and args.workload == "c2" and kernel.startswith("k_chain_persist"):
+        prob1, opts1 = build_problem(args.workload, n_loc, n_glob, rank, 3 * ITERS_PER_STEP, device)
+        c1 = S.hip_context(prob1, opts1)
+        c1.set_persistent(False)
+        c1.step(ITERS_PER_STEP)
+        t1 = time.perf_counter()
+        c1.step_async(ITERS_PER_STEP); c1.sync()
+        w1 = time.perf_counter() - t1
+        c1.set_profiling(2)
+        c1.step(ITERS_PER_STEP)
+        k1 = c1.timing().iter_kernel_ms * 1e3 / ITERS_PER_STEP
+        roof["one_launch_per_iteration"] = {"kernel": "k_chain_iter_norm<2, true>", "avg_kernel_us": k1, "us_per_iteration": w1 / ITERS_PER_STEP * 1e6,
+                                            "chain_evals_per_s": n_loc * ITERS_PER_STEP / w1,
+                                            "frac": n_loc * W["flop"] / (k1 * 1e-6) / 1e12 / PEAK_FP64_ADD_TFLOPS if k1 > 0 else None,
+                                            "note": "the same context with smm_set_persistent(0): one launch per iteration, the exchange walk in its prologue"}
+        info = ctx.persistent_info()
+        roof["persistent"] = {"launches": info[1], "repairs": info[2]}
+        del c1
     # the same chain kernel without the exchange walk in its prologue (single shard, C2): what the fused launch consists of
     if roof is not None and not sharded and args.workload == "c2" and not args.no_unfused and os.path.exists(S._abi.HOOKS_LIB_PATH):
         # (a seam of the TEST build of the library, libsmmhip_hooks.so: the shipped one has no switch for it)

@@ -11,6 +11,9 @@ B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-
 rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-unfused > /dev/null 2>&1
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 echo "# kernel_source_sha16=$(cd $GRAFT_REPO_ROOT && python -c 'import bench; print(bench.kernel_source_hash())')" > $out/pmc_summary.txt
+# (the persistent chain kernel covers many iterations per launch: per-iteration figures = totals over the chain kernels / iterations of the command;
+#  bench.py runs warmup + steps + one profiled step of 200 iterations each)
+echo "# iterations_kernel_trace=1400 iterations_pmc=800" >> $out/pmc_summary.txt
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS" "SQC_ICACHE_REQ SQC_ICACHE_MISSES TCC_HIT_sum TCC_MISS_sum"; do
   rm -rf /tmp/pm && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pm -- $B > /dev/null 2>&1
   python $GRAFT_REPO_ROOT/tools/summarise_pmc.py $(find /tmp/pm -name "*counter_collection.csv" | head -1) >> $out/pmc_summary.txt
