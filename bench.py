@@ -271,41 +271,73 @@ def dry_launch(rank, world, local_rank):
                           "local_ranks": sorted(l for _, l, _ in seen), "pids": len({p for _, _, p in seen})}))
 
 
-def p2p_self_check(S, cm, torch, dist, rank, world, device, same_device):
-    """a short sharded run through the p2p windows and — where RCCL can run — through the record all-gather: identical histories
-    or the bench takes the collective form.  (rank-local verdicts are reduced: every rank takes the same branch.)"""
+def _all_ok(torch, dist, world, ok, same_device):
+    """every rank takes the same branch: the minimum of the ranks' verdicts (a collective every rank reaches, whatever happened to it)"""
+    if world <= 1:
+        return ok
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if same_device else "cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def p2p_self_check(S, cm, torch, dist, rank, world, device, same_device, n_loc=64, ns=500, T=24):
+    """a short sharded run through the p2p windows and — where RCCL can run — through the record all-gather, ON THE FORM THE TIMED RUN
+    WILL USE (the same N_global and chains per rank, ns = 10000, more iterations than the rows plan's first look-ahead pieces):
+    identical histories or the bench takes the collective form.  Every rank executes the same sequence of collectives whatever
+    happens to it: failures are caught per protocol, the barrier is always reached, the verdicts are reduced before anybody goes on."""
     import numpy as np
     from smm_jl_amd.dist import HipShardEngine, ShardedBGP
-    ok, why = True, "p2p == records on 64 chains per rank x 24 iterations"
-    try:
-        n, T = 64, 24
-        hist = {}
-        for proto in (("p2p",) if same_device else ("p2p", "records")):
-            prob, opts = cm.serial_normal(N=n * world, T=T, ns=500, N_local=n, chain_offset=rank * n, device=device)
+    hist, why = {}, None
+    protos = ("p2p",) if same_device else ("p2p", "records")
+    for proto in protos:
+        ok, err, ctx, sh = True, None, None, None
+        try:
+            prob, opts = cm.serial_normal(N=n_loc * world, T=T, ns=ns, N_local=n_loc, chain_offset=rank * n_loc, device=device)
             ctx = S.hip_context(prob, opts)
             sh = ShardedBGP(HipShardEngine(ctx, torch.device("cuda", device)), protocol=proto)
             sh.step(T)
             sh.sync()
             h = ctx.history()
             hist[proto] = [getattr(h, f).copy() for f in h.FIELDS]
-            if world > 1:
-                dist.barrier()   # nobody drops its window while a peer may still store into it
-            del sh, ctx
-        if not same_device:
-            ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(hist["p2p"], hist["records"]))
-            if not ok:
-                why = "p2p and the record all-gather disagree"
-        else:
-            why = "p2p ran (same-device form: no RCCL to compare with; tests/test_gpu_p2p.py holds the bit-exact comparison)"
-    except Exception as e:   # noqa: BLE001 -- any failure of the transport selects the collective form
-        ok, why = False, "p2p failed: %s" % (str(e)[:200],)
+        except Exception as e:   # noqa: BLE001 -- any failure of a transport is a verdict, not a crash
+            ok, err = False, "%s failed: %s" % (proto, str(e)[:200])
+        if world > 1:
+            dist.barrier()   # nobody drops its window while a peer may still store into it
+        del sh, ctx
+        if not _all_ok(torch, dist, world, ok, same_device):
+            return False, (err or "%s failed on another rank" % proto)
+    if same_device:
+        return True, "p2p ran on %d chains per rank x %d iterations, ns = %d (same-device form: no RCCL to compare with; tests/test_gpu_p2p.py holds the bit-exact comparison)" % (n_loc, T, ns)
+    same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(hist["p2p"], hist["records"]))
+    if not _all_ok(torch, dist, world, same, same_device):
+        return False, "p2p and the record all-gather disagree" if not same else "p2p and the record all-gather disagree on another rank"
+    return True, "p2p == records, bit-exact, on the timed run's form: %d chains per rank (%d in all) x %d iterations, ns = %d" % (n_loc, n_loc * world, T, ns)
+
+
+def cross_rank_check(ctx, torch, dist, rank, world, n_loc, same_device, last=8):
+    """after the timed run, outside the clock: do the shards agree on the exchange?  The `exchanged` rows of the last iterations are
+    all-gathered; a chain marked with partner p must find p marked in the same iteration (p may sit on any rank), and nobody is its
+    own partner.  Returns (ok, note)."""
+    import numpy as np
+    it = ctx.state().iter
+    t0 = max(0, it - last)
+    ex = np.ascontiguousarray(ctx.history(t0, it).exchanged.astype(np.int32))   # [last][n_loc], partner + 1 (global chain id) or 0
     if world > 1:
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if same_device else "cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if ok and not bool(flag.item()):
-            why = "p2p failed on another rank"
-        ok = bool(flag.item())
-    return ok, why
+        mine = torch.from_numpy(ex).to("cpu" if same_device else "cuda")
+        allx = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allx, mine)
+        full = np.concatenate([a.cpu().numpy() for a in allx], axis=1)       # [last][N_global]
+    else:
+        full = ex
+    bad = 0
+    for r in range(full.shape[0]):
+        row = full[r]
+        idx = np.nonzero(row)[0]
+        partners = row[idx] - 1
+        bad += int(np.count_nonzero(row[partners] == 0)) + int(np.count_nonzero(partners == idx))
+    frac = float(np.count_nonzero(full)) / max(1, full.size)
+    ok = bad == 0
+    return ok, "last %d iterations: %.3f of the chains exchanged, %d inconsistent partner marks across %d rank(s)" % (full.shape[0], frac, bad, world)
 
 
 def main():
@@ -361,48 +393,76 @@ def main():
         n_glob = n_loc * world
     K, Wm = args.steps, args.warmup
 
+    # the self-check runs the form the timed run will use: the same N_global and chains per rank (at least 1024: the large-population
+    # kernels at 4096 per rank), ns of the workload, 72 iterations (past the first look-ahead pieces of the rows plan)
+    chk = dict(n_loc=n_loc, ns=NS, T=72) if args.workload in ("c2", "c3") else dict()   # (c4 / c5: the generic form, checked on a small serialNormal population)
     protocol, proto_note = args.protocol, None
     if sharded and args.same_device and protocol in ("auto", "p2p"):
-        _, proto_note = p2p_self_check(S, cm, torch, dist, rank, world, device, True)
+        _, proto_note = p2p_self_check(S, cm, torch, dist, rank, world, device, True, **chk)
         protocol = "p2p"
     elif sharded and protocol == "auto":
-        ok, proto_note = p2p_self_check(S, cm, torch, dist, rank, world, device, False)
+        ok, proto_note = p2p_self_check(S, cm, torch, dist, rank, world, device, False, **chk)
         protocol = "p2p" if ok else "records"
     elif not sharded:
         protocol = None
 
     T = ITERS_PER_STEP * (K + Wm + 2)   # + the two profiled steps
-    prob, opts = build_problem(args.workload, n_loc, n_glob, rank, T, device)
-    ctx = S.hip_context(prob, opts)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    if not sharded:
-        def run_step():
-            ctx.step_async(ITERS_PER_STEP)
-        sync = ctx.sync
-    else:
-        from smm_jl_amd.dist import HipShardEngine, ShardedBGP
-        sh = ShardedBGP(HipShardEngine(ctx, torch.device("cuda", device)), protocol=protocol)
+    def timed_run(proto):
+        """warm-up + K timed steps on fresh contexts; returns (ctx, run_step, sync, seconds)"""
+        prob, opts = build_problem(args.workload, n_loc, n_glob, rank, T, device)
+        ctx = S.hip_context(prob, opts)
+        if not sharded:
+            def run_step():
+                ctx.step_async(ITERS_PER_STEP)
+            sync = ctx.sync
+        else:
+            from smm_jl_amd.dist import HipShardEngine, ShardedBGP
+            sh = ShardedBGP(HipShardEngine(ctx, torch.device("cuda", device)), protocol=proto)
 
-        def run_step():
-            sh.step(ITERS_PER_STEP)
-        sync = sh.sync
+            def run_step():
+                sh.step(ITERS_PER_STEP)
+            sync = sh.sync
+        for _ in range(Wm):
+            run_step()
+        sync(); torch.cuda.synchronize(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            run_step()
+        sync(); torch.cuda.synchronize(); barrier()
+        return ctx, run_step, sync, time.perf_counter() - t0
 
-    for _ in range(Wm):
-        run_step()
-    sync(); torch.cuda.synchronize(); barrier()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        run_step()
-    sync(); torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
+    # the p2p windows meet real links here for the first time in earnest: a failure (a peer's stores never arrive: SMM_ERR_HIP after
+    # ~4 s) must not kill the bench — every rank learns of it, the contexts are made anew, and the run is repeated on the collective form
+    err = None
+    try:
+        ctx, run_step, sync, dt = timed_run(protocol)
+    except Exception as e:   # noqa: BLE001
+        if not (sharded and protocol == "p2p"):
+            raise
+        err = str(e)[:200]
+    if sharded and protocol == "p2p" and world > 1:
+        if not _all_ok(torch, dist, world, err is None, args.same_device):
+            if args.same_device:
+                raise RuntimeError("the p2p run failed and RCCL cannot run with all ranks on one device: %s" % (err or "another rank"))
+            proto_note = "%s; TIMED RUN on p2p failed (%s): repeated on the record all-gather" % (proto_note, err or "on another rank")
+            protocol = "records"
+            barrier()
+            ctx, run_step, sync, dt = timed_run(protocol)
+    elif err is not None:
+        raise RuntimeError(err)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.same_device else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # outside the clock: do the shards agree on the exchange of the last iterations?
+    xok, xnote = cross_rank_check(ctx, torch, dist, rank, world, n_loc, args.same_device) if args.workload in ("c2", "c3", "c4", "c5") else (True, None)
+    if not xok:
+        raise RuntimeError("cross-rank check failed: " + xnote)
     evals = n_glob * ITERS_PER_STEP * K
     value = evals / dt
 
@@ -508,7 +568,9 @@ def main():
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s, %d BGP chains per GPU (%d total) x %d iterations per step" % (W["label"], n_loc, n_glob, ITERS_PER_STEP),
                           "chains_per_gpu": n_loc, "chains_total": n_glob, "iters_per_step": ITERS_PER_STEP, "ns": NS if args.workload in ("c2", "c3") else None,
-                          "exchange": exch, "protocol": protocol, "protocol_check": proto_note,
+                          "exchange": exch, "protocol": protocol, "protocol_check": proto_note, "cross_rank_check": xnote,
+                          "world_seen": (dist.get_world_size() if dist.is_initialized() else 1),
+                          "backend": (str(dist.get_backend()) if dist.is_initialized() else None),
                           "same_device": bool(args.same_device), "forced_sharded": force_sharded},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))

@@ -291,7 +291,16 @@ int  smm_bgp_sharded_finish(void* ctx, const void* gathered_dev);
  *        same order relative to each other's p2p calls (publications and pushes are counted).  A rank whose peers' stores never
  *        arrive gives up after ~4 s and reports SMM_ERR_HIP at the next smm_sync.
  *   smm_bgp_p2p_finish(ctx): settles the last iteration into the context (required before smm_get_history / smm_get_state /
- *        the other stepping forms).  Callers must not destroy a context while a peer may still be stepping. */
+ *        the other stepping forms).  Callers must not destroy a context while a peer may still be stepping.
+ *        A BARRIER ACROSS THE RANKS belongs between smm_bgp_p2p_finish (+ smm_sync) and the next smm_bgp_p2p_step: that step's
+ *        first publication rewrites the windows with a new epoch, and a rank still in its finish would find the words of the
+ *        last iteration replaced (a time-out in the tagged forms, other records without notice in the generic one).
+ *        smm.jl_amd/dist.py::ShardedBGP.sync does it.
+ *   Which of the three forms a context steps in is decided from what every rank knows (population, objective, thresholds),
+ *   never from a shard's own values.  A NaN value in an uploaded state (smm_set_state) reaches every window with the first
+ *   publication: the rows form resolves such iterations on the exact values, the one-launch form (N_global <= 8192) has no
+ *   second walk and reports SMM_ERR_HIP on every rank in the same iteration — step such a state once with smm_bgp_sharded_step
+ *   (or as a single shard) first. */
 #define SMM_P2P_HANDLE_BYTES 64
 int  smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out);
 int  smm_bgp_p2p_attach(void* ctx, int32_t rank, const void* ipc_handle, void* window_dev);

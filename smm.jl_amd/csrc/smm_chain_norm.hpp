@@ -297,7 +297,8 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
     const unsigned char* mine = P.p2p_self;
     const uint4* g_slots = (const uint4*)(mine + p2p_slot_off(P, tx & 1));
     const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
-    const uint32_t wflags = *(const uint32_t*)(mine + 128 * (size_t)P2P_MAXG + 0 * (size_t)(tid & 1));
+    // (the NaN word carries the publication epoch of the NaN it reports: a word left by an earlier publication — a state since rolled back — means nothing)
+    const uint32_t wflags = *(const uint32_t*)(mine + 128 * (size_t)P2P_MAXG + 0 * (size_t)(tid & 1)) == P.p2p_epoch ? 1u : 0u;
     uint4 p_[PR];
 #pragma unroll
     for (int r = 0; r < PR; ++r) {
@@ -816,7 +817,7 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
                     p2p_store16u((uint4*)(w + p2p_llval_off(P, pb)) + gc, qv);
                     if constexpr (BIG) p2p_store4((uint32_t*)(w + p2p_slot4_off(P, pb)) + gc, p2p_slot4_word(P, v, t));   // (rows form: the kernel without the walk)
                     else p2p_store8((uint2*)(w + p2p_slot_off(P, pb)) + gc, p2p_slot_word(P, v, (uint32_t)gc, t));
-                    if (v != v) __hip_atomic_fetch_or((uint32_t*)(w + 128 * (size_t)P2P_MAXG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (v != v) __hip_atomic_fetch_max((uint32_t*)(w + 128 * (size_t)P2P_MAXG), P.p2p_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
         } else {
             P.vals_out[c] = v;

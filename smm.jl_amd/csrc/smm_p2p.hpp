@@ -33,7 +33,7 @@
 // (t-1) & 1 and writes parity t & 1; a rank that runs ahead cannot overwrite what a slower one still reads: before its kernel t+1
 // stores anything it has seen every chain's slot of iteration t, and a chain's slot is stored after its tile's prologue reads:
 //   arrived[P2P_MAXG]  u64, 128 bytes apart   arrivals from source rank r (generic form)
-//   nan                u32                    a NaN value entered the population (order keys do not cover it: sticky)
+//   nan                u32                    a NaN value entered the population in publication epoch <word> (order keys do not cover it; an older epoch's word means nothing)
 //   rec [2][Ng][RW], val [2][Ng + 4]          plain records / values
 //   slot[2][Ng + 4]    uint2                  tagged walk slots
 //   slot4[2][Ng + 4]   u32                    tagged 17-bit keys (rows form: 8192 < N_global <= 32768)
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_p2p_push(const KParams P, const int t, 
             } else if (!own) p2p_store8((double*)(w + p2p_val_off(P, b)) + P.offset + c0 + tid, vb);
             p2p_store8((uint2*)(w + p2p_slot_off(P, b)) + P.offset + c0 + tid, p2p_slot_word(P, v, (uint32_t)(P.offset + c0 + tid), t));
             if (LL) p2p_store4((uint32_t*)(w + p2p_slot4_off(P, b)) + P.offset + c0 + tid, p2p_slot4_word(P, v, t));
-            if (v != v) { __hip_atomic_fetch_or((uint32_t*)(w + 128 * (size_t)P2P_MAXG), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            if (v != v) { __hip_atomic_fetch_max((uint32_t*)(w + 128 * (size_t)P2P_MAXG), P.p2p_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     }
     if (LL) return;

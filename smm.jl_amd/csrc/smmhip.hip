@@ -1655,6 +1655,7 @@ int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathere
     if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     if (c->rec_external && !gathered_prev_dev) return fail(c, SMM_ERR_INVALID_ARG, "gathered_prev required: the last records live there");
     if (c->unresolved) return fail(c, SMM_ERR_STATE, "mixing smm_bgp_step and smm_bgp_sharded_step without a flush");
+    if (c && c->p2p_current) return fail(c, SMM_ERR_STATE, "the records of the last iteration are in the p2p windows: call smm_bgp_p2p_finish first");
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
@@ -1719,6 +1720,7 @@ int smm_bgp_sharded_finish(void* ctx, const void* gathered_dev) {
     if (!c) return SMM_ERR_INVALID_ARG;
     if (!c->rec_external) return SMM_OK;
     if (!gathered_dev) return SMM_ERR_INVALID_ARG;
+    if (c && c->p2p_current) return fail(c, SMM_ERR_STATE, "the records of the last iteration are in the p2p windows: call smm_bgp_p2p_finish first");
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
@@ -1855,7 +1857,12 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
         HIPCHK(hipEventRecord(c->ev0, c->stream));
         if (!c->p2p_current) {   // first publication: the state after iteration `iter`, its exchange settled, into every window
             flush(c);
-            c->p2p_mode_inline = (c->p2p_inline || c->p2p_rows) && !c->nan_values;
+            // the form is decided from what EVERY rank knows (population, objective, thresholds): a rank that looked at its own shard's
+            // values here (an uploaded state with a NaN) could choose differently from its peers, and each side would wait for words the
+            // other never sends.  A NaN in any shard reaches every window with the publication (the NaN word, tagged with the epoch): the
+            // rows form resolves such an iteration on the exact values inside its launch, the inline form (N_global <= 8192) reports it —
+            // on every rank, in the same iteration (include/smmhip.h).
+            c->p2p_mode_inline = c->p2p_inline || c->p2p_rows;
             c->P.p2p_epoch += 1;   // (a new generation of tags: words of an earlier publication are nobody's any more)
             launch_p2p_push(c, c->iter, c->rec[c->cur], c->p2p_mode_inline);
             c->p2p_current = true;

@@ -203,6 +203,11 @@ class ShardedBGP:
         if self.protocol == "p2p":
             self.e.p2p_finish()
             self.e.sync()
+            # nobody publishes again (the next step's first publication rewrites the windows' parity of the last iteration with a new
+            # epoch) before EVERY rank has read the last iteration out of its window: a rank still in its finish would otherwise find
+            # its words replaced — a time-out in the tagged forms, silently other records in the generic one (include/smmhip.h)
+            if self.world > 1:
+                dist.barrier(group=self.group)
             return
         if self.fused and self.gcur is not None:
             with self.e.stream_ctx():

@@ -39,3 +39,28 @@ def test_under_a_launcher_it_is_one_rank():
 def test_single_rank_dry_launch():
     d = run(["--dry-launch"])
     assert d["n_gpus"] == 1 and d["ranks"] == [0]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_rows_form_checks_itself():
+    # VERDICT r3 "Next #3": the self-check runs the form the timed run uses (2 x 8192 chains: the rows form through the windows,
+    # ns = 10000, 72 iterations), the timed run is wrapped (a p2p failure repeats it on the collective form), the shards' exchange
+    # marks are compared across ranks after the run, and the line says how many ranks the process group really had
+    d = run(["--gpus", "2", "--same-device", "--workload", "c3", "--chains", "8192", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and cfg["world_seen"] == 2 and cfg["backend"]
+    assert cfg["protocol"] == "p2p" and "8192 chains per rank" in cfg["protocol_check"] and "72 iterations" in cfg["protocol_check"]
+    assert "0 inconsistent partner marks across 2 rank(s)" in cfg["cross_rank_check"]
+    assert cfg["chains_total"] == 16384 and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_carries_the_persistent_kernel():
+    d = run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-unfused"])
+    r = d["roofline"]
+    assert r["kernel"].startswith("k_chain_persist_norm") and r["persistent"]["launches"] >= 2 and r["persistent"]["repairs"] == 0
+    assert r["one_launch_per_iteration"]["avg_kernel_us"] > r["avg_kernel_us"] > 0
+    assert "0 inconsistent partner marks" in d["config"]["cross_rank_check"]
