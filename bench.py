@@ -50,10 +50,13 @@ WORKLOADS = {
     # ~80 flop vs (2*10 + 10 + 8) * 8 = 304 B per chain evaluation: an HBM / latency stream
     "c4": dict(chains=8192, total=False, flop=80, bytes=304, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", kernel="k_chain_iter<0, 16, 2, true>",
                label="banana / Rosenbrock 10 params / 10 moments, 8192 chains (BASELINE configs[3])"),
-    # 2*256*256 + 2*256*50 flop per chain evaluation on FP64 MFMA
-    "c5": dict(chains=4096, total=False, flop=2 * 256 * 256 + 2 * 256 * 50, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma", peak=PEAK_FP64_MFMA_TFLOPS,
-               unit="TFLOP/s", kernel="k_chain_iter<2, 16",
-               label="synthetic dense simulation 50 params, 256x256 matvec per evaluation on FP64 MFMA, 4096 chains (BASELINE configs[4])"),
+    # dense simulation x = B theta (256 x np), h = tanh(x), y = A h (nm x 256) on v_mfma_f64_16x16x4: per 16-chain tile 16 tiles of hidden units x
+    # (13 + 16) MFMAs = 464 (np = 50 padded to 52, nm = 50 to 64), 2048 flop each => 59 392 EXECUTED flop per chain evaluation — what
+    # SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 counts; the un-padded algorithm is 2*256*50 + 2*50*256 = 51 200 (0.862 of it)
+    "c5": dict(chains=4096, total=False, flop=464 * 2048 // 16, useful_flop=2 * 256 * 50 + 2 * 50 * 256, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma",
+               peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_iter<2, 16",
+               label="synthetic dense simulation, 50 params -> 256 hidden units (tanh) -> 50 moments: the products 256x50 and 50x256 per evaluation "
+                     "on FP64 MFMA, 4096 chains (BASELINE configs[4]; NOT a 256x256 product: see roofline.note)"),
 }
 
 
@@ -164,6 +167,20 @@ def rocprof_kernel_us(kernel, workload="c2"):
         m = re.search(r"kernel_source_sha16=([0-9a-f]+)", open(tag).read())
         stale = (m.group(1) != kernel_source_hash()) if m else None
     return us, os.path.relpath(f, ROOT), stale
+
+
+def mfma_counter(kernel, workload):
+    """SQ_INSTS_VALU_MFMA_MOPS_F64 per launch of the dominant kernel from the newest committed PMC summary of the workload"""
+    import re
+    f = newest_profile("r[0-9][0-9]_%spmc_summary.txt" % profile_tag(workload))
+    if not f:
+        return None, None
+    for line in open(f):
+        if kernel in line and "SQ_INSTS_VALU_MFMA_MOPS_F64" in line:
+            m = re.search(r"mean_per_launch=\s*([0-9.]+)", line)
+            if m:
+                return float(m.group(1)), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def host_cores():
@@ -343,7 +360,7 @@ def cross_rank_check(ctx, torch, dist, rank, world, n_loc, same_device, last=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps of 200 iterations (default 5; c5: 8 = the steady state past 1600 iterations)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--protocol", choices=["auto", "p2p", "records", "values"], default=os.environ.get("SMM_BENCH_PROTOCOL", "auto"))
@@ -391,6 +408,8 @@ def main():
     else:
         n_loc = args.chains or (W["chains"] // world if args.same_device else W["chains"])
         n_glob = n_loc * world
+    if args.steps is None:
+        args.steps = 8 if args.workload == "c5" else 5
     K, Wm = args.steps, args.warmup
 
     # the self-check runs the form the timed run will use: the same N_global and chains per rank (at least 1024: the large-population
@@ -507,6 +526,20 @@ def main():
                 "algorithmic_per_launch": {"flop": n_loc * W["flop"], "hbm_bytes": n_loc * W["bytes"]},
                 "hbm": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
                         "note": "algorithmic %d B per chain-eval" % W["bytes"]}}
+        if W["bound"] == "mfma":
+            mops, msrc = mfma_counter(kernel, args.workload)
+            roof["useful"] = {"flop_per_launch": n_loc * W["useful_flop"], "achieved": n_loc * W["useful_flop"] / (k_us * 1e-6) / 1e12,
+                              "frac": n_loc * W["useful_flop"] / (k_us * 1e-6) / 1e12 / W["peak"], "note": "the un-padded algorithm: 2*256*np + 2*nm*256 flop per evaluation"}
+            roof["mfma_counter"] = None if mops is None else {
+                "SQ_INSTS_VALU_MFMA_MOPS_F64_per_launch": mops, "flop_per_launch": mops * 512.0, "source": msrc,
+                "achieved_at_avg_kernel_us": mops * 512.0 / (k_us * 1e-6) / 1e12,
+                "achieved_at_rocprof_kernel_us": (mops * 512.0 / (prof_us * 1e-6) / 1e12) if prof_us else None,
+                "flop_per_launch_counted_over_assumed": mops * 512.0 / work}
+            roof["note"] = ("achieved = EXECUTED MFMA flop (464 v_mfma_f64_16x16x4 per 16 chains, np / nm padded to 52 / 64) over the chain kernel's duration; "
+                            "mfma_counter = the same from SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the committed PMC pass (must agree within 5 %); the objective is "
+                            "x = B theta (256 x np), h = tanh x, y = A h (nm x 256): 51 200 useful flop per evaluation, not the 2*256*256 + ... = 156 672 of a "
+                            "256 x 256 product that rounds 2-3 credited (BASELINE.json's wording).  The run drifts as sigma adapts (longer redraw tails): "
+                            "quote it at >= 1600 iterations (--steps 8, the default for this workload); per-launch p50 / p99 in profiles/rNN_c5_launches.txt")
         if args.workload in ("c2", "c3"):
             roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "
                             "(FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)")
