@@ -25,7 +25,7 @@
 module SMMHipBackend
 
 using SMM
-using DataStructures: OrderedDict
+using OrderedCollections: OrderedDict          # (what SMM.jl itself depends on: Project.toml, src/SMM.jl:10)
 import SMM: MAlgo, MAlgoBGP, MProb, Eval, BGPChain, Slice, computeNextIteration!, run!, summary, history, save, readMalgo, restart!,
             extendBGPChain!
 import Base: getproperty, show
@@ -49,6 +49,7 @@ mutable struct MAlgoBGPHip <: MAlgo
     dist_fun::Function            # :503  `-` (:537) or the function of the menu entry chosen (device_dist_fun)
     hip::SMMHip.HipBGP            # the device context
     synced::Int                   # iterations already materialised in `chains`
+    stepped::Int                  # iterations enqueued on the device so far (host-side count: asking it needs no device synchronisation)
     pnames::Vector{Symbol}        # parameter order on the device = keys(m.params_to_sample)
     mnames::Vector{Symbol}        # moment order on the device = keys(m.moments)
 end
@@ -118,7 +119,7 @@ function MAlgoBGPHip(m::MProb, opts::Dict)
                             seed = Int(get(opts, "seed", 12)), device = Int(get(opts, "device", 0)),
                             chol_L = get(opts, "chol_L", nothing), dist_fun = dist_id)
     return MAlgoBGPHip(m, opts, 0, reference_chains(m, opts, N, temps, mi, acc), nothing,
-                       dist_fun isa Function ? dist_fun : host_dist_fun(dist_id), hip, 0, pnames, mnames)
+                       dist_fun isa Function ? dist_fun : host_dist_fun(dist_id), hip, 0, 0, pnames, mnames)
 end
 
 # opts["dist_fun"] (AlgoBGP.jl:494,537) -> smm_dist_fun_t.  The reference takes any function of two objective values; inside the
@@ -142,6 +143,7 @@ in support :409) is thrown as `SMMHip.SMMHipError`.
 """
 function computeNextIteration!(algo::MAlgoBGPHip)
     SMMHip.hip_step!(getfield(algo, :hip), 1)
+    setfield!(algo, :stepped, getfield(algo, :stepped) + 1)
     return nothing
 end
 
@@ -162,6 +164,7 @@ function run!(algo::MAlgoBGPHip)
             n = min(n, sf - (algo.i % sf))
         end
         SMMHip.hip_step!(getfield(algo, :hip), n)
+        setfield!(algo, :stepped, getfield(algo, :stepped) + n)
         algo.i += n
         if sf > 0 && fn != "" && algo.i % sf == 0
             save(algo, fn)
@@ -186,6 +189,9 @@ Called by `getproperty(algo, :chains)`; cheap when nothing new happened.
 function sync_chains!(algo::MAlgoBGPHip)
     hip = getfield(algo, :hip)
     chains = getfield(algo, :chains)
+    # nothing was stepped since the last sync: the chains are current (no device synchronisation, no download) — `algo.chains` is read
+    # by every reader the reference defines, often many times in a row
+    getfield(algo, :stepped) == getfield(algo, :synced) && return chains
     st = SMMHip.hip_state(hip)
     done = st.iter
     first = getfield(algo, :synced)
@@ -318,6 +324,7 @@ function MAlgoBGPHip(ref::MAlgoBGP; extra_iter::Int = 0)
              best_id = bid, exchanged = exch, accepted = accd, status = stt)
         SMMHip.hip_set_state!(hip, s, h)
     end
+    setfield!(algo, :stepped, done)
     algo.i = done
     return algo
 end
@@ -335,6 +342,7 @@ function restart!(algo::MAlgoBGPHip, extraIter::Int)
     setfield!(algo, :chains, getfield(ext, :chains))
     setfield!(algo, :opts, getfield(ext, :opts))
     setfield!(algo, :synced, 0)
+    setfield!(algo, :stepped, getfield(ext, :stepped))
     run!(algo)
     return nothing
 end

@@ -195,3 +195,36 @@ def test_glue_refuses_animate():
     # AlgoBGP.jl:621-624: the reference's per-iteration animation hook cannot be served by lazily filled chains
     glue = open(GLUE).read()
     assert re.search(r'get\(opts, "animate", false\) == true\s*&&\s*\n?\s*throw\(ArgumentError', glue)
+
+
+JULIA_STDLIB = {"Base", "Core", "Libdl", "Random", "Statistics", "LinearAlgebra", "Distributed", "Logging", "Test", "Printf", "Dates", "Serialization",
+                "SharedArrays", "SparseArrays", "Sockets", "Mmap", "InteractiveUtils", "DelimitedFiles", "Pkg", "UUIDs"}
+# [deps] of the reference's Project.toml (:6-26): what `using SMM` guarantees to be installed in the user's environment
+SMM_DEPS = {"DataFrames", "DataFramesMeta", "Distributed", "Distributions", "Documenter", "FileIO", "GLM", "JLD2", "JSON", "LinearAlgebra", "Logging",
+            "OrderedCollections", "PDMats", "Plots", "ProgressMeter", "Random", "Revise", "Statistics", "StatsPlots", "Test"}
+
+
+def test_every_package_the_julia_files_load_is_available_next_to_smm():
+    """`using DataStructures` failed at load time in SMM.jl's own environment (it depends on
+    OrderedCollections, /root/reference/Project.toml:18, src/SMM.jl:10).  Every `using` / `import` of both files must name the
+    standard library, a dependency of SMM.jl, SMM itself or this repository's own modules."""
+    if os.path.isfile("/root/reference/Project.toml"):   # (the committed list above is the reference's [deps] block: keep it honest)
+        deps = set(re.findall(r"(?m)^(\w+)\s*=\s*\"[0-9a-f-]{36}\"", open("/root/reference/Project.toml").read().split("[deps]")[1].split("[compat]")[0]))
+        assert deps == SMM_DEPS, deps ^ SMM_DEPS
+    own = {"SMM", "SMMHip", "SMMHipBackend"}
+    for path in (RAW, GLUE):
+        src = strip_julia(open(path).read())
+        for m in re.finditer(r"(?m)^\s*(?:using|import)\s+([^\n]+)", src):
+            for item in m.group(1).split(":")[0].split(","):
+                pkg = item.strip().lstrip(".").split(".")[0]
+                assert pkg in JULIA_STDLIB | SMM_DEPS | own, "%s loads %r: neither the standard library nor a dependency of SMM.jl" % (os.path.basename(path), pkg)
+
+
+def test_sync_chains_returns_at_once_when_nothing_was_stepped():
+    glue = strip_julia(open(GLUE).read())
+    body = re.search(r"function sync_chains!\(algo::MAlgoBGPHip\)(.*?)\nend", glue, re.S).group(1)
+    early = body.index("getfield(algo, :stepped) == getfield(algo, :synced) && return chains")
+    assert early < body.index("hip_state(hip)"), "the early return must come before anything that synchronises with the device"
+    # ... and every path that enqueues iterations counts them
+    assert len(re.findall(r"setfield!\(algo, :stepped,", glue)) >= 4
+    assert os.path.isfile(os.path.join(ROOT, "julia", "FIRST_RUN.md"))
