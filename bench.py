@@ -368,7 +368,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="all ranks on GPU 0 (1-GPU lease: gloo bootstrap, p2p transport)")
     ap.add_argument("--dry-launch", action="store_true", help="bring the ranks up and report them; no GPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-unfused", action="store_true", help="skip the reference timing of the unfused kernels (profiling runs)")
+    ap.add_argument("--no-unfused", action="store_true", help="skip the reference timings on other contexts (the one-launch-per-iteration path, the unfused kernels): profiling runs")
     args = ap.parse_args()
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -544,7 +544,7 @@ def main():
             roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "
                             "(FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)")
     # the one-launch-per-iteration path on the same problem (what the persistent kernel replaced): smm_set_persistent(0)
-    if roof is not None and not sharded and args.workload == "c2" and kernel.startswith("k_chain_persist"):
+    if roof is not None and not sharded and args.workload == "c2" and kernel.startswith("k_chain_persist") and not args.no_unfused:
         prob1, opts1 = build_problem(args.workload, n_loc, n_glob, rank, 3 * ITERS_PER_STEP, device)
         c1 = S.hip_context(prob1, opts1)
         c1.set_persistent(False)
@@ -559,9 +559,10 @@ def main():
                                             "chain_evals_per_s": n_loc * ITERS_PER_STEP / w1,
                                             "frac": n_loc * W["flop"] / (k1 * 1e-6) / 1e12 / PEAK_FP64_ADD_TFLOPS if k1 > 0 else None,
                                             "note": "the same context with smm_set_persistent(0): one launch per iteration, the exchange walk in its prologue"}
+        del c1
+    if roof is not None and not sharded and args.workload == "c2" and kernel.startswith("k_chain_persist"):
         info = ctx.persistent_info()
         roof["persistent"] = {"launches": info[1], "repairs": info[2]}
-        del c1
     # the same chain kernel without the exchange walk in its prologue (single shard, C2): what the fused launch consists of
     if roof is not None and not sharded and args.workload == "c2" and not args.no_unfused and os.path.exists(S._abi.HOOKS_LIB_PATH):
         # (a seam of the TEST build of the library, libsmmhip_hooks.so: the shipped one has no switch for it)

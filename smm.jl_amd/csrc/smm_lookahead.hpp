@@ -61,6 +61,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
     unsigned long long* out = plan + (size_t)blockIdx.x * K;
     double* out_mi = plan_mi + (size_t)blockIdx.x * K;
 
+    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 80] = wall_clock64();
     for (int c = tid; c < Ng; c += XWG) cnt[c] = 0;
     if (P.pairtab) {
         for (int q = tid; q < K; q += XWG) {
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         }
     }
     __syncthreads();
+    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 81] = wall_clock64();
     for (int q = tid; q < K; q += XWG) {  // histogram of endpoints
         atomicAdd(&cnt[pi[q]], 1u);
         atomicAdd(&cnt[pj[q]], 1u);
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         }
     }
     __syncthreads();
+    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 82] = wall_clock64();
     // ---- dependency levels: level(q) = 1 + max(level of q's predecessor on chain i, on chain j) ----
     // buckets re-written in rank order, so that the predecessor of rank r is the entry of rank r-1
 #pragma unroll
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         }
         changed = __syncthreads_or(mine);
     }
+    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 83] = wall_clock64();
     // counting sort of the pairs by level
     for (int c = tid; c < Ng + 2; c += XWG) lhist[c] = 0;
     __syncthreads();
@@ -287,6 +291,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
             ci[m] = (uint16_t)i; cj[m] = (uint16_t)j; lvq[m] = (uint16_t)lv;
         }
     }
+    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 84] = wall_clock64();
     // ---- the cones (smm_cone.hpp): for every workgroup of the chain kernel the pairs its chains' outcome depends on ----
     // A pair is in a workgroup's cone when it is the last pair of one of its chains, or the predecessor (on either chain) of a pair of
     // the cone: one bit per workgroup and pair, seeded at the chains' last pairs and OR-ed into the predecessors level by level from
@@ -332,6 +337,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
                 if (lastj[m]) seed(cj[m], q);
             }
         }
+        if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 85] = wall_clock64();
         __syncthreads();
         for (int l = nlev; l >= 2; --l) {
 #pragma unroll
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
             }
             __syncthreads();
         }
+        if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 86] = wall_clock64();
 #pragma unroll
         for (int m = 0; m < MAXPP; ++m) {   // count
             const int q = tid + m * XWG;
@@ -362,6 +369,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
                 }
         }
         __syncthreads();
+        if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 87] = wall_clock64();
         for (int b = tid; b < nb; b += XWG) {   // sub-levels: counts out, starting words in
             uint32_t sub = 0;
             uint32_t hw[CONE_HDRW];
@@ -384,6 +392,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
             for (int x = 0; x < CONE_HDRW; ++x) o_hdr[(size_t)(b0 + b) * CONE_HDRW + x] = hw[x];
         }
         __syncthreads();
+        if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 88] = wall_clock64();
 #pragma unroll
         for (int m = 0; m < MAXPP; ++m) {   // scatter
             const int q = tid + m * XWG;
@@ -422,6 +431,7 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         }
     }
     __syncthreads();
+    if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 89] = wall_clock64();
     if (tid == 0) *o_ok = s_bad ? 0u : 1u;
 }
 // LDS of the cone passes (k_exch_plan's request is the larger of this and its own)
