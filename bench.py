@@ -48,7 +48,7 @@ WORKLOADS = {
                kernel="k_chain_iter_norm_narrow<2>",
                label="serialNormal objfunc_norm 2p/2m, ns=10000, 32768 chains = 8 temperature levels x 4096 (BASELINE configs[2])"),
     # ~80 flop vs (2*10 + 10 + 8) * 8 = 304 B per chain evaluation: an HBM / latency stream
-    "c4": dict(chains=8192, total=False, flop=80, bytes=304, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", kernel="k_chain_iter<0, 16, 2, true>",
+    "c4": dict(chains=8192, total=False, flop=80, bytes=304, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", kernel="k_chain_persist_gen",
                label="banana / Rosenbrock 10 params / 10 moments, 8192 chains (BASELINE configs[3])"),
     # dense simulation x = B theta (256 x np), h = tanh(x), y = A h (nm x 256) on v_mfma_f64_16x16x4: per 16-chain tile 16 tiles of hidden units x
     # (13 + 16) MFMAs = 464 (np = 50 padded to 52, nm = 50 to 64), 2048 flop each => 59 392 EXECUTED flop per chain evaluation — what
@@ -82,7 +82,9 @@ def profile_tag(workload):
     return "" if workload == "c2" else workload + "_"   # (no committed profile of c3: its lines carry no rocprof / traffic figures)
 
 
-CHAIN_KERNELS_C2 = ("k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>")   # the persistent launches + the single iterations at window boundaries
+# the persistent launches + the single iterations at window boundaries, per workload
+CHAIN_KERNELS = {"c2": ("k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>"),
+                 "c4": ("k_chain_persist_gen", "k_chain_iter<0, 16, 2, true>")}
 
 
 def _profile_iterations(summary_path, which):
@@ -119,7 +121,7 @@ def pmc_traffic(kernel, workload="c2"):
         if m:
             src_hash = m.group(1)
         if per_iter:
-            if any(k in line for k in CHAIN_KERNELS_C2):
+            if any(k in line for k in CHAIN_KERNELS.get(workload, ())):
                 m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+launches=\s*\d+\s+mean_per_launch=\s*[0-9.]+\s+total=\s*([0-9.]+)", line)
                 if m:
                     tot[m.group(1)] += float(m.group(2))
@@ -153,13 +155,14 @@ def rocprof_kernel_us(kernel, workload="c2"):
     for row in csv.DictReader(l for l in open(f) if not l.startswith("#")):
         name = row.get("Name") or row.get("KernelName") or ""
         if per_iter:
-            if any(k in name for k in CHAIN_KERNELS_C2) and "TotalDurationNs" in row:
+            if any(k in name for k in CHAIN_KERNELS.get(workload, ())) and "TotalDurationNs" in row:
                 total_ns += float(row["TotalDurationNs"])
         elif kernel in name and "AverageNs" in row:
             us = float(row["AverageNs"]) / 1e3
             break
     if per_iter:
-        iters = _profile_iterations(tag, "kernel_trace")
+        own = f.replace("kernel_stats.csv", "pmc_summary.txt")   # (the workload's own summary says how many iterations its commands ran)
+        iters = _profile_iterations(own, "kernel_trace") or _profile_iterations(tag, "kernel_trace")
         us = total_ns / 1e3 / iters if iters and total_ns else None
     stale = None
     if os.path.exists(tag):
@@ -544,7 +547,7 @@ def main():
             roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "
                             "(FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)")
     # the one-launch-per-iteration path on the same problem (what the persistent kernel replaced): smm_set_persistent(0)
-    if roof is not None and not sharded and args.workload == "c2" and kernel.startswith("k_chain_persist") and not args.no_unfused:
+    if roof is not None and not sharded and args.workload in ("c2", "c4") and kernel.startswith("k_chain_persist") and not args.no_unfused:
         prob1, opts1 = build_problem(args.workload, n_loc, n_glob, rank, 3 * ITERS_PER_STEP, device)
         c1 = S.hip_context(prob1, opts1)
         c1.set_persistent(False)
@@ -555,12 +558,13 @@ def main():
         c1.set_profiling(2)
         c1.step(ITERS_PER_STEP)
         k1 = c1.timing().iter_kernel_ms * 1e3 / ITERS_PER_STEP
-        roof["one_launch_per_iteration"] = {"kernel": "k_chain_iter_norm<2, true>", "avg_kernel_us": k1, "us_per_iteration": w1 / ITERS_PER_STEP * 1e6,
+        roof["one_launch_per_iteration"] = {"kernel": "k_chain_iter_norm<2, true>" if args.workload == "c2" else "k_chain_iter<0, 16, 2, true>",
+                                            "avg_kernel_us": k1, "us_per_iteration": w1 / ITERS_PER_STEP * 1e6,
                                             "chain_evals_per_s": n_loc * ITERS_PER_STEP / w1,
-                                            "frac": n_loc * W["flop"] / (k1 * 1e-6) / 1e12 / PEAK_FP64_ADD_TFLOPS if k1 > 0 else None,
+                                            "frac": (n_loc * (W["flop"] if W["bound"] != "hbm" else W["bytes"]) / (k1 * 1e-6) / (1e12 if W["bound"] != "hbm" else 1e9) / W["peak"]) if k1 > 0 else None,
                                             "note": "the same context with smm_set_persistent(0): one launch per iteration, the exchange walk in its prologue"}
         del c1
-    if roof is not None and not sharded and args.workload == "c2" and kernel.startswith("k_chain_persist"):
+    if roof is not None and not sharded and kernel.startswith("k_chain_persist"):
         info = ctx.persistent_info()
         roof["persistent"] = {"launches": info[1], "repairs": info[2]}
     # the same chain kernel without the exchange walk in its prologue (single shard, C2): what the fused launch consists of

@@ -57,6 +57,7 @@ using namespace smm;
 #include "smm_p2p.hpp"
 #include "smm_chain_norm.hpp"
 #include "smm_chain_persist.hpp"
+#include "smm_chain_persist_gen.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
 
@@ -235,6 +236,7 @@ struct Ctx {
     double* ext_vals_out = nullptr;            // p2p generic form: the accept step's values go into the window
     // the persistent chain kernel (smm_chain_persist.hpp): one launch for a run of iterations
     bool persist = false;                      // this context can run it (objfunc_norm np <= 2, single shard of at most one tile per CU, key walk)
+    bool persist_gen = false;                  // ... its form for objectives without a simulation (smm_chain_persist_gen.hpp: banana, 4096 < N <= 8192)
     int persist_on = 1;                        // smm_set_persistent
     bool persist_broken = false;               // a launch gave up waiting (tiles not resident together?): the form is off for this context
     uint32_t pr_epoch = 0;                     // launches so far
@@ -314,12 +316,14 @@ int exchange_K(const Ctx* c) { return c->P.pairtab ? c->P.n_pairs_tab : n_exchan
 bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P.Ng > 1; }  // AlgoBGP.jl:637
 
 // make the look-ahead tables cover iteration t (1-based): a new window simply starts at t
-void ensure_windows(Ctx* c, int t) {
+void ensure_windows(Ctx* c, int t, bool rng = true) {
     KParams& P = c->P;
     // (k_chain_iter_norm generates its randomness itself unless tables are injected: no randomness blocks)
-    const bool pregen = !(c->norm_fast && !P.user_ntab && !P.user_utab);
+    const bool pregen = rng && !(c->norm_fast && !P.user_ntab && !P.user_utab);
     if (pregen && !(t >= c->rng_t0 && t < c->rng_t0 + c->rng_w)) {
-        const int W = std::min(c->win_cap, P.T - t + 1);
+        int W = std::min(c->win_cap, P.T - t + 1);
+        // (k_chain_persist_gen draws in the kernel too: blocks only for the iterations between its launches)
+        if (c->persist_gen && c->persist && c->persist_on && !c->persist_broken && !c->in_repair && !P.user_ntab && !P.user_utab) W = std::min(W, 2);
         const size_t Q = (size_t)(P.np + 1) / 2;
         const size_t per_iter = (size_t)P.rb_tries * Q * P.N;   // (< 2^31: checked at creation)
         hipLaunchKernelGGL(k_pregen_rng, dim3((unsigned)((per_iter + 255) / 256), (unsigned)W), dim3(256), 0, c->stream, P, t, W, c->win_rb);
@@ -822,8 +826,9 @@ void persist_snapshot(Ctx* c) {
 // iterations c->iter + 1 .. as ONE launch, as far as the look-ahead windows reach; returns how many it covers (0: not this time)
 int launch_chain_persist(Ctx* c, int n_left) {
     const int t0 = c->iter + 1;
-    if (!c->unresolved) ensure_windows(c, t0);   // (with an exchange pending the window holds its plan and this iteration's: persist_usable)
-    const bool pregen = !(c->norm_fast && !c->P.user_ntab && !c->P.user_utab);
+    // (k_chain_persist_norm and _gen draw in the kernel unless tables are injected)
+    const bool pregen = c->persist_gen ? (c->P.user_ntab || c->P.user_utab) : !(c->norm_fast && !c->P.user_ntab && !c->P.user_utab);
+    if (!c->unresolved) ensure_windows(c, t0, pregen);   // (with an exchange pending the window holds its plan and this iteration's: persist_usable)
     if (pregen && !(t0 >= c->rng_t0 && t0 < c->rng_t0 + c->rng_w)) ensure_windows(c, t0);
     int t1 = std::min(c->iter + n_left, c->plan_t0 + c->plan_w - 1);
     if (pregen) t1 = std::min(t1, c->rng_t0 + c->rng_w - 1);
@@ -838,21 +843,41 @@ int launch_chain_persist(Ctx* c, int n_left) {
     KParams& P = c->P;
     P.pr_epoch = c->pr_epoch;
     point_values(c, P, t0 - 1, t1);   // (nothing is read from the value arrays: the last iteration writes them)
-    PersistArgs A{};
-    A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
-    A.pr_slot = P.pr_slot; A.pr_rec = P.pr_rec; A.pr_progress = P.pr_progress; A.pr_ctl = P.pr_ctl;
-    A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
-    A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
-    A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp;
-    A.rb = pregen ? P.rb : nullptr;
-    A.N = P.N; A.Ng = P.Ng; A.ns = P.ns; A.zstride = P.zstride; A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from;
-    A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
-    A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
-    A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
-    A.walk_first = c->unresolved ? 1 : 0;
-    A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
-    A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed;
-    if (P.np == 1) launch_chain_persist_t<1>(c, A); else launch_chain_persist_t<2>(c, A);
+    if (c->persist_gen) {
+        PersistGenArgs A{};
+        A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
+        A.pr_slot = P.pr_slot; A.pr_rec = P.pr_rec; A.pr_progress = P.pr_progress; A.pr_ctl = P.pr_ctl;
+        A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
+        A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
+        A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w;
+        A.rb = pregen ? P.rb : nullptr;
+        A.N = P.N; A.Ng = P.Ng; A.np = P.np; A.nm = P.nm; A.RW = P.RW; A.HW = P.HW; A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from;
+        A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
+        A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n; A.obj = P.obj;
+        A.walk_first = c->unresolved ? 1 : 0;
+        A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
+        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed;
+        const dim3 grid(P.N / PG_CT), block(1024);
+        const size_t smem = persist_gen_smem_bytes(P.Ng, P.np, P.RW, P.HW);
+        if (c->kev0) hipExtLaunchKernelGGL(k_chain_persist_gen, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
+        else hipLaunchKernelGGL(k_chain_persist_gen, grid, block, smem, c->stream, A);
+    } else {
+        PersistArgs A{};
+        A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
+        A.pr_slot = P.pr_slot; A.pr_rec = P.pr_rec; A.pr_progress = P.pr_progress; A.pr_ctl = P.pr_ctl;
+        A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
+        A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
+        A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp;
+        A.rb = pregen ? P.rb : nullptr;
+        A.N = P.N; A.Ng = P.Ng; A.ns = P.ns; A.zstride = P.zstride; A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from;
+        A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
+        A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
+        A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
+        A.walk_first = c->unresolved ? 1 : 0;
+        A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
+        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed;
+        if (P.np == 1) launch_chain_persist_t<1>(c, A); else launch_chain_persist_t<2>(c, A);
+    }
     c->cur ^= 1;
     ++c->persist_launches;
     return t1 - t0 + 1;
@@ -1294,10 +1319,16 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const bool want_persist = c->norm_fast && np <= 2 && ns <= WG * PR_ZR && N == Ng && Ng >= 2 && c->inline_walk && P.mi_uniform && P.mi_value == 0.0 &&
                                       opts->dist_fun == SMM_DIST_MINUS && K <= XLVL_MAX && Ng <= XLVL_MAX && !c->deep_plan && (N + NORM_CT - 1) / NORM_CT <= n_cus &&
                                       persist_smem_bytes(Ng, np) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
-            const size_t persist_tiles = (size_t)(N + NORM_CT - 1) / NORM_CT;
+            // ... and its form for objectives without a simulation (smm_chain_persist_gen.hpp): where k_chain_iter walks its workgroups'
+            // cones inline (4096 < N <= 8192 in whole workgroups of 32 chains, one per CU), one proposal batch, isotropic proposals
+            const bool want_persist_gen = want_cone && c->obj == SMM_OBJ_BANANA && np <= PG_MAXP && nm <= PG_MAXP && opts->batch_size == np && !opts->chol_L &&
+                                          N == Ng && N / PG_CT <= n_cus && !c->deep_plan && P.dbg == 0 &&
+                                          persist_gen_smem_bytes(Ng, np, P.RW, P.HW) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
+            const size_t persist_tiles = want_persist_gen ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             const size_t plan_iter = (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
                                      (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / 32) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
-                                     (want_persist ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0);
+                                     (want_persist ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
+                                     (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
             c->win_cap = std::min(c->win_cap, T);
             c->plan_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)1536 << 20) / plan_iter));
@@ -1349,8 +1380,23 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                             P.cone_tiles = (int)tiles; P.cone_ct = 32;
                             P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
                             P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
-                            P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64));
+                            P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);   // (+: whole 1 KB pieces are fetched)
                             HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
+                            if (want_persist_gen) {
+                                P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP + 512);
+                                P.pr_slot = (uint2*)dalloc<unsigned char>(c, persist_ring_slot_bytes(Ng));
+                                P.pr_rec = (uint4*)dalloc<unsigned char>(c, persist_ring_rec_bytes(Ng, P.RW));
+                                P.pr_progress = dalloc<uint32_t>(c, tiles);
+                                P.pr_ctl = dalloc<uint32_t>(c, 4);
+                                HIPCHK(hipMemset(P.pr_slot, 0, persist_ring_slot_bytes(Ng)));
+                                HIPCHK(hipMemset(P.pr_rec, 0, persist_ring_rec_bytes(Ng, P.RW)));
+                                HIPCHK(hipMemset(P.pr_progress, 0, tiles * 4));
+                                HIPCHK(hipMemset(P.pr_ctl, 0, 16));
+                                c->persist = true; c->persist_gen = true;
+                                if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
+                                if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
+                                if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
+                            }
                         }
                         if (want_persist && lean_walk_unit(Ng) == 8 && c->norm_fast) {
                             const size_t tiles = persist_tiles;
@@ -1422,7 +1468,14 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const unsigned long long e = ERR_NONE;
             HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
         }
-        if (c->persist) {
+        if (c->persist_gen) {
+            const size_t smem = persist_gen_smem_bytes(Ng, np, P.RW, P.HW);
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_persist_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            int per_cu = 0, cus = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_persist_gen, 1024, smem));
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            if (N / PG_CT > per_cu * cus) { c->persist = false; c->persist_gen = false; }
+        } else if (c->persist) {
             // all tiles of the persistent kernel must be resident together (they wait for each other): one per CU
             const size_t smem = persist_smem_bytes(Ng, np);
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_persist_norm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -59,7 +59,7 @@ def test_two_ranks_on_one_device_rows_form_checks_itself():
 
 @pytest.mark.gpu
 def test_single_gpu_line_carries_the_persistent_kernel():
-    d = run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-unfused"])
+    d = run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
     r = d["roofline"]
     assert r["kernel"].startswith("k_chain_persist_norm") and r["persistent"]["launches"] >= 2 and r["persistent"]["repairs"] == 0
     assert r["one_launch_per_iteration"]["avg_kernel_us"] > r["avg_kernel_us"] > 0

@@ -1,0 +1,121 @@
+"""The persistent form of smm_bgp_step for objectives without a simulation (smm.jl_amd/csrc/smm_chain_persist_gen.hpp: BASELINE config 4,
+banana with 10 parameters on 4096 < N <= 8192 chains) against the oracle and against the one-launch-per-iteration kernel
+k_chain_iter<0, 16, 2, true>.  Replaces the loop of run! over computeNextIteration! (AlgoAbstract.jl:38-45, AlgoBGP.jl:589-640)."""
+import numpy as np
+import pytest
+
+import common as cm
+from smm_jl_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+
+
+def banana(S, N, T, npar=10, seed=3, sigma0=0.02, init=1.2):
+    prob = S.Problem(init=np.full(npar, init), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1,
+                     objective_id=A.SMM_OBJ_BANANA)
+    opts = S.BGPOpts(N=N, maxiter=T, sigma=sigma0 * cm.temps(N, 5), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N), seed=seed)
+    return prob, opts
+
+
+def _pair(S, O, prob, opts, tab=None):
+    h = S.hip_context(prob, opts, tab)
+    t = tab if tab is not None else S.Tables()
+    o = O.OracleContext(prob, opts, S.Tables(probs_acc=t.probs_acc, prop_normals=t.prop_normals, pairs=t.pairs, Z=h.Z()))
+    return h, o
+
+
+@pytest.mark.parametrize("N,npar,steps", [(8192, 10, [40]), (5024, 10, [1, 5, 2, 14, 8]), (4128, 3, [300]), (8192, 12, [12]), (6400, 7, [25])])
+def test_persistent_gen_form_against_oracle_and_per_iteration_kernel(S, O, N, npar, steps):
+    T = sum(steps)
+    prob, opts = banana(S, N, T, npar)
+    h, o = _pair(S, O, prob, opts)
+    c = S.hip_context(prob, opts)
+    c.set_persistent(False)
+    for n in steps:
+        h.step(n); o.step(n); c.step(n)
+    avail, launches, repairs = h.persistent_info()
+    assert launches >= 1 and repairs == 0, (launches, repairs)
+    assert c.persistent_info()[1] == 0
+    hh = h.history()
+    cm.assert_history_equal(hh, o.history(), atol=1e-12)     # (parameters pass through 0: lb + x (ub - lb) cancels)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-12)
+    cm.assert_history_equal(hh, c.history(), exact_floats=True)   # the two forms: identical to the bit
+    cm.assert_state_equal(h.state(), c.state(), rtol=0)
+    assert (hh.exchanged != 0).any() and (T < 25 or (hh.exchanged != 0).mean() > 0.01)
+
+
+def test_persistent_gen_form_injected_tables(S, O):
+    # every source of randomness injected (probs_acc, proposal normals incl. tries past the first two, pair lists)
+    prob, opts = banana(S, 4160, 24, sigma0=0.01)
+    tab = cm.random_tables(prob, opts, tries=6, seed=11)
+    h, o = _pair(S, O, prob, opts, tab)
+    for n in (2, 12, 10):
+        h.step(n); o.step(n)
+    assert h.persistent_info()[1] >= 2 and h.persistent_info()[2] == 0
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-12)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-12)
+
+
+def test_persistent_gen_form_mixed_with_read_backs_and_restart(S, O):
+    prob, opts = banana(S, 4224, 50)
+    h, o = _pair(S, O, prob, opts)
+    h.step(7); o.step(7)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-12)          # flush in between
+    h.step(1); o.step(1)
+    h.step(12); o.step(12)
+    st, hi = h.state(), h.history(0, 20)
+    h2 = S.hip_context(prob, opts)
+    h2.set_state(st, hi)
+    h2.step(30); h.step(30); o.step(30)
+    assert h.persistent_info()[1] >= 3 and h.persistent_info()[2] == 0 and h2.persistent_info()[1] >= 1
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-12)
+    cm.assert_history_equal(h.history(), h2.history(), exact_floats=True)
+    cm.assert_state_equal(h.state(), h2.state(), rtol=0)
+
+
+def test_persistent_gen_form_hard_error_is_replayed(S, O):
+    N, T, tfail = 4128, 16, 9
+    prob, opts = banana(S, N, T, sigma0=0.005)
+    tab = cm.random_tables(prob, opts, tries=4)
+    tab.prop_normals[tfail - 1] = 1e9
+    h, o = _pair(S, O, prob, opts, tab)
+    h.step(3); o.step(3)
+    with pytest.raises(A.SMMHipError) as eh:
+        h.step(12)
+    with pytest.raises(A.SMMHipError):
+        o.step(12)
+    assert eh.value.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT and "iteration %d" % tfail in str(eh.value)
+    assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 1
+    assert h.state().iter == tfail
+    hh, ho = h.history(0, T), o.history(0, T)
+    for f in cm.INT_FIELDS:
+        np.testing.assert_array_equal(getattr(hh, f)[:tfail - 1], getattr(ho, f)[:tfail - 1], err_msg=f)
+
+
+@pytest.mark.parametrize("ring,slow_us", [(2, 0), (2, 30), (4, 10)])
+def test_persistent_gen_form_under_skew_and_a_short_ring(S, O, monkeypatch, hooks, ring, slow_us):
+    monkeypatch.setenv("SMMHIP_PR_RING", str(ring))
+    if slow_us:
+        monkeypatch.setenv("SMMHIP_PR_SLOW_TILE", "3")
+        monkeypatch.setenv("SMMHIP_PR_SLOW_US", str(slow_us))
+    prob, opts = banana(S, 4992, 60)
+    h, o = _pair(S, O, prob, opts)
+    h.step(60); o.step(60)
+    assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 0
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-12)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-12)
+
+
+def test_persistent_gen_form_where_it_does_not_apply(S):
+    prob, opts = banana(S, 6000, 4)          # not whole workgroups of 32 chains
+    h = S.hip_context(prob, opts)
+    assert h.persistent_info()[0] == 0
+    prob, opts = banana(S, 4096, 4)          # the 16-byte walk's population
+    h = S.hip_context(prob, opts)
+    assert h.persistent_info()[0] == 0
+    prob, opts = banana(S, 8192, 6)
+    h = S.hip_context(prob, opts)
+    assert h.persistent_info()[0] == 1
+    h.set_persistent(False)
+    h.step(6)
+    assert h.persistent_info() == (0, 0, 0)
