@@ -71,6 +71,7 @@ __device__ inline bool acc_writer(int lane) {
 // chunk (of this or of the next moment) are loaded from the L2-resident matrix while the current
 // chunk is added up.  Chunk 0 of moment 0 is loaded by the caller before its serial prologue.
 constexpr int ZU = 8;
+constexpr int SMM_SCOUT_AFTER = 2;   // rounds of one try per lane segment before the remaining tries of mysample are scouted (k_chain_iter)
 
 // The shock matrix is read through a buffer descriptor: row = scalar byte offset (SALU), lane = one constant
 // 32-bit vector offset, so a chunk load is ZU buffer_load instructions and no vector address arithmetic.
@@ -611,7 +612,7 @@ __device__ inline bool exchange_walk_tile_lean(const KParams& P, const int tx, u
 // levels or a value is NaN — the host does not launch this form where it knows of either; loud where it happens anyway.
 template <int NT>
 __device__ inline bool exchange_walk_tile_keys(const KParams& P, const int tx, unsigned char* lds, const int tid, const bool valid, const int gc,
-                                               unsigned long long& xr, const int ts_tile) {
+                                               unsigned long long& xr, const int ts_tile, const int gc2 = -1, uint32_t* src2 = nullptr) {
     const int Ng = P.Ng;
     const int w = tx - P.plan_t0;
     const uint32_t* __restrict__ g_offp = P.lv_offp + (size_t)w * LV_OFFP;
@@ -661,6 +662,7 @@ __device__ inline bool exchange_walk_tile_keys(const KParams& P, const int tx, u
         const uint32_t partner = P.lean_unit == 8 ? lean_partner<0>(lds, pbase, meta, (uint32_t)gc) : lean_partner<1>(lds, pbase, meta, (uint32_t)gc);
         xr = (unsigned long long)(meta & 0xffffu) | ((unsigned long long)partner << 32);
     }
+    if (gc2 >= 0) *src2 = slot[gc2].y & 0xffffu;   // (the dense kind: the record source of the chain this lane loads)
     __syncthreads();   // (from here on the tile's blocks may overwrite the pair list)
     return true;
 }
@@ -868,7 +870,8 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         // the dense kind (long blocks: 832-byte records, 808 bytes of randomness per chain at 50 parameters) without an inline walk:
         // every wave of the tile moves the blocks, 32 lanes per chain — two round trips of two or three 16-byte loads per lane
         // (the control wave alone, 4 lanes per chain: 13 + 13 pieces per lane, most of them load-store round trips: 6 us)
-        const bool wide_load = KIND == 2 && !(flags & F_WALK_INLINE);
+        // (with the key walk in the prologue — P.gen_lean == 2, N_global <= 4096 — as well: its slots and lists lie UNDER the tile's blocks)
+        const bool wide_load = KIND == 2 && (!(flags & F_WALK_INLINE) || P.gen_lean == 2);
         if (wide_load) {
             constexpr int L2 = WG / CT;
             const int ccw = tid / L2, rw = tid % L2;
@@ -881,10 +884,24 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             const double* g_rbw = P.rb + ((size_t)(t > 1 ? t - P.rb_t0 : 0) * N + cwc) * RBW;
             const int rbww = t > 1 ? RBW : 0;
             unsigned long long xrw = (unsigned long long)(unsigned)gcw;
+            const bool walk_here = IW && (flags & F_WALK_INLINE);
             if (vw) {
-                if (flags & F_HAS_PENDING) xrw = P.xres[gcw];
+                if ((flags & F_HAS_PENDING) && !walk_here) xrw = P.xres[gcw];
                 coop_fetch_n<1>(w_cs, g_csw, CSW, rw, L2);
                 coop_fetch_n<2>(w_rb, g_rbw, rbww, rw, L2);
+            }
+            unsigned long long xr_ctl = (unsigned long long)(unsigned)gc;
+            if constexpr (IW && KIND == 2 && TPW == 1) {
+                if (walk_here) {
+                    // exchangeMoves! of iteration t-1 by the tile's own walk over its cone (smm_cone.hpp; where the plan kernel made none: over
+                    // the whole list), while the blocks above are in flight; nothing of the tile has been written to LDS yet
+                    uint32_t srcw = (uint32_t)gcw;
+                    bool done = false;
+                    if (P.cone_ok) done = exchange_walk_tile_cone<WG, 0>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr_ctl, (int)blockIdx.x, tile, vw ? gcw : -1, &srcw);
+                    if (!done && !exchange_walk_tile_keys<WG>(P, t - 1, (unsigned char*)smem, (int)threadIdx.x, valid, gc, xr_ctl, tile, vw ? gcw : -1, &srcw) && threadIdx.x == 0)
+                        report_error(P, 3, t, gc);
+                    xrw = (unsigned long long)srcw;
+                }
             }
             if (wave1) {  // problem constants into the tile's LDS
                 if (k1 < np) { S.lb[k1] = c_lb; S.ub[k1] = c_ub; S.init[k1] = c_init; }
@@ -900,7 +917,8 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                 coop_put_n<2>(S.rb + ccw * RBW, w_rb, g_rbw, rbww, rw, L2);
                 coop_put_n<2>(S.rec + ccw * RW, w_rec, g_recw, RW, rw, L2);
             }
-            if (valid && (flags & F_HAS_PENDING)) partner = (int)(P.xres[gc] >> 32);   // (the control wave's lanes serve other chains than they loaded)
+            if (walk_here) { if (valid) partner = (int)(xr_ctl >> 32); }
+            else if (valid && (flags & F_HAS_PENDING)) partner = (int)(P.xres[gc] >> 32);   // (the control wave's lanes serve other chains than they loaded)
         } else {
         const int cc = valid ? c : 0;
         const double* g_cs = P.cs + (size_t)cc * CSW;
@@ -1067,12 +1085,13 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                     // i, i + n, i + 2n, ..., each evaluating one further try, and the lowest successful try wins — the tries,
                     // their order and the winner are those of the serial loop.  Scratch: the (still unused) history rows of the
                     // tile: slot s keeps its candidate in row s, chain u its success mask in the head of row u.
-                    for (int base = n_pre;;) {
+                    int base = n_pre;
+                    for (int rounds = 0;; ++rounds) {
                         unsigned long long* head = (unsigned long long*)(S.h + cc * HW);   // [0]: open, [1]: successful offsets
                         ++round_id;
                         if (sl == 0) { head[0] = done ? 0ull : 1ull; head[1] = 0ull; if (!done) *round_word = round_id; }
                         __syncthreads();
-                        if (*round_word != round_id || base >= max_tries) break;   // (uniform over the workgroup: nobody open, or no try left)
+                        if (*round_word != round_id || base >= max_tries || rounds >= P.scout_after) break;   // (uniform over the workgroup: nobody open, no try left, or the stubborn chains' turn below)
                         const unsigned long long open = __ballot(lane < CT && *(const unsigned long long*)(S.h + lane * HW) != 0ull);
                         const int n_open = __popcll(open);
                         const int per = n_open ? CT / n_open : 0;      // tries per open chain in this round (>= 1)
@@ -1102,6 +1121,102 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                         if (!done && head[1] != 0ull) done = true;
                         __syncthreads();
                         base += max(per, 1);
+                    }
+                    // The chains still open after those rounds are the stubborn ones (adapted sigmas, 50 parameters: one try in hundreds or
+                    // thousands is inside the box late in a run — C5: 38 us per iteration in the first 200 of 2000, 244 in the last, at 16
+                    // tries per 1.5 us and tile).  A try that fails fails EARLY, so the remaining tries are scouted by groups of 8 lanes, 8
+                    // pairs at a time, and given up at the first group of pairs with a component outside the box: 64 tries in flight
+                    // per tile instead of 16, most of them one trip long.  The groups TAKE their tries — a counter per chain hands them
+                    // out in order — from whichever chain of the tile still has tries worth making (below its lowest successful one),
+                    // so that the tile's unluckiest chain ends up with all 64 groups; a try that gets through all its pairs enters the
+                    // chain's minimum.  The lowest successful try wins — the tries, their order and the winner are the serial loop's —
+                    // and is then evaluated once more, in full, by the chain's own lanes (one_try: the same arithmetic as ever).
+                    // Scratch: the head of the chain's (still unused) history row — [0]: open, [1]: lowest successful try, [3]: next try
+                    // to hand out ([2] of row 0 is the workgroup's round word); row 0, doubles 4..11: the open chains' numbers.
+                    {
+                        unsigned long long* head = (unsigned long long*)(S.h + cc * HW);
+                        ++round_id;
+                        const bool more = !done && base < max_tries;
+                        if (sl == 0) { head[0] = more ? 1ull : 0ull; head[1] = ~0ull; head[3] = (unsigned long long)base; if (more) *round_word = round_id; }
+                        __syncthreads();
+                        if (*round_word == round_id) {   // (uniform over the workgroup: somebody is open)
+                            const unsigned long long open = __ballot(lane < CT && *(const unsigned long long*)(S.h + lane * HW) != 0ull);
+                            const int n_open = __popcll(open);
+                            int* olist = (int*)(S.h + 4);
+                            if (tid < CT && ((open >> tid) & 1ull)) olist[__popcll(open & ((1ull << tid) - 1ull))] = tid;
+                            __syncthreads();
+                            if (n_open) {
+                                const int GLr = 64 * nwv >= 128 ? P.scout_gl : 4;   // lanes of a group (one try at a time; the slim launch: one wave per tile)
+                                const int G = tid / GLr, gj = tid - G * GLr;
+                                const int g_lead = lane & ~(GLr - 1);
+                                const unsigned long long gseg = ((1ull << GLr) - 1ull) << g_lead;   // the group's lanes in the wave
+                                const int qlo = b0 >> 1, qhi = (min(b0 + bs, np) + 1) >> 1;   // the pairs with a component of this batch
+                                const unsigned long long cap = (unsigned long long)max_tries;
+                                int oi = G % n_open;        // where the group looks first
+                                int u = 0, q0 = qlo;
+                                unsigned long long rr = 0ull;
+                                uint32_t gu = 0u;
+                                double sgu = 0.0;
+                                const double* m01u = S.rout;
+                                bool have = false, quit = false;
+                                while (__ballot(!quit) != 0ull) {
+                                    if (!quit && !have) {   // the group's next try: from a chain that has tries below its lowest successful one
+                                        int found = -1;
+                                        unsigned long long r0 = 0ull;
+                                        if (gj == 0) {
+                                            for (int sft = 0; sft < n_open && found < 0; ++sft) {
+                                                const int idx = oi + sft < n_open ? oi + sft : oi + sft - n_open;
+                                                const int v = olist[idx];
+                                                unsigned long long* hv = (unsigned long long*)(S.h + v * HW);
+                                                const unsigned long long lim = min(__hip_atomic_load(hv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
+                                                if (__hip_atomic_load(hv + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < lim) {
+                                                    r0 = __hip_atomic_fetch_add(hv + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                                    if (r0 < lim) { found = v; oi = idx; }
+                                                }
+                                            }
+                                        }
+                                        found = __shfl(found, g_lead, 64);
+                                        r0 = (unsigned long long)(unsigned)__shfl((int)(unsigned)r0, g_lead, 64) | ((unsigned long long)(unsigned)__shfl((int)(unsigned)(r0 >> 32), g_lead, 64) << 32);
+                                        if (found < 0) quit = true;
+                                        else {
+                                            u = found; rr = r0; q0 = qlo; have = true;
+                                            gu = (uint32_t)(P.offset + tile * CT + u);
+                                            sgu = S.cs[u * CSW + CS_SIGMA];
+                                            m01u = S.rout + u * RW;
+                                        }
+                                    }
+                                    bool okp = true;
+                                    const int q = q0 + gj;
+                                    if (have && q < qhi) {
+                                        const double2 zz2 = rng_prop_normal2_outofline(P.seed, gu, (uint32_t)t, (uint32_t)rr, (uint32_t)q);
+#pragma unroll
+                                        for (int e = 0; e < 2; ++e) {
+                                            const int k = 2 * q + e;
+                                            if (k >= b0 && k < b0 + bs && k < np) {
+                                                const double step = sgu * (e ? zz2.y : zz2.x);   // MvNormal(mu01, sigma): x = mu + sigma*z
+                                                const double x = m01u[k] + step;
+                                                if (!(x >= 0.0 && x <= 1.0)) okp = false;         // inclusive bounds, :405
+                                            }
+                                        }
+                                    }
+                                    const bool gok = (__ballot(okp) & gseg) == gseg;   // all pairs of the trip inside the box
+                                    if (have) {
+                                        if (gok && q0 + GLr >= qhi) {   // the try's last pairs: a candidate for the chain's first successful try
+                                            if (gj == 0) atomicMin((unsigned long long*)(S.h + u * HW) + 1, rr);
+                                            have = false;
+                                        } else if (gok) q0 += GLr;
+                                        else have = false;
+                                    }
+                                }
+                            }
+                            __syncthreads();
+                            if (more) {   // the chain's own lanes: its winning try in full (or, when none got through, the last one: :409 below)
+                                const unsigned long long won = head[1];
+                                (void)one_try(cc, gcc, sgc, won != ~0ull ? (int)won : max_tries - 1, b0, thc);
+                                if (won != ~0ull) done = true;
+                            }
+                        }
+                        __syncthreads();
                     }
                     if (!done && sl == 0) report_error(P, 2, t, (int)gcc);  // :409
                 }

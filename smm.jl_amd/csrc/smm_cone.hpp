@@ -17,10 +17,12 @@
 // decides the same).  min_improve == 0, dist_fun = -, like the key walk itself.
 // ------------------------------------------------------------------------------------------
 // false (uniform; nothing done that the key walk's staging does not overwrite): not this iteration
+// (gc2 / src2: a second chain whose record source a lane wants — the dense kind's loads are spread over all lanes of the tile; -1: none)
 template <int NT, int US>
 __device__ inline bool exchange_walk_tile_cone(const KParams& P, const int tx, unsigned char* lds, const int tid, const bool valid, const int gc,
-                                               unsigned long long& xr, const int wg, const int ts_tile) {
-    static_assert(NT == 1024 && CONE_LEVELS == 32, "a wave per sub-level, two rounds");
+                                               unsigned long long& xr, const int wg, const int ts_tile, const int gc2 = -1, uint32_t* src2 = nullptr) {
+    static_assert((NT == 1024 || NT == 512) && CONE_LEVELS == 32, "a wave per sub-level, two or four rounds");
+    constexpr int NWV = NT / 64, RND = CONE_LEVELS / NWV;
     const int Ng = P.Ng;
     const int w = tx - P.plan_t0;
     const int lane = tid & 63;
@@ -33,9 +35,9 @@ __device__ inline bool exchange_walk_tile_cone(const KParams& P, const int tx, u
     const uint32_t* __restrict__ g_hdr = P.cone_hdr + ((size_t)w * P.cone_tiles + wg) * CONE_HDRW;
     const uint32_t hv = g_hdr[min(lane, CONE_HDRW - 1)];   // lane 0: sub-levels; lanes 1..8: their counts, a byte each
     const uint32_t* __restrict__ g_cp = P.cone_pairs + ((size_t)w * P.cone_tiles + wg) * (CONE_LEVELS * 64);
-    uint32_t pw[2];
-    pw[0] = g_cp[wv * 64 + lane];                          // sub-levels wv and wv + 16 (anything past the list: not used)
-    pw[1] = g_cp[(wv + 16) * 64 + lane];
+    uint32_t pw[RND];
+#pragma unroll
+    for (int r = 0; r < RND; ++r) pw[r] = g_cp[(wv + NWV * r) * 64 + lane];   // sub-levels wv, wv + 16 (8), ... (anything past the list: not used)
     uint2 own = make_uint2(0u, 0u);
     const int c_own = wg * P.cone_ct + tid;
     if (tid < P.cone_ct) own = P.slot8[c_own];
@@ -44,8 +46,8 @@ __device__ inline bool exchange_walk_tile_cone(const KParams& P, const int tx, u
     uint2* slot = (uint2*)lds;
     const uint32_t dummy = ((8u >> US) * Ng4) | (((8u >> US) * (Ng4 + 1u)) << 16);   // the two slots behind the chains': keys 1 < 2, "no swap"
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int s = wv + 16 * r;
+    for (int r = 0; r < RND; ++r) {
+        const int s = wv + NWV * r;
         if (s < nsub) {   // (wave-uniform)
             const uint32_t cnt_s = ((uint32_t)__builtin_amdgcn_readlane((int)hv, 1 + (s >> 2)) >> (8 * (s & 3))) & 0xffu;
             const bool has = (uint32_t)lane < cnt_s;
@@ -68,6 +70,7 @@ __device__ inline bool exchange_walk_tile_cone(const KParams& P, const int tx, u
         const uint32_t partner = lean_partner<US>(lds, pbase, meta, (uint32_t)gc);
         xr = (unsigned long long)(meta & 0xffffu) | ((unsigned long long)partner << 32);
     }
+    if (gc2 >= 0) *src2 = slot[gc2].y & 0xffffu;
     __syncthreads();   // (from here on the tile's blocks may overwrite the pair list)
     return true;
 }

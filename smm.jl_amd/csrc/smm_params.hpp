@@ -114,6 +114,8 @@ struct KParams {
     double* hrec;  // [T][N][HW]
     unsigned long long* err;
     int dbg;                 // SMMHIP_DBG timing experiments (results invalid when != 0)
+    int scout_gl;            // ... lanes per scouting group (16; test hook: 8)
+    int scout_after;         // k_chain_iter: rounds of one try per lane segment before mysample's remaining tries are scouted by groups of 8 lanes
     unsigned long long* ts;  // SMMHIP_TS=1: per-workgroup phase timestamps of k_chain_iter (tools/)
     int ts_levels;           // SMMHIP_TS=2: and one per level of the inline exchange walk
     // the p2p form of the sharded iteration (smm_p2p.hpp): every rank's window (this rank's own at index p2p_rank), mapped through

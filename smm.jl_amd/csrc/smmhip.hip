@@ -196,6 +196,7 @@ struct Ctx {
     bool nan_values = false;     // the uploaded state holds NaN values (smm_set_state)
     bool gen_lean = false;       // k_chain_iter walks inline on the lean form (16-byte slots) when the plan fits it
     bool gen_keys = false;       // ... on the lean KEY form (8-byte slots): single shards of 4096 < N <= 8192 chains without a simulation (two 16-chain tiles per workgroup)
+    bool dense_keys = false;     // ... and the dense objective's tiles (one 16-chain tile per workgroup, N <= 4096): the walk's slots and lists UNDER the tile's blocks
     bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
     bool lvl_exchange = false;
@@ -301,6 +302,7 @@ size_t tile_smem(const Ctx* c, int ct, int tpw = 1) {   // dynamic LDS of k_chai
     const size_t base = tile_smem_base(c, ct);           // walk its chain slots in front and its pair list under the tiles
     const size_t tiles = (size_t)tpw * ((base + 15) & ~(size_t)15);
     if (!c->inline_walk) return tiles;
+    if (c->dense_keys) return std::max(tiles, (size_t)(((c->P.Ng + 3) & ~3) + 4) * 8 + std::max((size_t)CONE_LEVELS * 64 * 4, (size_t)lean_walk_Kp(c->P.plan_K) * 4));
     if (c->gen_keys) return (size_t)(((c->P.Ng + 3) & ~3) + 4) * 8 + std::max(tiles, (size_t)lean_walk_Kp(c->P.plan_K) * 4);
     return c->gen_lean ? tile_lean_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)lean_walk_Kp(c->P.plan_K) * 4)
                        : walk_slot_bytes(c->P.Ng) + std::max(tiles, (size_t)c->P.plan_K * 4);
@@ -1124,6 +1126,10 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             c->force_any_exchange = e && e[0] == '1';
             const char* d = getenv("SMMHIP_DBG");
             P.dbg = d ? atoi(d) : 0;
+            const char* sa = SMM_HOOK("SMMHIP_SCOUT_AFTER");   // test hook: rounds before the scouting form of mysample's late tries
+            P.scout_after = sa ? atoi(sa) : SMM_SCOUT_AFTER;
+            const char* sg = SMM_HOOK("SMMHIP_SCOUT_GL");
+            P.scout_gl = (sg && atoi(sg) == 8) ? 8 : 16;
             const char* tsv = getenv("SMMHIP_TS");
             if (tsv && (tsv[0] == '1' || tsv[0] == '2')) P.ts = dalloc<unsigned long long>(c, (size_t)8 * 65536);
             P.ts_levels = tsv && tsv[0] == '2';   // also a stamp per level of the inline walk (the stamps stretch the levels: not with '1')
@@ -1295,6 +1301,14 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                               Ng <= XLDS_MAX && K <= XLDS_MAX && c->lds_exchange && P.mi_uniform && P.mi_value == 0.0 && opts->dist_fun == SMM_DIST_MINUS &&
                               !(kw0 && kw0[0] == '0') && slots + std::max(2 * tile16, (size_t)lean_walk_Kp(K) * 4) <= (size_t)160 * 1024;
                 if (c->gen_keys) { c->inline_walk = true; c->tpw = 2; P.gen_lean = 2; P.tile_off = (int)(slots / sizeof(double)); }
+                // the dense objective (BASELINE config 5): its tile fills a CU's LDS (143 KB at 50 parameters / 50 moments), so the key
+                // walk's slots and lists lie UNDER the tile's blocks — the walk is over before anything of the tile is written
+                const char* dk = SMM_HOOK("SMMHIP_DENSE_KEYS");   // test hook: "0" keeps the stand-alone resolution
+                c->dense_keys = !c->inline_walk && !c->gen_keys && !(iw && iw[0] == '0') && !(dk && dk[0] == '0') && c->obj == SMM_OBJ_DENSE && N == Ng &&
+                                Ng >= 2 && Ng <= XLVL_MAX && K <= XLVL_MAX && c->lds_exchange && P.mi_uniform && P.mi_value == 0.0 &&
+                                opts->dist_fun == SMM_DIST_MINUS && !(kw0 && kw0[0] == '0') && lean_walk_unit(Ng) == 8 &&
+                                std::max(tile16, slots + std::max((size_t)CONE_LEVELS * 64 * 4, (size_t)lean_walk_Kp(K) * 4)) <= (size_t)160 * 1024;
+                if (c->dense_keys) { c->gen_keys = true; c->inline_walk = true; c->tpw = 1; P.gen_lean = 2; P.tile_off = 0; }
                 // (its slots are written by the accept step, like the headline kernel's: allocated further down, with the lean plan)
             }
         }
@@ -1309,7 +1323,9 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const size_t rb_iter = (size_t)P.RBW * N * 8;
             // the workgroups' cones of the inline key walk (smm_cone.hpp): where k_chain_iter walks 8192 chains' keys in every workgroup
             const char* nc = SMM_HOOK("SMMHIP_NO_CONE");   // test hook: every workgroup walks the whole list
-            const bool want_cone = c->gen_keys && c->tpw == 2 && N % 32 == 0 && N / 32 <= 256 && !(nc && nc[0] == '1');
+            const bool want_cone = c->gen_keys && !(nc && nc[0] == '1') &&
+                                   (c->dense_keys ? (N % 16 == 0 && N / 16 <= 256) : (c->tpw == 2 && N % 32 == 0 && N / 32 <= 256));
+            const int cone_ct = c->dense_keys ? 16 : 32;
             // the persistent chain kernel (smm_chain_persist.hpp): objfunc_norm with at most two moments (the lane's shocks of ONE moment
             // stay in registers), a single shard of at most one 16-chain tile per CU, the key walk's conditions (one threshold 0, `-`),
             // a pair list the lean plan holds
@@ -1321,12 +1337,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                       persist_smem_bytes(Ng, np) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
             // ... and its form for objectives without a simulation (smm_chain_persist_gen.hpp): where k_chain_iter walks its workgroups'
             // cones inline (4096 < N <= 8192 in whole workgroups of 32 chains, one per CU), one proposal batch, isotropic proposals
-            const bool want_persist_gen = want_cone && c->obj == SMM_OBJ_BANANA && np <= PG_MAXP && nm <= PG_MAXP && opts->batch_size == np && !opts->chol_L &&
+            const bool want_persist_gen = want_cone && !c->dense_keys && c->obj == SMM_OBJ_BANANA && np <= PG_MAXP && nm <= PG_MAXP && opts->batch_size == np && !opts->chol_L &&
                                           N == Ng && N / PG_CT <= n_cus && !c->deep_plan && P.dbg == 0 &&
                                           persist_gen_smem_bytes(Ng, np, P.RW, P.HW) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
             const size_t persist_tiles = want_persist_gen ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             const size_t plan_iter = (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
-                                     (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / 32) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
+                                     (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / cone_ct) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
                                      (want_persist ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
                                      (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
@@ -1375,9 +1391,9 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                         P.walk_flags = dalloc<uint32_t>(c, 4);
                         HIPCHK(hipMemset(P.walk_flags, 0, 16));
                         if (want_cone) {
-                            const size_t tiles = (size_t)N / 32;
+                            const size_t tiles = (size_t)N / cone_ct;
                             c->cone = true;
-                            P.cone_tiles = (int)tiles; P.cone_ct = 32;
+                            P.cone_tiles = (int)tiles; P.cone_ct = cone_ct;
                             P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
                             P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
                             P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);   // (+: whole 1 KB pieces are fetched)

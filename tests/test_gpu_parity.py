@@ -1301,3 +1301,41 @@ def test_lean_walk_across_plan_windows(S, O, monkeypatch, hooks):
     o.step(T)
     cm.assert_history_equal(a.history(), o.history(), atol=1e-13)
     cm.assert_state_equal(a.state(), o.state(), atol=1e-13)
+
+
+@pytest.mark.parametrize("scout_after,gl", [(0, 16), (0, 8), (1, 16), (1000000, 16)])
+def test_late_tries_scouted_by_lane_groups_equal_the_rounds(S, O, monkeypatch, hooks, scout_after, gl):
+    # mysample's tries past the pre-generated ones (AlgoBGP.jl:400-410) in k_chain_iter: rounds of one try per lane segment, then — for
+    # the chains still open — tries handed out by a counter per chain to groups of 8 / 16 lanes that give a try up at its first
+    # group of pairs outside the box.  Whatever the split (all scouted, one round first, never scouted), whatever the group size:
+    # the first successful try in order wins.  50 parameters, sigmas so wide that a proposal takes tens to hundreds of tries
+    monkeypatch.setenv("SMMHIP_SCOUT_AFTER", str(scout_after))
+    monkeypatch.setenv("SMMHIP_SCOUT_GL", str(gl))
+    prob, opts = dense_problem(S, O, 50, 50, N=200, T=12)
+    opts.sigma[:] = 0.05 * cm.temps(200, 2.0)
+    opts.smpl_iters = 100000
+    h, o = make_pair(S, O, prob, opts)
+    h.step(12); o.step(12)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+
+
+@pytest.mark.parametrize("N,no_cone", [(4096, False), (4096, True), (1000, False), (48, False), (2, False)])
+def test_dense_tiles_walk_the_exchange_in_their_prologue(S, O, monkeypatch, hooks, N, no_cone):
+    # BASELINE config 5 runs ONE launch per iteration: the dense objective's tiles walk the key exchange themselves (their cone where
+    # the population is whole tiles of 16 chains; the whole list otherwise, or with the cones switched off), slots and lists UNDER the
+    # tile's blocks in LDS.  Against the oracle and, to the bit, against the stand-alone resolution (SMMHIP_DENSE_KEYS=0)
+    T = 14
+    prob, opts = dense_problem(S, O, 50, 50, N=N, T=T)
+    if no_cone:
+        monkeypatch.setenv("SMMHIP_NO_CONE", "1")
+    h, o = make_pair(S, O, prob, opts, threads=16)
+    for n in (1, 5, 8):
+        h.step(n); o.step(n)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+    monkeypatch.setenv("SMMHIP_DENSE_KEYS", "0")
+    c = S.hip_context(prob, opts)
+    c.step(T)
+    cm.assert_history_equal(h.history(), c.history(), exact_floats=True)
+    assert N == 2 or (h.history().exchanged != 0).any()
