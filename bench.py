@@ -541,7 +541,9 @@ def main():
             roof["note"] = ("achieved = EXECUTED MFMA flop (464 v_mfma_f64_16x16x4 per 16 chains, np / nm padded to 52 / 64) over the chain kernel's duration; "
                             "mfma_counter = the same from SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the committed PMC pass (must agree within 5 %); the objective is "
                             "x = B theta (256 x np), h = tanh x, y = A h (nm x 256): 51 200 useful flop per evaluation, not the 2*256*256 + ... = 156 672 of a "
-                            "256 x 256 product that rounds 2-3 credited (BASELINE.json's wording).  The run drifts as sigma adapts (longer redraw tails): "
+                            "256 x 256 product that rounds 2-3 credited (BASELINE.json's wording).  One launch per iteration (the tiles walk the key exchange in their prologue).  "
+                            "The run drifts as sigma adapts — the synthetic objective accepts 99 % of the proposals, so every sigma grows without bound and "
+                            "mysample needs ever more tries per proposal (late tries are scouted by groups of 16 lanes: tools/c5_tail.py) —: "
                             "quote it at >= 1600 iterations (--steps 8, the default for this workload); per-launch p50 / p99 in profiles/rNN_c5_launches.txt")
         if args.workload in ("c2", "c3"):
             roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "

@@ -402,6 +402,8 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
         asm volatile("" ::: "memory");
         unsigned long long ts4 = 0, ts5 = 0;
         if (A.ts && tid == 0) ts4 = wall_clock64();
+        const int first_valid_lane = 0;   // (chains ascend with the lanes: lane 0 serves a chain whenever the wave serves any)
+        if (!__builtin_amdgcn_readfirstlane(valid ? 1 : 0) && lane == 0) __hip_atomic_fetch_add(s_pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a wave without chains)
         if (valid) {
             // ---- objective (banana, ObjExamples.jl:251-265, generalised to np dimensions; the terms in order), doAcceptReject! (:324-392) ----
             // (every lane of the quad computes the same value: its lanes read the proposal out of LDS, whose writes completed in order)
@@ -456,6 +458,9 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
                 for (int i = 2 * r; i < RW; i += 8)   // lane r: the pairs of doubles r, r + 4, ... (a 32-byte granule each)
                     pr_store_ll(g_ll + (size_t)i * 16, *(const double2*)(rout + i), tag);
             }
+            // the gather's clock: this wave has published (the other tiles publish at about the same time; the gather touches other
+            // tiles' slots only, so it may run under the bookkeeping below)
+            if (lane == first_valid_lane) __hip_atomic_fetch_add(s_pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             // ================= behind the publication =================
             asm volatile("" ::: "memory");
             if (A.ts && tid == 0) ts5 = wall_clock64();
@@ -512,8 +517,7 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
                 __hip_atomic_fetch_and(s_xmask, wave == 0 ? 0xffff0000u : 0x0000ffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_or(s_xmask, wave == 0 ? m : m << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the records, rows and slots are written before the publication is announced
-            if (lane == 0) __hip_atomic_fetch_add(s_pub, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the records, rows and slots are written before the wave goes to the barrier)
         }
         if (A.ts && tid == 0) { const unsigned long long ts7 = wall_clock64(); s_ts[1] += ts2 - ts1; s_ts[2] += ts3 - ts2; s_ts[3] += ts4 - ts3; s_ts[4] += ts5 - ts4; s_ts[5] += ts7 - ts5; s_ts[7] = ts7; }
     }

@@ -42,6 +42,10 @@ for on in (1, 0, 1):
         ph = buf[:, :6].astype(np.float64).mean(axis=0) / 100.0 / nit   # the LAST launch's sums (100 MHz ticks) -> us per iteration
         print("   phases of the last launch, %d iterations (us per iteration, mean over workgroups):" % nit, " wait at the barrier (gather) %.2f | walk %.2f | barrier + donor record %.2f | proposal %.2f | "
               "objective, accept, publish %.2f | bookkeeping %.2f | sum %.2f" % (*ph, ph.sum()))
+        per = buf[:, :6].astype(np.float64) / 100.0 / nit
+        busy = per[:, 1:].sum(axis=1)
+        print("   over the workgroups (min / mean / max): walk %.2f / %.2f / %.2f | everything but the wait %.2f / %.2f / %.2f | wait %.2f / %.2f / %.2f"
+              % (per[:, 1].min(), per[:, 1].mean(), per[:, 1].max(), busy.min(), busy.mean(), busy.max(), per[:, 0].min(), per[:, 0].mean(), per[:, 0].max()))
     h = ctx.history()
     hist[on] = h
     del ctx
