@@ -331,10 +331,12 @@ int  smm_get_timing(void* ctx, smm_timing_t* out);
  * dispatch-begin to dispatch-end durations the command processor stamps, i.e. what rocprofv3
  * --kernel-trace reports; null_bracket_ms = 0.   on = 0: off. */
 int  smm_set_profiling(void* ctx, int32_t on);
-/* The persistent form of smm_bgp_step (smm.jl_amd/csrc/smm_chain_persist.hpp; replaces the loop of run!, AlgoAbstract.jl:38-45,
- * over computeNextIteration!, AlgoBGP.jl:589-640): where a context qualifies — objfunc_norm with at most two moments and
- * ns <= 10240, a single shard of at most one 16-chain tile per compute unit, min_improve == 0 for all chains, dist_fun = `-` —
- * a step of n >= 2 iterations is ONE kernel launch per look-ahead window instead of one per iteration.  Results are bit-identical.
+/* The persistent form of smm_bgp_step (smm.jl_amd/csrc/smm_chain_persist.hpp, smm_chain_persist_gen.hpp; replaces the loop of run!,
+ * AlgoAbstract.jl:38-45, over computeNextIteration!, AlgoBGP.jl:589-640): where a context qualifies — objfunc_norm with at most two
+ * moments and ns <= 10240 on a single shard of at most one 16-chain tile per compute unit, or the banana objective with at most 16
+ * parameters (one proposal batch, isotropic) on a single shard of 4096 < N <= 8192 chains in whole groups of 32; min_improve == 0 for
+ * all chains, dist_fun = `-` — a step of n >= 2 iterations is ONE kernel launch per look-ahead window instead of one per iteration.
+ * Results are bit-identical.
  * on = 0 keeps the one-launch-per-iteration kernels (default: on).  A hard error of the algorithm inside such a launch is found at
  * the next call that checks (smm_sync, smm_bgp_step, the state readers): the library then repeats those iterations from the state
  * it saved on the one-launch-per-iteration path, so that the context stands at the failing iteration exactly as documented above.
