@@ -45,7 +45,7 @@ WORKLOADS = {
                kernel="k_chain_persist_norm<2>",
                label="serialNormal objfunc_norm 2 params / 2 moments, ns=10000 (BASELINE configs[1])"),
     "c3": dict(chains=32768, total=True, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
-               kernel="k_chain_iter_norm_narrow<2>",
+               kernel="k_chain_iter_norm_narrow_cone<2>",
                label="serialNormal objfunc_norm 2p/2m, ns=10000, 32768 chains = 8 temperature levels x 4096 (BASELINE configs[2])"),
     # ~80 flop vs (2*10 + 10 + 8) * 8 = 304 B per chain evaluation: an HBM / latency stream
     "c4": dict(chains=8192, total=False, flop=80, bytes=304, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", kernel="k_chain_persist_gen",

@@ -374,7 +374,8 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
 // kernel the headline kernel spilled 8 scalar registers in its latency-bound prologue and took 0.3 us longer)
 // (P2P: a shard of the p2p form, smm_p2p.hpp — records, values and walk slots of ALL chains live in this rank's window, the accept
 // step stores its results into every rank's window and arrives; WALK then means "when the launch says so", F_WALK_INLINE)
-template <int NP, bool WALK, bool WIDE, bool LEAN, bool P2P = false, bool P2P_BIG = true, int HALVES = 2>
+// (CONEL: no walk of the whole list, but — when the launch says F_WALK_INLINE — the tile's own, locally numbered cone: smm_cone.hpp)
+template <int NP, bool WALK, bool WIDE, bool LEAN, bool P2P = false, bool P2P_BIG = true, int HALVES = 2, bool CONEL = false>
 __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int t, const double* __restrict__ rec_in_arg,
                                                      double* __restrict__ rec_out, const int flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -435,7 +436,13 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
                 if (NORM_NR + r < P.rb_tries) zB[k] = g_rb[1 + (NORM_NR + r) * NP + k];
             }
         }
-        if (!walk_now && (flags & F_HAS_PENDING)) xr = P.xres[gc];
+        if (!walk_now && !(CONEL && (flags & F_WALK_INLINE)) && (flags & F_HAS_PENDING)) xr = P.xres[gc];
+    }
+    if constexpr (CONEL) {
+        // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716) over the tile's cone, while those loads are in flight; its slots and pair
+        // words lie UNDER the tile's blocks: nothing of the tile has been written yet
+        if (flags & F_WALK_INLINE)
+            if (!exchange_walk_cone_local<(WG * HALVES)>(P, t - 1, (unsigned char*)smem, tid, valid, cl, xr, tile) && tid == 0) report_error(P, 3, t, gc);
     }
     // (LDS survives from workgroup to workgroup: the hand-over flags are reset before anybody can look at them — the walk's first
     // barrier, or the one below, orders the reset)
@@ -688,6 +695,12 @@ template <int NP>
 __global__ __launch_bounds__(NORM_WG / 2, 4) void k_chain_iter_norm_narrow(const KParams P, const int t, const double* __restrict__ rec_in,
                                                                            double* __restrict__ rec_out, const int flags) {
     chain_iter_norm_body<NP, false, false, true, false, true, 1>(P, t, rec_in, rec_out, flags);
+}
+// ... with the exchange of the last iteration walked by every tile over its own cone (large single shards: smm_cone_big.hpp)
+template <int NP>
+__global__ __launch_bounds__(NORM_WG / 2, 4) void k_chain_iter_norm_narrow_cone(const KParams P, const int t, const double* __restrict__ rec_in,
+                                                                                double* __restrict__ rec_out, const int flags) {
+    chain_iter_norm_body<NP, false, false, true, false, true, 1, true>(P, t, rec_in, rec_out, flags);
 }
 template <int NP>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_iter_norm_wide(const KParams P, const int t, const double* __restrict__ rec_in,

@@ -74,3 +74,72 @@ __device__ inline bool exchange_walk_tile_cone(const KParams& P, const int tx, u
     __syncthreads();   // (from here on the tile's blocks may overwrite the pair list)
     return true;
 }
+
+// ------------------------------------------------------------------------------------------
+// The same for LARGE single shards (8192 < N <= 32768 chains), where 8 bytes of LDS per chain of the population do not fit: the plan
+// numbers a cone's chains LOCALLY (smm_cone_big.hpp: k_cone_chains, k_cone_tiles) — the tile's own 16 are 0..15, the others 16, 17, ...
+// in the order of its gather list — and the pair words hold the LDS offsets of those local slots.
+// ------------------------------------------------------------------------------------------
+constexpr int CONEB_LOCAL = 16 + CONE_GCAP + 2;                    // local slots: own chains, gathered chains, the dummy pair's two
+constexpr uint32_t CONEB_PBASE = ((8u * CONEB_LOCAL + 127u) & ~127u);   // LDS offset of the pair words behind the local slots
+// consumer: the prologue of a chain kernel's tile (NT lanes).  LDS from address 0: local slots | pair words | the gather list; nothing
+// of the tile may have been written yet.  xr = src | (partner + 1) << 32 for the chain (valid, gc) of the control wave's lanes.
+template <int NT>
+__device__ inline bool exchange_walk_cone_local(const KParams& P, const int tx, unsigned char* lds, const int tid, const bool valid, const int cl,
+                                                unsigned long long& xr, const int tile) {
+    constexpr int NWV = NT / 64, RND = CONE_LEVELS / NWV;
+    const int w = tx - P.plan_t0;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t okw = P.cone_ok[w];
+    const uint32_t wflags = P.walk_flags[0];
+    const uint32_t* __restrict__ g_hdr = P.cone_hdr + ((size_t)w * P.cone_tiles + tile) * CONE_HDRW;
+    const uint32_t hv = g_hdr[min(lane, CONE_HDRW - 1)];
+    const uint32_t* __restrict__ g_cp = P.cone_pairs + ((size_t)w * P.cone_tiles + tile) * (CONE_LEVELS * 64);
+    const uint16_t* __restrict__ g_gl = P.cone_gather + ((size_t)w * P.cone_tiles + tile) * CONE_GCAP;
+    const int c0 = tile * P.cone_ct;
+    // (the first two sub-levels of every wave and the first NT entries of the gather list are requested TOGETHER with the header, not
+    // behind it: a cone of 16 chains is ~10 sub-levels and ~100 chains — one round trip less on the tile's serial path)
+    uint32_t pw[RND];
+#pragma unroll
+    for (int r = 0; r < RND; ++r) pw[r] = r < 2 ? g_cp[(wv + NWV * r) * 64 + lane] : 0u;
+    uint32_t g_first = tid < CONE_GCAP ? (uint32_t)g_gl[tid] : 0u;
+    uint2 own = make_uint2(0u, 0u);
+    if (tid < P.cone_ct && c0 + tid < P.N) own = P.slot8[c0 + tid];
+    const uint32_t hw0 = (uint32_t)__builtin_amdgcn_readlane((int)hv, 0);
+    const int nsub = (int)(hw0 & 0xffffu), ngat = (int)(hw0 >> 16);
+#pragma unroll
+    for (int r = 2; r < RND; ++r) { const int s = wv + NWV * r; if (s < nsub) pw[r] = g_cp[s * 64 + lane]; }
+    if (okw == 0u || wflags != 0u || (uint32_t)(size_t)lds != 0u) return false;
+    uint2* slot = (uint2*)lds;
+    uint16_t* s_gl = (uint16_t*)(lds + CONEB_PBASE + CONE_LEVELS * 64 * 4);
+    for (int e = tid; e < ngat; e += NT) {   // the cone's other chains: their slots as the accept step wrote them
+        const uint32_t g = e == tid ? g_first : (uint32_t)g_gl[e];
+        s_gl[e] = (uint16_t)g;
+        slot[P.cone_ct + e] = P.slot8[g];
+    }
+    const uint32_t nloc = (uint32_t)(P.cone_ct + ngat);
+    const uint32_t dummy = (8u * nloc) | ((8u * (nloc + 1u)) << 16);   // the two slots behind the cone's: keys 1 < 2, "no swap"
+#pragma unroll
+    for (int r = 0; r < RND; ++r) {
+        const int s = wv + NWV * r;
+        if (s < nsub) {
+            const uint32_t cnt_s = ((uint32_t)__builtin_amdgcn_readlane((int)hv, 1 + (s >> 2)) >> (8 * (s & 3))) & 0xffu;
+            *(uint32_t*)(lds + CONEB_PBASE + 4u * (uint32_t)(s * 64 + lane)) = (uint32_t)lane < cnt_s ? pw[r] : dummy;
+        }
+    }
+    if (tid < P.cone_ct) slot[tid] = own;
+    if (tid == NT - 1) { slot[nloc] = make_uint2(1u, 0u); slot[nloc + 1u] = make_uint2(2u, 0u); }
+    __syncthreads();
+    if (tid < 64) lean_walk_levels<64, 0>(P.vals, 1, CONEB_PBASE, (uint32_t)(64 * lane), nsub, tid, 0);
+    __syncthreads();
+    if (valid) {
+        const uint32_t meta = slot[cl].y;
+        uint32_t partner = lean_partner<0>(lds, CONEB_PBASE, meta, (uint32_t)cl);   // 1 + the partner's LOCAL number (0: none)
+        if (partner) partner = 1u + (partner - 1u < (uint32_t)P.cone_ct ? (uint32_t)c0 + partner - 1u : (uint32_t)s_gl[partner - 1u - (uint32_t)P.cone_ct]);
+        xr = (unsigned long long)(meta & 0xffffu) | ((unsigned long long)partner << 32);
+    }
+    __syncthreads();   // (from here on the tile's blocks may overwrite the walk's)
+    return true;
+}
+__host__ __device__ inline size_t cone_local_lds_bytes() { return (size_t)CONEB_PBASE + CONE_LEVELS * 64 * 4 + CONE_GCAP * 2; }

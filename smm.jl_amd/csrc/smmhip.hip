@@ -60,6 +60,7 @@ using namespace smm;
 #include "smm_chain_persist_gen.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
+#include "smm_cone_big.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -196,6 +197,9 @@ struct Ctx {
     bool nan_values = false;     // the uploaded state holds NaN values (smm_set_state)
     bool gen_lean = false;       // k_chain_iter walks inline on the lean form (16-byte slots) when the plan fits it
     bool gen_keys = false;       // ... on the lean KEY form (8-byte slots): single shards of 4096 < N <= 8192 chains without a simulation (two 16-chain tiles per workgroup)
+    bool cone_big = false;       // large single shards of objfunc_norm (8192 < N <= 32768): the narrow chain kernel's tiles walk their own, locally numbered cones (smm_cone_big.hpp)
+    uint32_t* cb_scratch = nullptr;
+    std::vector<uint32_t> cone_big_ok;   // per iteration of the plan window: its cones fit their caps
     bool dense_keys = false;     // ... and the dense objective's tiles (one 16-chain tile per workgroup, N <= 4096): the walk's slots and lists UNDER the tile's blocks
     bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
@@ -295,7 +299,8 @@ size_t tile_smem_base(const Ctx* c, int ct) {
     return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, obj_kind(c->obj)) * sizeof(double);
 }
 size_t norm_smem(const Ctx* c) {   // k_chain_iter_norm: [walk: chain slots | pair list] theta, partial sums, parked state
-    return (size_t)c->P.tile_off * sizeof(double) + norm_tile_doubles(c->P.np) * sizeof(double);
+    const size_t b = (size_t)c->P.tile_off * sizeof(double) + norm_tile_doubles(c->P.np) * sizeof(double);
+    return c->cone_big ? std::max(b, cone_local_lds_bytes()) : b;   // (the local cone walk lies UNDER the tile's blocks)
 }
 size_t tile_smem(const Ctx* c, int ct, int tpw = 1) {   // dynamic LDS of k_chain_iter: tpw tiles; with the inline exchange
     if (c->norm_fast) return norm_smem(c);
@@ -338,6 +343,17 @@ void ensure_windows(Ctx* c, int t, bool rng = true) {
                            c->win_lv_off, c->win_lv_rows, c->win_lv_rowinfo);
         c->plan_t0 = t; c->plan_w = W;
         P.plan_t0 = t;
+        if (c->cone_big) {   // the tiles' locally numbered cones, from the plan's scratch (pairs in list order, their levels)
+            hipLaunchKernelGGL(k_cone_chains, dim3(W), dim3(XWG), (size_t)P.Ng * 4, c->stream, P, (const uint32_t*)c->win_lv_pairs, (const uint32_t*)c->win_lv_off, c->cb_scratch);
+            hipLaunchKernelGGL(k_cone_tiles, dim3((unsigned)(((P.cone_tiles + CONEB_WAVES - 1) / CONEB_WAVES) * ((W + 7) & ~7))), dim3(64 * CONEB_WAVES), cone_tiles_lds_bytes(),
+                               c->stream, P, W, (const uint32_t*)c->cb_scratch);
+            HIPCHK(hipGetLastError());
+            // a cone that does not fit its caps (a pair list of very deep dependency chains: the user's, or an unlucky sample) sends its
+            // iteration to the stand-alone resolution: the host looks at the window's flags once (one synchronisation per window)
+            c->cone_big_ok.resize((size_t)W);
+            HIPCHK(hipMemcpyAsync(c->cone_big_ok.data(), P.cone_ok, (size_t)W * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
         P.lv_rows = c->win_lv_rows; P.lv_rowinfo = c->win_lv_rowinfo;
         P.lv_pairs = c->win_lv_pairs; P.lv_mi = c->win_lv_mi; P.lv_off = c->win_lv_off;
     }
@@ -415,8 +431,28 @@ void launch_chain_iter_norm_any_t(Ctx* c, int t, int flags) {
     else
         hipLaunchKernelGGL((k_chain_iter_norm_any<NP>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
 }
+template <int NP>
+void launch_chain_iter_norm_narrow_cone_t(Ctx* c, int t, int flags) {
+    const KParams& P = c->P;
+    const dim3 grid((P.N + NORM_CT - 1) / NORM_CT), block(NORM_WG / 2);
+    const double* rin = (const double*)c->rec[c->cur];
+    double* rout = c->rec[c->cur ^ 1];
+    if (c->kev0)
+        hipExtLaunchKernelGGL((k_chain_iter_norm_narrow_cone<NP>), grid, block, norm_smem(c), c->stream, c->kev0, c->kev1, 0, P, t, rin, rout, flags);
+    else
+        hipLaunchKernelGGL((k_chain_iter_norm_narrow_cone<NP>), grid, block, norm_smem(c), c->stream, P, t, rin, rout, flags);
+}
 void launch_chain_iter_norm(Ctx* c, int t, int flags) {
     const bool walk = (flags & F_WALK_INLINE) != 0;
+    if (walk && c->cone_big) {   // large single shards: every tile walks its own, locally numbered cone (smm_cone_big.hpp)
+        switch (c->P.np) {
+            case 1: launch_chain_iter_norm_narrow_cone_t<1>(c, t, flags); break;
+            case 2: launch_chain_iter_norm_narrow_cone_t<2>(c, t, flags); break;
+            case 3: launch_chain_iter_norm_narrow_cone_t<3>(c, t, flags); break;
+            default: launch_chain_iter_norm_narrow_cone_t<4>(c, t, flags); break;
+        }
+        return;
+    }
     // the lean walks need a padded plan of at most 31 levels and values without NaN: where that is not given — per-chain or
     // negative thresholds (no padded plan), an injected pair list that goes deeper, an uploaded state with NaN values — the
     // kernel with the walk on 16-byte slots {value, src, partner} runs
@@ -924,7 +960,9 @@ void enqueue_iterations(Ctx* c, int n_iters) {
         if (c->profiling) c->pev_exch[slot] = 0;
         c->unresolved = false;
         if (exchange_active(c, t)) {
-            if (c->inline_walk && !(c->gen_keys && (c->deep_plan || c->nan_values))) {   // (the key form has no second walk to fall back to)
+            const bool cone_next = c->cone_big && !c->nan_values && !c->ext_rec_in && !c->ext_rec_out && !c->ext_vals_out && !c->rec_external &&
+                                   t >= c->plan_t0 && t < c->plan_t0 + c->plan_w && c->cone_big_ok[(size_t)(t - c->plan_t0)] != 0u;
+            if (cone_next || (c->inline_walk && !(c->gen_keys && (c->deep_plan || c->nan_values)))) {   // (the key form has no second walk to fall back to)
                 c->unresolved = true;   // resolved in the prologue of the next chain kernel (or by resolve_now)
             } else {
                 if (kscoped) { c->kev0 = c->pev[4 * slot + 2]; c->kev1 = c->pev[4 * slot + 3]; c->pev_exch[slot] = 1; }
@@ -1341,7 +1379,14 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                           N == Ng && N / PG_CT <= n_cus && !c->deep_plan && P.dbg == 0 &&
                                           persist_gen_smem_bytes(Ng, np, P.RW, P.HW) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
             const size_t persist_tiles = want_persist_gen ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
-            const size_t plan_iter = (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
+            // large single shards of objfunc_norm (C3 on one GPU): the narrow chain kernel's tiles walk their own, locally numbered cones
+            // (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two launches
+            const char* cbh = SMM_HOOK("SMMHIP_CONE_BIG");   // test hook: "0" keeps k_exch_resolve_rows between the launches
+            const char* kwb = SMM_HOOK("SMMHIP_KEY_WALK");
+            const bool want_cone_big = c->big_exchange && c->key_exchange && P.mi_uniform && P.mi_value == 0.0 && !(kwb && kwb[0] == '0') && c->norm_fast && c->norm_narrow &&
+                                       N == Ng && N % NORM_CT == 0 && Ng <= 32768 && K <= 65535 && P.dbg == 0 && !(cbh && cbh[0] == '0') &&
+                                       (size_t)Ng * 4 <= (size_t)160 * 1024;
+            const size_t plan_iter = (want_cone_big ? (size_t)(N / NORM_CT) * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + cone_big_scratch_words(Ng, K) * 4 : 0) + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
                                      (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / cone_ct) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
                                      (want_persist ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
                                      (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0);
@@ -1365,6 +1410,21 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                     c->slots17 = dalloc<uint32_t>(c, (size_t)Ng + 4);
                     c->nan_flags = dalloc<uint32_t>(c, 4);
                     HIPCHK(hipMemset(c->nan_flags, 0, 16));
+                    if (want_cone_big) {
+                        const size_t tiles = (size_t)N / NORM_CT;
+                        c->cone_big = true;
+                        P.cone_tiles = (int)tiles; P.cone_ct = NORM_CT;
+                        P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
+                        P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
+                        P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64));
+                        P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP);
+                        HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
+                        c->cb_scratch = dalloc<uint32_t>(c, (size_t)c->plan_cap * cone_big_scratch_words(Ng, K));
+                        for (int b = 0; b < 2; ++b) c->slot8_buf[b] = dalloc<uint2>(c, (size_t)N + 4 + 128);
+                        P.slot8 = c->slot8_buf[0];
+                        P.walk_flags = dalloc<uint32_t>(c, 4);
+                        HIPCHK(hipMemset(P.walk_flags, 0, 16));
+                    }
                 }
             }
             if (c->lds_exchange) {
@@ -1571,6 +1631,11 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow_cone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow_cone<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow_cone<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_narrow_cone<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+            if (c->cone_big) HIPCHK(hipFuncSetAttribute((const void*)k_cone_chains, hipFuncAttributeMaxDynamicSharedMemorySize, Ng * 4));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_iter_norm_wide<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -2429,6 +2494,23 @@ int smm_debug_ts(void* ctx, unsigned long long* out, int n_wg) {
     if (hipMemcpy(out, c->P.ts, (size_t)n_wg * 8 * 8, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
     return SMM_OK;
 }
+
+#ifdef SMM_TEST_HOOKS
+// debug (test build only, not part of the public header): the cone of one tile in iteration plan_t0 + w of the current plan window
+int smm_debug_cone(void* ctx, int w, int tile, uint32_t* hdr, uint32_t* pairs, uint16_t* gather, int32_t* info) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !c->P.cone_hdr) return SMM_ERR_INVALID_ARG;
+    const KParams& P = c->P;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return SMM_ERR_HIP;
+    if (hipMemcpy(hdr, P.cone_hdr + ((size_t)w * P.cone_tiles + tile) * CONE_HDRW, CONE_HDRW * 4, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
+    if (hipMemcpy(pairs, P.cone_pairs + ((size_t)w * P.cone_tiles + tile) * (CONE_LEVELS * 64), CONE_LEVELS * 64 * 4, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
+    if (P.cone_gather && hipMemcpy(gather, P.cone_gather + ((size_t)w * P.cone_tiles + tile) * CONE_GCAP, CONE_GCAP * 2, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
+    uint32_t ok = 0;
+    if (hipMemcpy(&ok, P.cone_ok + w, 4, hipMemcpyDeviceToHost) != hipSuccess) return SMM_ERR_HIP;
+    info[0] = c->plan_t0; info[1] = c->plan_w; info[2] = (int32_t)ok; info[3] = P.cone_ct;
+    return SMM_OK;
+}
+#endif
 
 int smm_get_Z(void* ctx, double* Z) {
     Ctx* c = (Ctx*)ctx;

@@ -1339,3 +1339,38 @@ def test_dense_tiles_walk_the_exchange_in_their_prologue(S, O, monkeypatch, hook
     c.step(T)
     cm.assert_history_equal(h.history(), c.history(), exact_floats=True)
     assert N == 2 or (h.history().exchanged != 0).any()
+
+
+@pytest.mark.parametrize("N,T", [(8208, 12), (20000, 8), (32768, 6)])
+def test_large_shard_tiles_walk_their_own_cones(S, O, monkeypatch, hooks, N, T):
+    # large single shards of objfunc_norm (8192 < N <= 32768: BASELINE config 3 on one GPU): the narrow chain kernel's tiles walk the
+    # exchange over their own, LOCALLY numbered cones (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two
+    # launches.  Against the oracle and, to the bit, against that resolution (SMMHIP_CONE_BIG=0); uneven steps, a read-back in between
+    prob, opts = cm.serial_normal(N=N, T=T, ns=48)
+    h, o = make_pair(S, O, prob, opts, threads=16)
+    for n in (1, 3, T - 4):
+        h.step(n); o.step(n)
+        if n == 3:
+            cm.assert_state_equal(h.state(), o.state(), atol=1e-13)   # (simulated moments cross zero)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+    monkeypatch.setenv("SMMHIP_CONE_BIG", "0")
+    c = S.hip_context(prob, opts)
+    c.step(T)
+    cm.assert_history_equal(h.history(), c.history(), exact_floats=True)
+    assert (h.history().exchanged != 0).mean() > 0.05
+
+
+def test_large_shard_cone_that_does_not_fit_takes_the_resolution(S, O):
+    # injected pair lists: odd iterations carry one chain of tile 0 at the end of a dependency chain 700 pairs long (a cone of more than
+    # 384 pairs and 63 levels): the plan flags the iteration, the host sends it to k_exch_resolve_rows; even iterations walk cones
+    N, T = 8208, 6
+    prob, opts = cm.serial_normal(N=N, T=T, ns=32, sigma0=0.02)
+    tab = cm.random_tables(prob, opts, tries=24)
+    chain = [(100 + k, 101 + k) for k in range(700)] + [(3, 800)]        # ... -> (799, 800) -> (3, 800): chain 3's cone is all of it
+    rest = [(1000 + 2 * (k % 3600), 1001 + 2 * (k % 3600)) for k in range(N - len(chain))]   # (the other chains among themselves)
+    pt = np.array(chain + rest, np.int32)
+    tab.pairs[1::2] = pt[None]
+    h, o = run_both(S, O, prob, opts, tab)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    assert (h.history().exchanged != 0).any()
