@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_objectives.sh <tag>: rocprofv3 evidence for BASELINE configs C4 (banana, 8192 chains) and C5 (dense, FP64 MFMA).
+# tools/profile_objectives.sh <tag>: rocprofv3 evidence for BASELINE configs C3 (32768 chains on one GPU), C4 (banana, 8192 chains) and C5 (dense, FP64 MFMA).
 # The profiled commands are bench.py's own (C5: its default --steps 8 = the steady state past 1600 iterations), so that every figure of
 # profiles/<tag>_bench_c5.json can be recomputed from <tag>_c5_kernel_stats.csv and <tag>_c5_pmc_summary.txt; the per-launch
 # distribution of the chain kernel (p50 / p99 / max over the run) goes to <tag>_c5_launches.txt.
@@ -7,7 +7,7 @@ tag=${1:-rXX}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for cfg in c4 c5; do
+for cfg in c3 c4 c5; do
   B="python $GRAFT_REPO_ROOT/bench.py --workload $cfg --no-cpu-baseline --no-unfused"
   rm -rf /tmp/kt && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $B > $out/${cfg}_run.txt 2>&1
   cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $out/${cfg}_kernel_stats.csv
@@ -29,7 +29,7 @@ PY
   [ $cfg = c4 ] && echo "# iterations_kernel_trace=1400 iterations_pmc=800" >> $out/${cfg}_pmc_summary.txt
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
     rm -rf /tmp/pm && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pm -- $B --steps 2 > /dev/null 2>&1
-    python $GRAFT_REPO_ROOT/tools/summarise_pmc.py $(find /tmp/pm -name "*counter_collection.csv" | head -1) | grep -a "k_chain_iter\|k_chain_persist\|k_exch_resolve\|k_exch_plan\|k_pregen\|^#" >> $out/${cfg}_pmc_summary.txt
+    python $GRAFT_REPO_ROOT/tools/summarise_pmc.py $(find /tmp/pm -name "*counter_collection.csv" | head -1) | grep -a "k_chain_iter\|k_chain_persist\|k_cone_\|k_exch_resolve\|k_exch_plan\|k_pregen\|^#" >> $out/${cfg}_pmc_summary.txt
   done
   grep -a "^{" $out/${cfg}_run.txt > $out/bench_${cfg}.json
   head -4 $out/${cfg}_kernel_stats.csv | cut -c1-200
