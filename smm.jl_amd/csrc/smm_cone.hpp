@@ -131,7 +131,12 @@ __device__ inline bool exchange_walk_cone_local(const KParams& P, const int tx, 
     if (tid < P.cone_ct) slot[tid] = own;
     if (tid == NT - 1) { slot[nloc] = make_uint2(1u, 0u); slot[nloc + 1u] = make_uint2(2u, 0u); }
     __syncthreads();
-    if (tid < 64) lean_walk_levels<64, 0>(P.vals, 1, CONEB_PBASE, (uint32_t)(64 * lane), nsub, tid, 0);
+    if (tid < 64) {   // (the walk is this wave's instruction stream — ~65 instructions per sub-level —, and its SIMD is shared with the simulating waves of
+                      // the CU's other workgroup: ahead of them while it lasts)
+        __builtin_amdgcn_s_setprio(3);
+        lean_walk_levels<64, 0>(P.vals, 1, CONEB_PBASE, (uint32_t)(64 * lane), nsub, tid, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
     __syncthreads();
     if (valid) {
         const uint32_t meta = slot[cl].y;
