@@ -1124,11 +1124,11 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                     }
                     // The chains still open after those rounds are the stubborn ones (adapted sigmas, 50 parameters: one try in hundreds or
                     // thousands is inside the box late in a run — C5: 38 us per iteration in the first 200 of 2000, 244 in the last, at 16
-                    // tries per 1.5 us and tile).  A try that fails fails EARLY, so the remaining tries are scouted by groups of 8 lanes, 8
-                    // pairs at a time, and given up at the first group of pairs with a component outside the box: 64 tries in flight
+                    // tries per 1.5 us and tile).  A try that fails fails EARLY, so the remaining tries are scouted by groups of 16 lanes, 16
+                    // pairs at a time, and given up at the first group of pairs with a component outside the box: 32 tries in flight
                     // per tile instead of 16, most of them one trip long.  The groups TAKE their tries — a counter per chain hands them
                     // out in order — from whichever chain of the tile still has tries worth making (below its lowest successful one),
-                    // so that the tile's unluckiest chain ends up with all 64 groups; a try that gets through all its pairs enters the
+                    // so that the tile's unluckiest chain ends up with all 32 groups; a try that gets through all its pairs enters the
                     // chain's minimum.  The lowest successful try wins — the tries, their order and the winner are the serial loop's —
                     // and is then evaluated once more, in full, by the chain's own lanes (one_try: the same arithmetic as ever).
                     // Scratch: the head of the chain's (still unused) history row — [0]: open, [1]: lowest successful try, [3]: next try

@@ -11,14 +11,15 @@
 //     1024 lanes by role: waves 0 and 1 are the CONTROL waves (16 chains each, four lanes per chain, lane r of a quad takes the
 //     component pairs r, r + 4, ...), wave 0 walks the workgroup's cone; wave 2 makes the next iteration's randomness (the MH uniform
 //     and the normals of the first tries: in the kernel — no k_pregen_rng window — unless tables are injected) and reads the tiles'
-//     progress; wave 3 brings the gather list and stores the history rows out of LDS; waves 4..7 gather; waves 8..15 bring the next
-//     pair list by LDS-DMA and pad it;
+//     progress; wave 3 brings the gather list and stores the history rows out of LDS; waves 4..11 gather (a lane per chain of the
+//     cone: ~200-400); waves 8..15 bring the next pair list by LDS-DMA and pad it first;
 //   * the ring holds the walk slot {order_key32(value), chain | tag << 16} and the self-validating record (value, prob, status,
 //     parameters, moments: RW doubles, a uint4 each); the gather takes the slots only — with 10 parameters the donors' parameters are
 //     fetched behind the walk, by the exchanged chains alone;
-//   * the chain's line (state block fields + the record it continues from) lives in LDS for the whole launch; settling the previous
-//     iteration, counters, sigma, best values and the history rows run behind the publication.
-// np == nm <= 16 in one proposal batch, isotropic proposals, banana (or any built-in without a simulation), min_improve == 0,
+//   * the chains' state blocks and records live in LDS for the whole launch (the records in two parities: what the chain continues
+//     from / its last accepted record after the accept step); settling the previous iteration, counters, sigma, best values and the
+//     history rows run behind the publication.
+// np, nm <= 16 in one proposal batch, isotropic proposals, banana, min_improve == 0,
 // dist_fun = -, 4096 < N <= 8192 in whole workgroups of 32 (the key walk's population: its 8-byte slots are addressed in halved
 // units).  Results are bit-identical to k_chain_iter<0, 16, 2, true>'s.  Errors, ring overrun guard, time-outs, repair: as in
 // smm_chain_persist.hpp.
@@ -35,7 +36,7 @@ struct PersistGenArgs {
     const double *lb, *ub, *mom, *w;
     const double* rb;                 // randomness blocks of injected tables (null: drawn in the kernel)
     int N, Ng, np, nm, RW, HW, plan_t0, exch_from, sigma_update_steps, smpl_iters, t0, t1;
-    int rb_t0, RBW, rb_tries, user_n, obj;
+    int rb_t0, RBW, rb_tries, user_n;
     int ring_k, slow_tile, slow_ticks, walk_first;
     uint32_t epoch;
     double sigma_adjust_by;
@@ -402,8 +403,6 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
         asm volatile("" ::: "memory");
         unsigned long long ts4 = 0, ts5 = 0;
         if (A.ts && tid == 0) ts4 = wall_clock64();
-        const int first_valid_lane = 0;   // (chains ascend with the lanes: lane 0 serves a chain whenever the wave serves any)
-        if (!__builtin_amdgcn_readfirstlane(valid ? 1 : 0) && lane == 0) __hip_atomic_fetch_add(s_pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a wave without chains)
         if (valid) {
             // ---- objective (banana, ObjExamples.jl:251-265, generalised to np dimensions; the terms in order), doAcceptReject! (:324-392) ----
             // (every lane of the quad computes the same value: its lanes read the proposal out of LDS, whose writes completed in order)
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
             }
             // the gather's clock: this wave has published (the other tiles publish at about the same time; the gather touches other
             // tiles' slots only, so it may run under the bookkeeping below)
-            if (lane == first_valid_lane) __hip_atomic_fetch_add(s_pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_fetch_add(s_pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (N is whole workgroups: lane 0 serves a chain)
             // ================= behind the publication =================
             asm volatile("" ::: "memory");
             if (A.ts && tid == 0) ts5 = wall_clock64();

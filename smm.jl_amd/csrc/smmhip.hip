@@ -891,7 +891,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.rb = pregen ? P.rb : nullptr;
         A.N = P.N; A.Ng = P.Ng; A.np = P.np; A.nm = P.nm; A.RW = P.RW; A.HW = P.HW; A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from;
         A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
-        A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n; A.obj = P.obj;
+        A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
         A.walk_first = c->unresolved ? 1 : 0;
         A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
         A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed;
