@@ -1374,3 +1374,41 @@ def test_large_shard_cone_that_does_not_fit_takes_the_resolution(S, O):
     h, o = run_both(S, O, prob, opts, tab)
     cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
     assert (h.history().exchanged != 0).any()
+
+
+@pytest.mark.parametrize("N", [8208, 32768])
+def test_large_shard_cones_are_exactly_the_pairs_that_matter(S, hooks, N):
+    # the plan side of smm_cone_big.hpp on its own (test build: smm_debug_cone): a tile's cone must hold exactly the pairs its 16 chains'
+    # outcome depends on — found here by walking the injected pair list backwards on the CPU —, every chain's pairs in list order
+    # across the sub-levels, the local numbers consistent with the gather list
+    import ctypes as C
+    prob, opts = cm.serial_normal(N=N, T=4, ns=8)
+    tab = cm.random_tables(prob, opts, tries=8)
+    a = S.hip_context(prob, opts, tab)
+    a.step(2)
+    lib = S._abi.load_hooks()
+    hdr = np.zeros(9, np.uint32); pairs = np.zeros(2048, np.uint32); gl = np.zeros(512, np.uint16); info = np.zeros(4, np.int32)
+    for tile in (0, 7, N // 16 - 1):
+        for w in (1, 2):
+            assert lib.smm_debug_cone(a._ctx, w, tile, hdr.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p), gl.ctypes.data_as(C.c_void_p),
+                                      info.ctypes.data_as(C.c_void_p)) == 0
+            assert info[2] == 1 and info[3] == 16
+            pl = tab.pairs[info[0] + w - 1]
+            nsub, ngat = int(hdr[0] & 0xffff), int(hdr[0] >> 16)
+            cnts = [int((hdr[1 + (s >> 2)] >> (8 * (s & 3))) & 0xff) for s in range(nsub)]
+            loc = list(range(tile * 16, tile * 16 + 16)) + [int(x) for x in gl[:ngat]]
+            assert len(set(loc)) == len(loc)
+            cone = [(loc[(int(pairs[s * 64 + l]) & 0xffff) >> 3], loc[(int(pairs[s * 64 + l]) >> 16) >> 3], s) for s in range(nsub) for l in range(cnts[s])]
+            need, exp = set(range(tile * 16, tile * 16 + 16)), set()
+            for q in range(len(pl) - 1, -1, -1):
+                i, j = int(pl[q, 0]), int(pl[q, 1])
+                if i in need or j in need:
+                    exp.add((i, j)); need.add(i); need.add(j)
+            assert set((i, j) for (i, j, s) in cone) == exp and len(cone) == len(exp)
+            posq = {(int(pl[q, 0]), int(pl[q, 1])): q for q in range(len(pl))}
+            last = {}
+            for (i, j, s) in cone:
+                q = posq[(i, j)]
+                for ch in (i, j):
+                    assert ch not in last or (last[ch][0] < q and last[ch][1] < s)
+                    last[ch] = (q, s)
