@@ -1359,6 +1359,15 @@ def test_large_shard_tiles_walk_their_own_cones(S, O, monkeypatch, hooks, N, T):
     c.step(T)
     cm.assert_history_equal(h.history(), c.history(), exact_floats=True)
     assert (h.history().exchanged != 0).mean() > 0.05
+    # a run continued from an uploaded state (smm_set_state in the middle of the plan window) ends where the uninterrupted one does
+    monkeypatch.delenv("SMMHIP_CONE_BIG")
+    a = S.hip_context(prob, opts)
+    a.step(T - 3)
+    b = S.hip_context(prob, opts)
+    b.set_state(a.state(), a.history(0, T - 3))
+    b.step(3)
+    cm.assert_history_equal(h.history(), b.history(), exact_floats=True)
+    cm.assert_state_equal(h.state(), b.state(), rtol=0)
 
 
 def test_large_shard_cone_that_does_not_fit_takes_the_resolution(S, O):
