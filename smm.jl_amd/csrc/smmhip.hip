@@ -1004,6 +1004,10 @@ void persist_repair(Ctx* c) {
     c->iter = c->snap_iter; c->cur = c->snap_cur; c->slots_iter = c->snap_slots_iter;
     c->pending = c->snap_pending; c->prev_open = c->snap_prev_open; c->unresolved = c->snap_unresolved; c->exch_done = c->snap_exch_done;
     c->plan_w = 0; c->rng_w = 0;   // (the windows are rebuilt: cheap, and nothing assumes where the failed run left them)
+    // ... with the exchange of the snapshot's iteration still to be applied, its plan must be in the window the replay starts with: the
+    // failed launches may have moved the window on (a step across a window boundary), and what enqueue_iterations does for an
+    // iteration outside the window — resolve the pending exchange from "the window that just ended" — would read another window's plan
+    if (c->unresolved) ensure_windows(c, c->iter);
     const int prof = c->profiling;
     c->profiling = 0;
     enqueue_iterations(c, n);

@@ -153,3 +153,27 @@ def test_persistent_form_can_be_switched_off_and_reports_itself(S):
     assert S.hip_context(p2, o2).persistent_info()[0] is False
     p3, o3 = cm.general_normal(4, N=32, T=10, ns=200)
     assert S.hip_context(p3, o3).persistent_info()[0] is False
+
+
+def test_persistent_form_hard_error_in_a_step_across_a_plan_window(S, O):
+    # found by tools/soak.py (C2, iteration 110224 of bench.py's seed: a legitimate AlgoBGP.jl:409): the failing step starts with an
+    # exchange still to be applied and its launches cross the end of a look-ahead window (256 iterations), so that the plan window has
+    # moved on when the library rolls back to the snapshot — the replay must rebuild the window of the snapshot's iteration, not resolve
+    # the pending exchange out of the wrong one (it read another window's plan: out-of-range at best, a memory fault at worst)
+    N, T, tfail = 48, 400, 300
+    prob, opts = cm.serial_normal(N=N, T=T, ns=100, sigma0=0.01)
+    tab = cm.random_tables(prob, opts, tries=8)
+    tab.prop_normals[tfail - 1] = 1e9
+    h, o = _pair(S, O, prob, opts, tab)
+    h.step_async(250); h.sync()          # (no read-back: the exchange of iteration 250 stays pending)
+    o.step(250)
+    with pytest.raises(A.SMMHipError) as eh:
+        h.step_async(100); h.sync()      # 251 .. 350: window boundary at 256, failure at 300
+    with pytest.raises(A.SMMHipError):
+        o.step(100)
+    assert eh.value.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT and "iteration %d" % tfail in str(eh.value)
+    assert h.persistent_info()[2] == 1 and h.state().iter == tfail
+    hh, ho = h.history(0, T), o.history(0, T)
+    for f in cm.INT_FIELDS:
+        np.testing.assert_array_equal(getattr(hh, f)[:tfail - 1], getattr(ho, f)[:tfail - 1], err_msg=f)
+    np.testing.assert_allclose(hh.value[:tfail - 1], ho.value[:tfail - 1], rtol=1e-9)
