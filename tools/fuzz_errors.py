@@ -1,0 +1,56 @@
+"""Randomised sweep of the HARD-ERROR paths of the persistent chain kernel (AlgoBGP.jl:409 injected at a random iteration through the
+proposal tables): random populations, step patterns (asynchronous steps with and without read-backs in between, across the 256-iteration
+look-ahead windows), against the oracle — same error, same failing iteration, same history before it.
+python tools/fuzz_errors.py [cases] [seed]   (GPU box; test infrastructure)"""
+import sys
+import numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import smm_jl_amd as S, common as cm
+from smm_jl_amd import _abi as A
+from oracle import oracle as O
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for it in range(cases):
+    N = int(rng.choice([16, 40, 64, 200, 400]))
+    T = int(rng.integers(280, 700))
+    tfail = int(rng.integers(5, T - 2))
+    prob, opts = cm.serial_normal(N=N, T=T, ns=int(rng.choice([16, 100])), sigma0=0.01, seed=int(rng.integers(1, 10 ** 6)))
+    tab = cm.random_tables(prob, opts, tries=8, seed=int(rng.integers(1, 10 ** 6)))
+    tab.prop_normals[tfail - 1] = 1e9
+    h = S.hip_context(prob, opts, tab)
+    o = O.OracleContext(prob, opts, S.Tables(probs_acc=tab.probs_acc, prop_normals=tab.prop_normals, pairs=tab.pairs, Z=h.Z()))
+    eh = None
+    done = 0
+    try:
+        while done < T:
+            n = int(min(T - done, rng.choice([1, 2, 7, 50, 120, 300])))
+            h.step_async(n)
+            if rng.random() < 0.6: h.sync()
+            if rng.random() < 0.2: h.state()
+            done += n
+        h.sync()
+    except A.SMMHipError as e:
+        eh = e
+    eo = None
+    try:
+        o.step(T)
+    except A.SMMHipError as e:
+        eo = e
+    import re
+    if eh is not None:   # (a table of 8 tries may fail earlier all by itself: wherever the oracle fails is where the library must)
+        tfail = int(re.search(r"iteration (\d+)", str(eh)).group(1))
+    it_o = o.state().iter if eo is not None else -1
+    ok = eh is not None and eo is not None and eh.code == eo.code and it_o + 1 == tfail and h.state().iter == tfail   # (the oracle stops IN iteration tfail: its counter stands at tfail - 1)
+    if ok:
+        hh, ho = h.history(0, T), o.history(0, T)
+        for f in cm.INT_FIELDS:
+            ok = ok and np.array_equal(getattr(hh, f)[:tfail - 1], getattr(ho, f)[:tfail - 1])
+        ok = ok and np.allclose(hh.value[:tfail - 1], ho.value[:tfail - 1], rtol=1e-9, equal_nan=True)
+    info = h.persistent_info()
+    print("case %3d N %4d T %3d tfail %3d: %s (persistent launches %d, repairs %d)%s" % (it, N, T, tfail, "ok" if ok else "FAILED", info[1], info[2], "" if ok else "  oracle: iter %d %s | " % (it_o, str(eo)[:60]) + str(eh)[:100]), flush=True)
+    bad += 0 if ok else 1
+    del h, o
+print("%d of %d cases failed" % (bad, cases))
+sys.exit(1 if bad else 0)
