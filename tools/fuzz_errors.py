@@ -16,11 +16,18 @@ for it in range(cases):
     N = int(rng.choice([16, 40, 64, 200, 400]))
     T = int(rng.integers(280, 700))
     tfail = int(rng.integers(5, T - 2))
-    prob, opts = cm.serial_normal(N=N, T=T, ns=int(rng.choice([16, 100])), sigma0=0.01, seed=int(rng.integers(1, 10 ** 6)))
-    tab = cm.random_tables(prob, opts, tries=8, seed=int(rng.integers(1, 10 ** 6)))
+    if it % 5 == 4:   # the persistent kernel of simulation-free objectives (banana, 4096 < N <= 8192 in whole workgroups of 32)
+        N, npar = 32 * int(rng.integers(129, 140)), int(rng.choice([2, 3]))
+        T = int(rng.integers(270, 330)); tfail = int(rng.integers(5, T - 2))
+        prob = S.Problem(init=np.full(npar, 0.5), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1, objective_id=A.SMM_OBJ_BANANA)
+        opts = S.BGPOpts(N=N, maxiter=T, sigma=0.004 * cm.temps(N, 3), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N), seed=int(rng.integers(1, 10 ** 6)))
+        tab = cm.random_tables(prob, opts, tries=4, seed=int(rng.integers(1, 10 ** 6)))
+    else:
+        prob, opts = cm.serial_normal(N=N, T=T, ns=int(rng.choice([16, 100])), sigma0=0.01, seed=int(rng.integers(1, 10 ** 6)))
+        tab = cm.random_tables(prob, opts, tries=8, seed=int(rng.integers(1, 10 ** 6)))
     tab.prop_normals[tfail - 1] = 1e9
     h = S.hip_context(prob, opts, tab)
-    o = O.OracleContext(prob, opts, S.Tables(probs_acc=tab.probs_acc, prop_normals=tab.prop_normals, pairs=tab.pairs, Z=h.Z()))
+    o = O.OracleContext(prob, opts, S.Tables(probs_acc=tab.probs_acc, prop_normals=tab.prop_normals, pairs=tab.pairs, Z=h.Z()), threads=16)
     eh = None
     done = 0
     try:
