@@ -200,6 +200,20 @@ struct Ctx {
     bool cone_big = false;       // large single shards of objfunc_norm (8192 < N <= 32768): the narrow chain kernel's tiles walk their own, locally numbered cones (smm_cone_big.hpp)
     uint32_t* cb_scratch = nullptr;
     std::vector<uint32_t> cone_big_ok;   // per iteration of the plan window: its cones fit their caps
+    // ... their windows are planned AHEAD: the plan of a window depends on (seed, iteration) only, so while the chain kernels of one
+    // window run, the three plan kernels of the next run beside them on a second stream into the other of two sets of tables
+    struct PlanSet {
+        uint32_t *lv_pairs = nullptr, *lv_off = nullptr, *lv_rows = nullptr, *lv_rowinfo = nullptr, *cone_ok = nullptr, *cone_hdr = nullptr, *cone_pairs = nullptr;
+        double* lv_mi = nullptr;
+        uint16_t* cone_gather = nullptr;
+        uint32_t* ok_host = nullptr;   // (pinned) cone_ok as the host reads it
+        hipEvent_t done = nullptr;
+        int t0 = 0, w = 0;             // iterations [t0, t0 + w) are (being) planned into this set
+    } ps[2];
+    int ps_act = 0;                      // the set the chain kernels read
+    bool plan_ahead = false;
+    hipStream_t pstream = nullptr;
+    hipEvent_t ev_free = nullptr;        // main stream: every launch that reads the set about to be planned into has been enqueued before it
     bool dense_keys = false;     // ... and the dense objective's tiles (one 16-chain tile per workgroup, N <= 4096): the walk's slots and lists UNDER the tile's blocks
     bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
@@ -322,6 +336,25 @@ size_t resolve_lvl_bytes(int Ng, int K) { return (size_t)Ng * 16 + (size_t)K * 1
 int exchange_K(const Ctx* c) { return c->P.pairtab ? c->P.n_pairs_tab : n_exchange_pairs(c->P.Ng); }
 bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P.Ng > 1; }  // AlgoBGP.jl:637
 
+void launch_cone_big(Ctx* c, const KParams& Pw, int W, const uint32_t* lv_pairs, const uint32_t* lv_off, hipStream_t st) {
+    hipLaunchKernelGGL(k_cone_chains, dim3(W), dim3(XWG), (size_t)Pw.Ng * 4, st, Pw, lv_pairs, lv_off, c->cb_scratch);
+    hipLaunchKernelGGL(k_cone_tiles, dim3((unsigned)(((Pw.cone_tiles + CONEB_WAVES - 1) / CONEB_WAVES) * ((W + 7) & ~7))), dim3(64 * CONEB_WAVES), cone_tiles_lds_bytes(),
+                       st, Pw, W, (const uint32_t*)c->cb_scratch);
+    HIPCHK(hipGetLastError());
+}
+// the plan window starting at iteration t into set k, on the plan stream (the kernels' scratch is theirs alone: one window at a time there)
+void plan_window_into(Ctx* c, int k, int t) {
+    Ctx::PlanSet& S = c->ps[k];
+    KParams Pw = c->P;
+    Pw.cone_ok = S.cone_ok; Pw.cone_hdr = S.cone_hdr; Pw.cone_pairs = S.cone_pairs; Pw.cone_gather = S.cone_gather;
+    const int W = std::min(c->plan_cap, Pw.T - t + 1);
+    hipLaunchKernelGGL(k_exch_plan_big, dim3(W), dim3(XWG), plan_big_lds_bytes(Pw.Ng), c->pstream, Pw, t, c->big_scratch, S.lv_pairs, S.lv_mi, S.lv_off, S.lv_rows, S.lv_rowinfo);
+    launch_cone_big(c, Pw, W, S.lv_pairs, S.lv_off, c->pstream);
+    HIPCHK(hipMemcpyAsync(S.ok_host, S.cone_ok, (size_t)W * 4, hipMemcpyDeviceToHost, c->pstream));
+    HIPCHK(hipEventRecord(S.done, c->pstream));
+    S.t0 = t; S.w = W;
+}
+
 // make the look-ahead tables cover iteration t (1-based): a new window simply starts at t
 void ensure_windows(Ctx* c, int t, bool rng = true) {
     KParams& P = c->P;
@@ -337,17 +370,34 @@ void ensure_windows(Ctx* c, int t, bool rng = true) {
         c->rng_t0 = t; c->rng_w = W;
         P.rb = c->win_rb; P.rb_t0 = t;
     }
-    if (c->big_exchange && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
+    if (c->plan_ahead && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
+        const int nx = c->ps_act ^ 1;
+        Ctx::PlanSet& S = c->ps[nx];
+        if (!(S.w > 0 && S.t0 == t)) plan_window_into(c, nx, t);   // (the first window, a jump: not the window planned ahead)
+        HIPCHK(hipEventSynchronize(S.done));                         // the host reads the window's flags (long there when planned ahead)
+        HIPCHK(hipStreamWaitEvent(c->stream, S.done, 0));
+        c->ps_act = nx; c->plan_t0 = S.t0; c->plan_w = S.w;
+        P.plan_t0 = S.t0;
+        P.lv_rows = S.lv_rows; P.lv_rowinfo = S.lv_rowinfo; P.lv_pairs = S.lv_pairs; P.lv_mi = S.lv_mi; P.lv_off = S.lv_off;
+        P.cone_ok = S.cone_ok; P.cone_hdr = S.cone_hdr; P.cone_pairs = S.cone_pairs; P.cone_gather = S.cone_gather;
+        c->cone_big_ok.assign(S.ok_host, S.ok_host + S.w);
+        // the next window, into the set the launches enqueued so far read: behind them
+        Ctx::PlanSet& O = c->ps[nx ^ 1];
+        O.w = 0;
+        if (S.t0 + S.w <= P.T) {
+            HIPCHK(hipEventRecord(c->ev_free, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->pstream, c->ev_free, 0));
+            plan_window_into(c, nx ^ 1, S.t0 + S.w);
+        }
+    }
+    if (c->big_exchange && !c->plan_ahead && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->plan_cap, P.T - t + 1);
         hipLaunchKernelGGL(k_exch_plan_big, dim3(W), dim3(XWG), plan_big_lds_bytes(P.Ng), c->stream, P, t, c->big_scratch, c->win_lv_pairs, c->win_lv_mi,
                            c->win_lv_off, c->win_lv_rows, c->win_lv_rowinfo);
         c->plan_t0 = t; c->plan_w = W;
         P.plan_t0 = t;
         if (c->cone_big) {   // the tiles' locally numbered cones, from the plan's scratch (pairs in list order, their levels)
-            hipLaunchKernelGGL(k_cone_chains, dim3(W), dim3(XWG), (size_t)P.Ng * 4, c->stream, P, (const uint32_t*)c->win_lv_pairs, (const uint32_t*)c->win_lv_off, c->cb_scratch);
-            hipLaunchKernelGGL(k_cone_tiles, dim3((unsigned)(((P.cone_tiles + CONEB_WAVES - 1) / CONEB_WAVES) * ((W + 7) & ~7))), dim3(64 * CONEB_WAVES), cone_tiles_lds_bytes(),
-                               c->stream, P, W, (const uint32_t*)c->cb_scratch);
-            HIPCHK(hipGetLastError());
+            launch_cone_big(c, P, W, c->win_lv_pairs, c->win_lv_off, c->stream);
             // a cone that does not fit its caps (a pair list of very deep dependency chains: the user's, or an unlucky sample) sends its
             // iteration to the stand-alone resolution: the host looks at the window's flags once (one synchronisation per window)
             c->cone_big_ok.resize((size_t)W);
@@ -1003,7 +1053,7 @@ void persist_repair(Ctx* c) {
     HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
     c->iter = c->snap_iter; c->cur = c->snap_cur; c->slots_iter = c->snap_slots_iter;
     c->pending = c->snap_pending; c->prev_open = c->snap_prev_open; c->unresolved = c->snap_unresolved; c->exch_done = c->snap_exch_done;
-    c->plan_w = 0; c->rng_w = 0;   // (the windows are rebuilt: cheap, and nothing assumes where the failed run left them)
+    c->plan_w = 0; c->rng_w = 0; c->ps[0].w = c->ps[1].w = 0;   // (the windows are rebuilt: cheap, and nothing assumes where the failed run left them)
     // ... with the exchange of the snapshot's iteration still to be applied, its plan must be in the window the replay starts with: the
     // failed launches may have moved the window on (a step across a window boundary), and what enqueue_iterations does for an
     // iteration outside the window — resolve the pending exchange from "the window that just ended" — would read another window's plan
@@ -1099,6 +1149,9 @@ void smm_ctx_destroy(void* ctx) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->pstream) { (void)hipStreamSynchronize(c->pstream); (void)hipStreamDestroy(c->pstream); }
+    if (c->ev_free) (void)hipEventDestroy(c->ev_free);
+    for (Ctx::PlanSet& S : c->ps) { if (S.done) (void)hipEventDestroy(S.done); if (S.ok_host) (void)hipHostFree(S.ok_host); }
     for (void* p : c->allocs) (void)hipFree(p);
     for (void* w : c->p2p_opened) if (w) (void)hipIpcCloseMemHandle(w);
     if (c->p2p_mine) (void)hipFree(c->p2p_mine);
@@ -1398,6 +1451,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             c->win_cap = std::min(c->win_cap, T);
             c->plan_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)1536 << 20) / plan_iter));
             c->plan_cap = std::min(c->plan_cap, T);
+            if (const char* pc = SMM_HOOK("SMMHIP_PLAN_CAP")) c->plan_cap = std::max(1, std::min(c->plan_cap, atoi(pc)));   // test hook: short plan windows
             c->win_rb = dalloc<double>(c, (size_t)c->win_cap * N * P.RBW);
             HIPCHK(hipMemset(c->win_rb, 0, (size_t)c->win_cap * N * P.RBW * 8));
             if (c->big_exchange) {
@@ -1424,6 +1478,26 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                         P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP);
                         HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
                         c->cb_scratch = dalloc<uint32_t>(c, (size_t)c->plan_cap * cone_big_scratch_words(Ng, K));
+                        const char* pah = SMM_HOOK("SMMHIP_PLAN_AHEAD");   // test hook: "0" plans each window on the main stream when it is entered
+                        if (!(pah && pah[0] == '0')) {
+                            c->plan_ahead = true;
+                            HIPCHK(hipStreamCreateWithFlags(&c->pstream, hipStreamNonBlocking));
+                            HIPCHK(hipEventCreateWithFlags(&c->ev_free, hipEventDisableTiming));
+                            for (int b = 0; b < 2; ++b) {
+                                Ctx::PlanSet& S = c->ps[b];
+                                S.lv_pairs = b ? dalloc<uint32_t>(c, (size_t)c->plan_cap * K) : c->win_lv_pairs;
+                                S.lv_mi = b ? dalloc<double>(c, (size_t)c->plan_cap * K) : c->win_lv_mi;
+                                S.lv_off = b ? dalloc<uint32_t>(c, (size_t)c->plan_cap * (K + 2)) : c->win_lv_off;
+                                S.lv_rows = b ? dalloc<uint32_t>(c, (size_t)c->plan_cap * P.rows_cap * XWG) : c->win_lv_rows;
+                                S.lv_rowinfo = b ? dalloc<uint32_t>(c, (size_t)c->plan_cap * 4) : c->win_lv_rowinfo;
+                                S.cone_ok = b ? dalloc<uint32_t>(c, (size_t)c->plan_cap) : (uint32_t*)P.cone_ok;
+                                S.cone_hdr = b ? dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW) : (uint32_t*)P.cone_hdr;
+                                S.cone_pairs = b ? dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64)) : (uint32_t*)P.cone_pairs;
+                                S.cone_gather = b ? dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP) : P.cone_gather;
+                                HIPCHK(hipHostMalloc((void**)&S.ok_host, (size_t)c->plan_cap * 4, hipHostMallocDefault));
+                                HIPCHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+                            }
+                        }
                         for (int b = 0; b < 2; ++b) c->slot8_buf[b] = dalloc<uint2>(c, (size_t)N + 4 + 128);
                         P.slot8 = c->slot8_buf[0];
                         P.walk_flags = dalloc<uint32_t>(c, 4);

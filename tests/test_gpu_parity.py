@@ -1370,6 +1370,47 @@ def test_large_shard_tiles_walk_their_own_cones(S, O, monkeypatch, hooks, N, T):
     cm.assert_state_equal(h.state(), b.state(), rtol=0)
 
 
+@pytest.mark.parametrize("cap", [1, 7])
+def test_large_shard_plan_windows_are_planned_ahead(S, O, monkeypatch, hooks, cap):
+    # the windows of exchange plans (with the tiles' cones) of large shards are planned AHEAD on a second stream, into the other of two
+    # sets of tables, while the chain kernels of the current window run.  Short windows (test hook) so that a short run crosses many of
+    # them: against the oracle and, to the bit, against the windows planned in place on the main stream (SMMHIP_PLAN_AHEAD=0); uneven
+    # asynchronous steps with read-backs in between; a continuation from an uploaded state (its first window starts in the middle of
+    # one of the uninterrupted run's: not the window planned ahead); two contexts side by side (each has its plan stream)
+    N, T = 8208, 40
+    prob, opts = cm.serial_normal(N=N, T=T, ns=32)
+    monkeypatch.setenv("SMMHIP_PLAN_CAP", str(cap))
+    h, o = make_pair(S, O, prob, opts, threads=16)
+    g = S.hip_context(prob, opts)
+    done = 0
+    for n in (1, 5, 2, 9, 14, T - 31):
+        h.step_async(n); g.step_async(n); done += n
+        if n in (2, 14):
+            cm.assert_history_equal(h.history(done - 2, done), g.history(done - 2, done), exact_floats=True)
+    o.step(T)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+    cm.assert_history_equal(h.history(), g.history(), exact_floats=True)
+    assert (h.history().exchanged != 0).mean() > 0.05
+    import ctypes as C
+    hdr = np.zeros(9, np.uint32); pairs = np.zeros(2048, np.uint32); gl = np.zeros(512, np.uint16); info = np.zeros(4, np.int32)
+    assert S._abi.load_hooks().smm_debug_cone(h._ctx, 0, 0, hdr.ctypes.data_as(C.c_void_p), pairs.ctypes.data_as(C.c_void_p), gl.ctypes.data_as(C.c_void_p),
+                                              info.ctypes.data_as(C.c_void_p)) == 0
+    assert info[1] <= cap and info[0] + info[1] - 1 == T        # (the last of the short windows)
+    a = S.hip_context(prob, opts)
+    a.step(T - 11)
+    b = S.hip_context(prob, opts)
+    b.set_state(a.state(), a.history(0, T - 11))   # from iteration T - 10 on
+    b.step(4); b.step_async(7); b.sync()
+    cm.assert_history_equal(h.history(), b.history(), exact_floats=True)
+    cm.assert_state_equal(h.state(), b.state(), rtol=0)
+    monkeypatch.setenv("SMMHIP_PLAN_AHEAD", "0")
+    c = S.hip_context(prob, opts)
+    c.step(T)
+    cm.assert_history_equal(h.history(), c.history(), exact_floats=True)
+    cm.assert_state_equal(h.state(), c.state(), rtol=0)
+
+
 def test_large_shard_cone_that_does_not_fit_takes_the_resolution(S, O):
     # injected pair lists: odd iterations carry one chain of tile 0 at the end of a dependency chain 700 pairs long (a cone of more than
     # 384 pairs and 63 levels): the plan flags the iteration, the host sends it to k_exch_resolve_rows; even iterations walk cones

@@ -2,7 +2,7 @@
 with synchronisations, state / history read-backs, objective batches, switching the persistent form off and on, and a state upload
 (into a fresh context) — the final history and state against the oracle stepped straight through.
 python tools/fuzz_api.py [cases] [seed]   (GPU box; test infrastructure)"""
-import sys
+import os, sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import smm_jl_amd as S, common as cm
@@ -12,8 +12,15 @@ from oracle import oracle as O
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
+A_ = S._abi
+A_.use_test_hooks(True)
 for it in range(cases):
-    if it % 4 == 3:
+    os.environ.pop("SMMHIP_PLAN_CAP", None)
+    if it % 4 == 2:   # large shards: plan windows (short ones: test hook) planned ahead on the second stream
+        N, T = 16 * int(rng.integers(513, 700)), int(rng.integers(40, 140))
+        os.environ["SMMHIP_PLAN_CAP"] = str(int(rng.choice([1, 3, 10, 50])))
+        prob, opts = cm.serial_normal(N=N, T=T, ns=16, seed=int(rng.integers(1, 10 ** 6)))
+    elif it % 4 == 3:
         N, npar = 32 * int(rng.integers(129, 200)), int(rng.choice([2, 5, 10]))
         T = int(rng.integers(60, 330))
         prob = S.Problem(init=np.full(npar, 0.8), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1, objective_id=A.SMM_OBJ_BANANA)
