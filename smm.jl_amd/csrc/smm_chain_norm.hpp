@@ -439,6 +439,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
         if (!walk_now && !(CONEL && (flags & F_WALK_INLINE)) && (flags & F_HAS_PENDING)) xr = P.xres[gc];
     }
     if constexpr (CONEL) {
+        __builtin_amdgcn_s_setprio(1);   // (ahead of the waves of the next window's plan kernels, which run beside this kernel: smmhip.hip, plan_window_into)
         // exchangeMoves! of iteration t-1 (AlgoBGP.jl:647-716) over the tile's cone, while those loads are in flight; its slots and pair
         // words lie UNDER the tile's blocks: nothing of the tile has been written yet
         if (flags & F_WALK_INLINE)

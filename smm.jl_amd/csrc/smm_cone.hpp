@@ -135,7 +135,7 @@ __device__ inline bool exchange_walk_cone_local(const KParams& P, const int tx, 
                       // the CU's other workgroup: ahead of them while it lasts)
         __builtin_amdgcn_s_setprio(3);
         lean_walk_levels<64, 0>(P.vals, 1, CONEB_PBASE, (uint32_t)(64 * lane), nsub, tid, 0);
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(1);
     }
     __syncthreads();
     if (valid) {
