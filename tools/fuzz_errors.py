@@ -2,7 +2,7 @@
 proposal tables): random populations, step patterns (asynchronous steps with and without read-backs in between, across the 256-iteration
 look-ahead windows), against the oracle — same error, same failing iteration, same history before it.
 python tools/fuzz_errors.py [cases] [seed]   (GPU box; test infrastructure)"""
-import sys
+import os, sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import smm_jl_amd as S, common as cm
@@ -12,7 +12,9 @@ from oracle import oracle as O
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
+A.use_test_hooks(True)
 for it in range(cases):
+    os.environ.pop("SMMHIP_PLAN_CAP", None)
     N = int(rng.choice([16, 40, 64, 200, 400]))
     T = int(rng.integers(280, 700))
     tfail = int(rng.integers(5, T - 2))
@@ -22,6 +24,11 @@ for it in range(cases):
         prob = S.Problem(init=np.full(npar, 0.5), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1, objective_id=A.SMM_OBJ_BANANA)
         opts = S.BGPOpts(N=N, maxiter=T, sigma=0.004 * cm.temps(N, 3), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N), seed=int(rng.integers(1, 10 ** 6)))
         tab = cm.random_tables(prob, opts, tries=4, seed=int(rng.integers(1, 10 ** 6)))
+    elif it % 5 == 3:   # large shards: the tiles walk their cones, the plan windows (short ones: test hook) are planned ahead on the second stream
+        N, T = 16 * int(rng.integers(513, 600)), int(rng.integers(30, 90)); tfail = int(rng.integers(5, T - 2))
+        os.environ["SMMHIP_PLAN_CAP"] = str(int(rng.choice([1, 4, 11, 256])))
+        prob, opts = cm.serial_normal(N=N, T=T, ns=8, sigma0=0.01, seed=int(rng.integers(1, 10 ** 6)))
+        tab = cm.random_tables(prob, opts, tries=8, seed=int(rng.integers(1, 10 ** 6)))
     else:
         prob, opts = cm.serial_normal(N=N, T=T, ns=int(rng.choice([16, 100])), sigma0=0.01, seed=int(rng.integers(1, 10 ** 6)))
         tab = cm.random_tables(prob, opts, tries=8, seed=int(rng.integers(1, 10 ** 6)))
