@@ -604,7 +604,7 @@ def main():
         out = {"metric": "chain-evals/sec (whole node), serialNormal 2p/2m, 4096 chains x 200 iters" if args.workload == "c2"
                          else "chain-evals/sec (whole node), %s" % args.workload,
                "value": value, "unit": "chain-evals/s", "n_gpus": world, "steps": K, "warmup": Wm,
-               "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if W["total"] else "weak", "vs_baseline": None,
+               "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if (W["total"] or (world > 1 and args.same_device and not args.chains)) else "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s, %d BGP chains per GPU (%d total) x %d iterations per step" % (W["label"], n_loc, n_glob, ITERS_PER_STEP),
                           "chains_per_gpu": n_loc, "chains_total": n_glob, "iters_per_step": ITERS_PER_STEP, "ns": NS if args.workload in ("c2", "c3") else None,
