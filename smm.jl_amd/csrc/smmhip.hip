@@ -213,7 +213,7 @@ struct Ctx {
     int ps_act = 0;                      // the set the chain kernels read
     bool plan_ahead = false;
     hipStream_t pstream = nullptr;
-    hipEvent_t ev_free = nullptr;        // main stream: every launch that reads the set about to be planned into has been enqueued before it
+    hipEvent_t ev_free = nullptr;        // main stream: every launch that reads the set about to be planned into has been enqueued before it (plan_window_into)
     bool dense_keys = false;     // ... and the dense objective's tiles (one 16-chain tile per workgroup, N <= 4096): the walk's slots and lists UNDER the tile's blocks
     bool lean_resolve = false;   // one min_improve >= 0 for all chains, N_global <= 8192 (~7400 when > 0): k_exch_resolve_lean is the stand-alone resolve kernel
     double* win_lv_mi = nullptr;
@@ -342,10 +342,13 @@ void launch_cone_big(Ctx* c, const KParams& Pw, int W, const uint32_t* lv_pairs,
                        st, Pw, W, (const uint32_t*)c->cb_scratch);
     HIPCHK(hipGetLastError());
 }
-// the plan window starting at iteration t into set k, on the plan stream (the kernels' scratch is theirs alone: one window at a time there)
+// the plan window starting at iteration t into set k, on the plan stream (the kernels' scratch is theirs alone: one window at a time
+// there) — behind every launch enqueued on the main stream so far: the ones that read set k are all among them (k is not the active set)
 void plan_window_into(Ctx* c, int k, int t) {
     Ctx::PlanSet& S = c->ps[k];
     KParams Pw = c->P;
+    HIPCHK(hipEventRecord(c->ev_free, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->pstream, c->ev_free, 0));
     Pw.cone_ok = S.cone_ok; Pw.cone_hdr = S.cone_hdr; Pw.cone_pairs = S.cone_pairs; Pw.cone_gather = S.cone_gather;
     const int W = std::min(c->plan_cap, Pw.T - t + 1);
     hipLaunchKernelGGL(k_exch_plan_big, dim3(W), dim3(XWG), plan_big_lds_bytes(Pw.Ng), c->pstream, Pw, t, c->big_scratch, S.lv_pairs, S.lv_mi, S.lv_off, S.lv_rows, S.lv_rowinfo);
@@ -381,14 +384,9 @@ void ensure_windows(Ctx* c, int t, bool rng = true) {
         P.lv_rows = S.lv_rows; P.lv_rowinfo = S.lv_rowinfo; P.lv_pairs = S.lv_pairs; P.lv_mi = S.lv_mi; P.lv_off = S.lv_off;
         P.cone_ok = S.cone_ok; P.cone_hdr = S.cone_hdr; P.cone_pairs = S.cone_pairs; P.cone_gather = S.cone_gather;
         c->cone_big_ok.assign(S.ok_host, S.ok_host + S.w);
-        // the next window, into the set the launches enqueued so far read: behind them
-        Ctx::PlanSet& O = c->ps[nx ^ 1];
-        O.w = 0;
-        if (S.t0 + S.w <= P.T) {
-            HIPCHK(hipEventRecord(c->ev_free, c->stream));
-            HIPCHK(hipStreamWaitEvent(c->pstream, c->ev_free, 0));
-            plan_window_into(c, nx ^ 1, S.t0 + S.w);
-        }
+        // the next window, into the set the launches enqueued so far read
+        c->ps[nx ^ 1].w = 0;
+        if (S.t0 + S.w <= P.T) plan_window_into(c, nx ^ 1, S.t0 + S.w);
     }
     if (c->big_exchange && !c->plan_ahead && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->plan_cap, P.T - t + 1);
