@@ -15,12 +15,16 @@ for wl, n, steps in CASES:
     ctx = S.hip_context(prob, opts)
     if os.environ.get("SOAK_PERSIST") == "0": ctx.set_persistent(False)
     t0 = time.perf_counter()
-    for s in range(steps):
-        ctx.step_async(200)
-        if s % 100 == 99 or len(sys.argv) > 3:
-            ctx.sync()
-            if len(sys.argv) > 3 and s % 20 == 19: print("  step", s + 1, flush=True)
-    ctx.sync()
+    try:
+        for s in range(steps):
+            ctx.step_async(200)
+            if s % 100 == 99 or len(sys.argv) > 3:
+                ctx.sync()
+                if len(sys.argv) > 3 and s % 20 == 19: print("  step", s + 1, flush=True)
+        ctx.sync()
+    except S._abi.SMMHipError as e:   # (the algorithm's own hard error — AlgoBGP.jl:409: sigma adapted until no draw falls into the box — ends a long run: C2's seed at 110224)
+        print("%s: stopped by %s" % (wl, e), flush=True)
+        T = ctx.state().iter
     dt = time.perf_counter() - t0
     info = ctx.persistent_info()
     st = ctx.state()
