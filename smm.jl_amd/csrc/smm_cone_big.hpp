@@ -24,8 +24,8 @@
 // kernel (sampled lists stay far below the caps).
 // ------------------------------------------------------------------------------------------
 constexpr int CONEB_PAIRS = 384;     // pairs of a cone (16 chains: ~100, 209 the largest seen at 4096 chains)
-constexpr int CONEB_PHASH = 1024;    // slots of a wave's table of the pairs met (load <= 0.375)
-constexpr int CONEB_CHASH = 1024;    // slots of a wave's table of chains (16 + at most 512 entries)
+constexpr int CONEB_CHASH = 512;     // slots of a wave's table of chains (every pair of a cone brings at most ONE chain its successor on
+                                     // the walk back did not have: <= 16 + 384 entries)
 constexpr int CONEB_WAVES = 4;       // tiles per workgroup of k_cone_tiles
 
 // scratch per iteration of the window, by POSITION in the level-ordered pair list (lv_pairs): the predecessor of the pair on its first /
@@ -66,8 +66,12 @@ __global__ __launch_bounds__(XWG) void k_cone_chains(const KParams P, const uint
     for (int c = tid; c < Ng; c += XWG) C.lastpair[c] = cc_last[c];
 }
 
-__host__ __device__ inline size_t cone_tiles_wave_bytes() { return (size_t)CONEB_PHASH * 2 + CONEB_PAIRS * 2 + CONEB_CHASH * 4 + 64 * 4 * 3 + 16; }
-__host__ __device__ inline size_t cone_tiles_lds_bytes() { return CONEB_WAVES * ((cone_tiles_wave_bytes() + 15) & ~(size_t)15); }
+// (a wave's LDS: table of chains, level counters, the cone's list, and ONE BIT per pair of the iteration for "met": 4 KB at 32768 pairs —
+// a table of the pairs met instead, 2 KB, let 20 instead of 16 tiles run per CU, but its look-ups were nested compare-and-swap loops under
+// divergent control and the kernel is bound by instruction issue: EXPERIMENTS.md §R4.11)
+__host__ __device__ inline size_t cone_tiles_met_words(int K) { return ((size_t)K + 127) / 128 * 4; }   // (whole 16-byte pieces)
+__host__ __device__ inline size_t cone_tiles_wave_bytes(int K) { return cone_tiles_met_words(K) * 4 + CONEB_PAIRS * 2 + CONEB_CHASH * 4 + 64 * 4 * 3 + 16; }
+__host__ __device__ inline size_t cone_tiles_lds_bytes(int K) { return CONEB_WAVES * ((cone_tiles_wave_bytes(K) + 15) & ~(size_t)15); }
 
 __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P, const int n_iters, const uint32_t* __restrict__ cone_scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
@@ -82,41 +86,28 @@ __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P
     if (w >= n_iters || tile >= tiles) return;   // (no workgroup barrier below: every wave is on its own)
     ConeBigScratch C;
     C.carve((uint32_t*)cone_scratch + (size_t)w * cone_big_scratch_words(Ng, K), Ng, K);
-    unsigned char* base = cb_smem + (size_t)wave * ((cone_tiles_wave_bytes() + 15) & ~(size_t)15);
+    unsigned char* base = cb_smem + (size_t)wave * ((cone_tiles_wave_bytes(K) + 15) & ~(size_t)15);
     uint32_t* chash = (uint32_t*)base;                                 // [CONEB_CHASH]: (chain + 1) << 16 | local number (0: free)
     uint32_t* lcnt = chash + CONEB_CHASH;                              // [64]: pairs of level l; then the level's cursor
     uint32_t* lsub = lcnt + 64;                                        // [64]: first sub-level of level l
     uint32_t* subc = lsub + 64;                                        // [64]: counts of the sub-levels (32 used)
     uint32_t* misc = subc + 64;                                        // [0]: gathered chains
-    uint16_t* phash = (uint16_t*)(misc + 4);                           // [CONEB_PHASH]: position + 1 of a pair met (0: free)
-    uint16_t* list = phash + CONEB_PHASH;                              // [CONEB_PAIRS]: the cone's pairs (positions)
+    uint32_t* met = misc + 4;                                          // [K / 32]: a bit per pair (position) met
+    const int metw = (int)cone_tiles_met_words(K);
+    uint16_t* list = (uint16_t*)(met + metw);                          // [CONEB_PAIRS]: the cone's pairs (positions)
     uint32_t* o_hdr = (uint32_t*)P.cone_hdr + ((size_t)w * tiles + tile) * CONE_HDRW;
     uint32_t* o_cp = (uint32_t*)P.cone_pairs + ((size_t)w * tiles + tile) * (CONE_LEVELS * 64);
     uint16_t* o_gl = (uint16_t*)P.cone_gather + ((size_t)w * tiles + tile) * CONE_GCAP;
     const int c0 = tile * P.cone_ct;
     auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
-    for (int x = lane; x < CONEB_PHASH / 2; x += 64) ((uint32_t*)phash)[x] = 0u;
+    for (int x = lane; x < metw / 4; x += 64) ((uint4*)met)[x] = make_uint4(0u, 0u, 0u, 0u);
     for (int x = lane; x < CONEB_CHASH; x += 64) chash[x] = 0u;
     lcnt[lane] = 0u; subc[lane] = 0u;
     if (lane == 0) misc[0] = 0u;
     wave_sync();
-    // has this pair been met?  16-bit slots, claimed through the 32-bit word they live in
     auto meet = [&](const uint32_t pos) -> bool {   // true: met for the first time
-        const uint32_t key = pos + 1u;
-        uint32_t h = (pos * 2654435761u) >> 22;     // 10 bits
-        for (;;) {
-            uint32_t* wp = (uint32_t*)phash + (h >> 1);
-            const uint32_t sh = (h & 1u) * 16u;
-            uint32_t cur = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (;;) {
-                const uint32_t k = (cur >> sh) & 0xffffu;
-                if (k == key) return false;
-                if (k != 0u) break;
-                const uint32_t want = cur | (key << sh);
-                if (__hip_atomic_compare_exchange_strong(wp, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return true;
-            }
-            h = (h + 1u) & (CONEB_PHASH - 1);
-        }
+        const uint32_t bit = 1u << (pos & 31u);
+        return (atomicOr(&met[pos >> 5], bit) & bit) == 0u;
     };
     // ---- the cone: the chains' last pairs, then back over the predecessor links ----
     int n = 0;
@@ -135,17 +126,15 @@ __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P
         int pa = -1, pb = -1;
         if (lane < batch) { const uint4 rq = C.rec[list[head + lane]]; pa = (int)rq.y; pb = (int)rq.z; }
         head += batch;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int p = side ? pb : pa;
-            const bool fresh = p >= 0 && meet((uint32_t)p);
-            const unsigned long long m = __ballot(fresh);
-            const int at = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (fresh && at < CONEB_PAIRS) list[at] = (uint16_t)p;
-            n += __popcll(m);
-            if (n > CONEB_PAIRS) { bad = true; n = CONEB_PAIRS; }   // (the table of pairs must not fill up: stop)
-            wave_sync();
-        }
+        // (appended in the order: every lane's first predecessor, then every lane's second)
+        const bool fa = pa >= 0 && meet((uint32_t)pa), fb = pb >= 0 && meet((uint32_t)pb);
+        const unsigned long long ma = __ballot(fa), mb = __ballot(fb), below = (1ull << lane) - 1ull;
+        const int na = __popcll(ma), aa = n + __popcll(ma & below), ab = n + na + __popcll(mb & below);
+        if (fa && aa < CONEB_PAIRS) list[aa] = (uint16_t)pa;
+        if (fb && ab < CONEB_PAIRS) list[ab] = (uint16_t)pb;
+        n += na + __popcll(mb);
+        if (n > CONEB_PAIRS) { bad = true; n = CONEB_PAIRS; }   // (the list must not run over: stop)
+        wave_sync();
     }
     // ---- by level: counts, sub-levels of 64 words ----
     for (int x = lane; x < n; x += 64) {
@@ -170,7 +159,8 @@ __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P
     if (nsub > CONE_LEVELS) { bad = true; nsub = CONE_LEVELS; }
     wave_sync();
     // ---- the tile's own chains are 0 .. cone_ct - 1 ----
-    auto cslot = [&](const uint32_t chain) { return (chain * 2654435761u) >> 22; };   // 10 bits
+    auto cslot = [&](const uint32_t chain) { return (chain * 2654435761u) >> 23; };   // 9 bits
+    static_assert(CONEB_CHASH == 512 && CONEB_PAIRS + 16 < CONEB_CHASH, "cslot: 9 bits");
     if (lane < P.cone_ct) {
         const uint32_t chain = (uint32_t)(c0 + lane);
         uint32_t h = cslot(chain);

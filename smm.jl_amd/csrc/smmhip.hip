@@ -338,7 +338,7 @@ bool exchange_active(const Ctx* c, int t) { return t >= c->exchange_from && c->P
 
 void launch_cone_big(Ctx* c, const KParams& Pw, int W, const uint32_t* lv_pairs, const uint32_t* lv_off, hipStream_t st) {
     hipLaunchKernelGGL(k_cone_chains, dim3(W), dim3(XWG), (size_t)Pw.Ng * 4, st, Pw, lv_pairs, lv_off, c->cb_scratch);
-    hipLaunchKernelGGL(k_cone_tiles, dim3((unsigned)(((Pw.cone_tiles + CONEB_WAVES - 1) / CONEB_WAVES) * ((W + 7) & ~7))), dim3(64 * CONEB_WAVES), cone_tiles_lds_bytes(),
+    hipLaunchKernelGGL(k_cone_tiles, dim3((unsigned)(((Pw.cone_tiles + CONEB_WAVES - 1) / CONEB_WAVES) * ((W + 7) & ~7))), dim3(64 * CONEB_WAVES), cone_tiles_lds_bytes(Pw.plan_K),
                        st, Pw, W, (const uint32_t*)c->cb_scratch);
     HIPCHK(hipGetLastError());
 }
