@@ -358,6 +358,12 @@ void plan_window_into(Ctx* c, int k, int t) {
     S.t0 = t; S.w = W;
 }
 
+// iteration t lies behind the plan window, the exchange of t - 1 is still to be walked: does the window planned ahead hold both?
+bool plan_ahead_covers(const Ctx* c, int t) {
+    const Ctx::PlanSet& S = c->ps[c->ps_act ^ 1];
+    return c->plan_ahead && S.w >= 2 && S.t0 == t - 1;
+}
+
 // make the look-ahead tables cover iteration t (1-based): a new window simply starts at t
 void ensure_windows(Ctx* c, int t, bool rng = true) {
     KParams& P = c->P;
@@ -376,7 +382,9 @@ void ensure_windows(Ctx* c, int t, bool rng = true) {
     if (c->plan_ahead && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int nx = c->ps_act ^ 1;
         Ctx::PlanSet& S = c->ps[nx];
-        if (!(S.w > 0 && S.t0 == t)) plan_window_into(c, nx, t);   // (the first window, a jump: not the window planned ahead)
+        // (the window planned ahead starts with the LAST iteration of the one before it, so that an exchange of that iteration still
+        // to be walked by this launch's tiles finds its cones in the new window: plan_ahead_covers)
+        if (!(S.w > 0 && (S.t0 == t || (S.t0 == t - 1 && S.w >= 2)))) plan_window_into(c, nx, t);   // (the first window, a jump: not the window planned ahead)
         HIPCHK(hipEventSynchronize(S.done));                         // the host reads the window's flags (long there when planned ahead)
         HIPCHK(hipStreamWaitEvent(c->stream, S.done, 0));
         c->ps_act = nx; c->plan_t0 = S.t0; c->plan_w = S.w;
@@ -386,7 +394,7 @@ void ensure_windows(Ctx* c, int t, bool rng = true) {
         c->cone_big_ok.assign(S.ok_host, S.ok_host + S.w);
         // the next window, into the set the launches enqueued so far read
         c->ps[nx ^ 1].w = 0;
-        if (S.t0 + S.w <= P.T) plan_window_into(c, nx ^ 1, S.t0 + S.w);
+        if (S.t0 + S.w <= P.T) plan_window_into(c, nx ^ 1, S.t0 + S.w - (S.w >= 2 && c->plan_cap >= 2 ? 1 : 0));
     }
     if (c->big_exchange && !c->plan_ahead && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) {
         const int W = std::min(c->plan_cap, P.T - t + 1);
@@ -994,7 +1002,7 @@ void enqueue_iterations(Ctx* c, int n_iters) {
             continue;
         }
         // an exchange left to this chain kernel needs its plan: resolve it now if the plan window is about to move on
-        if (c->unresolved && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w)) resolve_now(c);
+        if (c->unresolved && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w) && !plan_ahead_covers(c, t)) resolve_now(c);
         ensure_windows(c, t);
         const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0) | (c->unresolved ? F_WALK_INLINE : 0);
         const bool kscoped = c->profiling == 2 && c->lvl_exchange && c->lvl_wg == 1024;
