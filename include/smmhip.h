@@ -306,7 +306,9 @@ int  smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out);
 int  smm_bgp_p2p_attach(void* ctx, int32_t rank, const void* ipc_handle, void* window_dev);
 int  smm_bgp_p2p_step(void* ctx, int32_t n_iters);
 int  smm_bgp_p2p_finish(void* ctx);
-/* the HIP stream all of the ctx's work is enqueued on (hipStream_t as void*) */
+/* the HIP stream all of the ctx's work is enqueued on (hipStream_t as void*).  (Large single shards, 8192 < N <= 32768, also own a
+ * private second stream on which the NEXT window's exchange plan is computed ahead; the work on smm_stream waits for it through
+ * events, so everything a caller can observe is ordered by smm_stream alone; smm_ctx_destroy drains both.) */
 void* smm_stream(void* ctx);
 
 /* batched evaluateObjective(m,p) (mprob.jl:175-188) for M parameter vectors
