@@ -121,10 +121,15 @@ __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P
         n += __popcll(m);
     }
     wave_sync();
+    bool deep = false;   // (a pair of level 64 or more)
     for (int head = 0; head < n && !bad;) {
         const int batch = min(64, n - head);   // (what the list holds now; what this step appends is the next steps')
         int pa = -1, pb = -1;
-        if (lane < batch) { const uint4 rq = C.rec[list[head + lane]]; pa = (int)rq.y; pb = (int)rq.z; }
+        if (lane < batch) {   // (every pair of the list is read here exactly once, unless the list runs over: its level is counted on the way)
+            const uint4 rq = C.rec[list[head + lane]];
+            pa = (int)rq.y; pb = (int)rq.z;
+            if (rq.w < 64u) atomicAdd(&lcnt[rq.w], 1u); else deep = true;
+        }
         head += batch;
         // (appended in the order: every lane's first predecessor, then every lane's second)
         const bool fa = pa >= 0 && meet((uint32_t)pa), fb = pb >= 0 && meet((uint32_t)pb);
@@ -136,11 +141,8 @@ __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P
         if (n > CONEB_PAIRS) { bad = true; n = CONEB_PAIRS; }   // (the list must not run over: stop)
         wave_sync();
     }
-    // ---- by level: counts, sub-levels of 64 words ----
-    for (int x = lane; x < n; x += 64) {
-        const uint32_t lv = C.rec[list[x]].w;
-        if (lv < 64u) atomicAdd(&lcnt[lv], 1u); else bad = true;
-    }
+    // ---- by level (counted above): sub-levels of 64 words ----
+    if (deep) bad = true;
     wave_sync();
     int nsub = 0;
     {
