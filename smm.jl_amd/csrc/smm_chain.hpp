@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                     // chain's minimum.  The lowest successful try wins — the tries, their order and the winner are the serial loop's —
                     // and is then evaluated once more, in full, by the chain's own lanes (one_try: the same arithmetic as ever).
                     // Scratch: the head of the chain's (still unused) history row — [0]: open, [1]: lowest successful try, [3]: next try
-                    // to hand out ([2] of row 0 is the workgroup's round word); row 0, doubles 4..11: the open chains' numbers.
+                    // to hand out ([2] of row 0 is the workgroup's round word); double 4 of rows 0 .. CT / 8 - 1: the open chains' numbers, a byte each.
                     {
                         unsigned long long* head = (unsigned long long*)(S.h + cc * HW);
                         ++round_id;
@@ -1142,8 +1142,12 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                         if (*round_word == round_id) {   // (uniform over the workgroup: somebody is open)
                             const unsigned long long open = __ballot(lane < CT && *(const unsigned long long*)(S.h + lane * HW) != 0ull);
                             const int n_open = __popcll(open);
-                            int* olist = (int*)(S.h + 4);
-                            if (tid < CT && ((open >> tid) & 1ull)) olist[__popcll(open & ((1ull << tid) - 1ull))] = tid;
+                            // (a BYTE per open chain, eight to double 4 of each of the first CT / 8 rows — a word no head uses: sixteen ints in
+                            // a row of HW = 10, one parameter and one moment, reached into row 1's head words; nothing any
+                            // wave reads in its ballot above lies there)
+                            static_assert(CT <= 64 && CT % 8 == 0, "olist: a byte per chain of the tile");
+                            auto olist = [&](const int idx) -> unsigned char* { return (unsigned char*)(S.h + (idx >> 3) * HW + 4) + (idx & 7); };
+                            if (tid < CT && ((open >> tid) & 1ull)) *olist(__popcll(open & ((1ull << tid) - 1ull))) = (unsigned char)tid;
                             __syncthreads();
                             if (n_open) {
                                 const int GLr = 64 * nwv >= 128 ? P.scout_gl : 4;   // lanes of a group (one try at a time; the slim launch: one wave per tile)
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                                         if (gj == 0) {
                                             for (int sft = 0; sft < n_open && found < 0; ++sft) {
                                                 const int idx = oi + sft < n_open ? oi + sft : oi + sft - n_open;
-                                                const int v = olist[idx];
+                                                const int v = (int)*olist(idx);
                                                 unsigned long long* hv = (unsigned long long*)(S.h + v * HW);
                                                 const unsigned long long lim = min(__hip_atomic_load(hv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
                                                 if (__hip_atomic_load(hv + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < lim) {

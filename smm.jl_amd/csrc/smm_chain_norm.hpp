@@ -338,7 +338,22 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
     }
     if (timed_out) report_error(P, 3, tx + 1, P.offset);   // (everybody goes on to the barriers below; the failure is reported)
     const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
-    const bool form_ok = __builtin_amdgcn_readlane((int)ov, 34) != 0 && __builtin_amdgcn_readfirstlane((int)wflags) == 0 && (uint32_t)(size_t)lds == 0u;
+    bool form_ok = __builtin_amdgcn_readlane((int)ov, 34) != 0 && __builtin_amdgcn_readfirstlane((int)wflags) == 0 && (uint32_t)(size_t)lds == 0u;
+    {   // a NaN value: its slot says so itself (P2P_KEY_NAN arrives with the tag that validated the word; the window's NaN word, read at
+        // the top, may lag behind the slots).  Every wave must decide the same: a byte per wave in the two spare slots behind the dummy pair's
+        bool nan_seen = false;
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int g = 4 * (tid + r * NT) + 2 * hh;
+                const uint4 q = s_[2 * r + hh];
+                nan_seen = nan_seen || (g < Ng && q.x == P2P_KEY_NAN) || (g + 1 < Ng && q.z == P2P_KEY_NAN);
+            }
+        }
+        const bool wnan = __ballot(nan_seen) != 0ull;
+        if (lane == 0) lds[8u * (Ng4 + 2u) + (uint32_t)(tid >> 6)] = wnan ? (unsigned char)1 : (unsigned char)0;
+    }
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
         const int q = tid + r * NT;
@@ -356,7 +371,11 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
     const int ltail = lean_walk_tail(ov, nlev, lane);
     __syncthreads();
     if (P.ts && tid == 0) P.ts[(size_t)ts_tile * 8 + 5] = wall_clock64();   // staged
-    if (!form_ok) return false;   // (wave-uniform AND the same in every wave: plan and flag are what they are for the whole launch)
+    {
+        const uint4 nf = *(const uint4*)(lds + 8u * (Ng4 + 2u));   // the 16 waves' bytes
+        if ((nf.x | nf.y | nf.z | nf.w) != 0u) form_ok = false;
+    }
+    if (!form_ok) return false;   // (wave-uniform AND the same in every wave: the plan is what it is for the whole launch, the NaN bytes are read behind the barrier)
     const P2PWalkValues values{P, tx};
     if (NMAX <= XLVL_MAX || P.lean_unit == 8) lean_walk_levels<NORM_WG, 0, false, P2PWalkValues>(nullptr, 1, pbase, ov, nlev, tid, ltail, 0.0, values);
     else lean_walk_levels<NORM_WG, 1, false, P2PWalkValues>(nullptr, 1, pbase, ov, nlev, tid, ltail, 0.0, values);

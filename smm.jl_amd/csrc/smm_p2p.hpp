@@ -67,8 +67,11 @@ __device__ inline size_t p2p_slot4_off(const KParams& P, const int b) { return b
 // words for the new ones: the epoch (publications so far, the same on every rank) is part of the tag
 __host__ __device__ inline uint32_t p2p_tag_of(const int t, const uint32_t epoch) { return 0x8000u | ((epoch & 0x7ffu) << 4) | ((uint32_t)t & 0xfu); }
 __device__ inline uint32_t p2p_tag(const KParams& P, const int t) { return p2p_tag_of(t, P.p2p_epoch); }
+// (a NaN value travels IN the slot word — the reserved key P2P_KEY_NAN, which no other value has —, so a reader learns of it with the very
+// word it validates: the window's NaN word is stored separately and may become visible after the slot)
+constexpr uint32_t P2P_KEY_NAN = 0xffffffffu;
 __device__ inline unsigned long long p2p_slot_word(const KParams& P, const double v, const uint32_t gchain, const int t) {
-    return (unsigned long long)order_key32(v) | ((unsigned long long)(gchain | (p2p_tag(P, t) << 16)) << 32);
+    return (unsigned long long)(v != v ? P2P_KEY_NAN : order_key32(v)) | ((unsigned long long)(gchain | (p2p_tag(P, t) << 16)) << 32);
 }
 // The rows form (8192 < N_global <= 32768; k_exch_resolve_rows<., true>) keeps a chain's walk slot in FOUR bytes: the 17-bit order key of
 // its value (smm_params.hpp; the last bucket also says "NaN": the reader then resolves that iteration on the exact values) over a

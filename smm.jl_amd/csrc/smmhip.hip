@@ -260,6 +260,7 @@ struct Ctx {
     bool persist_broken = false;               // a launch gave up waiting (tiles not resident together?): the form is off for this context
     uint32_t pr_epoch = 0;                     // launches so far
     int persist_launches = 0, persist_repairs = 0;
+    int pregen_seen_launches = 0;              // persist_launches when the last window of randomness blocks was made (ensure_windows)
     int pr_ring_k = PR_K, pr_slow_tile = -1, pr_slow_ticks = 0;   // (test build: SMMHIP_PR_RING, SMMHIP_PR_SLOW_TILE, SMMHIP_PR_SLOW_US)
     bool in_repair = false;
     // ... and what persist_repair restores when a launch of it ends with the error word set: the state before the FIRST such launch
@@ -372,7 +373,11 @@ void ensure_windows(Ctx* c, int t, bool rng = true) {
     if (pregen && !(t >= c->rng_t0 && t < c->rng_t0 + c->rng_w)) {
         int W = std::min(c->win_cap, P.T - t + 1);
         // (k_chain_persist_gen draws in the kernel too: blocks only for the iterations between its launches)
-        if (c->persist_gen && c->persist && c->persist_on && !c->persist_broken && !c->in_repair && !P.user_ntab && !P.user_utab) W = std::min(W, 2);
+        // — and only where such launches are really being made: a caller that steps one iteration at a time (the reference's run! loop
+        // over computeNextIteration!, AlgoAbstract.jl:38-45) never takes the persistent form and keeps its full windows
+        if (c->persist_gen && c->persist && c->persist_on && !c->persist_broken && !c->in_repair && !P.user_ntab && !P.user_utab &&
+            c->persist_launches != c->pregen_seen_launches) W = std::min(W, 2);
+        c->pregen_seen_launches = c->persist_launches;
         const size_t Q = (size_t)(P.np + 1) / 2;
         const size_t per_iter = (size_t)P.rb_tries * Q * P.N;   // (< 2^31: checked at creation)
         hipLaunchKernelGGL(k_pregen_rng, dim3((unsigned)((per_iter + 255) / 256), (unsigned)W), dim3(256), 0, c->stream, P, t, W, c->win_rb);

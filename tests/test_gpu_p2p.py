@@ -93,6 +93,34 @@ def test_p2p_inline_equals_single(S, O, G, N, T, fe):
         cm.assert_history_equal(single.history(), o.history())
 
 
+def test_p2p_inline_nan_in_one_shard_is_reported_by_every_rank_in_the_same_iteration(S):
+    # a NaN value in ONE shard's uploaded state.  The one-launch form has no second walk: every rank must report
+    # SMM_ERR_HIP, for the same iteration, and promptly — the NaN fact travels in the slot word itself (P2P_KEY_NAN), so no rank can
+    # validate a peer's slots and miss it (the window's separate NaN word may become visible later than the slots)
+    import time
+    G, N, T0 = 2, 64, 4
+    prob, opts = cm.serial_normal(N=N, T=40, ns=64)
+    ctxs = p2p_contexts(S, prob, opts, G)
+    p2p_run_lockstep(ctxs, T0)
+    st = [c.state() for c in ctxs]
+    hs = [c.history() for c in ctxs]
+    st[1].la_value[5] = np.nan          # rank 1 only
+    for c, s_, h_ in zip(ctxs, st, hs):
+        c.set_state(s_, h_)
+    t0 = time.perf_counter()
+    for c in ctxs:
+        c.p2p_step(3)
+    errs = []
+    for c in ctxs:
+        with pytest.raises(S.SMMError) as ei:
+            c.sync()
+        errs.append(str(ei.value))
+    assert time.perf_counter() - t0 < 3.0, "a rank sat in its time-out"
+    assert all("could not be resolved" in e for e in errs), errs
+    its = [e.split("iteration ")[1].split()[0] for e in errs]
+    assert its[0] == its[1], errs
+
+
 @pytest.mark.parametrize("G,N,T,fe,failbox", [(4, 16384, 8, None, False), (8, 32768, 6, 4, False), (2, 20000, 6, None, False), (3, 9000, 8, 3, False),
                                               (4, 16384, 6, None, True), (8, 32768, 5, None, True), (2, 10000, 300, None, False)])
 def test_p2p_rows_equals_single(S, G, N, T, fe, failbox):
