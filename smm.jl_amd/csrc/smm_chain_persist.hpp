@@ -49,6 +49,7 @@ constexpr int PR_MAX_ITERS = 4000;   // iterations per launch (12 bits of the ta
 #endif
 constexpr int PR_GATHER_DELAY = SMM_EXP_PR_DELAY;   // s_sleep units (64 clocks) between this tile's publication and the gather's first look
 constexpr int PR_STW = 12;       // doubles of chain state in front of the record in a tile's LDS line
+constexpr unsigned long long PERSIST_TMO_FIRST = 40000000ull;   // 0.4 s of the 100 MHz wall clock: the spins of a context's first launches (smmhip.hip, launch_chain_persist)
 
 // LDS of a tile: [walk slots: 8 bytes per chain of the population + 4] [pair lists x 2] [gather lists x 2] [headers x 4] and, as doubles:
 // theta[16][NP] part[NP][8][16] lines[16][LW] rng[2][64][1 + 2 NP] hrow[16][HW] xrow[16][HW] z0[PR_ZR][64] const[16] misc[16] donor[2][64] (uint4) gth[Ng4][NP]
@@ -72,7 +73,7 @@ __device__ inline uint32_t pr_progress_word(const uint32_t epoch, const int rel)
 // The ring is written with write-through stores and read past the caches.  Scope: the tiles are workgroups of ONE device, so the
 // agent scope (sc1) is enough; SMM_EXP_PR_SYS=1 makes it the system scope (sc0 sc1) of the p2p windows, for comparison.
 #ifndef SMM_EXP_PR_SYS
-#define SMM_EXP_PR_SYS 0
+#define SMM_EXP_PR_SYS 1   // (round 5: the same words also travel between the ranks' windows, smm_chain_persist_loc.hpp — one scope for all; measured equal, EXPERIMENTS.md R4.3)
 #endif
 #if SMM_EXP_PR_SYS
 #define PR_SC "sc0 sc1"
@@ -84,7 +85,7 @@ __device__ inline unsigned long long pr_load8_sys(const void* p) {
     asm volatile("global_load_dwordx2 %0, %1, off " PR_SC "\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-__device__ inline uint32_t pr_load4_sys(const void* p) { return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t pr_load4_sys(const void* p) { return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline uint4 pr_load16_sys(const void* p) {
     p2p_u32x4 q;
     asm volatile("global_load_dwordx4 %0, %1, off " PR_SC "\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(p) : "memory");
@@ -133,6 +134,7 @@ struct PersistArgs {
     int ring_k;                       // entries of the ring in use (a power of two <= PR_K)
     int slow_tile, slow_ticks;        // test build: this tile's control wave idles so many wall-clock ticks before it publishes (skew)
     int walk_first;                   // the exchange of iteration t0 - 1 is still to be applied: the first iteration walks it on the launch's input records
+    unsigned long long tmo;           // ticks a spin may last (PERSIST_TMO_FIRST until a launch of the context has come through, then P2P_TIMEOUT_TICKS)
     uint32_t epoch;
     double sigma_adjust_by;
     uint64_t seed;
@@ -140,13 +142,13 @@ struct PersistArgs {
 
 // (what the out-of-line helpers need travels BY VALUE: a reference to the kernel's argument block would make the compiler copy the
 // whole block into scratch memory and read every field from there)
-struct PrWait { unsigned long long* err; uint32_t* pr_ctl; unsigned* s_abort; uint32_t epoch; };
+struct PrWait { unsigned long long* err; uint32_t* pr_ctl; unsigned* s_abort; uint32_t epoch; unsigned long long tmo; /* ticks a spin may last */ };
 __device__ inline void pr_report(unsigned long long* err, int kind, int t, int chain) {
     const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)chain << 2) | (unsigned)kind;
     atomicMin(err, key);
 }
 __device__ inline bool pr_give_up(const PrWait W, const unsigned long long w0) {   // time-out, or another tile has given up
-    return wall_clock64() - w0 > P2P_TIMEOUT_TICKS || pr_load4_sys(W.pr_ctl) == W.epoch;
+    return wall_clock64() - w0 > W.tmo || pr_load4_sys(W.pr_ctl) == W.epoch;
 }
 __device__ inline void pr_abort(const PrWait W, int t, int chain) {
     pr_report(W.err, 3, t, chain);
@@ -357,7 +359,7 @@ struct PersistLds {   // where things are in a tile's LDS (byte offsets from its
 
 // out of line (once per launch / almost never): proposal tries past the first four of mysample (AlgoBGP.jl:400-410) for the chains of the
 // control wave that have not found a point inside the box yet; the same loop as k_chain_iter_norm's
-struct PrTries { const double* rb; uint64_t seed; int rb_t0, N, RBW, rb_tries, user_n, smpl_iters; };
+struct PrTries { const double* rb; uint64_t seed; int rb_t0, N, RBW, rb_tries, user_n, smpl_iters, goff /* first chain of the shard in the population */; };
 template <int NP>
 struct PrTh { double th[NP]; bool found; };
 template <int NP>
@@ -390,7 +392,7 @@ __device__ __attribute__((noinline)) PrTh<NP> persist_late_tries(const PrTries A
 #pragma unroll
                 for (int q = 0; 2 * q < NP; ++q) {
                     double z0, z1;
-                    rng_prop_normal2(A.seed, (uint32_t)c, (uint32_t)t, (uint32_t)j, (uint32_t)q, z0, z1);
+                    rng_prop_normal2(A.seed, (uint32_t)(A.goff + c), (uint32_t)t, (uint32_t)j, (uint32_t)q, z0, z1);
                     zz[2 * q] = z0;
                     if (2 * q + 1 < NP) zz[2 * q + 1] = z1;
                 }
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
     const LY Y(lds, Ng4);
     const uint32_t epoch = A.epoch;
     const int t0 = A.t0, t1 = A.t1;
-    const PrWait W{A.err, A.pr_ctl, Y.s_abort, A.epoch};
+    const PrWait W{A.err, A.pr_ctl, Y.s_abort, A.epoch, A.tmo};
     const int rmask = A.ring_k - 1;   // (the ring's depth: PR_K; the test build can make it smaller)
     const bool exch_any = A.Ng > 1;
     auto exch_on = [&](const int tx) { return exch_any && tx >= A.exch_from; };   // AlgoBGP.jl:637
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_norm(const Persist
                 }
             }
             if (__builtin_expect(__any(!found), 0)) {
-                const PrTries TR{A.rb, A.seed, A.rb_t0, A.N, A.RBW, A.rb_tries, A.user_n, A.smpl_iters};
+                const PrTries TR{A.rb, A.seed, A.rb_t0, A.N, A.RBW, A.rb_tries, A.user_n, A.smpl_iters, 0};
                 const PrTh<NP> lt = persist_late_tries<NP>(TR, o, t, c, valid, lane, found, sigma, mu01[0], mu01[NP - 1], Y.s_const, th[0], th[NP - 1]);
 #pragma unroll
                 for (int k = 0; k < NP; ++k) th[k] = lt.th[k];

@@ -38,6 +38,7 @@ struct PersistGenArgs {
     int N, Ng, np, nm, RW, HW, plan_t0, exch_from, sigma_update_steps, smpl_iters, t0, t1;
     int rb_t0, RBW, rb_tries, user_n;
     int ring_k, slow_tile, slow_ticks, walk_first;
+    unsigned long long tmo;           // ticks a spin may last
     uint32_t epoch;
     double sigma_adjust_by;
     uint64_t seed;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
     uint4* s_land = (uint4*)(s_ts + 16);                        // [2][NPC][64]
     const uint32_t epoch = A.epoch;
     const int t0 = A.t0, t1 = A.t1;
-    const PrWait W{A.err, A.pr_ctl, s_abort, A.epoch};
+    const PrWait W{A.err, A.pr_ctl, s_abort, A.epoch, A.tmo};
     const int rmask = A.ring_k - 1;
     const bool exch_any = A.Ng > 1;
     auto exch_on = [&](const int tx) { return exch_any && tx >= A.exch_from; };   // AlgoBGP.jl:637

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P
     uint32_t* o_hdr = (uint32_t*)P.cone_hdr + ((size_t)w * tiles + tile) * CONE_HDRW;
     uint32_t* o_cp = (uint32_t*)P.cone_pairs + ((size_t)w * tiles + tile) * (CONE_LEVELS * 64);
     uint16_t* o_gl = (uint16_t*)P.cone_gather + ((size_t)w * tiles + tile) * CONE_GCAP;
-    const int c0 = tile * P.cone_ct;
+    const int c0 = P.offset + tile * P.cone_ct;   // (a shard lists the cones of its OWN tiles over the population's pair list: smm_chain_persist_loc.hpp)
     auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
     for (int x = lane; x < metw / 4; x += 64) ((uint4*)met)[x] = make_uint4(0u, 0u, 0u, 0u);
     for (int x = lane; x < CONEB_CHASH; x += 64) chash[x] = 0u;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P
     bool bad = K > 65534;
     {
         int q = -1;
-        if (lane < P.cone_ct && c0 + lane < Ng) q = C.lastpair[c0 + lane];
+        if (lane < P.cone_ct && c0 + lane < P.offset + P.N) q = C.lastpair[c0 + lane];
         const bool fresh = q >= 0 && meet((uint32_t)q);
         const unsigned long long m = __ballot(fresh);
         if (fresh) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)q;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * CONEB_WAVES) void k_cone_tiles(const KParams P
     // ---- the tile's own chains are 0 .. cone_ct - 1 ----
     auto cslot = [&](const uint32_t chain) { return (chain * 2654435761u) >> 23; };   // 9 bits
     static_assert(CONEB_CHASH == 512 && CONEB_PAIRS + 16 < CONEB_CHASH, "cslot: 9 bits");
-    if (lane < P.cone_ct) {
+    if (lane < P.cone_ct && c0 + lane < P.offset + P.N) {   // (a shard's ragged last tile: the chains behind it are somebody else's)
         const uint32_t chain = (uint32_t)(c0 + lane);
         uint32_t h = cslot(chain);
         while (atomicCAS(&chash[h], 0u, ((chain + 1u) << 16) | (uint32_t)lane) != 0u) h = (h + 1u) & (CONEB_CHASH - 1);

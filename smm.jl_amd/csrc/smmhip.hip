@@ -58,6 +58,7 @@ using namespace smm;
 #include "smm_chain_norm.hpp"
 #include "smm_chain_persist.hpp"
 #include "smm_chain_persist_gen.hpp"
+#include "smm_chain_persist_loc.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
 #include "smm_cone_big.hpp"
@@ -256,6 +257,11 @@ struct Ctx {
     // the persistent chain kernel (smm_chain_persist.hpp): one launch for a run of iterations
     bool persist = false;                      // this context can run it (objfunc_norm np <= 2, single shard of at most one tile per CU, key walk)
     bool persist_gen = false;                  // ... its form for objectives without a simulation (smm_chain_persist_gen.hpp: banana, 4096 < N <= 8192)
+    bool persist_loc = false;                  // ... on locally numbered cones (smm_chain_persist_loc.hpp): thresholds (min_improve > 0), shards
+    bool persist_wide = false;                 // ... its 16-byte slots: one min_improve > 0 (or NaN) for all chains
+    unsigned char* prw = nullptr;              // persist_loc, single shard: the ring's window (pr_win_layout)
+    bool persist_proven = false;               // a launch of the persistent form has come through: its spins may last P2P_TIMEOUT_TICKS from now on
+    int persist_strikes = 0;                   // time-outs so far (two: the form is off for the context)
     int persist_on = 1;                        // smm_set_persistent
     bool persist_broken = false;               // a launch gave up waiting (tiles not resident together?): the form is off for this context
     uint32_t pr_epoch = 0;                     // launches so far
@@ -271,7 +277,6 @@ struct Ctx {
     double *snap_cs = nullptr, *snap_rec = nullptr, *snap_vals[2] = {nullptr, nullptr}, *hist_fill = nullptr;
     uint2* snap_slot8[2] = {nullptr, nullptr};
     unsigned long long* snap_xres = nullptr;
-    uint32_t snap_walk_flags[4] = {0, 0, 0, 0};
 };
 
 #define HIPCHK(call)                                                                                  \
@@ -730,11 +735,16 @@ int check_device_error(Ctx* c) {
     if (e != ERR_NONE && c->snap_valid && !c->in_repair) {
         // launches of the persistent kernel ran since the last check: their tiles do not stop at the failing iteration.  Back to the
         // state before the first of them, and the same iterations again on the one-launch-per-iteration path, which does.
-        if ((e & 3) == 3) c->persist_broken = true;   // (a tile gave up waiting, or a cone did not fit: not this form again)
+        // (a tile gave up waiting, or a cone did not fit.  Once may be somebody else's doing — another context or process held compute
+        // units while the tiles wanted to be resident together —: the form is tried again; the second time it is off for the context)
+        if ((e & 3) == 3 && ++c->persist_strikes >= 2) c->persist_broken = true;
         persist_repair(c);
         HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
     }
-    if (!c->in_repair) c->snap_valid = false;
+    if (!c->in_repair) {
+        if (e == ERR_NONE && c->snap_valid) c->persist_proven = true;   // launches of the persistent form came through: its tiles ARE resident together
+        c->snap_valid = false;
+    }
     if (e == ERR_NONE) return SMM_OK;
     const int kind = (int)(e & 3), chain = (int)((e >> 2) & 0xffffffffu), it = (int)(e >> 34);
     char b[256];
@@ -936,13 +946,48 @@ int launch_chain_persist(Ctx* c, int n_left) {
     if (!c->snap_valid) persist_snapshot(c);
     ++c->pr_epoch;
     if ((c->pr_epoch & 0x7fu) == 0u) {   // the slot tags' epoch bits start over: nothing older may look current
-        HIPCHK(hipMemsetAsync(c->P.pr_slot, 0, persist_ring_slot_bytes(c->P.Ng), c->stream));
-        HIPCHK(hipMemsetAsync(c->P.pr_rec, 0, persist_ring_rec_bytes(c->P.Ng, c->P.RW), c->stream));
+        if (c->persist_loc) {
+            const PrWin WL = pr_win_layout(c->P.Ng, c->P.RW, 1, (c->P.N + NORM_CT - 1) / NORM_CT);
+            HIPCHK(hipMemsetAsync(c->prw + WL.slot, 0, WL.total - WL.slot, c->stream));
+        } else {
+            HIPCHK(hipMemsetAsync(c->P.pr_slot, 0, persist_ring_slot_bytes(c->P.Ng), c->stream));
+            HIPCHK(hipMemsetAsync(c->P.pr_rec, 0, persist_ring_rec_bytes(c->P.Ng, c->P.RW), c->stream));
+        }
     }
     KParams& P = c->P;
     P.pr_epoch = c->pr_epoch;
     point_values(c, P, t0 - 1, t1);   // (nothing is read from the value arrays: the last iteration writes them)
-    if (c->persist_gen) {
+    // (a spin of the form may last 4 s — a peer is gone, not late — once a launch of this context has come through; until then a
+    // tenth of that: tiles that are not resident together, a masked or partitioned device, must not look like a hang)
+    const unsigned long long tmo = c->persist_proven ? P2P_TIMEOUT_TICKS : PERSIST_TMO_FIRST;
+    if (c->persist_loc) {
+        PersistLocArgs A{};
+        const PrWin WL = pr_win_layout(P.Ng, P.RW, 1, (P.N + NORM_CT - 1) / NORM_CT);
+        A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
+        for (int r = 0; r < P2P_MAXG; ++r) A.win[r] = nullptr;
+        A.win[0] = c->prw; A.self = c->prw;
+        A.o_ctl = WL.ctl; A.o_arrive = WL.arrive; A.o_progress = WL.progress; A.o_slot = WL.slot; A.o_rec = WL.rec;
+        A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
+        A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
+        A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp;
+        A.rb = pregen ? P.rb : nullptr;
+        A.N = P.N; A.Ng = P.Ng; A.offset = P.offset; A.G = 1; A.rank = 0; A.ns = P.ns; A.zstride = P.zstride; A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from;
+        A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
+        A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
+        A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
+        A.walk_first = c->unresolved ? 1 : 0;
+        A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
+        A.tables_local = 0; A.unit_sh = P.lean_unit == 16 ? 4 : (P.lean_unit == 8 ? 3 : 2);
+        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo;
+        const dim3 grid((A.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
+        const size_t smem = persist_loc_smem_bytes(P.np);
+        auto go = [&](auto kern) {
+            if (c->kev0) hipExtLaunchKernelGGL(kern, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
+            else hipLaunchKernelGGL(kern, grid, block, smem, c->stream, A);
+        };
+        if (P.np == 1) { if (c->persist_wide) go(k_chain_persist_loc<1, true, false>); else go(k_chain_persist_loc<1, false, false>); }
+        else { if (c->persist_wide) go(k_chain_persist_loc<2, true, false>); else go(k_chain_persist_loc<2, false, false>); }
+    } else if (c->persist_gen) {
         PersistGenArgs A{};
         A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
         A.pr_slot = P.pr_slot; A.pr_rec = P.pr_rec; A.pr_progress = P.pr_progress; A.pr_ctl = P.pr_ctl;
@@ -955,7 +1000,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
         A.walk_first = c->unresolved ? 1 : 0;
         A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
-        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed;
+        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed; A.tmo = tmo;
         const dim3 grid(P.N / PG_CT), block(1024);
         const size_t smem = persist_gen_smem_bytes(P.Ng, P.np, P.RW, P.HW);
         if (c->kev0) hipExtLaunchKernelGGL(k_chain_persist_gen, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
@@ -974,7 +1019,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
         A.walk_first = c->unresolved ? 1 : 0;
         A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
-        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed;
+        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed; A.tmo = tmo;
         if (P.np == 1) launch_chain_persist_t<1>(c, A); else launch_chain_persist_t<2>(c, A);
     }
     c->cur ^= 1;
@@ -1312,7 +1357,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.dist_fun = opts->dist_fun;
         P.mi_uniform = 1; P.mi_value = opts->min_improve[0];
         for (int i = 1; i < Ng; ++i)
-            if (!(opts->min_improve[i] == P.mi_value)) P.mi_uniform = 0;
+            if (!(opts->min_improve[i] == P.mi_value || (opts->min_improve[i] != opts->min_improve[i] && P.mi_value != P.mi_value))) P.mi_uniform = 0;   // (NaN everywhere is one threshold too: nothing ever swaps)
         const size_t TN = (size_t)T * N;
         if (tab && tab->probs_acc) P.user_utab = dupload(c, tab->probs_acc, TN);
         if (tab && tab->prop_normals && tab->prop_tries > 0) {
@@ -1438,6 +1483,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* pe = SMM_HOOK("SMMHIP_PERSIST");   // test hook: "0" never
             int n_cus = 256;
             (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+            const char* ploc = SMM_HOOK("SMMHIP_PERSIST_LOC");   // test hook: "1" the locally numbered form wherever it applies, "0" never
             const bool want_persist = c->norm_fast && np <= 2 && ns <= WG * PR_ZR && N == Ng && Ng >= 2 && c->inline_walk && P.mi_uniform && P.mi_value == 0.0 &&
                                       opts->dist_fun == SMM_DIST_MINUS && K <= XLVL_MAX && Ng <= XLVL_MAX && !c->deep_plan && (N + NORM_CT - 1) / NORM_CT <= n_cus &&
                                       persist_smem_bytes(Ng, np) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
@@ -1446,6 +1492,13 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const bool want_persist_gen = want_cone && !c->dense_keys && c->obj == SMM_OBJ_BANANA && np <= PG_MAXP && nm <= PG_MAXP && opts->batch_size == np && !opts->chol_L &&
                                           N == Ng && N / PG_CT <= n_cus && !c->deep_plan && P.dbg == 0 &&
                                           persist_gen_smem_bytes(Ng, np, P.RW, P.HW) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
+            // ... and on LOCALLY NUMBERED cones (smm_chain_persist_loc.hpp): the same objective with one threshold >= 0 (or NaN: nothing
+            // ever swaps) for all chains — min_improve > 0 is the reference's default (AlgoBGP.jl:522) —, whatever the population's size
+            // does to the tile's LDS
+            const bool want_persist_loc = c->norm_fast && np <= 2 && ns <= WG * PR_ZR && N == Ng && Ng >= 2 && c->inline_walk && P.mi_uniform && !(P.mi_value < 0.0) &&
+                                          opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan && (N + NORM_CT - 1) / NORM_CT <= n_cus &&
+                                          P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0') &&
+                                          ((ploc && ploc[0] == '1') || !(want_persist && lean_walk_unit(Ng) == 8));
             const size_t persist_tiles = want_persist_gen ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             // large single shards of objfunc_norm (C3 on one GPU): the narrow chain kernel's tiles walk their own, locally numbered cones
             // (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two launches
@@ -1456,7 +1509,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (size_t)Ng * 4 <= (size_t)160 * 1024;
             const size_t plan_iter = (want_cone_big ? (size_t)(N / NORM_CT) * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + cone_big_scratch_words(Ng, K) * 4 : 0) + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
                                      (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / cone_ct) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
-                                     (want_persist ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
+                                     ((want_persist || want_persist_loc) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
                                      (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
             c->win_cap = std::min(c->win_cap, T);
@@ -1563,7 +1616,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                 if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                             }
                         }
-                        if (want_persist && lean_walk_unit(Ng) == 8 && c->norm_fast) {
+                        if (want_persist && lean_walk_unit(Ng) == 8 && c->norm_fast && !(ploc && ploc[0] == '1')) {
                             const size_t tiles = persist_tiles;
                             P.cone_tiles = (int)tiles; P.cone_ct = NORM_CT;
                             P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
@@ -1584,6 +1637,22 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                             if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
                             if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                         }
+                    }
+                    if (want_persist_loc && !c->persist && c->norm_fast) {   // (the lean plan stands: k_exch_plan lists the tiles' cones behind it)
+                        const size_t tiles = persist_tiles;
+                        P.cone_tiles = (int)tiles; P.cone_ct = NORM_CT;
+                        P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
+                        P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
+                        P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);   // (+: whole 1 KB pieces are fetched)
+                        P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP + 512);
+                        HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
+                        const PrWin WL = pr_win_layout(Ng, P.RW, 1, (int)tiles);
+                        c->prw = dalloc<unsigned char>(c, WL.total);
+                        HIPCHK(hipMemset(c->prw, 0, WL.total));
+                        c->persist = true; c->persist_loc = true; c->persist_wide = wide;
+                        if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
+                        if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
+                        if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                     }
                 }
             }
@@ -1640,6 +1709,15 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_persist_gen, 1024, smem));
             HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             if (N / PG_CT > per_cu * cus) { c->persist = false; c->persist_gen = false; }
+        } else if (c->persist_loc) {
+            const size_t smem = persist_loc_smem_bytes(np);
+            const void* fn = np == 1 ? (c->persist_wide ? (const void*)k_chain_persist_loc<1, true, false> : (const void*)k_chain_persist_loc<1, false, false>)
+                                     : (c->persist_wide ? (const void*)k_chain_persist_loc<2, true, false> : (const void*)k_chain_persist_loc<2, false, false>);
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            int per_cu = 0, cus = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NORM_WG, smem));
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            if ((N + NORM_CT - 1) / NORM_CT > per_cu * cus) { c->persist = false; c->persist_loc = false; }
         } else if (c->persist) {
             // all tiles of the persistent kernel must be resident together (they wait for each other): one per CU
             const size_t smem = persist_smem_bytes(Ng, np);

@@ -112,7 +112,7 @@ def test_p2p_inline_nan_in_one_shard_is_reported_by_every_rank_in_the_same_itera
         c.p2p_step(3)
     errs = []
     for c in ctxs:
-        with pytest.raises(S.SMMError) as ei:
+        with pytest.raises(A.SMMHipError) as ei:
             c.sync()
         errs.append(str(ei.value))
     assert time.perf_counter() - t0 < 3.0, "a rank sat in its time-out"

@@ -1,0 +1,134 @@
+"""The persistent form on LOCALLY NUMBERED cones (smm.jl_amd/csrc/smm_chain_persist_loc.hpp): what the round-4 persistent kernel could not
+serve — one min_improve > 0 for all chains (the reference's DEFAULT is 0.5, AlgoBGP.jl:522; its own test uses 0.05,
+test/test_algoBGP.jl:123-193) — against the oracle and against the one-launch-per-iteration kernels; and, forced by the test seam
+SMMHIP_PERSIST_LOC=1, the same kernel on the threshold-free problems the round-4 kernel serves (every wave role, the re-numbering table,
+the launch's "iteration 0" publication are the same code in both forms).
+Replaces run!'s loop over computeNextIteration! (AlgoAbstract.jl:38-45, AlgoBGP.jl:589-640, exchangeMoves! :647-716)."""
+import numpy as np
+import pytest
+
+import common as cm
+from smm_jl_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(S, O, prob, opts, tab=None):
+    h = S.hip_context(prob, opts, tab)
+    t = tab if tab is not None else S.Tables()
+    o = O.OracleContext(prob, opts, S.Tables(probs_acc=t.probs_acc, prop_normals=t.prop_normals, pairs=t.pairs, Z=h.Z()))
+    return h, o
+
+
+def _same(ha, hb, sa, sb):
+    cm.assert_history_equal(ha, hb, exact_floats=True)
+    cm.assert_state_equal(sa, sb, rtol=0)
+
+
+@pytest.mark.parametrize("N,ns,mi,steps", [(17, 200, 0.05, [40]), (64, 1000, 0.5, [1, 5, 2, 20, 12]), (333, 10000, 0.05, [25, 25]), (2, 100, 0.01, [30]),
+                                          (16, 100, 0.05, [30]), (100, 64, 0.002, [300]), (1000, 300, 0.05, [30]), (64, 300, np.nan, [20]),
+                                          (64, 300, np.inf, [20]), (4096, 64, 0.05, [40])])
+def test_threshold_persistent_form_against_oracle_and_per_iteration_kernels(S, O, N, ns, mi, steps):
+    T = sum(steps)
+    prob, opts = cm.serial_normal(N=N, T=T, ns=ns, seed=7, min_improve=mi)
+    h, o = _pair(S, O, prob, opts)
+    c = S.hip_context(prob, opts)
+    c.set_persistent(False)
+    for n in steps:
+        h.step(n); o.step(n); c.step(n)
+    avail, launches, repairs = h.persistent_info()
+    assert launches >= 1 and repairs == 0, (launches, repairs)
+    assert c.persistent_info()[1] == 0
+    if N <= 1000:
+        cm.assert_history_equal(h.history(), o.history())
+        cm.assert_state_equal(h.state(), o.state())
+    _same(h.history(), c.history(), h.state(), c.state())
+    if mi == mi and mi < 1.0 and N > 2:
+        assert (h.history().exchanged != 0).any()
+    if mi != mi or mi == np.inf:
+        assert not (h.history().exchanged != 0).any()
+
+
+def test_reference_default_options_take_the_persistent_form(S, O):
+    # MAlgoBGP's defaults (AlgoBGP.jl:505-537): min_improve 0.5 and acc_tuner 2.0 for every chain, sigma 0.05, sigma_update_steps 10,
+    # dist_fun `-` — through the host mirror of the reference's constructor
+    m = S.MProb()
+    S.addSampledParam(m, "p1", 0.2, -3.0, 3.0)
+    S.addSampledParam(m, "p2", -0.2, -20.0, 20.0)
+    S.addMoment(m, "mu1", -1.0, 1.0)
+    S.addMoment(m, "mu2", 10.0, 1.0)
+    S.addEvalFunc(m, S.objfunc_norm)
+    algo = S.MAlgoBGP(m, {"N": 48, "maxiter": 60, "maxtemp": 5})
+    assert np.all(algo._bopts.min_improve == 0.5)
+    S.run(algo)
+    avail, launches, repairs = algo._ctx.persistent_info()
+    assert launches >= 1 and repairs == 0, (launches, repairs)
+    o = O.OracleContext(algo._prob, algo._bopts, S.Tables(Z=algo._ctx.Z()))
+    o.step(60)
+    cm.assert_history_equal(algo._ctx.history(), o.history())
+
+
+def test_threshold_persistent_form_c2_size_across_plan_windows(S, O):
+    # BASELINE configs[1]'s population (4096 chains, ns = 10000) with the threshold of the reference's own test, over 300 iterations
+    prob, opts = cm.serial_normal(N=4096, T=300, min_improve=0.05)
+    h, o = _pair(S, O, prob, opts)
+    h.step(300); o.step(300)
+    assert h.persistent_info()[1] >= 2 and h.persistent_info()[2] == 0
+    cm.assert_history_equal(h.history(), o.history())
+    cm.assert_state_equal(h.state(), o.state())
+    assert 0.02 < (h.history().exchanged != 0).mean() < 0.4
+
+
+@pytest.mark.parametrize("mi", [0.0, 0.05])
+def test_local_form_injected_tables_failbox_restart_and_hard_error(S, O, monkeypatch, hooks, mi):
+    # the locally numbered kernel on everything the round-4 suite asks of the persistent form: injected tables (tries past the first
+    # four), one parameter, a failing objective (status -2), read-backs between steps, a hard error replayed, the short ring under skew
+    monkeypatch.setenv("SMMHIP_PERSIST_LOC", "1")
+    for npar in (1, 2):
+        if npar == 2:
+            prob, opts = cm.serial_normal(N=80, T=50, ns=700, seed=3, sigma0=0.02, min_improve=mi)
+        else:
+            prob, opts = cm.general_normal(1, N=80, T=50, ns=700)
+            opts.min_improve[:] = mi
+        tab = cm.random_tables(prob, opts, tries=7)
+        h, o = _pair(S, O, prob, opts, tab)
+        h.step(50); o.step(50)
+        assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 0
+        cm.assert_history_equal(h.history(), o.history())
+        cm.assert_state_equal(h.state(), o.state())
+    # a failing objective and mixed stepping with read-backs
+    prob, opts = cm.serial_normal(N=200, T=64, ns=300, objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[0.4, 1.2], sigma0=0.3, min_improve=mi)
+    h, o = _pair(S, O, prob, opts)
+    for n in (7, 1, 20, 2, 34):
+        h.step(n); o.step(n)
+        cm.assert_history_equal(h.history(), o.history())
+    assert (h.history().status == -2).any()
+    assert h.persistent_info()[1] >= 3 and h.persistent_info()[2] == 0
+    cm.assert_state_equal(h.state(), o.state())
+    # the short ring under skew
+    monkeypatch.setenv("SMMHIP_PR_RING", "2")
+    monkeypatch.setenv("SMMHIP_PR_SLOW_TILE", "3")
+    monkeypatch.setenv("SMMHIP_PR_SLOW_US", "25")
+    prob, opts = cm.serial_normal(N=640, T=40, ns=300, min_improve=mi)
+    h, o = _pair(S, O, prob, opts)
+    h.step(40); o.step(40)
+    assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 0
+    cm.assert_history_equal(h.history(), o.history())
+
+
+def test_threshold_persistent_form_hard_error_is_replayed(S, O):
+    # smpl_iters exhausted inside a persistent launch (AlgoBGP.jl:409): the tiles run on, the host rolls back and replays on the
+    # per-iteration path, which stops at the failing iteration with the documented state
+    prob, opts = cm.serial_normal(N=64, T=60, ns=100, sigma0=40.0, smpl_iters=2, min_improve=0.05)
+    h = S.hip_context(prob, opts)
+    c = S.hip_context(prob, opts)
+    c.set_persistent(False)
+    errs = []
+    for ctx in (h, c):
+        with pytest.raises(A.SMMHipError) as ei:
+            ctx.step(60)
+        errs.append(str(ei.value))
+    assert errs[0] == errs[1], errs
+    assert "no draw in support" in errs[0]
+    assert h.persistent_info()[2] >= 1
+    _same(h.history(), c.history(), h.state(), c.state())

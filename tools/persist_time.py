@@ -16,10 +16,15 @@ import smm_jl_amd as S, common as cm
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 IT = 200
-lib = S._abi.load()
+if os.environ.get("SMM_TEST_BUILD") == "hooks":   # the test build: its seams (SMMHIP_PERSIST_LOC=1: the locally numbered kernel on this problem) are live
+    S._abi.use_test_hooks(True)
+    lib = S._abi.load_hooks()
+else:
+    lib = S._abi.load()
+MI = float(os.environ.get("PT_MIN_IMPROVE", "0"))
 hist = {}
 for on in (1, 0, 1):
-    prob, opts = cm.serial_normal(N=N, T=IT * (K + 1))
+    prob, opts = cm.serial_normal(N=N, T=IT * (K + 1), min_improve=MI)
     ctx = S.hip_context(prob, opts)
     ctx.set_persistent(on)
     ctx.step(IT)
