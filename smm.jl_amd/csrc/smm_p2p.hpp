@@ -255,3 +255,12 @@ __global__ __launch_bounds__(256) void k_p2p_unpack(const KParams P, const int t
         dst[i] = p2p_ll_double(q);
     }
 }
+
+// this rank's OWN records after iteration t out of their self-validating form in its window into a plain array [N][RW] (the hand-over
+// to the persistent form, smm_chain_persist_loc.hpp): they are the previous launch's own stores — complete, nothing to wait for
+__global__ __launch_bounds__(256) void k_p2p_own_records(const KParams P, const int t, double* __restrict__ dst) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= P.N * P.RW) return;
+    const uint4* src = (const uint4*)(P.p2p_self + p2p_llrec_off(P, t & 1) + (size_t)P.offset * P.RW * 16);
+    dst[i] = p2p_ll_double(p2p_load16_sys(src + i));
+}

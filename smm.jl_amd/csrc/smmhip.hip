@@ -259,7 +259,12 @@ struct Ctx {
     bool persist_gen = false;                  // ... its form for objectives without a simulation (smm_chain_persist_gen.hpp: banana, 4096 < N <= 8192)
     bool persist_loc = false;                  // ... on locally numbered cones (smm_chain_persist_loc.hpp): thresholds (min_improve > 0), shards
     bool persist_wide = false;                 // ... its 16-byte slots: one min_improve > 0 (or NaN) for all chains
-    unsigned char* prw = nullptr;              // persist_loc, single shard: the ring's window (pr_win_layout)
+    unsigned char* prw = nullptr;              // persist_loc: the ring's window (pr_win_layout) — a single shard's own allocation, a shard's: inside its p2p window
+    bool persist_sh = false;                   // ... as a SHARD of a sharded run: the ring lives in every rank's p2p window (smm_bgp_p2p_step)
+    bool persist_sh_big = false;               // ... of a population past 8192 chains: k_exch_plan_big + k_cone_chains + k_cone_tiles list its tiles' cones (locally numbered)
+    size_t prw_off = 0;                        // persist_sh: offset of the ring's window inside the p2p window
+    int p2p_ranks_here = 1;                    // ranks whose windows live on THIS device (this one included): their tiles must all be resident together
+    int persist_max_tiles = 0;                 // tiles of the persistent kernel this device holds at once (occupancy x compute units)
     bool persist_proven = false;               // a launch of the persistent form has come through: its spins may last P2P_TIMEOUT_TICKS from now on
     int persist_strikes = 0;                   // time-outs so far (two: the form is off for the context)
     int persist_on = 1;                        // smm_set_persistent
@@ -419,6 +424,8 @@ void ensure_windows(Ctx* c, int t, bool rng = true) {
             c->cone_big_ok.resize((size_t)W);
             HIPCHK(hipMemcpyAsync(c->cone_big_ok.data(), P.cone_ok, (size_t)W * 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
+        } else if (c->persist_sh_big) {   // (the persistent kernel looks at the window's flags itself: no synchronisation)
+            launch_cone_big(c, P, W, c->win_lv_pairs, c->win_lv_off, c->stream);
         }
         P.lv_rows = c->win_lv_rows; P.lv_rowinfo = c->win_lv_rowinfo;
         P.lv_pairs = c->win_lv_pairs; P.lv_mi = c->win_lv_mi; P.lv_off = c->win_lv_off;
@@ -716,6 +723,7 @@ void resolve_now(Ctx* c) {
 
 void flush(Ctx* c) {
     if (c->rec_external) throw std::string("records are in the gather buffer: call smm_bgp_sharded_finish first");
+    if (c->unresolved && c->P.N < c->P.Ng) throw std::string("the exchange of the last iteration needs every shard's records: call smm_bgp_p2p_finish first");
     if (!c->pending && !c->prev_open) return;
     resolve_now(c);
     const KParams& P = c->P;
@@ -728,6 +736,7 @@ void flush(Ctx* c) {
 }
 
 void persist_repair(Ctx* c);
+void p2p_enqueue(Ctx* c, int n_iters);
 int check_device_error(Ctx* c) {
     if (c->failed) return c->failed;   // err holds the message of the first failure
     unsigned long long e = ERR_NONE;
@@ -894,7 +903,13 @@ void launch_resolve_rows_window(Ctx* c, int t) {
         else hipLaunchKernelGGL((k_exch_resolve_rows<false, true>), dim3(1), dim3(XWG), smem, c->stream, P, t, (const double*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     }
 }
-// ---- the persistent chain kernel (smm_chain_persist.hpp) ----
+// ---- the persistent chain kernels (smm_chain_persist.hpp, smm_chain_persist_loc.hpp) ----
+const void* persist_loc_fn(int np, bool wide, bool sh) {
+    if (np == 1) return wide ? (sh ? (const void*)k_chain_persist_loc<1, true, true> : (const void*)k_chain_persist_loc<1, true, false>)
+                             : (sh ? (const void*)k_chain_persist_loc<1, false, true> : (const void*)k_chain_persist_loc<1, false, false>);
+    return wide ? (sh ? (const void*)k_chain_persist_loc<2, true, true> : (const void*)k_chain_persist_loc<2, true, false>)
+                : (sh ? (const void*)k_chain_persist_loc<2, false, true> : (const void*)k_chain_persist_loc<2, false, false>);
+}
 template <int NP>
 void launch_chain_persist_t(Ctx* c, const PersistArgs& A) {
     const dim3 grid((A.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
@@ -914,8 +929,18 @@ bool persist_usable(const Ctx* c, int n_left) {
         return false;
     if (c->iter < 1 || !c->prev_open || c->exch_done || (c->pending && !c->unresolved)) return false;
     const int t0 = c->iter + 1;
-    if (c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) return false;
+    // (the locally numbered form starts a new plan window at the pending exchange's iteration instead: launch_chain_persist)
+    if (!c->persist_loc && c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) return false;
     return true;
+}
+// ... as a shard (smm_bgp_p2p_step): from the p2p state — the records after iteration `iter` in the windows, its exchange not resolved
+// yet — or behind a launch of its own; the first iteration of a run, the iteration behind a settled state are the per-iteration forms'
+bool persist_sh_usable(const Ctx* c, int n_left) {
+    if (!(c->persist_sh && c->persist_on && !c->persist_broken && !c->in_repair && !c->nan_values && n_left >= 2 && c->p2p_mine)) return false;
+    if (c->p2p_ranks_here * ((c->P.N + NORM_CT - 1) / NORM_CT) > c->persist_max_tiles) return false;   // (ranks sharing this device: not resident together)
+    if (c->iter < 1 || !c->prev_open || c->exch_done || c->a2a_open) return false;
+    if (c->p2p_current) return c->rec_external && (c->pending_ext || !exchange_active(c, c->iter));
+    return !c->rec_external && (c->unresolved || !c->pending);
 }
 // the state a failed launch of the persistent kernel is rolled back to (device copies on the stream, before anything of the step runs)
 void persist_snapshot(Ctx* c) {
@@ -937,7 +962,12 @@ int launch_chain_persist(Ctx* c, int n_left) {
     const int t0 = c->iter + 1;
     // (k_chain_persist_norm and _gen draw in the kernel unless tables are injected)
     const bool pregen = c->persist_gen ? (c->P.user_ntab || c->P.user_utab) : !(c->norm_fast && !c->P.user_ntab && !c->P.user_utab);
-    if (!c->unresolved) ensure_windows(c, t0, pregen);   // (with an exchange pending the window holds its plan and this iteration's: persist_usable)
+    if (c->persist_loc && c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) {
+        // the pending exchange's plan is not in a window that also reaches past this iteration: a new window from ITS iteration on (one
+        // iteration planned twice per window; no per-iteration launch, no stand-alone resolution at the windows' ends)
+        c->plan_w = 0;
+        ensure_windows(c, t0 - 1, pregen);
+    } else if (!c->unresolved) ensure_windows(c, t0, pregen);   // (with an exchange pending the window holds its plan and this iteration's: persist_usable)
     if (pregen && !(t0 >= c->rng_t0 && t0 < c->rng_t0 + c->rng_w)) ensure_windows(c, t0);
     int t1 = std::min(c->iter + n_left, c->plan_t0 + c->plan_w - 1);
     if (pregen) t1 = std::min(t1, c->rng_t0 + c->rng_w - 1);
@@ -946,9 +976,10 @@ int launch_chain_persist(Ctx* c, int n_left) {
     if (!c->snap_valid) persist_snapshot(c);
     ++c->pr_epoch;
     if ((c->pr_epoch & 0x7fu) == 0u) {   // the slot tags' epoch bits start over: nothing older may look current
-        if (c->persist_loc) {
-            const PrWin WL = pr_win_layout(c->P.Ng, c->P.RW, 1, (c->P.N + NORM_CT - 1) / NORM_CT);
-            HIPCHK(hipMemsetAsync(c->prw + WL.slot, 0, WL.total - WL.slot, c->stream));
+        if (c->persist_loc) {   // (a shard zeroes its own window's ring: its peers store into it only behind the launch's start barrier)
+            const PrWin WL = pr_win_layout(c->P.Ng, c->P.RW, c->persist_sh ? c->P.p2p_G : 1, (c->P.N + NORM_CT - 1) / NORM_CT);
+            unsigned char* base = c->persist_sh ? c->p2p_mine + c->prw_off : c->prw;
+            HIPCHK(hipMemsetAsync(base + WL.slot, 0, WL.total - WL.slot, c->stream));
         } else {
             HIPCHK(hipMemsetAsync(c->P.pr_slot, 0, persist_ring_slot_bytes(c->P.Ng), c->stream));
             HIPCHK(hipMemsetAsync(c->P.pr_rec, 0, persist_ring_rec_bytes(c->P.Ng, c->P.RW), c->stream));
@@ -962,31 +993,43 @@ int launch_chain_persist(Ctx* c, int n_left) {
     const unsigned long long tmo = c->persist_proven ? P2P_TIMEOUT_TICKS : PERSIST_TMO_FIRST;
     if (c->persist_loc) {
         PersistLocArgs A{};
-        const PrWin WL = pr_win_layout(P.Ng, P.RW, 1, (P.N + NORM_CT - 1) / NORM_CT);
+        const int G = c->persist_sh ? P.p2p_G : 1;
+        const int tiles = (P.N + NORM_CT - 1) / NORM_CT;
+        const PrWin WL = pr_win_layout(P.Ng, P.RW, G, tiles);
         A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
         for (int r = 0; r < P2P_MAXG; ++r) A.win[r] = nullptr;
-        A.win[0] = c->prw; A.self = c->prw;
+        if (c->persist_sh) {
+            for (int r = 0; r < G; ++r) A.win[r] = P.p2p_win[r] + c->prw_off;
+            A.self = c->p2p_mine + c->prw_off;
+        } else { A.win[0] = c->prw; A.self = c->prw; }
         A.o_ctl = WL.ctl; A.o_arrive = WL.arrive; A.o_progress = WL.progress; A.o_slot = WL.slot; A.o_rec = WL.rec;
         A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
         A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
         A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp;
         A.rb = pregen ? P.rb : nullptr;
-        A.N = P.N; A.Ng = P.Ng; A.offset = P.offset; A.G = 1; A.rank = 0; A.ns = P.ns; A.zstride = P.zstride; A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from;
+        A.N = P.N; A.Ng = P.Ng; A.offset = P.offset; A.G = G; A.rank = c->persist_sh ? P.p2p_rank : 0; A.ns = P.ns; A.zstride = P.zstride; A.plan_t0 = P.plan_t0;
+        A.exch_from = c->exchange_from;
         A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
         A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
         A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
         A.walk_first = c->unresolved ? 1 : 0;
         A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
-        A.tables_local = 0; A.unit_sh = P.lean_unit == 16 ? 4 : (P.lean_unit == 8 ? 3 : 2);
+        A.tables_local = c->persist_sh_big ? 1 : 0; A.unit_sh = P.lean_unit == 16 ? 4 : (P.lean_unit == 8 ? 3 : 2);
         A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo;
-        const dim3 grid((A.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
+        const dim3 grid(tiles), block(NORM_WG);
         const size_t smem = persist_loc_smem_bytes(P.np);
         auto go = [&](auto kern) {
             if (c->kev0) hipExtLaunchKernelGGL(kern, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
             else hipLaunchKernelGGL(kern, grid, block, smem, c->stream, A);
         };
-        if (P.np == 1) { if (c->persist_wide) go(k_chain_persist_loc<1, true, false>); else go(k_chain_persist_loc<1, false, false>); }
-        else { if (c->persist_wide) go(k_chain_persist_loc<2, true, false>); else go(k_chain_persist_loc<2, false, false>); }
+        const bool wd = c->persist_wide, sh = c->persist_sh;
+        if (P.np == 1) {
+            if (wd) { if (sh) go(k_chain_persist_loc<1, true, true>); else go(k_chain_persist_loc<1, true, false>); }
+            else { if (sh) go(k_chain_persist_loc<1, false, true>); else go(k_chain_persist_loc<1, false, false>); }
+        } else {
+            if (wd) { if (sh) go(k_chain_persist_loc<2, true, true>); else go(k_chain_persist_loc<2, true, false>); }
+            else { if (sh) go(k_chain_persist_loc<2, false, true>); else go(k_chain_persist_loc<2, false, false>); }
+        }
     } else if (c->persist_gen) {
         PersistGenArgs A{};
         A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
@@ -1116,7 +1159,10 @@ void persist_repair(Ctx* c) {
     if (c->unresolved) ensure_windows(c, c->iter);
     const int prof = c->profiling;
     c->profiling = 0;
-    enqueue_iterations(c, n);
+    if (P.N < P.Ng) {   // a shard: the same iterations through the windows, one (or two) launches each — every rank does (smm_sync agrees on the error first)
+        c->rec_external = false; c->pending_ext = false; c->p2p_current = false; c->p2p_unwaited = false;
+        p2p_enqueue(c, n);
+    } else enqueue_iterations(c, n);
     c->profiling = prof;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1128,6 +1174,128 @@ void settle_persist(Ctx* c) {
     if (!c->snap_valid) return;
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)check_device_error(c);
+}
+
+// ---- a shard between its two states (smm_bgp_p2p_step) ----
+// "p2p": the records after iteration `iter` are in the ranks' windows (rec_external), the exchange of `iter` not resolved yet (pending_ext);
+// "plain": they are in the context's own array, as the persistent form reads and leaves them (unresolved: the exchange still pending).
+// plain -> p2p: a publication.  With the exchange of `iter` still pending it travels as it is — a shard cannot settle it alone.
+void p2p_publish(Ctx* c) {
+    if (c->p2p_current) return;
+    const bool carry = c->unresolved && c->P.N < c->P.Ng;
+    if (!carry) flush(c);
+    // the form is decided from what EVERY rank knows (population, objective, thresholds): a rank that looked at its own shard's
+    // values here (an uploaded state with a NaN) could choose differently from its peers, and each side would wait for words the
+    // other never sends.  A NaN in any shard reaches every window with the publication (in the slot words themselves, and the NaN word
+    // tagged with the epoch): the rows form resolves such an iteration on the exact values inside its launch, the inline form
+    // (N_global <= 8192) reports it — on every rank, in the same iteration (include/smmhip.h).
+    c->p2p_mode_inline = c->p2p_inline || c->p2p_rows;
+    c->P.p2p_epoch += 1;   // (a new generation of tags: words of an earlier publication are nobody's any more)
+    launch_p2p_push(c, c->iter, c->rec[c->cur], c->p2p_mode_inline);
+    c->p2p_current = true;
+    c->pending_ext = false;
+    if (carry) { c->pending_ext = true; c->rec_external = true; c->pending = false; c->unresolved = false; }
+}
+// p2p -> plain: this rank's own records after iteration `iter` out of its window into the context's array (its own stores: complete)
+void p2p_to_plain(Ctx* c) {
+    if (!c->p2p_current) return;
+    const KParams& P = c->P;
+    const P2PLayout L = p2p_layout(P.Ng, P.RW);
+    if (c->p2p_mode_inline)
+        hipLaunchKernelGGL(k_p2p_own_records, dim3((unsigned)((P.N * P.RW + 255) / 256)), dim3(256), 0, c->stream, P, c->iter, c->rec[c->cur]);
+    else
+        HIPCHK(hipMemcpyAsync(c->rec[c->cur], (const double*)(c->p2p_mine + L.rec[c->iter & 1]) + (size_t)P.offset * P.RW, (size_t)P.N * P.RW * 8,
+                              hipMemcpyDeviceToDevice, c->stream));
+    c->unresolved = c->pending_ext; c->pending = c->pending_ext;
+    c->pending_ext = false; c->rec_external = false; c->p2p_current = false; c->p2p_unwaited = false;
+}
+
+// n iterations of a shard onto the stream (smm_bgp_p2p_step; persist_repair with the persistent form off)
+void p2p_enqueue(Ctx* c, int n_iters) {
+    KParams& P = c->P;
+    const P2PLayout L = p2p_layout(P.Ng, P.RW);
+    int slot = 0;   // profiling: events of this launch
+    for (int it = 0; it < n_iters; ++it) {
+        if (persist_sh_usable(c, n_iters - it)) {   // as many of the remaining iterations as the look-ahead windows hold, in ONE launch
+            p2p_to_plain(c);
+            if (c->profiling == 2) { c->kev0 = c->pev[4 * slot]; c->kev1 = c->pev[4 * slot + 1]; }
+            const int n = launch_chain_persist(c, n_iters - it);
+            c->kev0 = c->kev1 = nullptr;
+            if (n > 0) {
+                const int t1 = c->iter + n;
+                c->prev_open = true; c->pending = false; c->unresolved = false;
+                if (exchange_active(c, t1)) { c->unresolved = true; c->pending = true; }
+                c->iter = t1; c->exch_done = false;
+                it += n - 1; ++slot;
+                continue;
+            }
+        }
+        p2p_publish(c);
+        const int t = c->iter + 1;
+        const bool prof = c->profiling == 2;
+        int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
+        if (c->p2p_mode_inline) {
+            if (c->pending_ext) {
+                flags |= F_HAS_PENDING;
+                // the walk of iteration t-1 needs that iteration's plan: where the plan window is about to move on, the
+                // exchange is resolved by the stand-alone kernel first (once per window of 256 iterations)
+                if (c->p2p_rows) {
+                    if (prof) { c->kev0 = c->pev[4 * slot + 2]; c->kev1 = c->pev[4 * slot + 3]; c->pev_exch[slot] = 1; }
+                    launch_resolve_rows_window(c, t - 1);
+                    c->kev0 = c->kev1 = nullptr;
+#ifdef SMM_TEST_HOOKS
+                    if (SMM_HOOK("SMMHIP_ROWS_WIN_CHECK")) {   // the same exchange through the unpacked values and the plain kernels
+                        std::vector<unsigned long long> a((size_t)P.Ng), b((size_t)P.Ng);
+                        HIPCHK(hipStreamSynchronize(c->stream));
+                        HIPCHK(hipMemcpy(a.data(), P.xres, a.size() * 8, hipMemcpyDeviceToHost));
+                        launch_p2p_unpack(c, t - 1);
+                        launch_resolve_window(c, t - 1);
+                        HIPCHK(hipStreamSynchronize(c->stream));
+                        HIPCHK(hipMemcpy(b.data(), P.xres, b.size() * 8, hipMemcpyDeviceToHost));
+                        int bad = 0;
+                        for (int g = 0; g < P.Ng; ++g)
+                            if (a[g] != b[g] && bad++ < 8) fprintf(stderr, "rows window check: iteration %d chain %d: %llx != %llx\n", t - 1, g, a[g], b[g]);
+                        fprintf(stderr, "rows window check: iteration %d: %d of %d differ\n", t - 1, bad, P.Ng);
+                    }
+#endif
+                } else if (t >= c->plan_t0 && t < c->plan_t0 + c->plan_w) flags |= F_WALK_INLINE;
+                else {
+                    launch_p2p_unpack(c, t - 1);
+                    launch_resolve_window(c, t - 1);
+                }
+            }
+            ensure_windows(c, t);
+            if (prof) { c->kev0 = c->pev[4 * slot]; c->kev1 = c->pev[4 * slot + 1]; }
+            launch_chain_iter_norm_p2p(c, t, flags);
+            c->kev0 = c->kev1 = nullptr;
+        } else {
+            if (c->pending_ext) {   // exchangeMoves! of iteration t-1 (before its plan window can move on)
+                if (c->p2p_unwaited) launch_p2p_wait(c);
+                if (prof && c->lean_resolve) { c->kev0 = c->pev[4 * slot + 2]; c->kev1 = c->pev[4 * slot + 3]; c->pev_exch[slot] = 1; }
+                launch_resolve_window(c, t - 1);
+                c->kev0 = c->kev1 = nullptr;
+                flags |= F_HAS_PENDING;
+            }
+            ensure_windows(c, t);
+            c->ext_rec_in = (const double*)(c->p2p_mine + L.rec[(t - 1) & 1]);
+            c->ext_rec_out = (double*)(c->p2p_mine + L.rec[t & 1]) + (size_t)P.offset * P.RW;
+            c->ext_vals_out = (double*)(c->p2p_mine + L.val[t & 1]) + P.offset;
+            if (prof) { c->kev0 = c->pev[4 * slot]; c->kev1 = c->pev[4 * slot + 1]; }
+            launch_chain_iter(c, t, flags);
+            c->kev0 = c->kev1 = nullptr;
+            c->ext_rec_in = nullptr; c->ext_rec_out = nullptr; c->ext_vals_out = nullptr;
+            launch_p2p_push(c, t, nullptr, false);
+        }
+        c->prev_open = true;
+        c->pending = false;
+        c->rec_external = true;
+        c->pending_ext = exchange_active(c, t);
+        c->iter = t; c->exch_done = false;
+        ++slot;
+    }
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipGetLastError());
+    if (c->profiling == 2) c->pev_iters = slot;
 }
 
 }  // namespace
@@ -1499,6 +1667,11 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                           opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan && (N + NORM_CT - 1) / NORM_CT <= n_cus &&
                                           P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0') &&
                                           ((ploc && ploc[0] == '1') || !(want_persist && lean_walk_unit(Ng) == 8));
+            // ... and as a shard of a sharded run (one process per GPU: smm_bgp_p2p_step): the same kernel, the ring in the ranks' windows
+            const bool want_persist_sh = N < Ng && N > 0 && Ng % N == 0 && opts->chain_offset % N == 0 && Ng / N <= P2P_MAXG && N % NORM_CT == 0 && c->norm_fast && np <= 2 &&
+                                         ns <= WG * PR_ZR && P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && !c->deep_plan && N / NORM_CT <= n_cus &&
+                                         P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0') &&
+                                         (c->lds_exchange ? K <= XLDS_MAX : (c->big_exchange && Ng <= 32768 && K <= 65535 && (size_t)Ng * 4 <= (size_t)160 * 1024));
             const size_t persist_tiles = want_persist_gen ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             // large single shards of objfunc_norm (C3 on one GPU): the narrow chain kernel's tiles walk their own, locally numbered cones
             // (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two launches
@@ -1509,7 +1682,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (size_t)Ng * 4 <= (size_t)160 * 1024;
             const size_t plan_iter = (want_cone_big ? (size_t)(N / NORM_CT) * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + cone_big_scratch_words(Ng, K) * 4 : 0) + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
                                      (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / cone_ct) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
-                                     ((want_persist || want_persist_loc) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
+                                     ((want_persist || want_persist_loc || want_persist_sh) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
+                                     ((want_persist_sh && c->big_exchange) ? cone_big_scratch_words(Ng, K) * 4 : 0) +
                                      (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
             c->win_cap = std::min(c->win_cap, T);
@@ -1568,6 +1742,20 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                         HIPCHK(hipMemset(P.walk_flags, 0, 16));
                     }
                 }
+            }
+            if (c->big_exchange && want_persist_sh) {   // a shard of a large population: its own tiles' cones, locally numbered (smm_cone_big.hpp)
+                const size_t tiles = persist_tiles;
+                P.cone_tiles = (int)tiles; P.cone_ct = NORM_CT;
+                P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
+                P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
+                P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);
+                P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP + 512);
+                HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
+                c->cb_scratch = dalloc<uint32_t>(c, (size_t)c->plan_cap * cone_big_scratch_words(Ng, K));
+                c->persist = true; c->persist_loc = true; c->persist_wide = P.mi_value != 0.0; c->persist_sh = true; c->persist_sh_big = true;
+                if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
+                if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
+                if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
             }
             if (c->lds_exchange) {
                 c->win_plan = dalloc<unsigned long long>(c, (size_t)c->plan_cap * K);
@@ -1638,7 +1826,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                             if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                         }
                     }
-                    if (want_persist_loc && !c->persist && c->norm_fast) {   // (the lean plan stands: k_exch_plan lists the tiles' cones behind it)
+                    if ((want_persist_loc || want_persist_sh) && !c->persist && c->norm_fast) {   // (the lean plan stands: k_exch_plan lists the tiles' cones behind it)
                         const size_t tiles = persist_tiles;
                         P.cone_tiles = (int)tiles; P.cone_ct = NORM_CT;
                         P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
@@ -1646,10 +1834,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                         P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);   // (+: whole 1 KB pieces are fetched)
                         P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP + 512);
                         HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
-                        const PrWin WL = pr_win_layout(Ng, P.RW, 1, (int)tiles);
-                        c->prw = dalloc<unsigned char>(c, WL.total);
-                        HIPCHK(hipMemset(c->prw, 0, WL.total));
-                        c->persist = true; c->persist_loc = true; c->persist_wide = wide;
+                        if (!want_persist_sh) {   // (a shard's ring lives in its p2p window: smm_bgp_p2p_init)
+                            const PrWin WL = pr_win_layout(Ng, P.RW, 1, (int)tiles);
+                            c->prw = dalloc<unsigned char>(c, WL.total);
+                            HIPCHK(hipMemset(c->prw, 0, WL.total));
+                        }
+                        c->persist = true; c->persist_loc = true; c->persist_wide = wide; c->persist_sh = want_persist_sh;
                         if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
                         if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
                         if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
@@ -1711,13 +1901,13 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             if (N / PG_CT > per_cu * cus) { c->persist = false; c->persist_gen = false; }
         } else if (c->persist_loc) {
             const size_t smem = persist_loc_smem_bytes(np);
-            const void* fn = np == 1 ? (c->persist_wide ? (const void*)k_chain_persist_loc<1, true, false> : (const void*)k_chain_persist_loc<1, false, false>)
-                                     : (c->persist_wide ? (const void*)k_chain_persist_loc<2, true, false> : (const void*)k_chain_persist_loc<2, false, false>);
+            const void* fn = persist_loc_fn(np, c->persist_wide, c->persist_sh);
             HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             int per_cu = 0, cus = 0;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NORM_WG, smem));
             HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-            if ((N + NORM_CT - 1) / NORM_CT > per_cu * cus) { c->persist = false; c->persist_loc = false; }
+            c->persist_max_tiles = per_cu * cus;
+            if ((N + NORM_CT - 1) / NORM_CT > per_cu * cus) { c->persist = false; c->persist_loc = false; c->persist_sh = false; }
         } else if (c->persist) {
             // all tiles of the persistent kernel must be resident together (they wait for each other): one per CU
             const size_t smem = persist_smem_bytes(Ng, np);
@@ -2059,10 +2249,16 @@ int smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out) {
             // lines that an earlier allocation at the same address had left behind; the cache maintenance at kernel boundaries, which
             // plain memory gets, does not seem to cover it.  Within a launch nothing relies on the caches: stores into a window are
             // system-scope stores, self-validating words are re-read past the caches until their tag is the wanted one.)
+            // (a shard that can run the persistent form keeps its ring behind the p2p window proper: one allocation, one IPC handle)
+            size_t total = L.total;
+            if (c->persist_sh) {
+                c->prw_off = (L.total + 255) & ~(size_t)255;
+                total = c->prw_off + pr_win_layout(P.Ng, P.RW, c->a2a_G, (P.N + NORM_CT - 1) / NORM_CT).total;
+            }
             void* w = nullptr;
-            HIPCHK(hipMalloc(&w, L.total));
+            HIPCHK(hipMalloc(&w, total));
             c->p2p_mine = (unsigned char*)w;
-            HIPCHK(hipMemset(w, 0, L.total));
+            HIPCHK(hipMemset(w, 0, total));
             HIPCHK(hipDeviceSynchronize());
             P.p2p_G = c->a2a_G;
             P.p2p_rank = P.offset / P.N;
@@ -2114,9 +2310,15 @@ int smm_bgp_p2p_attach(void* ctx, int32_t rank, const void* ipc_handle, void* wi
             memcpy(&h, ipc_handle, sizeof h);
             HIPCHK(hipIpcOpenMemHandle(&w, h, hipIpcMemLazyEnablePeerAccess));
             c->p2p_opened[rank] = w;
+            // (a peer PROCESS on this very device — several ranks on one GPU, the tests' way: its tiles compete with this rank's for
+            // the compute units, and the persistent form needs all of them resident at once)
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, w) == hipSuccess && at.device == c->device) c->p2p_ranks_here += 1;
+            (void)hipGetLastError();
         } else {   // a context of this process: on another device the two must see each other
             hipPointerAttribute_t at;
             HIPCHK(hipPointerGetAttributes(&at, w));
+            if (at.device == c->device) c->p2p_ranks_here += 1;
             if (at.device != c->device) {
                 const hipError_t e = hipDeviceEnablePeerAccess(at.device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e);
@@ -2145,7 +2347,6 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
         settle_persist(c);
         if (c->failed) return c->failed;
         KParams& P = c->P;
-        const P2PLayout L = p2p_layout(P.Ng, P.RW);
         if (c->profiling == 2) {
             while ((int)c->pev.size() < 4 * n_iters) {
                 hipEvent_t e;
@@ -2156,84 +2357,7 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
         }
         c->pev_iters = 0;
         HIPCHK(hipEventRecord(c->ev0, c->stream));
-        if (!c->p2p_current) {   // first publication: the state after iteration `iter`, its exchange settled, into every window
-            flush(c);
-            // the form is decided from what EVERY rank knows (population, objective, thresholds): a rank that looked at its own shard's
-            // values here (an uploaded state with a NaN) could choose differently from its peers, and each side would wait for words the
-            // other never sends.  A NaN in any shard reaches every window with the publication (the NaN word, tagged with the epoch): the
-            // rows form resolves such an iteration on the exact values inside its launch, the inline form (N_global <= 8192) reports it —
-            // on every rank, in the same iteration (include/smmhip.h).
-            c->p2p_mode_inline = c->p2p_inline || c->p2p_rows;
-            c->P.p2p_epoch += 1;   // (a new generation of tags: words of an earlier publication are nobody's any more)
-            launch_p2p_push(c, c->iter, c->rec[c->cur], c->p2p_mode_inline);
-            c->p2p_current = true;
-            c->pending_ext = false;
-        }
-        for (int it = 0; it < n_iters; ++it) {
-            const int t = c->iter + 1;
-            const bool prof = c->profiling == 2;
-            int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
-            if (c->p2p_mode_inline) {
-                if (c->pending_ext) {
-                    flags |= F_HAS_PENDING;
-                    // the walk of iteration t-1 needs that iteration's plan: where the plan window is about to move on, the
-                    // exchange is resolved by the stand-alone kernel first (once per window of 256 iterations)
-                    if (c->p2p_rows) {
-                        if (prof) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
-                        launch_resolve_rows_window(c, t - 1);
-                        c->kev0 = c->kev1 = nullptr;
-#ifdef SMM_TEST_HOOKS
-                        if (SMM_HOOK("SMMHIP_ROWS_WIN_CHECK")) {   // the same exchange through the unpacked values and the plain kernels
-                            std::vector<unsigned long long> a((size_t)P.Ng), b((size_t)P.Ng);
-                            HIPCHK(hipStreamSynchronize(c->stream));
-                            HIPCHK(hipMemcpy(a.data(), P.xres, a.size() * 8, hipMemcpyDeviceToHost));
-                            launch_p2p_unpack(c, t - 1);
-                            launch_resolve_window(c, t - 1);
-                            HIPCHK(hipStreamSynchronize(c->stream));
-                            HIPCHK(hipMemcpy(b.data(), P.xres, b.size() * 8, hipMemcpyDeviceToHost));
-                            int bad = 0;
-                            for (int g = 0; g < P.Ng; ++g)
-                                if (a[g] != b[g] && bad++ < 8) fprintf(stderr, "rows window check: iteration %d chain %d: %llx != %llx\n", t - 1, g, a[g], b[g]);
-                            fprintf(stderr, "rows window check: iteration %d: %d of %d differ\n", t - 1, bad, P.Ng);
-                        }
-#endif
-                    } else if (t >= c->plan_t0 && t < c->plan_t0 + c->plan_w) flags |= F_WALK_INLINE;
-                    else {
-                        launch_p2p_unpack(c, t - 1);
-                        launch_resolve_window(c, t - 1);
-                    }
-                }
-                ensure_windows(c, t);
-                if (prof) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
-                launch_chain_iter_norm_p2p(c, t, flags);
-                c->kev0 = c->kev1 = nullptr;
-            } else {
-                if (c->pending_ext) {   // exchangeMoves! of iteration t-1 (before its plan window can move on)
-                    if (c->p2p_unwaited) launch_p2p_wait(c);
-                    if (prof && c->lean_resolve) { c->kev0 = c->pev[4 * it + 2]; c->kev1 = c->pev[4 * it + 3]; c->pev_exch[it] = 1; }
-                    launch_resolve_window(c, t - 1);
-                    c->kev0 = c->kev1 = nullptr;
-                    flags |= F_HAS_PENDING;
-                }
-                ensure_windows(c, t);
-                c->ext_rec_in = (const double*)(c->p2p_mine + L.rec[(t - 1) & 1]);
-                c->ext_rec_out = (double*)(c->p2p_mine + L.rec[t & 1]) + (size_t)P.offset * P.RW;
-                c->ext_vals_out = (double*)(c->p2p_mine + L.val[t & 1]) + P.offset;
-                if (prof) { c->kev0 = c->pev[4 * it]; c->kev1 = c->pev[4 * it + 1]; }
-                launch_chain_iter(c, t, flags);
-                c->kev0 = c->kev1 = nullptr;
-                c->ext_rec_in = nullptr; c->ext_rec_out = nullptr; c->ext_vals_out = nullptr;
-                launch_p2p_push(c, t, nullptr, false);
-            }
-            c->prev_open = true;
-            c->pending = false;
-            c->rec_external = true;
-            c->pending_ext = exchange_active(c, t);
-            c->iter = t; c->exch_done = false;
-        }
-        HIPCHK(hipEventRecord(c->ev1, c->stream));
-        HIPCHK(hipGetLastError());
-        if (c->profiling == 2) c->pev_iters = n_iters;
+        p2p_enqueue(c, n_iters);
         c->pending_timing = true;
         c->timing.iters = n_iters;
         c->timing.chain_evals = (int64_t)n_iters * P.N;
@@ -2248,11 +2372,13 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
 int smm_bgp_p2p_finish(void* ctx) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return SMM_ERR_INVALID_ARG;
-    if (!c->p2p_current || !c->rec_external) return SMM_OK;
+    if (c->p2p_current && !c->rec_external) return SMM_OK;
+    if (!c->p2p_current && !(c->p2p_mine && c->unresolved && c->P.N < c->P.Ng)) return SMM_OK;
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
         if (c->failed) return c->failed;
+        p2p_publish(c);   // (behind a launch of the persistent form: the records after `iter` into the windows, their exchange still to be resolved)
         const KParams& P = c->P;
         const P2PLayout L = p2p_layout(P.Ng, P.RW);
         int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;

@@ -1,0 +1,136 @@
+"""A SHARD in the persistent form (smm.jl_amd/csrc/smm_chain_persist_loc.hpp, SH = true; include/smmhip.h: smm_bgp_p2p_step): the ring
+of tagged slots and self-validating records lives in every rank's p2p window, a tile publishes into all of them, gathers its locally
+numbered cone from its own, and the ranks' launches meet in a start barrier — one launch per look-ahead window and rank instead of one
+or two per iteration.  No multi-GPU node is available to this build: the ranks are PROCESSES on the one GPU, their windows mapped through
+HIP IPC (all tiles co-resident: at most 256 in all), free running; every shard's whole history and state must equal the single shard's
+to the bit, and the single shard's the oracle's.
+Replaces the pmap branch of computeNextIteration! (AlgoBGP.jl:596-605) + exchangeMoves! (:647-691) + swap_ev_ij! (:734-749)."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common as cm
+from smm_jl_amd import _abi as A
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, pickle, time
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import smm_jl_amd as S, common as cm
+from smm_jl_amd import _abi as A
+if os.environ.get("SMM_TEST_BUILD") == "hooks":
+    S._abi.use_test_hooks(True)
+from test_gpu_p2p import shard_opts
+rank, G, N, T, ns, d, mi, kind = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], float(sys.argv[7]), sys.argv[8]
+kw = dict(sigma0=40.0, smpl_iters=2) if kind == "error" else {{}}
+prob, opts = cm.serial_normal(N=N, T=T, ns=ns, min_improve=mi, **kw)
+c = S.hip_context(prob, shard_opts(opts, G, rank))
+handle, _ = c.p2p_init()
+def put(tag, data=b""):
+    open(os.path.join(d, "%s_%d.tmp" % (tag, rank)), "wb").write(data); os.rename(os.path.join(d, "%s_%d.tmp" % (tag, rank)), os.path.join(d, "%s_%d" % (tag, rank)))
+def get(tag, r):
+    p = os.path.join(d, "%s_%d" % (tag, r)); t0 = time.time()
+    while not os.path.exists(p):
+        time.sleep(0.002)
+        if time.time() - t0 > 120: raise SystemExit("rank %d: no %s from rank %d" % (rank, tag, r))
+    return open(p, "rb").read()
+put("handle", handle)
+for r in range(G):
+    if r != rank: c.p2p_attach(r, handle=get("handle", r))
+put("mapped"); [get("mapped", r) for r in range(G)]
+err = None
+try:
+    steps = [1, T // 3, T - 1 - T // 3] if kind != "chunks" else [1, 7, 2, 1, T - 11]
+    for k, n in enumerate(steps):     # free running: kernels of different processes wait for each other on the device
+        c.p2p_step(n)
+        if kind == "chunks" and k == 2:
+            c.p2p_finish(); c.sync(); put("mid"); [get("mid", r) for r in range(G)]     # a read-back in the middle (the ranks meet: include/smmhip.h)
+            assert c.history().value.shape[0] == 10
+    c.p2p_finish(); c.sync()
+except A.SMMHipError as e:
+    err = str(e)
+h, st = c.history(), c.state()
+put("result", pickle.dumps(({{f: getattr(h, f) for f in h.FIELDS}}, {{f: getattr(st, f) for f in st.FIELDS}}, c.persistent_info(), err, st.iter)))
+[get("result", r) for r in range(G)]            # nobody unmaps a window a peer may still store into
+"""
+
+
+def _run(tmp_path, G, N, T, ns, mi, kind, env_extra=None):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(G), str(N), str(T), str(ns), str(tmp_path), repr(float(mi)), kind], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(G)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    return [pickle.loads((tmp_path / ("result_%d" % r)).read_bytes()) for r in range(G)]
+
+
+def _check(S, O, res, G, N, T, ns, mi, oracle=True):
+    prob, opts = cm.serial_normal(N=N, T=T, ns=ns, min_improve=mi)
+    single = S.hip_context(prob, opts)
+    single.step(T)
+    hs, ss = single.history(), single.state()
+    n = N // G
+    for r in range(G):
+        h, st, pinfo, err, it = res[r]
+        assert err is None, err
+        assert pinfo[1] >= 1 and pinfo[2] == 0, "rank %d: launches of the persistent form %d, repairs %d" % (r, pinfo[1], pinfo[2])
+        for f in A.HistoryBuffers.FIELDS:
+            a, b = h[f], getattr(hs, f)[..., r * n:(r + 1) * n]
+            if not np.array_equal(a, b, equal_nan=True):
+                bad = np.argwhere(~((a == b) | ((a != a) & (b != b))))
+                raise AssertionError("history field %s of rank %d: %d entries differ, first at %s" % (f, r, len(bad), bad[0].tolist()))
+        for f in A.StateBuffers.FIELDS:
+            assert np.array_equal(st[f], getattr(ss, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+    assert (hs.exchanged != 0).any()
+    if oracle:
+        o = O.OracleContext(prob, opts, S.Tables(Z=single.Z()), threads=O.max_threads())
+        o.step(T)
+        cm.assert_history_equal(hs, o.history())
+        cm.assert_state_equal(ss, o.state())
+
+
+@pytest.mark.parametrize("G,N,ns,mi", [(2, 4096, 10000, 0.0), (4, 4096, 10000, 0.0), (2, 2048, 1000, 0.05), (4, 1024, 300, 0.5), (8, 1024, 300, 0.0), (2, 64, 100, 0.0)])
+def test_sharded_persistent_form_as_processes_over_hip_ipc(S, O, tmp_path, G, N, ns, mi):
+    # VERDICT r4 "Next #1" (i): 2 x 2048 and 4 x 1024 chains at the real ns (the headline population split over 2 and 4 ranks), thresholds,
+    # eight ranks, a population of one tile per rank
+    T = 40
+    res = _run(tmp_path, G, N, T, ns, mi, "plain")
+    _check(S, O, res, G, N, T, ns, mi)
+
+
+def test_sharded_persistent_form_with_read_backs_and_short_steps(S, O, tmp_path):
+    # steps of 1, 7, 2, 1 iterations, a finish + read-back in the middle, then the rest: the form's launches between the per-iteration
+    # forms of the windows (publications carry a pending exchange over: p2p_publish), states handed back and forth
+    G, N, T, ns = 2, 1024, 40, 200
+    res = _run(tmp_path, G, N, T, ns, 0.0, "chunks")
+    _check(S, O, res, G, N, T, ns, 0.0)
+
+
+@pytest.mark.parametrize("mi", [0.0, 0.05])
+def test_sharded_persistent_form_on_the_big_plan_with_local_cone_tables(S, O, tmp_path, mi):
+    # populations past 8192 chains (8 x 4096: BASELINE configs[2]) get their cones from k_exch_plan_big + k_cone_chains + k_cone_tiles —
+    # locally numbered, each rank its own tiles'.  2048 tiles cannot be resident on the one GPU, so the test seam forces that plan onto
+    # a population that can (SMMHIP_BIG_EXCHANGE=1, the test build): the same kernels, the same tables, 128 tiles
+    G, N, T, ns = 2, 2048, 40, 300
+    res = _run(tmp_path, G, N, T, ns, mi, "plain", dict(SMM_TEST_BUILD="hooks", SMMHIP_BIG_EXCHANGE="1"))
+    _check(S, O, res, G, N, T, ns, mi)
+
+
+@pytest.mark.parametrize("ring,slow_us", [(2, 30), (4, 15)])
+def test_sharded_persistent_form_under_skew_and_a_short_ring(S, O, tmp_path, ring, slow_us):
+    # VERDICT r4 "Next #1" (ii): one tile of EVERY rank idles before each publication, the ring holds 2 / 4 iterations: the overrun guard
+    # (progress words of all ranks' tiles in every window) is what keeps a fast rank from overwriting what a slow one still reads
+    G, N, T, ns = 2, 1024, 40, 200
+    res = _run(tmp_path, G, N, T, ns, 0.0, "plain", dict(SMM_TEST_BUILD="hooks", SMMHIP_PR_RING=str(ring), SMMHIP_PR_SLOW_TILE="3", SMMHIP_PR_SLOW_US=str(slow_us)))
+    _check(S, O, res, G, N, T, ns, 0.0)
