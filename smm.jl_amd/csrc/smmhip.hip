@@ -33,7 +33,9 @@
 #include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
 #include <dlfcn.h>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -735,13 +737,58 @@ void flush(Ctx* c) {
     c->prev_open = false;
 }
 
-void persist_repair(Ctx* c);
+void persist_repair(Ctx* c, int n_replay = -1);
 void p2p_enqueue(Ctx* c, int n_iters);
+// The ranks of a sharded run agree on what their launches of the persistent form ended with: every rank writes its error word into
+// every rank's window — {word, number of its last launch} — and reads its own window until all ranks' words of that launch are there
+// (the host side of a rendezvous every rank reaches: smm_sync / smm_bgp_p2p_finish behind the same steps).  The smallest word wins,
+// as it does among the chains of one device: the first failing iteration, the first failing chain of the population.
+unsigned long long p2p_agree_error(Ctx* c, unsigned long long e_local) {
+    const KParams& P = c->P;
+    const int G = P.p2p_G;
+    const PrWin WL = pr_win_layout(P.Ng, P.RW, G, (P.N + NORM_CT - 1) / NORM_CT);
+    const uint32_t seq = c->pr_epoch;
+    for (int r = 0; r < G; ++r)
+        HIPCHK(hipMemcpy(P.p2p_win[r] + c->prw_off + WL.fin + 128 * (size_t)P.p2p_rank, &e_local, 8, hipMemcpyHostToDevice));
+    for (int r = 0; r < G; ++r)   // (the word is there before the number that says so)
+        HIPCHK(hipMemcpy(P.p2p_win[r] + c->prw_off + WL.fin + 128 * (size_t)P.p2p_rank + 8, &seq, 4, hipMemcpyHostToDevice));
+    std::vector<unsigned char> buf((size_t)128 * G);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long e = e_local;
+    for (;;) {
+        HIPCHK(hipMemcpy(buf.data(), c->p2p_mine + c->prw_off + WL.fin, buf.size(), hipMemcpyDeviceToHost));
+        bool all = true;
+        e = e_local;
+        for (int r = 0; r < G; ++r) {
+            uint32_t s_r; unsigned long long e_r;
+            memcpy(&e_r, buf.data() + 128 * (size_t)r, 8); memcpy(&s_r, buf.data() + 128 * (size_t)r + 8, 4);
+            if (s_r != seq) { all = false; break; }
+            e = std::min(e, e_r);
+        }
+        if (all) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) throw std::string("sharded run: a rank did not report the end of its step within 30 s (is every rank calling smm_sync / smm_bgp_p2p_finish?)");
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
 int check_device_error(Ctx* c) {
     if (c->failed) return c->failed;   // err holds the message of the first failure
     unsigned long long e = ERR_NONE;
     HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
-    if (e != ERR_NONE && c->snap_valid && !c->in_repair) {
+    if (c->persist_sh && c->snap_valid && !c->in_repair && c->p2p_mine) {
+        // launches of the persistent form ran on every rank: what one of them ended with concerns all (its tiles did not stop either)
+        const unsigned long long eg = p2p_agree_error(c, e);
+        if (eg != ERR_NONE) {
+            const int kind = (int)(eg & 3), it = (int)(eg >> 34);
+            if (kind == 3 && ++c->persist_strikes >= 2) c->persist_broken = true;
+            // a hard error (AlgoBGP.jl:341,409): every rank replays up to and including the failing iteration — which completes for all
+            // chains, as everywhere — and stands there; a time-out or a cone that did not fit: the whole step again, on the other forms
+            persist_repair(c, (kind == 1 || kind == 2) ? it - c->snap_iter : -1);
+            HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
+            if (kind == 1 || kind == 2) e = std::min(e, eg);   // (the first failing chain of the POPULATION — maybe another rank's: every rank reports the same)
+        }
+        c->snap_valid = false;
+        if (eg == ERR_NONE) c->persist_proven = true;
+    } else if (e != ERR_NONE && c->snap_valid && !c->in_repair) {
         // launches of the persistent kernel ran since the last check: their tiles do not stop at the failing iteration.  Back to the
         // state before the first of them, and the same iterations again on the one-launch-per-iteration path, which does.
         // (a tile gave up waiting, or a cone did not fit.  Once may be somebody else's doing — another context or process held compute
@@ -1131,10 +1178,10 @@ void enqueue_iterations(Ctx* c, int n_iters) {
 // up waiting).  Its tiles do not stop at the failing iteration, so: the state of before (persist_snapshot), the history rows of the
 // iterations since filled as the constructor fills them, the error word cleared, and the same iterations again, one launch each —
 // that path stops at the failing iteration with the documented state (include/smmhip.h), or runs through if the failure was the form's.
-void persist_repair(Ctx* c) {
+void persist_repair(Ctx* c, int n_replay) {
     KParams& P = c->P;
     const size_t N = P.N;
-    const int n = c->iter - c->snap_iter;
+    const int n = n_replay >= 0 ? std::min(n_replay, c->iter - c->snap_iter) : c->iter - c->snap_iter;
     c->in_repair = true;
     ++c->persist_repairs;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2344,7 +2391,9 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
     if (c->a2a_open) return fail(c, SMM_ERR_STATE, "smm_bgp_a2a_apply_dev comes first");
     try {
         HIPCHK(hipSetDevice(c->device));
-        settle_persist(c);
+        // (launches of the persistent form that this step simply continues are looked at — and agreed upon by the ranks — when the run is
+        // synchronised, not between two steps: the host stays out of the way)
+        if (!(!c->p2p_current && persist_sh_usable(c, n_iters))) settle_persist(c);
         if (c->failed) return c->failed;
         KParams& P = c->P;
         if (c->profiling == 2) {

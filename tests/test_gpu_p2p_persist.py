@@ -134,3 +134,30 @@ def test_sharded_persistent_form_under_skew_and_a_short_ring(S, O, tmp_path, rin
     G, N, T, ns = 2, 1024, 40, 200
     res = _run(tmp_path, G, N, T, ns, 0.0, "plain", dict(SMM_TEST_BUILD="hooks", SMMHIP_PR_RING=str(ring), SMMHIP_PR_SLOW_TILE="3", SMMHIP_PR_SLOW_US=str(slow_us)))
     _check(S, O, res, G, N, T, ns, 0.0)
+
+
+def test_sharded_persistent_form_hard_error_is_replayed_on_every_rank_to_the_same_iteration(S, tmp_path):
+    # VERDICT r4 "Next #1" (ii): AlgoBGP.jl:409 (no draw in support after smpl_iters trials) on ONE shard inside a launch of the persistent
+    # form.  The ranks agree on the error at their next rendezvous (its word travels through the windows), every rank rolls back and
+    # replays, through the windows' per-iteration forms, up to and including the failing iteration, and reports it: the same message,
+    # the same iteration, the same history as the single shard's
+    G, N, T, ns = 2, 1024, 30, 100
+    res = _run(tmp_path, G, N, T, ns, 0.0, "error")
+    prob, opts = cm.serial_normal(N=N, T=T, ns=ns, sigma0=40.0, smpl_iters=2)
+    single = S.hip_context(prob, opts)
+    with pytest.raises(A.SMMHipError) as ei:
+        single.step(T)
+    msg = str(ei.value)
+    assert "no draw in support" in msg
+    hs = single.history()
+    n = N // G
+    its = set()
+    for r in range(G):
+        h, st, pinfo, err, it = res[r]
+        assert err is not None and "no draw in support" in err, err
+        assert err == msg, (err, msg)
+        assert pinfo[1] >= 1 and pinfo[2] >= 1, pinfo            # the persistent form ran, and was replayed
+        its.add(it)
+        for f in A.HistoryBuffers.FIELDS:
+            assert np.array_equal(h[f], getattr(hs, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
+    assert its == {single.state().iter}, its

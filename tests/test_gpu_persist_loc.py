@@ -74,8 +74,10 @@ def test_threshold_persistent_form_c2_size_across_plan_windows(S, O):
     h, o = _pair(S, O, prob, opts)
     h.step(300); o.step(300)
     assert h.persistent_info()[1] >= 2 and h.persistent_info()[2] == 0
-    cm.assert_history_equal(h.history(), o.history())
-    cm.assert_state_equal(h.state(), o.state())
+    # (atol: a simulated moment that happens to lie within 1e-5 of zero — theta + mean(z) cancels — carries the proposal's ulps of ocml's
+    # sincos / log against glibc's at 1e-9 of ITSELF; 1e-13 is far below anything the objective resolves)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
     assert 0.02 < (h.history().exchanged != 0).mean() < 0.4
 
 
