@@ -42,7 +42,7 @@ PEAK_HBM_GBS = 8000.0
 WORKLOADS = {
     # 2*nm*ns FP64 adds + ~100 for proposal/objective/accept; 128 B of HBM traffic (state read 40 B + history record 88 B)
     "c2": dict(chains=4096, total=False, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
-               kernel="k_chain_persist_norm<2>",
+               kernel="k_chain_persist_loc<2, false, false>",
                label="serialNormal objfunc_norm 2 params / 2 moments, ns=10000 (BASELINE configs[1])"),
     "c3": dict(chains=32768, total=True, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
                kernel="k_chain_iter_norm_narrow_cone<2>",
@@ -83,7 +83,7 @@ def profile_tag(workload):
 
 
 # the persistent launches + the single iterations at window boundaries, per workload
-CHAIN_KERNELS = {"c2": ("k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>"),
+CHAIN_KERNELS = {"c2": ("k_chain_persist_loc<2, false, false>", "k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>"),
                  "c4": ("k_chain_persist_gen", "k_chain_iter<0, 16, 2, true>")}
 
 
@@ -504,7 +504,10 @@ def main():
         ach = work / (k_us * 1e-6) / (1e12 if W["bound"] != "hbm" else 1e9)
         hbm = n_loc * W["bytes"] / (k_us * 1e-6) / 1e9
         norm_p2p = sharded and protocol == "p2p" and args.workload in ("c2", "c3")
-        kernel = (W["kernel"] if not sharded else "k_chain_iter_norm_p2p<2>" if norm_p2p and n_glob <= 8192      # the walk inline
+        pinfo = ctx.persistent_info()
+        shard_persist = norm_p2p and pinfo[1] > 0     # the shard ran the persistent form: the ring across the windows (smm_chain_persist_loc.hpp)
+        kernel = (W["kernel"] if not sharded else "k_chain_persist_loc<2, false, true>" if shard_persist
+                  else "k_chain_iter_norm_p2p<2>" if norm_p2p and n_glob <= 8192      # the walk inline
                   else "k_chain_iter_norm_p2p_rows<2>" if norm_p2p and n_glob <= 32768                       # + k_exch_resolve_rows<., true>
                   else W["kernel"].replace("true", "false"))
         traffic, traffic_src, traffic_stale = pmc_traffic(kernel, args.workload)
@@ -566,7 +569,7 @@ def main():
                                             "frac": (n_loc * (W["flop"] if W["bound"] != "hbm" else W["bytes"]) / (k1 * 1e-6) / (1e12 if W["bound"] != "hbm" else 1e9) / W["peak"]) if k1 > 0 else None,
                                             "note": "the same context with smm_set_persistent(0): one launch per iteration, the exchange walk in its prologue"}
         del c1
-    if roof is not None and not sharded and kernel.startswith("k_chain_persist"):
+    if roof is not None and kernel.startswith("k_chain_persist"):
         info = ctx.persistent_info()
         roof["persistent"] = {"launches": info[1], "repairs": info[2]}
     # the same chain kernel without the exchange walk in its prologue (single shard, C2): what the fused launch consists of
@@ -609,6 +612,10 @@ def main():
                "config": {"workload": "%s, %d BGP chains per GPU (%d total) x %d iterations per step" % (W["label"], n_loc, n_glob, ITERS_PER_STEP),
                           "chains_per_gpu": n_loc, "chains_total": n_glob, "iters_per_step": ITERS_PER_STEP, "ns": NS if args.workload in ("c2", "c3") else None,
                           "exchange": exch, "protocol": protocol, "protocol_check": proto_note, "cross_rank_check": xnote,
+                          "shard_form": (None if not sharded else
+                                         ("persistent: one launch per look-ahead window and rank, the ring of tagged slots in every rank's window (%d launches, %d repairs on rank 0)"
+                                          % (ctx.persistent_info()[1], ctx.persistent_info()[2])) if ctx.persistent_info()[1] > 0
+                                         else "per-iteration launches (the windows' inline / rows / generic forms)"),
                           "world_seen": (dist.get_world_size() if dist.is_initialized() else 1),
                           "backend": (str(dist.get_backend()) if dist.is_initialized() else None),
                           "same_device": bool(args.same_device), "forced_sharded": force_sharded},

@@ -289,7 +289,9 @@ int  smm_bgp_sharded_finish(void* ctx, const void* gathered_dev);
  *   smm_bgp_p2p_attach(ctx, rank, handle, window): rank's window, by IPC handle or by device pointer (exactly one non-NULL).
  *   smm_bgp_p2p_step(ctx, n): enqueues n iterations and returns (smm_sync waits).  All ranks call it with the same n, in the
  *        same order relative to each other's p2p calls (publications and pushes are counted).  A rank whose peers' stores never
- *        arrive gives up after ~4 s and reports SMM_ERR_HIP at the next smm_sync.
+ *        arrive gives up after ~4 s and reports SMM_ERR_HIP at the next smm_sync.  Where the context qualifies (smm_set_persistent,
+ *        below) n >= 2 iterations behind a completed one are ONE launch per look-ahead window and rank; smm_sync of such steps is a
+ *        rendezvous of the ranks (their error words travel through the windows): every rank must reach it.
  *   smm_bgp_p2p_finish(ctx): settles the last iteration into the context (required before smm_get_history / smm_get_state /
  *        the other stepping forms).  Callers must not destroy a context while a peer may still be stepping.
  *        A BARRIER ACROSS THE RANKS belongs between smm_bgp_p2p_finish (+ smm_sync) and the next smm_bgp_p2p_step: that step's
@@ -333,15 +335,25 @@ int  smm_get_timing(void* ctx, smm_timing_t* out);
  * dispatch-begin to dispatch-end durations the command processor stamps, i.e. what rocprofv3
  * --kernel-trace reports; null_bracket_ms = 0.   on = 0: off. */
 int  smm_set_profiling(void* ctx, int32_t on);
-/* The persistent form of smm_bgp_step (smm.jl_amd/csrc/smm_chain_persist.hpp, smm_chain_persist_gen.hpp; replaces the loop of run!,
- * AlgoAbstract.jl:38-45, over computeNextIteration!, AlgoBGP.jl:589-640): where a context qualifies — objfunc_norm with at most two
- * moments and ns <= 10240 on a single shard of at most one 16-chain tile per compute unit, or the banana objective with at most 16
- * parameters (one proposal batch, isotropic) on a single shard of 4096 < N <= 8192 chains in whole groups of 32; min_improve == 0 for
- * all chains, dist_fun = `-` — a step of n >= 2 iterations is ONE kernel launch per look-ahead window instead of one per iteration.
- * Results are bit-identical.
+/* The persistent form of smm_bgp_step and smm_bgp_p2p_step (smm.jl_amd/csrc/smm_chain_persist_loc.hpp, smm_chain_persist_gen.hpp;
+ * replaces the loop of run!, AlgoAbstract.jl:38-45, over computeNextIteration!, AlgoBGP.jl:589-640): where a context qualifies a step of
+ * n >= 2 iterations is ONE kernel launch per look-ahead window (<= 256 iterations) instead of one per iteration.  Results are
+ * bit-identical.  A context qualifies with
+ *   - objfunc_norm with at most two parameters / moments and ns <= 10240, one proposal batch, isotropic proposals, dist_fun = `-`, ONE
+ *     min_improve >= 0 (or NaN) for all chains — 0, or the reference's default 0.5 (AlgoBGP.jl:522) —, at most one 16-chain tile per
+ *     compute unit: a single shard of up to 4096 chains (smm_bgp_step), or a SHARD of a sharded run (smm_bgp_p2p_step: N a multiple
+ *     of 16, N <= 4096 per rank, N_global <= 32768; the ring of tagged words then lives in every rank's window, a hard error inside
+ *     such a launch is agreed upon by the ranks at their next smm_sync / smm_bgp_p2p_finish and replayed by every rank up to the
+ *     failing iteration);
+ *   - the banana objective with at most 16 parameters (one proposal batch, isotropic, min_improve == 0) on a single shard of
+ *     4096 < N <= 8192 chains in whole groups of 32.
+ * Per-chain thresholds, other dist_fun, more than two moments, Cholesky proposals, user objectives: the per-iteration kernels.
  * on = 0 keeps the one-launch-per-iteration kernels (default: on).  A hard error of the algorithm inside such a launch is found at
  * the next call that checks (smm_sync, smm_bgp_step, the state readers): the library then repeats those iterations from the state
  * it saved on the one-launch-per-iteration path, so that the context stands at the failing iteration exactly as documented above.
+ * All tiles of such a launch must be resident together; on a device that shows the process fewer compute units than it reports (a CU
+ * mask, a partition) the first launch gives up after 0.4 s, the step is replayed on the per-iteration kernels, and after the second
+ * such time-out the form is off for the context (smm_get_persistent says so).
  * smm_get_persistent: whether the next step would take this form; launches of it so far; repairs so far. */
 int  smm_set_persistent(void* ctx, int32_t on);
 int  smm_get_persistent(void* ctx, int32_t* available, int32_t* launches, int32_t* repairs);

@@ -17,6 +17,7 @@ export HipBGP, hip_create, hip_destroy!, hip_step!, hip_iter, hip_history, hip_s
        hip_register_objective, hip_record_doubles
 export hip_eval_batch_noseed, hip_stream, hip_sync, hip_local_step!, hip_export_records!, hip_exchange!, hip_sharded_step!, hip_sharded_finish!,
        hip_a2a_capacity, hip_export_values!, hip_a2a_pack!, hip_a2a_apply!, hip_record_doubles
+export hip_step_async!, hip_p2p_init, hip_p2p_attach!, hip_p2p_step!, hip_p2p_finish!, hip_set_persistent!, hip_persistent_info, P2P_HANDLE_BYTES
 
 const ABI_VERSION = 3
 const LIB = Ref{Ptr{Cvoid}}(C_NULL)
@@ -216,6 +217,26 @@ function hip_step!(h::HipBGP, n::Integer = 1)
     return h
 end
 
+"""
+    hip_step_async!(h, n)
+
+The same, enqueued only: returns at once, `hip_sync(h)` waits (and reports a hard error of the reference, AlgoBGP.jl:341,409).
+Steps of n >= 2 iterations take the persistent form where the context qualifies (include/smmhip.h, smm_set_persistent).
+"""
+function hip_step_async!(h::HipBGP, n::Integer = 1)
+    check(h.ctx, ccall(sym(:smm_bgp_step_async), Cint, (Ptr{Cvoid}, Cint), h.ctx, n))
+    return h
+end
+
+"the persistent form of `hip_step!` (include/smmhip.h): on by default where the context qualifies"
+hip_set_persistent!(h::HipBGP, on::Bool) = (check(h.ctx, ccall(sym(:smm_set_persistent), Cint, (Ptr{Cvoid}, Cint), h.ctx, on ? 1 : 0)); h)
+"(would the next step take the persistent form, launches of it so far, repairs so far)"
+function hip_persistent_info(h::HipBGP)
+    a = Ref{Int32}(0); l = Ref{Int32}(0); r = Ref{Int32}(0)
+    check(h.ctx, ccall(sym(:smm_get_persistent), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}), h.ctx, a, l, r))
+    return (a[] != 0, Int(l[]), Int(r[]))
+end
+
 "completed iterations (after a hard error: the failing iteration, see include/smmhip.h)"
 hip_iter(h::HipBGP) = hip_state(h).iter
 
@@ -238,6 +259,27 @@ hip_export_values!(h::HipBGP, vals::Ptr{Cvoid}) = (check(h.ctx, ccall(sym(:smm_b
 hip_a2a_pack!(h::HipBGP, vals_all::Ptr{Cvoid}, send::Ptr{Cvoid}) =
     (check(h.ctx, ccall(sym(:smm_bgp_a2a_pack_dev), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, vals_all, send)); h)
 hip_a2a_apply!(h::HipBGP, recv::Ptr{Cvoid}) = (check(h.ctx, ccall(sym(:smm_bgp_a2a_apply_dev), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h.ctx, recv)); h)
+
+# The p2p form (no collective at all: every rank owns a window that the others map through HIP IPC; include/smmhip.h).  The handles
+# are 64 plain bytes: any transport hands them round once — julia/SMMHipSharded.jl does it with Distributed alone.
+const P2P_HANDLE_BYTES = 64
+"this rank's window: returns its IPC handle (for the other PROCESSES) as a Vector{UInt8}"
+function hip_p2p_init(h::HipBGP)
+    handle = zeros(UInt8, P2P_HANDLE_BYTES)
+    win = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve handle check(h.ctx, ccall(sym(:smm_bgp_p2p_init), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ref{Ptr{Cvoid}}), h.ctx, pointer(handle), win))
+    return handle
+end
+"rank `rank`'s window by its IPC handle (ranks are 0-based: chain_offset / N)"
+function hip_p2p_attach!(h::HipBGP, rank::Integer, handle::Vector{UInt8})
+    length(handle) == P2P_HANDLE_BYTES || throw(ArgumentError("an IPC handle is $P2P_HANDLE_BYTES bytes"))
+    GC.@preserve handle check(h.ctx, ccall(sym(:smm_bgp_p2p_attach), Cint, (Ptr{Cvoid}, Cint, Ptr{UInt8}, Ptr{Cvoid}), h.ctx, rank, pointer(handle), C_NULL))
+    return h
+end
+"n iterations of this shard, enqueued (every rank calls it with the same n); `hip_sync` waits"
+hip_p2p_step!(h::HipBGP, n::Integer) = (check(h.ctx, ccall(sym(:smm_bgp_p2p_step), Cint, (Ptr{Cvoid}, Cint), h.ctx, n)); h)
+"settle the last iteration into the context (before history / state are read); every rank calls it"
+hip_p2p_finish!(h::HipBGP) = (check(h.ctx, ccall(sym(:smm_bgp_p2p_finish), Cint, (Ptr{Cvoid},), h.ctx)); h)
 
 """
     hip_history(h, t0, t1) -> NamedTuple

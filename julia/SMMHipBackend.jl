@@ -31,7 +31,7 @@ import SMM: MAlgo, MAlgoBGP, MProb, Eval, BGPChain, Slice, computeNextIteration!
 import Base: getproperty, show
 using ..SMMHip
 
-export MAlgoBGPHip, sync_chains!, serialNormalHip, evaluateObjectivesHip, doSlicesHip, FD_gradient_hip, getSigmaHip
+export MAlgoBGPHip, sync_chains!, flush_steps!, hip_context, serialNormalHip, evaluateObjectivesHip, doSlicesHip, FD_gradient_hip, getSigmaHip
 
 """
     MAlgoBGPHip(m::MProb, opts::Dict)
@@ -50,6 +50,7 @@ mutable struct MAlgoBGPHip <: MAlgo
     hip::SMMHip.HipBGP            # the device context
     synced::Int                   # iterations already materialised in `chains`
     stepped::Int                  # iterations enqueued on the device so far (host-side count: asking it needs no device synchronisation)
+    deferred::Int                 # single steps of computeNextIteration! counted but not enqueued yet (flush_steps!)
     pnames::Vector{Symbol}        # parameter order on the device = keys(m.params_to_sample)
     mnames::Vector{Symbol}        # moment order on the device = keys(m.moments)
 end
@@ -89,11 +90,13 @@ function reference_chains(m::MProb, opts::Dict, N::Int, temps::Vector{Float64}, 
                              batch_size = get(opts, "batch_size", length(m.params_to_sample))) for i in 1:N]
 end
 
-function MAlgoBGPHip(m::MProb, opts::Dict)
-    # opts["animate"] (AlgoBGP.jl:621-624) makes the reference push a plot frame of its chains into algo.anim every iteration:
-    # that is a host-side per-iteration hook on objects this backend fills lazily; refused rather than silently ignored
-    get(opts, "animate", false) == true &&
-        throw(ArgumentError("opts[\"animate\"] is not supported by the GPU backend: run without it and plot the synced chains afterwards"))
+"""
+    hip_context(m, opts; N_local, chain_offset, device) -> (hip, N, temps, mi, acc, dist_fun, dist_id, pnames, mnames)
+
+The device context of `MAlgoBGP(m, opts)` (AlgoBGP.jl:505-537): ladder, per-chain vectors, flat problem.  `N_local` / `chain_offset`
+make it ONE SHARD of the population `opts["N"]` (julia/SMMHipSharded.jl: one process per GPU); the per-chain vectors stay global.
+"""
+function hip_context(m::MProb, opts::Dict; N_local::Int = Int(opts["N"]), chain_offset::Int = 0, device::Int = Int(get(opts, "device", 0)))
     N = Int(opts["N"])
     temps = N > 1 ? collect(range(1.0, stop = Float64(opts["maxtemp"]), length = N)) : [1.0]      # AlgoBGP.jl:508
     mi = chain_vector(opts, "min_improve", 0.5, N)                                                  # :522
@@ -116,10 +119,20 @@ function MAlgoBGPHip(m::MProb, opts::Dict)
                             sigma_adjust_by = Float64(get(opts, "sigma_adjust_by", 0.01)),
                             smpl_iters = Int(get(opts, "smpl_iters", 1000)),
                             batch_size = Int(get(opts, "batch_size", length(init))),
-                            seed = Int(get(opts, "seed", 12)), device = Int(get(opts, "device", 0)),
+                            seed = Int(get(opts, "seed", 12)), device = device,
+                            N = N_local, N_global = N, chain_offset = chain_offset,
                             chol_L = get(opts, "chol_L", nothing), dist_fun = dist_id)
+    return hip, N, temps, mi, acc, dist_fun, dist_id, pnames, mnames
+end
+
+function MAlgoBGPHip(m::MProb, opts::Dict)
+    # opts["animate"] (AlgoBGP.jl:621-624) makes the reference push a plot frame of its chains into algo.anim every iteration:
+    # that is a host-side per-iteration hook on objects this backend fills lazily; refused rather than silently ignored
+    get(opts, "animate", false) == true &&
+        throw(ArgumentError("opts[\"animate\"] is not supported by the GPU backend: run without it and plot the synced chains afterwards"))
+    hip, N, temps, mi, acc, dist_fun, dist_id, pnames, mnames = hip_context(m, opts)
     return MAlgoBGPHip(m, opts, 0, reference_chains(m, opts, N, temps, mi, acc), nothing,
-                       dist_fun isa Function ? dist_fun : host_dist_fun(dist_id), hip, 0, 0, pnames, mnames)
+                       dist_fun isa Function ? dist_fun : host_dist_fun(dist_id), hip, 0, 0, 0, pnames, mnames)
 end
 
 # opts["dist_fun"] (AlgoBGP.jl:494,537) -> smm_dist_fun_t.  The reference takes any function of two objective values; inside the
@@ -142,8 +155,31 @@ One BGP iteration of all chains on the device: next_eval for every chain (AlgoBG
 in support :409) is thrown as `SMMHip.SMMHipError`.
 """
 function computeNextIteration!(algo::MAlgoBGPHip)
-    SMMHip.hip_step!(getfield(algo, :hip), 1)
-    setfield!(algo, :stepped, getfield(algo, :stepped) + 1)
+    # Nothing is enqueued per call, and nobody waits for the device: the reference's unchanged loop (`for i in 1:maxiter ...
+    # computeNextIteration!(algo)`, AlgoAbstract.jl:38-45) would otherwise pay a library call and a device synchronisation per
+    # iteration and — one iteration at a time — never take the persistent form (include/smmhip.h: steps of n >= 2).  The calls are
+    # COUNTED and handed to the library as one asynchronous step when somebody looks (`algo.chains`, `save`, `summary`, ...) or a
+    # look-ahead window's worth has come together.  A hard error of the reference (AlgoBGP.jl:341,409) therefore surfaces at that
+    # point, naming its iteration, not inside the call of that iteration.
+    d = getfield(algo, :deferred) + 1
+    setfield!(algo, :deferred, d)
+    d >= DEFER_MAX && flush_steps!(algo)
+    return nothing
+end
+
+const DEFER_MAX = 256            # a look-ahead window of the library
+
+"""
+    flush_steps!(algo)
+
+Enqueue the iterations `computeNextIteration!` has counted since the last flush as ONE asynchronous step (no device synchronisation).
+"""
+function flush_steps!(algo::MAlgoBGPHip)
+    d = getfield(algo, :deferred)
+    d == 0 && return nothing
+    setfield!(algo, :deferred, 0)
+    SMMHip.hip_step_async!(getfield(algo, :hip), d)       # (throws before anything is enqueued: a step past maxiter, a failed context)
+    setfield!(algo, :stepped, getfield(algo, :stepped) + d)
     return nothing
 end
 
@@ -163,8 +199,16 @@ function run!(algo::MAlgoBGPHip)
         if sf > 0 && fn != ""
             n = min(n, sf - (algo.i % sf))
         end
-        SMMHip.hip_step!(getfield(algo, :hip), n)
-        setfield!(algo, :stepped, getfield(algo, :stepped) + n)
+        flush_steps!(algo)
+        try
+            SMMHip.hip_step!(getfield(algo, :hip), n)
+            setfield!(algo, :stepped, getfield(algo, :stepped) + n)
+        catch
+            # a hard error: the device stands at the failing iteration (include/smmhip.h) — what was completed before it must still
+            # reach `algo.chains` (ADVICE r4: the count was only raised behind a successful call)
+            setfield!(algo, :stepped, SMMHip.hip_iter(getfield(algo, :hip)))
+            rethrow()
+        end
         algo.i += n
         if sf > 0 && fn != "" && algo.i % sf == 0
             save(algo, fn)
@@ -191,7 +235,14 @@ function sync_chains!(algo::MAlgoBGPHip)
     chains = getfield(algo, :chains)
     # nothing was stepped since the last sync: the chains are current (no device synchronisation, no download) — `algo.chains` is read
     # by every reader the reference defines, often many times in a row
+    flush_steps!(algo)
     getfield(algo, :stepped) == getfield(algo, :synced) && return chains
+    try
+        SMMHip.hip_sync(hip)          # (the steps were only enqueued; a hard error of the reference is reported here)
+    catch
+        setfield!(algo, :stepped, SMMHip.hip_iter(hip))    # the failing iteration: everything up to it is materialised by the next read
+        rethrow()
+    end
     st = SMMHip.hip_state(hip)
     done = st.iter
     first = getfield(algo, :synced)
@@ -343,6 +394,7 @@ function restart!(algo::MAlgoBGPHip, extraIter::Int)
     setfield!(algo, :opts, getfield(ext, :opts))
     setfield!(algo, :synced, 0)
     setfield!(algo, :stepped, getfield(ext, :stepped))
+    setfield!(algo, :deferred, 0)
     run!(algo)
     return nothing
 end

@@ -957,15 +957,6 @@ const void* persist_loc_fn(int np, bool wide, bool sh) {
     return wide ? (sh ? (const void*)k_chain_persist_loc<2, true, true> : (const void*)k_chain_persist_loc<2, true, false>)
                 : (sh ? (const void*)k_chain_persist_loc<2, false, true> : (const void*)k_chain_persist_loc<2, false, false>);
 }
-template <int NP>
-void launch_chain_persist_t(Ctx* c, const PersistArgs& A) {
-    const dim3 grid((A.N + NORM_CT - 1) / NORM_CT), block(NORM_WG);
-    const size_t smem = persist_smem_bytes(A.Ng, NP);
-    if (c->kev0)
-        hipExtLaunchKernelGGL((k_chain_persist_norm<NP>), grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
-    else
-        hipLaunchKernelGGL((k_chain_persist_norm<NP>), grid, block, smem, c->stream, A);
-}
 // can the iterations from c->iter + 1 on run as one launch of it?  At least two (a single iteration is the ordinary kernel's), behind
 // an iteration some chain kernel has completed (the launch continues from the plain state blocks: no first iteration, no uploaded
 // state, no exchange applied by the three-phase calls), and an exchange left to "the next chain kernel" must have its plan in the
@@ -1095,22 +1086,6 @@ int launch_chain_persist(Ctx* c, int n_left) {
         const size_t smem = persist_gen_smem_bytes(P.Ng, P.np, P.RW, P.HW);
         if (c->kev0) hipExtLaunchKernelGGL(k_chain_persist_gen, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
         else hipLaunchKernelGGL(k_chain_persist_gen, grid, block, smem, c->stream, A);
-    } else {
-        PersistArgs A{};
-        A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
-        A.pr_slot = P.pr_slot; A.pr_rec = P.pr_rec; A.pr_progress = P.pr_progress; A.pr_ctl = P.pr_ctl;
-        A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
-        A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
-        A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp;
-        A.rb = pregen ? P.rb : nullptr;
-        A.N = P.N; A.Ng = P.Ng; A.ns = P.ns; A.zstride = P.zstride; A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from;
-        A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
-        A.rb_t0 = P.rb_t0; A.RBW = P.RBW; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
-        A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
-        A.walk_first = c->unresolved ? 1 : 0;
-        A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
-        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed; A.tmo = tmo;
-        if (P.np == 1) launch_chain_persist_t<1>(c, A); else launch_chain_persist_t<2>(c, A);
     }
     c->cur ^= 1;
     ++c->persist_launches;
@@ -1699,9 +1674,6 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             int n_cus = 256;
             (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, c->device);
             const char* ploc = SMM_HOOK("SMMHIP_PERSIST_LOC");   // test hook: "1" the locally numbered form wherever it applies, "0" never
-            const bool want_persist = c->norm_fast && np <= 2 && ns <= WG * PR_ZR && N == Ng && Ng >= 2 && c->inline_walk && P.mi_uniform && P.mi_value == 0.0 &&
-                                      opts->dist_fun == SMM_DIST_MINUS && K <= XLVL_MAX && Ng <= XLVL_MAX && !c->deep_plan && (N + NORM_CT - 1) / NORM_CT <= n_cus &&
-                                      persist_smem_bytes(Ng, np) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
             // ... and its form for objectives without a simulation (smm_chain_persist_gen.hpp): where k_chain_iter walks its workgroups'
             // cones inline (4096 < N <= 8192 in whole workgroups of 32 chains, one per CU), one proposal batch, isotropic proposals
             const bool want_persist_gen = want_cone && !c->dense_keys && c->obj == SMM_OBJ_BANANA && np <= PG_MAXP && nm <= PG_MAXP && opts->batch_size == np && !opts->chol_L &&
@@ -1712,8 +1684,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             // does to the tile's LDS
             const bool want_persist_loc = c->norm_fast && np <= 2 && ns <= WG * PR_ZR && N == Ng && Ng >= 2 && c->inline_walk && P.mi_uniform && !(P.mi_value < 0.0) &&
                                           opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan && (N + NORM_CT - 1) / NORM_CT <= n_cus &&
-                                          P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0') &&
-                                          ((ploc && ploc[0] == '1') || !(want_persist && lean_walk_unit(Ng) == 8));
+                                          P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0');
             // ... and as a shard of a sharded run (one process per GPU: smm_bgp_p2p_step): the same kernel, the ring in the ranks' windows
             const bool want_persist_sh = N < Ng && N > 0 && Ng % N == 0 && opts->chain_offset % N == 0 && Ng / N <= P2P_MAXG && N % NORM_CT == 0 && c->norm_fast && np <= 2 &&
                                          ns <= WG * PR_ZR && P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && !c->deep_plan && N / NORM_CT <= n_cus &&
@@ -1729,7 +1700,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (size_t)Ng * 4 <= (size_t)160 * 1024;
             const size_t plan_iter = (want_cone_big ? (size_t)(N / NORM_CT) * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + cone_big_scratch_words(Ng, K) * 4 : 0) + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
                                      (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / cone_ct) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
-                                     ((want_persist || want_persist_loc || want_persist_sh) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
+                                     ((want_persist_loc || want_persist_sh) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
                                      ((want_persist_sh && c->big_exchange) ? cone_big_scratch_words(Ng, K) * 4 : 0) +
                                      (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
@@ -1851,27 +1822,6 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                 if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                             }
                         }
-                        if (want_persist && lean_walk_unit(Ng) == 8 && c->norm_fast && !(ploc && ploc[0] == '1')) {
-                            const size_t tiles = persist_tiles;
-                            P.cone_tiles = (int)tiles; P.cone_ct = NORM_CT;
-                            P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
-                            P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
-                            P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);   // (+: whole 1 KB pieces are fetched)
-                            P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP + 512);
-                            HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
-                            P.pr_slot = (uint2*)dalloc<unsigned char>(c, persist_ring_slot_bytes(Ng));
-                            P.pr_rec = (uint4*)dalloc<unsigned char>(c, persist_ring_rec_bytes(Ng, P.RW));
-                            P.pr_progress = dalloc<uint32_t>(c, tiles);
-                            P.pr_ctl = dalloc<uint32_t>(c, 4);
-                            HIPCHK(hipMemset(P.pr_slot, 0, persist_ring_slot_bytes(Ng)));
-                            HIPCHK(hipMemset(P.pr_rec, 0, persist_ring_rec_bytes(Ng, P.RW)));
-                            HIPCHK(hipMemset(P.pr_progress, 0, tiles * 4));
-                            HIPCHK(hipMemset(P.pr_ctl, 0, 16));
-                            c->persist = true;
-                            if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
-                            if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
-                            if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
-                        }
                     }
                     if ((want_persist_loc || want_persist_sh) && !c->persist && c->norm_fast) {   // (the lean plan stands: k_exch_plan lists the tiles' cones behind it)
                         const size_t tiles = persist_tiles;
@@ -1955,16 +1905,6 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             c->persist_max_tiles = per_cu * cus;
             if ((N + NORM_CT - 1) / NORM_CT > per_cu * cus) { c->persist = false; c->persist_loc = false; c->persist_sh = false; }
-        } else if (c->persist) {
-            // all tiles of the persistent kernel must be resident together (they wait for each other): one per CU
-            const size_t smem = persist_smem_bytes(Ng, np);
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_persist_norm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            HIPCHK(hipFuncSetAttribute((const void*)k_chain_persist_norm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            int per_cu = 0, cus = 0;
-            if (np == 1) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_persist_norm<1>, NORM_WG, smem));
-            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_persist_norm<2>, NORM_WG, smem));
-            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-            if ((N + NORM_CT - 1) / NORM_CT > per_cu * cus) c->persist = false;
         }
         if (c->persist) {
             c->snap_cs = dalloc<double>(c, (size_t)N * CSW);

@@ -61,6 +61,18 @@ def test_two_ranks_on_one_device_rows_form_checks_itself():
 def test_single_gpu_line_carries_the_persistent_kernel():
     d = run(["--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
     r = d["roofline"]
-    assert r["kernel"].startswith("k_chain_persist_norm") and r["persistent"]["launches"] >= 2 and r["persistent"]["repairs"] == 0
+    assert r["kernel"].startswith("k_chain_persist_loc") and r["persistent"]["launches"] >= 2 and r["persistent"]["repairs"] == 0
     assert r["one_launch_per_iteration"]["avg_kernel_us"] > r["avg_kernel_us"] > 0
     assert "0 inconsistent partner marks" in d["config"]["cross_rank_check"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_take_the_persistent_form():
+    # VERDICT r4 "Next #1" (iii): bench.py --gpus N: the self-check passes on the form the timed run uses, the timed run takes the
+    # persistent form (2 x 2048 chains: all 256 tiles resident on the one GPU) and the line says which form ran
+    d = run(["--gpus", "2", "--same-device", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and cfg["world_seen"] == 2 and cfg["protocol"] == "p2p"
+    assert cfg["shard_form"].startswith("persistent"), cfg["shard_form"]
+    assert d["roofline"]["kernel"] == "k_chain_persist_loc<2, false, true>" and d["roofline"]["persistent"]["repairs"] == 0
+    assert "0 inconsistent partner marks across 2 rank(s)" in cfg["cross_rank_check"]

@@ -15,6 +15,7 @@ from smm_jl_amd import _abi as A
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(ROOT, "julia", "SMMHip.jl")
 GLUE = os.path.join(ROOT, "julia", "SMMHipBackend.jl")
+SHARDED = os.path.join(ROOT, "julia", "SMMHipSharded.jl")
 HEADER = os.path.join(ROOT, "include", "smmhip.h")
 
 JL2C = {"SmmProblem": "smm_problem_t", "SmmBgpOpts": "smm_bgp_opts_t", "SmmTables": "smm_tables_t",
@@ -145,7 +146,7 @@ def test_glue_has_the_reference_shape():
 def test_block_structure_is_balanced():
     """coarse syntax check: block openers at bracket depth 0 and `end`s balance, brackets balance"""
     openers = {"module", "struct", "function", "if", "for", "while", "begin", "let", "try", "do", "macro", "quote"}
-    for path in (RAW, GLUE):
+    for path in (RAW, GLUE, SHARDED):
         src = strip_julia(open(path).read())
         depth, blocks = 0, 0
         for tok in re.findall(r"[A-Za-z_]\w*!?|[()\[\]{}]", src):
@@ -212,7 +213,7 @@ def test_every_package_the_julia_files_load_is_available_next_to_smm():
         deps = set(re.findall(r"(?m)^(\w+)\s*=\s*\"[0-9a-f-]{36}\"", open("/root/reference/Project.toml").read().split("[deps]")[1].split("[compat]")[0]))
         assert deps == SMM_DEPS, deps ^ SMM_DEPS
     own = {"SMM", "SMMHip", "SMMHipBackend"}
-    for path in (RAW, GLUE):
+    for path in (RAW, GLUE, SHARDED):
         src = strip_julia(open(path).read())
         for m in re.finditer(r"(?m)^\s*(?:using|import)\s+([^\n]+)", src):
             for item in m.group(1).split(":")[0].split(","):
@@ -228,3 +229,37 @@ def test_sync_chains_returns_at_once_when_nothing_was_stepped():
     # ... and every path that enqueues iterations counts them
     assert len(re.findall(r"setfield!\(algo, :stepped,", glue)) >= 4
     assert os.path.isfile(os.path.join(ROOT, "julia", "FIRST_RUN.md"))
+
+
+def test_single_steps_are_counted_and_enqueued_asynchronously():
+    """VERDICT r4 "Next #6": the reference's unchanged run! loop (AlgoAbstract.jl:38-45) calls computeNextIteration! once per iteration;
+    the glue must neither synchronise with the device nor make a library call per iteration (one iteration at a time never takes the
+    persistent form): the calls are counted and flushed as ONE smm_bgp_step_async when somebody reads the chains"""
+    glue = strip_julia(open(GLUE).read())
+    body = re.search(r"function computeNextIteration!\(algo::MAlgoBGPHip\)(.*?)\nend", glue, re.S).group(1)
+    assert "hip_step" not in body and "hip_sync" not in body and ":deferred" in body and "flush_steps!" in body
+    flush = re.search(r"function flush_steps!\(algo::MAlgoBGPHip\)(.*?)\nend", glue, re.S).group(1)
+    assert "hip_step_async!" in flush and "hip_sync" not in flush
+    sync = re.search(r"function sync_chains!\(algo::MAlgoBGPHip\)(.*?)\nend", glue, re.S).group(1)
+    assert sync.index("flush_steps!(algo)") < sync.index("getfield(algo, :stepped) == getfield(algo, :synced) && return chains") < sync.index("hip_sync(hip)")
+    # a failing step still leaves the count at what the device completed (ADVICE r4)
+    assert len(re.findall(r"setfield!\(algo, :stepped, SMMHip\.hip_iter\(", glue)) >= 2
+    raw = strip_julia(open(RAW).read())
+    assert re.search(r"ccall\(sym\(:smm_bgp_step_async\)", raw)
+
+
+def test_sharded_driver_uses_only_distributed_and_the_binding():
+    """VERDICT r4 "Next #6": julia/SMMHipSharded.jl — a Distributed-only multi-GPU driver (no MPI.jl): every SMMHip function it calls is
+    defined in the binding, the handles travel by remotecall_fetch, step / finish run under @sync (the barrier the header asks for)"""
+    src = strip_julia(open(SHARDED).read())
+    raw = strip_julia(open(RAW).read())
+    glue = strip_julia(open(GLUE).read())
+    used = set(re.findall(r"\bSMMHip\.(hip_\w+!?)", src))
+    assert {"hip_p2p_init", "hip_p2p_attach!", "hip_p2p_step!", "hip_p2p_finish!", "hip_sync", "hip_history", "hip_state", "hip_destroy!"} <= used, used
+    for f in used:
+        assert re.search(r"(?m)^(?:function\s+)?%s\(" % re.escape(f), raw), "SMMHip.%s is not defined in the binding" % f
+    assert re.search(r"function hip_context\(m::MProb, opts::Dict; N_local::Int", glue) and "SMMHipBackend.hip_context(" in src
+    assert "using Distributed" in src and "MPI" not in src
+    assert len(re.findall(r"@sync for", src)) >= 5 and "remotecall_fetch(shard_finish" in src and "remotecall_fetch(shard_attach" in src
+    for name in ("smm_bgp_p2p_init", "smm_bgp_p2p_attach", "smm_bgp_p2p_step", "smm_bgp_p2p_finish", "smm_get_persistent", "smm_set_persistent"):
+        assert re.search(r"ccall\(sym\(:%s\)" % name, raw), name
