@@ -1679,6 +1679,13 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const bool want_persist_gen = want_cone && !c->dense_keys && c->obj == SMM_OBJ_BANANA && np <= PG_MAXP && nm <= PG_MAXP && opts->batch_size == np && !opts->chol_L &&
                                           N == Ng && N / PG_CT <= n_cus && !c->deep_plan && P.dbg == 0 &&
                                           persist_gen_smem_bytes(Ng, np, P.RW, P.HW) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
+            // ... and for the smaller populations of the same objective (up to 4096 chains in whole groups of 32: VERDICT r4 "banana at 2048
+            // chains takes the per-iteration path"): the same kernel — the cones are listed behind the lean plan whether or not the
+            // per-iteration kernel walks them
+            const bool want_persist_gen_small = !want_cone && c->obj == SMM_OBJ_BANANA && np <= PG_MAXP && nm <= PG_MAXP && opts->batch_size == np && !opts->chol_L &&
+                                                N == Ng && N % PG_CT == 0 && N / PG_CT >= 1 && N / PG_CT <= n_cus && c->inline_walk && c->lds_exchange && P.mi_uniform &&
+                                                P.mi_value == 0.0 && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && !c->deep_plan && P.dbg == 0 &&
+                                                persist_gen_smem_bytes(Ng, np, P.RW, P.HW) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
             // ... and on LOCALLY NUMBERED cones (smm_chain_persist_loc.hpp): the same objective with one threshold >= 0 (or NaN: nothing
             // ever swaps) for all chains — min_improve > 0 is the reference's default (AlgoBGP.jl:522) —, whatever the population's size
             // does to the tile's LDS
@@ -1690,7 +1697,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                          ns <= WG * PR_ZR && P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && !c->deep_plan && N / NORM_CT <= n_cus &&
                                          P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0') &&
                                          (c->lds_exchange ? K <= XLDS_MAX : (c->big_exchange && Ng <= 32768 && K <= 65535 && (size_t)Ng * 4 <= (size_t)160 * 1024));
-            const size_t persist_tiles = want_persist_gen ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
+            const size_t persist_tiles = (want_persist_gen || want_persist_gen_small) ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             // large single shards of objfunc_norm (C3 on one GPU): the narrow chain kernel's tiles walk their own, locally numbered cones
             // (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two launches
             const char* cbh = SMM_HOOK("SMMHIP_CONE_BIG");   // test hook: "0" keeps k_exch_resolve_rows between the launches
@@ -1702,7 +1709,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                      (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / cone_ct) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
                                      ((want_persist_loc || want_persist_sh) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
                                      ((want_persist_sh && c->big_exchange) ? cone_big_scratch_words(Ng, K) * 4 : 0) +
-                                     (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0);
+                                     (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0) +
+                                     (want_persist_gen_small ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
             c->win_cap = std::min(c->win_cap, T);
             c->plan_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)1536 << 20) / plan_iter));
@@ -1822,6 +1830,27 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                 if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                             }
                         }
+                    }
+                    if (want_persist_gen_small && keys && !c->persist) {
+                        const size_t tiles = persist_tiles;
+                        P.cone_tiles = (int)tiles; P.cone_ct = PG_CT;
+                        P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
+                        P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
+                        P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);
+                        P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP + 512);
+                        HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
+                        P.pr_slot = (uint2*)dalloc<unsigned char>(c, persist_ring_slot_bytes(Ng));
+                        P.pr_rec = (uint4*)dalloc<unsigned char>(c, persist_ring_rec_bytes(Ng, P.RW));
+                        P.pr_progress = dalloc<uint32_t>(c, tiles);
+                        P.pr_ctl = dalloc<uint32_t>(c, 4);
+                        HIPCHK(hipMemset(P.pr_slot, 0, persist_ring_slot_bytes(Ng)));
+                        HIPCHK(hipMemset(P.pr_rec, 0, persist_ring_rec_bytes(Ng, P.RW)));
+                        HIPCHK(hipMemset(P.pr_progress, 0, tiles * 4));
+                        HIPCHK(hipMemset(P.pr_ctl, 0, 16));
+                        c->persist = true; c->persist_gen = true;
+                        if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
+                        if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
+                        if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                     }
                     if ((want_persist_loc || want_persist_sh) && !c->persist && c->norm_fast) {   // (the lean plan stands: k_exch_plan lists the tiles' cones behind it)
                         const size_t tiles = persist_tiles;

@@ -807,6 +807,21 @@ def test_c5_dense_4096_chains(S, O):
     cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
 
 
+def test_c5_bench_instance_against_oracle(S, O):
+    # the instance bench.py --workload c5 times since round 5 (acc_tuner 60000 .. 3000: the cold chains accept 20-40 %, sigma is
+    # stationary — VERDICT r4 "Next #4"; tools/exp/c5_instance.py), 4096 chains, 60 iterations, whole history against the oracle
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    prob, opts = bench.build_problem("c5", 4096, 4096, 0, 60, 0)
+    h, o = make_pair(S, O, prob, opts, threads=16)
+    h.step(60); o.step(60)
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+    acc = h.history().accepted[1:].mean()
+    assert 0.2 < acc < 0.9, acc          # (not the 0.99 of the old instance)
+
+
 @pytest.mark.parametrize("kind,npar,N,sig,smpl,bs", [("dense", 50, 100, 0.08, 100000, None), ("dense", 50, 37, 0.12, 100000, 25),
                                                       ("dense", 50, 16, 0.3, 40, None), ("norm", 18, 70, 0.12, 100000, None),
                                                       ("norm", 32, 9, 0.15, 100000, 16), ("dense", 64, 33, 0.06, 100000, None)])

@@ -24,7 +24,10 @@ def _pair(S, O, prob, opts, tab=None):
     return h, o
 
 
-@pytest.mark.parametrize("N,npar,steps", [(8192, 10, [40]), (5024, 10, [1, 5, 2, 14, 8]), (4128, 3, [300]), (8192, 12, [12]), (6400, 7, [25])])
+# (round 5: the populations up to 4096 chains too — 2048, 256, one workgroup of 32, 4096, eight parameters and fewer: the per-iteration
+# path's eight pre-generated tries against the kernel's two — "banana at 2048 chains takes the per-iteration path")
+@pytest.mark.parametrize("N,npar,steps", [(8192, 10, [40]), (5024, 10, [1, 5, 2, 14, 8]), (4128, 3, [300]), (8192, 12, [12]), (6400, 7, [25]),
+                                          (2048, 10, [40]), (256, 10, [1, 5, 2, 14, 8]), (32, 4, [30]), (4096, 2, [300]), (1024, 16, [20])])
 def test_persistent_gen_form_against_oracle_and_per_iteration_kernel(S, O, N, npar, steps):
     T = sum(steps)
     prob, opts = banana(S, N, T, npar)
@@ -110,7 +113,10 @@ def test_persistent_gen_form_where_it_does_not_apply(S):
     prob, opts = banana(S, 6000, 4)          # not whole workgroups of 32 chains
     h = S.hip_context(prob, opts)
     assert h.persistent_info()[0] == 0
-    prob, opts = banana(S, 4096, 4)          # the 16-byte walk's population
+    prob, opts = banana(S, 4096, 4)          # round 5: the populations up to 4096 chains in whole groups of 32 too
+    h = S.hip_context(prob, opts)
+    assert h.persistent_info()[0] == 1
+    prob, opts = banana(S, 1000, 4)          # ... not 1000
     h = S.hip_context(prob, opts)
     assert h.persistent_info()[0] == 0
     prob, opts = banana(S, 8192, 6)

@@ -21,7 +21,7 @@ else:
     rng = np.random.default_rng(3)
     prob = S.Problem(init=rng.uniform(-0.3, 0.3, npar), lb=-np.ones(npar), ub=np.ones(npar), mom=rng.uniform(-0.5, 0.5, nm),
                      w=rng.uniform(0.5, 2.0, nm), ns=1, objective_id=A.SMM_OBJ_DENSE)
-    opts = S.BGPOpts(N=N, maxiter=T, sigma=0.004 * cm.temps(N, 3), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N),
+    opts = S.BGPOpts(N=N, maxiter=T, sigma=0.004 * cm.temps(N, 3), acc_tuner=3000.0 * np.geomspace(20, 1, N), min_improve=np.zeros(N),   # (bench.py: C5_ACC_SCALE)
                      N_global=N, seed=3, smpl_iters=100000)
 c = S.hip_context(prob, opts)
 c.step(200)
