@@ -1590,7 +1590,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* lw = SMM_HOOK("SMMHIP_LVL_WG");  // tuning hook
             if (lw) c->lvl_wg = atoi(lw);
             const char* be = SMM_HOOK("SMMHIP_BIG_EXCHANGE");  // test hook: force the global-memory level kernels
-            const bool force_big = be && be[0] == '1';
+            // (... and a SHARD whose population is past what the lean plan's 16-byte walk holds in LDS — one min_improve > 0 for all chains of
+            // 7400 < N_global <= 8192, e.g. 2 x 4096 with the reference's default threshold —: the global-memory plan lists its tiles' cones,
+            // locally numbered, so that the shard can still take the persistent form)
+            const bool shard_wide_big = N < Ng && c->lds_exchange && P.mi_uniform && P.mi_value != 0.0 && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS &&
+                                        resolve_lean_bytes(Ng, K, true) > (size_t)160 * 1024;
+            const bool force_big = (be && be[0] == '1') || shard_wide_big;
             c->big_exchange = Ng > 1 && Ng <= 65535 && K >= 1 && K <= Ng && !c->force_any_exchange && (force_big || !c->lds_exchange);
             if (c->big_exchange) { c->lds_exchange = false; c->lvl_exchange = false; c->lvl_soa_exchange = false; }
             const char* ke = SMM_HOOK("SMMHIP_KEY_EXCHANGE");   // test hook: "0" keeps the global-memory walk
@@ -2807,6 +2812,30 @@ int smm_debug_ts(void* ctx, unsigned long long* out, int n_wg) {
 }
 
 #ifdef SMM_TEST_HOOKS
+// debug (test build only, not part of the public header): the look-ahead window starting at iteration t, planned now; milliseconds of its
+// kernels on the stream (tools/exp/shard_plan_time.py: what a shard of 8 x 4096 spends on its plan per window)
+int smm_debug_plan_window(void* ctx, int t, double* ms_out, int* window_out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !ms_out) return SMM_ERR_INVALID_ARG;
+    try {
+        HIPCHK(hipSetDevice(c->device));
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        c->plan_w = 0;
+        HIPCHK(hipEventRecord(e0, c->stream));
+        ensure_windows(c, t, false);
+        HIPCHK(hipEventRecord(e1, c->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = ms;
+        if (window_out) *window_out = c->plan_w;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    } catch (const std::string& m) {
+        return fail(c, SMM_ERR_HIP, m);
+    }
+    return SMM_OK;
+}
 // debug (test build only, not part of the public header): the cone of one tile in iteration plan_t0 + w of the current plan window
 int smm_debug_cone(void* ctx, int w, int tile, uint32_t* hdr, uint32_t* pairs, uint16_t* gather, int32_t* info) {
     Ctx* c = (Ctx*)ctx;

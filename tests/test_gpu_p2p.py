@@ -190,7 +190,7 @@ def test_p2p_rows_with_a_deep_plan_and_injected_tables(S):
     assert_shards_equal_single(ctxs, single)
 
 
-@pytest.mark.parametrize("case", ["norm_16384", "norm_mi", "general_np6", "banana", "dense"])
+@pytest.mark.parametrize("case", ["norm_16384", "norm_mi", "norm_mi_8192", "general_np6", "banana", "dense"])
 def test_p2p_generic_equals_single(S, case):
     # everything the inline form does not cover: chain kernel into the own window + push kernel + resolve from the window
     G, T = 2, 10
@@ -199,6 +199,9 @@ def test_p2p_generic_equals_single(S, case):
         prob, opts = cm.serial_normal(N=16384, T=T, ns=64)
     elif case == "norm_mi":
         prob, opts = cm.serial_normal(N=96, T=T, ns=200, min_improve=0.05)
+    elif case == "norm_mi_8192":   # 2 x 4096 with a threshold: past the 16-byte lean walk's LDS, so the shards take the global-memory plan (round 5)
+        T = 6
+        prob, opts = cm.serial_normal(N=8192, T=T, ns=64, min_improve=0.05)
     elif case == "general_np6":
         prob, opts = cm.general_normal(6, 96, T, ns=200, batch_size=3)
     elif case == "banana":
