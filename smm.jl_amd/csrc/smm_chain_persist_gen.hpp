@@ -42,6 +42,7 @@ struct PersistGenArgs {
     uint32_t epoch;
     double sigma_adjust_by;
     uint64_t seed;
+    const double* udata; int n_udata; // a user objective's own data (SMM_GEN_USER: the kernel compiled with the user's source, below)
 };
 
 __host__ __device__ inline int persist_gen_rngw(int np) { return (1 + PG_TRIES * np + 1) & ~1; }
@@ -54,7 +55,17 @@ __host__ __device__ inline size_t persist_gen_smem_bytes(int Ng, int np, int RW,
     return slots + lists + dbl * 8 + land;
 }
 
+// A USER OBJECTIVE in this loop (round 5; mprob.jl:159,182 — "bring your own objective"): the library compiles THIS FILE once more with
+// hiprtc, together with the user's source (smm_register_user_objective: SMM_USER_OBJECTIVE(theta, np, mom, w, nm, udata, n_udata,
+// sim_moments, value, status)), as SMM_GEN_USER — the kernel is then smm_user_persist_kernel, lane 0 of every chain's quad calls the
+// user's function on the proposal in LDS (one thread per evaluation, as the stand-alone smm_user_eval_kernel does), the chain's simulated
+// moments are the function's, and a failing evaluation (status < 0) is the rejection of mprob.jl:183-186 / AlgoBGP.jl:336-338.
+__host__ __device__ inline size_t persist_gen_user_bytes() { return (size_t)PG_CT * PG_MAXP * 8 + (size_t)PG_CT * 8 + (size_t)PG_CT * 8; }
+#ifdef SMM_GEN_USER
+extern "C" __global__ __launch_bounds__(1024, 4) void smm_user_persist_kernel(const PersistGenArgs A) {
+#else
 __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenArgs A) {
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,6 +97,11 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
     unsigned* s_pub = s_flags + 4;                              // publications of this workgroup's control waves so far (two per iteration)
     unsigned* s_read = s_flags + 5;                             // ... and their completed reads of the ring's last entry
     uint4* s_land = (uint4*)(s_ts + 16);                        // [2][NPC][64]
+#ifdef SMM_GEN_USER
+    double* s_usm = (double*)(lds + persist_gen_smem_bytes(A.Ng, np, RW, HW));   // [32][PG_MAXP]: the user's simulated moments of this iteration's proposals
+    double* s_uval = s_usm + PG_CT * PG_MAXP;                   // [32]: ... values
+    double* s_ust = s_uval + PG_CT;                             // [32]: ... status (as a double)
+#endif
     const uint32_t epoch = A.epoch;
     const int t0 = A.t0, t1 = A.t1;
     const PrWait W{A.err, A.pr_ctl, s_abort, A.epoch, A.tmo};
@@ -409,6 +425,22 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
             // (every lane of the quad computes the same value: its lanes read the proposal out of LDS, whose writes completed in order)
             const double* thp = s_theta + cl * PG_MAXP;
             double value = 0.0;
+            int status = 1;
+#ifdef SMM_GEN_USER
+            // evaluateObjective(m, p) (mprob.jl:175-188) -> the user's function, by lane 0 of the chain's quad; the quad's other lanes read
+            // its results out of LDS (same wave: the writes complete in order)
+            if (r == 0) {
+                int st_u = 1;
+                double v_u = 0.0;
+                smm_user_objective(thp, np, s_const + 2 * PG_MAXP, s_const + 3 * PG_MAXP, nm, A.udata, A.n_udata, s_usm + cl * PG_MAXP, &v_u, &st_u);
+                s_uval[cl] = v_u; s_ust[cl] = (double)st_u;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            value = s_uval[cl];
+            status = (int)s_ust[cl];
+            const bool failed = status < 0;          // the objective's "exception": status -2, rejected with prob 0 (mprob.jl:183-186, AlgoBGP.jl:336-338)
+#else
             for (int i = 0; i + 1 < np; ++i) {
                 const double a = thp[i], b = thp[i + 1];
                 const double t1_ = b - a * a;
@@ -416,14 +448,16 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
                 const double term = 100.0 * (t1_ * t1_) + t2_ * t2_;
                 value = (i == 0) ? term : value + term;
             }
-            int status = 1;
+            const bool failed = false;
+#endif
             const double atun = cs[CS_ATUN];
             const double uu = rows[0];
             const double old = rin[0];
             double prob;
             bool acc;
-            if (!(value >= 0.0) && r == 0) pr_report(A.err, 1, t, c);   // :341
-            {
+            if (failed) { prob = 0.0; acc = false; }                     // :336-338
+            else {
+                if (!(value >= 0.0) && r == 0) pr_report(A.err, 1, t, c);   // :341
                 const double e = pr_exp(atun * (old - value));
                 prob = (e != e) ? e : (e < 1.0 ? e : 1.0);   // minimum([1.0,e]), NaN propagates (:344)
                 if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }   // :350-353
@@ -434,7 +468,11 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
             const double v = acc ? value : old;
             // ---- the chain's last accepted record (lastAccepted :209-215) = input of the exchange step: by the quad's lanes into LDS ----
             {
+#ifdef SMM_GEN_USER
+                const double* msim = s_usm + cl * PG_MAXP;
+#else
                 const double* msim = s_const + 4 * PG_MAXP;
+#endif
                 for (int k = r; k < np; k += 4) rout[3 + k] = acc ? thp[k] : rin[3 + k];
                 for (int k = r; k < nm; k += 4) rout[3 + np + k] = acc ? msim[k] : rin[3 + np + k];
                 if (r == 0) {
@@ -498,7 +536,11 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
                 if (HW > H_PARAMS + np + nm) hv[HW - 1] = 0.0;
             }
             for (int k = r; k < np; k += 4) hv[H_PARAMS + k] = thp[k];
+#ifdef SMM_GEN_USER
+            for (int k = r; k < nm; k += 4) hv[H_PARAMS + np + k] = s_usm[cl * PG_MAXP + k];
+#else
             for (int k = r; k < nm; k += 4) hv[H_PARAMS + np + k] = s_const[4 * PG_MAXP + k];
+#endif
             asm volatile("" ::: "memory");
             if (r == 0) {
                 slots[c] = make_uint2(order_key32(v), (uint32_t)c);

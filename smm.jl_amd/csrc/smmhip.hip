@@ -83,7 +83,18 @@ thread_local std::string g_create_err;
 // ------------------------------------------------------------------------------------------
 // user objectives: compiled with hiprtc (loaded lazily, the library does not link against it)
 // ------------------------------------------------------------------------------------------
-struct UserObjective { std::vector<char> code; int lanes = 0; /* 0: one thread per chain; else lanes per chain (map-reduce form) */ };
+struct UserObjective {
+    std::vector<char> code; int lanes = 0; /* 0: one thread per chain; else lanes per chain (map-reduce form) */
+    std::string source;                    // the user's text (one thread per chain form): compiled once more INTO the persistent kernel on demand
+    std::vector<char> persist_code;        // k_chain_persist_gen with the user's objective inside (smm_chain_persist_gen.hpp, SMM_GEN_USER)
+    int persist_state = 0;                 // 0: not tried yet, 1: persist_code stands, -1: did not compile (persist_log)
+    std::string persist_log;
+};
+// the device headers the persistent kernel is made of, as text: hiprtc compiles them together with the user's source
+struct EmbeddedSource { const char* name; const char* text; };
+const EmbeddedSource g_embedded[] = {
+#include "smm_embedded.inc"
+};
 std::vector<UserObjective> g_user_objectives;
 std::mutex g_user_mutex;
 
@@ -158,6 +169,58 @@ struct Hiprtc {
 };
 Hiprtc g_rtc;
 
+// k_chain_persist_gen with a user objective inside: the library's own device headers (embedded as text) + the user's source through
+// hiprtc, once per registered objective and on demand (the first context that qualifies for the persistent form: ~1.5 s).  false: the
+// form is not available for this objective (u.persist_log says why); the per-iteration launches serve it as before.
+bool user_persist_compile(UserObjective& u) {   // (g_user_mutex held)
+    if (u.persist_state != 0) return u.persist_state > 0;
+    u.persist_state = -1;
+    if (u.source.empty() || u.lanes != 0) { u.persist_log = "not the one-thread-per-chain form"; return false; }
+    std::string err;
+    if (!g_rtc.load(err)) { u.persist_log = err; return false; }
+    std::string tu =
+        "#include <type_traits>\n#include <stdint.h>\n#include <math.h>\n"
+        "#define SMM_USER_OBJECTIVE extern \"C\" __device__ void smm_user_objective\n"
+        "extern \"C\" __device__ void smm_user_objective(const double* theta, int np, const double* mom, const double* w, int nm,\n"
+        "        const double* udata, int n_udata, double* sim_moments, double* value, int* status);\n";
+    tu += u.source;
+    tu += "\n#define SMM_GEN_USER 1\n#include \"smmhip.h\"\n#include \"smm_rng.hpp\"\nusing namespace smm;\n#include \"smm_params.hpp\"\n"
+          "#include \"smm_walk_lean.hpp\"\n#include \"smm_chain.hpp\"\n#include \"smm_p2p.hpp\"\n#include \"smm_chain_norm.hpp\"\n"
+          "#include \"smm_chain_persist.hpp\"\n#include \"smm_chain_persist_gen.hpp\"\n";
+    std::vector<const char*> names, texts;
+    for (const EmbeddedSource& e : g_embedded) { names.push_back(e.name); texts.push_back(e.text); }
+    // (what the headers ask the host's toolchain for: hiprtc brings its own runtime header and has no system headers to lean on)
+    static const char* stub_stdint = "typedef unsigned int uint32_t; typedef unsigned long uint64_t; typedef int int32_t; typedef long int64_t;\n"
+                                     "typedef unsigned short uint16_t; typedef unsigned char uint8_t; typedef signed char int8_t; typedef short int16_t;\n";
+    static const char* stub_math = "#ifndef INFINITY\n#define INFINITY __builtin_huge_val()\n#endif\n#ifndef NAN\n#define NAN __builtin_nan(\"\")\n#endif\n";
+    names.push_back("hip/hip_runtime.h"); texts.push_back("\n");
+    names.push_back("stdint.h"); texts.push_back(stub_stdint);
+    names.push_back("math.h"); texts.push_back(stub_math);
+    hiprtcProgram prog = nullptr;
+    if (g_rtc.create(&prog, tu.c_str(), "smm_user_persist.hip", (int)names.size(), texts.data(), names.data()) != HIPRTC_SUCCESS) {
+        u.persist_log = "hiprtcCreateProgram failed";
+        return false;
+    }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};
+    const hiprtcResult rc = g_rtc.compile(prog, 5, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        g_rtc.log_size(prog, &n);
+        std::string log(n, ' ');
+        if (n) g_rtc.log(prog, &log[0]);
+        u.persist_log = log;
+        g_rtc.destroy(&prog);
+        return false;
+    }
+    size_t cs = 0;
+    g_rtc.code_size(prog, &cs);
+    u.persist_code.resize(cs);
+    g_rtc.code(prog, u.persist_code.data());
+    g_rtc.destroy(&prog);
+    u.persist_state = 1;
+    return true;
+}
+
 struct Ctx {
     KParams P{};
     int obj = 0, device = 0, exchange_from = 2;
@@ -231,6 +294,10 @@ struct Ctx {
     int n_objp = 0;                 // doubles in P.objp
     hipModule_t umod = nullptr;     // user objective: this context's module and kernel
     hipFunction_t ufn = nullptr;
+    hipModule_t upmod = nullptr;    // ... and the persistent kernel compiled with it inside (smm_chain_persist_gen.hpp, SMM_GEN_USER)
+    hipFunction_t upfn = nullptr;
+    bool persist_user = false;      // persist_gen launches upfn
+    bool defer_resolve = false;     // the exchange of an iteration is left unresolved until somebody needs it (the next launch may be the persistent kernel's)
     bool rec_external = false;  // the records after the last accept step were written to the caller's gather buffer (sharded_step)
     bool unresolved = false;    // exchangeMoves! of iteration `iter` is still to be resolved (inline, or by resolve_now)
     bool big_exchange = false;   // 8192 < N_global <= 65535: level plan and walk in global memory
@@ -1082,9 +1149,14 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.walk_first = c->unresolved ? 1 : 0;
         A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
         A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.seed = P.seed; A.tmo = tmo;
+        A.udata = P.objp; A.n_udata = c->n_objp;
         const dim3 grid(P.N / PG_CT), block(1024);
-        const size_t smem = persist_gen_smem_bytes(P.Ng, P.np, P.RW, P.HW);
-        if (c->kev0) hipExtLaunchKernelGGL(k_chain_persist_gen, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
+        const size_t smem = persist_gen_smem_bytes(P.Ng, P.np, P.RW, P.HW) + (c->persist_user ? persist_gen_user_bytes() : 0);
+        if (c->persist_user) {   // the same kernel, compiled with the user's objective inside (user_persist_compile)
+            void* args[] = {(void*)&A};
+            if (c->kev0) HIPCHK(hipExtModuleLaunchKernel(c->upfn, grid.x * 1024u, 1, 1, 1024, 1, 1, smem, c->stream, args, nullptr, c->kev0, c->kev1, 0));
+            else HIPCHK(hipModuleLaunchKernel(c->upfn, grid.x, 1, 1, 1024, 1, 1, (unsigned)smem, c->stream, args, nullptr));
+        } else if (c->kev0) hipExtLaunchKernelGGL(k_chain_persist_gen, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
         else hipLaunchKernelGGL(k_chain_persist_gen, grid, block, smem, c->stream, A);
     }
     c->cur ^= 1;
@@ -1118,6 +1190,9 @@ void enqueue_iterations(Ctx* c, int n_iters) {
         }
         // an exchange left to this chain kernel needs its plan: resolve it now if the plan window is about to move on
         if (c->unresolved && !(t >= c->plan_t0 && t < c->plan_t0 + c->plan_w) && !plan_ahead_covers(c, t)) resolve_now(c);
+        // ... or if this chain kernel cannot walk (a user objective's launches): the resolution was only put off in case the persistent
+        // kernel came next (defer_resolve)
+        if (c->unresolved && c->defer_resolve && !c->inline_walk) resolve_now(c);
         ensure_windows(c, t);
         const int flags = (c->prev_open ? F_CLOSE_PREV : 0) | (c->pending ? F_HAS_PENDING : 0) | (c->unresolved ? F_WALK_INLINE : 0);
         const bool kscoped = c->profiling == 2 && c->lvl_exchange && c->lvl_wg == 1024;
@@ -1133,7 +1208,8 @@ void enqueue_iterations(Ctx* c, int n_iters) {
         if (exchange_active(c, t)) {
             const bool cone_next = c->cone_big && !c->nan_values && !c->ext_rec_in && !c->ext_rec_out && !c->ext_vals_out && !c->rec_external &&
                                    t >= c->plan_t0 && t < c->plan_t0 + c->plan_w && c->cone_big_ok[(size_t)(t - c->plan_t0)] != 0u;
-            if (cone_next || (c->inline_walk && !(c->gen_keys && (c->deep_plan || c->nan_values)))) {   // (the key form has no second walk to fall back to)
+            if (cone_next || (c->inline_walk && !(c->gen_keys && (c->deep_plan || c->nan_values))) ||
+                (c->defer_resolve && c->persist_on && !c->persist_broken && !c->in_repair && !c->nan_values)) {   // (the key form has no second walk to fall back to)
                 c->unresolved = true;   // resolved in the prologue of the next chain kernel (or by resolve_now)
             } else {
                 if (kscoped) { c->kev0 = c->pev[4 * slot + 2]; c->kev1 = c->pev[4 * slot + 3]; c->pev_exch[slot] = 1; }
@@ -1335,7 +1411,7 @@ int smm_debug_has_test_hooks(void) {
 #endif
 }
 
-static int register_user_source(const std::string& src, int n_sums, int lanes, int32_t* objective_id_out) {
+static int register_user_source(const std::string& src, int n_sums, int lanes, int32_t* objective_id_out, const char* user_text = nullptr) {
     std::lock_guard<std::mutex> lock(g_user_mutex);
     std::string err;
     if (!g_rtc.load(err)) { g_create_err = err; return SMM_ERR_HIP; }
@@ -1361,6 +1437,7 @@ static int register_user_source(const std::string& src, int n_sums, int lanes, i
     UserObjective u;
     u.code.resize(cs);
     u.lanes = lanes;
+    if (user_text) u.source = user_text;
     g_rtc.code(prog, u.code.data());
     g_rtc.destroy(&prog);
     g_user_objectives.push_back(std::move(u));
@@ -1370,7 +1447,7 @@ static int register_user_source(const std::string& src, int n_sums, int lanes, i
 
 int smm_register_user_objective(const char* hip_source, int32_t* objective_id_out) {
     if (!hip_source || !objective_id_out) { g_create_err = "smm_register_user_objective: null argument"; return SMM_ERR_INVALID_ARG; }
-    return register_user_source(std::string(USER_PRELUDE) + hip_source + USER_KERNEL, 1, 0, objective_id_out);
+    return register_user_source(std::string(USER_PRELUDE) + hip_source + USER_KERNEL, 1, 0, objective_id_out, hip_source);
 }
 
 int smm_register_user_objective_lanes(const char* hip_source, int32_t n_sums, int32_t lanes, int32_t* objective_id_out) {
@@ -1402,6 +1479,7 @@ void smm_ctx_destroy(void* ctx) {
     for (void* w : c->p2p_opened) if (w) (void)hipIpcCloseMemHandle(w);
     if (c->p2p_mine) (void)hipFree(c->p2p_mine);
     if (c->umod) (void)hipModuleUnload(c->umod);
+    if (c->upmod) (void)hipModuleUnload(c->upmod);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->pev) (void)hipEventDestroy(e);
@@ -1691,6 +1769,12 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                                 N == Ng && N % PG_CT == 0 && N / PG_CT >= 1 && N / PG_CT <= n_cus && c->inline_walk && c->lds_exchange && P.mi_uniform &&
                                                 P.mi_value == 0.0 && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && !c->deep_plan && P.dbg == 0 &&
                                                 persist_gen_smem_bytes(Ng, np, P.RW, P.HW) <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
+            // ... and a USER objective (one thread per evaluation) in the same loop: the kernel is compiled with the user's source inside
+            // (user_persist_compile), on demand, further down
+            const bool want_persist_user = user_obj && c->u_lanes == 0 && np <= PG_MAXP && nm <= PG_MAXP && opts->batch_size == np && !opts->chol_L &&
+                                           N == Ng && N % PG_CT == 0 && N / PG_CT >= 1 && N / PG_CT <= n_cus && c->lds_exchange && P.mi_uniform &&
+                                           P.mi_value == 0.0 && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && !c->deep_plan && P.dbg == 0 &&
+                                           persist_gen_smem_bytes(Ng, np, P.RW, P.HW) + persist_gen_user_bytes() <= (size_t)160 * 1024 && !(pe && pe[0] == '0');
             // ... and on LOCALLY NUMBERED cones (smm_chain_persist_loc.hpp): the same objective with one threshold >= 0 (or NaN: nothing
             // ever swaps) for all chains — min_improve > 0 is the reference's default (AlgoBGP.jl:522) —, whatever the population's size
             // does to the tile's LDS
@@ -1702,7 +1786,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                          ns <= WG * PR_ZR && P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && !c->deep_plan && N / NORM_CT <= n_cus &&
                                          P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0') &&
                                          (c->lds_exchange ? K <= XLDS_MAX : (c->big_exchange && Ng <= 32768 && K <= 65535 && (size_t)Ng * 4 <= (size_t)160 * 1024));
-            const size_t persist_tiles = (want_persist_gen || want_persist_gen_small) ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
+            const size_t persist_tiles = (want_persist_gen || want_persist_gen_small || want_persist_user) ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             // large single shards of objfunc_norm (C3 on one GPU): the narrow chain kernel's tiles walk their own, locally numbered cones
             // (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two launches
             const char* cbh = SMM_HOOK("SMMHIP_CONE_BIG");   // test hook: "0" keeps k_exch_resolve_rows between the launches
@@ -1715,7 +1799,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                      ((want_persist_loc || want_persist_sh) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
                                      ((want_persist_sh && c->big_exchange) ? cone_big_scratch_words(Ng, K) * 4 : 0) +
                                      (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0) +
-                                     (want_persist_gen_small ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0);
+                                     ((want_persist_gen_small || want_persist_user) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0);
             c->win_cap = pregen ? (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)768 << 20) / rb_iter)) : 1;
             c->win_cap = std::min(c->win_cap, T);
             c->plan_cap = (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)1536 << 20) / plan_iter));
@@ -1836,7 +1920,17 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                             }
                         }
                     }
-                    if (want_persist_gen_small && keys && !c->persist) {
+                    bool user_ok = false;
+                    if (want_persist_user && keys && !c->persist) {   // the kernel with the user's objective inside: compiled now (once per registered objective)
+                        std::lock_guard<std::mutex> lock(g_user_mutex);
+                        UserObjective& u = g_user_objectives[prob->objective_id - SMM_OBJ_USER_BASE];
+                        if (user_persist_compile(u)) {
+                            HIPCHK(hipModuleLoadData(&c->upmod, u.persist_code.data()));
+                            HIPCHK(hipModuleGetFunction(&c->upfn, c->upmod, "smm_user_persist_kernel"));
+                            user_ok = true;
+                        } else if (getenv("SMMHIP_VERBOSE")) fprintf(stderr, "libsmmhip: the persistent form of this user objective is not available:\n%s\n", u.persist_log.c_str());
+                    }
+                    if ((want_persist_gen_small || user_ok) && keys && !c->persist) {
                         const size_t tiles = persist_tiles;
                         P.cone_tiles = (int)tiles; P.cone_ct = PG_CT;
                         P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
@@ -1852,7 +1946,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                         HIPCHK(hipMemset(P.pr_rec, 0, persist_ring_rec_bytes(Ng, P.RW)));
                         HIPCHK(hipMemset(P.pr_progress, 0, tiles * 4));
                         HIPCHK(hipMemset(P.pr_ctl, 0, 16));
-                        c->persist = true; c->persist_gen = true;
+                        c->persist = true; c->persist_gen = true; c->persist_user = user_ok; c->defer_resolve = user_ok;
                         if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
                         if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
                         if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
@@ -1923,7 +2017,15 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const unsigned long long e = ERR_NONE;
             HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
         }
-        if (c->persist_gen) {
+        if (c->persist_user) {
+            const size_t smem = persist_gen_smem_bytes(Ng, np, P.RW, P.HW) + persist_gen_user_bytes();
+            (void)hipFuncSetAttribute((const void*)c->upfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // (a module's function: where the runtime takes it)
+            (void)hipGetLastError();
+            int per_cu = 0, cus = 0;
+            HIPCHK(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->upfn, 1024, smem));
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            if (N / PG_CT > per_cu * cus) { c->persist = false; c->persist_gen = false; c->persist_user = false; c->defer_resolve = false; }
+        } else if (c->persist_gen) {
             const size_t smem = persist_gen_smem_bytes(Ng, np, P.RW, P.HW);
             HIPCHK(hipFuncSetAttribute((const void*)k_chain_persist_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             int per_cu = 0, cus = 0;

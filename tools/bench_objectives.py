@@ -52,14 +52,27 @@ def main():
                      objective_id=oid, obj_params=[400.0])
     opts = S.BGPOpts(N=N, maxiter=T, sigma=0.05 * cm.temps(N, 4.0), acc_tuner=np.geomspace(3.0, 0.5, N), min_improve=np.zeros(N),
                      seed=5, N_global=N)
-    rows.append(("user objective AR(1) T=400, N=4096", rate(S.hip_context(prob, opts), N)))
+    cu = S.hip_context(prob, opts)
+    rows.append(("user objective AR(1) T=400, persistent loop (kernel compiled with it inside), N=4096", rate(cu, N)))
+    assert cu.persistent_info()[1] >= 1
+    cu = S.hip_context(prob, opts)
+    cu.set_persistent(False)
+    rows.append(("user objective AR(1) T=400, three launches per iteration, N=4096", rate(cu, N)))
+    for T_ar in (40,):   # a cheap objective: what the loop itself costs
+        prob2 = S.Problem(init=[0.3, 1.0], lb=[-0.95, 0.1], ub=[0.95, 3.0], mom=[0.0, 0.12, 0.06], w=[0.05, 0.05, 0.05], ns=1,
+                          objective_id=oid, obj_params=[float(T_ar)])
+        cu = S.hip_context(prob2, opts)
+        rows.append(("user objective AR(1) T=%d, persistent loop, N=4096" % T_ar, rate(cu, N)))
+        cu = S.hip_context(prob2, opts)
+        cu.set_persistent(False)
+        rows.append(("user objective AR(1) T=%d, three launches per iteration, N=4096" % T_ar, rate(cu, N)))
     # user objective, map-reduce form: a panel of 4096 AR(1) agents x 40 periods per evaluation, 256 lanes per chain
     oid = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=256)
     prob = S.Problem(init=[0.3, 1.0], lb=[-0.95, 0.1], ub=[0.95, 3.0], mom=[0.0, 0.12, 0.06], w=[0.05, 0.05, 0.05], ns=1,
                      objective_id=oid, obj_params=[40.0, 4096.0])
     rows.append(("user map-reduce panel 4096x40, N=4096", rate(S.hip_context(prob, opts), N, iters=100)))
     for name, r in rows:
-        print("%-44s %8.1f M chain-evals/s  (%.1f us per iteration)" % (name, r / 1e6, 1e6 / (r / int(name.split("N=")[1]))))
+        print("%-88s %8.1f M chain-evals/s  (%.1f us per iteration)" % (name, r / 1e6, 1e6 / (r / int(name.split("N=")[1]))))
 
 
 if __name__ == "__main__":
