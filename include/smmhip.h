@@ -357,6 +357,10 @@ int  smm_set_profiling(void* ctx, int32_t on);
  * smm_get_persistent: whether the next step would take this form; launches of it so far; repairs so far. */
 int  smm_set_persistent(void* ctx, int32_t on);
 int  smm_get_persistent(void* ctx, int32_t* available, int32_t* launches, int32_t* repairs);
+/* one line naming the forms this context was given at creation — per-iteration chain kernel, where the exchange is walked, the stand-alone
+ * resolution, the persistent form, the look-ahead plan and its window: "chain=iter_norm walk=inline_lean exchange=lean persistent=loc
+ * plan=lds window=256" (diagnostic; tests/test_gpu_forms.py holds the table of what is chosen when) */
+int  smm_describe(void* ctx, char* out, int32_t cap);
 /* copy of the shock matrix actually used, [nm][ns] */
 int  smm_get_Z(void* ctx, double* Z);
 

@@ -140,6 +140,7 @@ SYMBOLS = [
     ("smm_set_profiling", C.c_int, [C.c_void_p, C.c_int32]),
     ("smm_set_persistent", C.c_int, [C.c_void_p, C.c_int32]),
     ("smm_get_persistent", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("smm_describe", C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
 ]
 
 

@@ -265,6 +265,12 @@ class BGPContext:
         """the persistent form of step() (one launch per look-ahead window; include/smmhip.h): on by default where a context qualifies"""
         self._check(self._fn("set_persistent")(self._ctx, int(bool(on))))
 
+    def describe(self):
+        """the forms this context was given at creation, as a dict (smm_describe: chain / walk / exchange / persistent / plan / window)"""
+        buf = C.create_string_buffer(256)
+        self._check(self._fn("describe")(self._ctx, buf, 256))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split())
+
     def persistent_info(self):
         """(would the next step take the persistent form, launches of it so far, repairs so far)"""
         a, l, r = C.c_int32(0), C.c_int32(0), C.c_int32(0)

@@ -2894,6 +2894,30 @@ int smm_get_persistent(void* ctx, int32_t* available, int32_t* launches, int32_t
     return SMM_OK;
 }
 
+// which forms this context was given at creation (one line; tests/test_gpu_forms.py pins the table)
+int smm_describe(void* ctx, char* out, int32_t cap) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !out || cap < 1) return SMM_ERR_INVALID_ARG;
+    const KParams& P = c->P;
+    const char* chain;
+    if (c->obj == SMM_OBJ_USER) chain = c->u_lanes ? "user_lanes_3launches" : "user_3launches";
+    else if (c->norm_fast)
+        chain = c->cone_big ? "iter_norm_narrow_cone" : (!c->win_lv_pairs_p || c->deep_plan || c->nan_values) && c->inline_walk ? "iter_norm_any"
+              : (P.lean_wide && c->inline_walk) ? "iter_norm_wide" : c->norm_narrow ? "iter_norm_narrow" : "iter_norm";
+    else chain = c->obj == SMM_OBJ_DENSE ? "iter<dense,16>" : is_sim(c->obj) ? (c->tpw == 2 ? "iter<sim,8,2>" : "iter<sim,8>")
+               : (c->gen_keys ? "iter<gen,16,2>" : c->tpw == 2 ? "iter<gen,8,2>" : "iter<gen,8>");
+    static const char* xk[] = {"lean", "lvl", "lvl_soa", "tickets", "rows", "key", "lvl_big", "any"};
+    const char* walk = c->cone_big ? "cone_local" : !c->inline_walk ? "standalone" : c->dense_keys ? "inline_keys_under_tile" : c->gen_keys ? (c->cone ? "inline_keys_cone" : "inline_keys")
+                     : c->norm_fast ? (P.lean_wide ? "inline_lean_wide" : c->win_lv_pairs_p ? "inline_lean" : "inline_slots") : c->gen_lean ? "inline_lean16" : "inline_slots";
+    const char* pers = !c->persist ? "none" : c->persist_loc ? (c->persist_sh ? (c->persist_sh_big ? (c->persist_wide ? "loc_wide_shard_bigplan" : "loc_shard_bigplan")
+                                                                                                    : (c->persist_wide ? "loc_wide_shard" : "loc_shard"))
+                                                                              : (c->persist_wide ? "loc_wide" : "loc"))
+                     : c->persist_user ? "gen_user" : "gen";
+    snprintf(out, (size_t)cap, "chain=%s walk=%s exchange=%s persistent=%s plan=%s window=%d", chain, walk, xk[c->xk], pers,
+             c->big_exchange ? (c->plan_ahead ? "big_ahead" : "big") : c->lds_exchange ? "lds" : "none", c->plan_cap);
+    return SMM_OK;
+}
+
 int smm_set_profiling(void* ctx, int32_t on) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return SMM_ERR_INVALID_ARG;

@@ -146,10 +146,12 @@ def test_product_does_not_reference_the_oracle():
 
 def test_the_shipped_library_has_no_test_seams():
     """VERDICT r2 #6 / ADVICE: the switches that force a kernel or shrink a capacity live in libsmmhip_hooks.so only.  The shipped
-    library reads two environment variables, both diagnostics (SMMHIP_TS, SMMHIP_DBG)."""
+    library reads three environment variables, all diagnostics (SMMHIP_TS, SMMHIP_DBG, and SMMHIP_VERBOSE: why a user objective's
+    persistent kernel did not compile).  (Round 5: the library carries its device headers as text — hiprtc compiles them with a user's
+    objective inside —, so the public header's own macros SMMHIP_H / SMMHIP_ABI_VERSION appear in the file too: not variables.)"""
     blob = open(A.LIB_PATH, "rb").read()
-    names = sorted(set(m.decode() for m in re.findall(rb"SMMHIP_[A-Z0-9_]+", blob)))
-    assert names == ["SMMHIP_DBG", "SMMHIP_TS"], names
+    names = sorted(set(m.decode() for m in re.findall(rb"SMMHIP_[A-Z0-9_]+", blob)) - {"SMMHIP_H", "SMMHIP_ABI_VERSION"})
+    assert names == ["SMMHIP_DBG", "SMMHIP_TS", "SMMHIP_VERBOSE"], names
     lib = A.load()
     lib.smm_debug_has_test_hooks.restype = C.c_int
     assert lib.smm_debug_has_test_hooks() == 0
