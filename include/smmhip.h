@@ -345,9 +345,12 @@ int  smm_set_profiling(void* ctx, int32_t on);
  *     of 16, N <= 4096 per rank, N_global <= 32768; the ring of tagged words then lives in every rank's window, a hard error inside
  *     such a launch is agreed upon by the ranks at their next smm_sync / smm_bgp_p2p_finish and replayed by every rank up to the
  *     failing iteration);
- *   - the banana objective with at most 16 parameters (one proposal batch, isotropic, min_improve == 0) on a single shard of
- *     4096 < N <= 8192 chains in whole groups of 32.
- * Per-chain thresholds, other dist_fun, more than two moments, Cholesky proposals, user objectives: the per-iteration kernels.
+ *   - the banana objective, or a USER objective in the one-thread-per-evaluation form (smm_register_user_objective: the library compiles
+ *     the persistent kernel once more with the user's source inside, through hiprtc, when the first such context is created: ~1.5 s),
+ *     with at most 16 parameters / moments (one proposal batch, isotropic, min_improve == 0) on a single shard of up to 8192 chains in
+ *     whole groups of 32.
+ * Per-chain thresholds, other dist_fun, more than two moments of objfunc_norm, Cholesky proposals, the dense objective, the map-reduce
+ * form of user objectives: the per-iteration kernels.
  * on = 0 keeps the one-launch-per-iteration kernels (default: on).  A hard error of the algorithm inside such a launch is found at
  * the next call that checks (smm_sync, smm_bgp_step, the state readers): the library then repeats those iterations from the state
  * it saved on the one-launch-per-iteration path, so that the context stands at the failing iteration exactly as documented above.

@@ -1095,7 +1095,8 @@ int launch_chain_persist(Ctx* c, int n_left) {
     point_values(c, P, t0 - 1, t1);   // (nothing is read from the value arrays: the last iteration writes them)
     // (a spin of the form may last 4 s — a peer is gone, not late — once a launch of this context has come through; until then a
     // tenth of that: tiles that are not resident together, a masked or partitioned device, must not look like a hang)
-    const unsigned long long tmo = c->persist_proven ? P2P_TIMEOUT_TICKS : PERSIST_TMO_FIRST;
+    // (a shard waits for its PEERS' launches at the start barrier: processes that start a second apart are late, not gone — 4 s from the start)
+    const unsigned long long tmo = (c->persist_proven || c->persist_sh) ? P2P_TIMEOUT_TICKS : PERSIST_TMO_FIRST;
     if (c->persist_loc) {
         PersistLocArgs A{};
         const int G = c->persist_sh ? P.p2p_G : 1;

@@ -14,7 +14,7 @@ def main(paths):
         for k in sorted(d):
             for c in sorted(d[k]):
                 v = d[k][c]
-                print("%-60s %-22s launches=%5d mean_per_launch=%16.1f total=%18.1f" % (k[:60], c, len(v), sum(v) / len(v), sum(v)))
+                print("%-96s %-22s launches=%5d mean_per_launch=%16.1f total=%18.1f" % (k.replace("(anonymous namespace)::", "")[:96], c, len(v), sum(v) / len(v), sum(v)))
         print()
 
 
