@@ -79,29 +79,32 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 struct ZBuf {
     __amdgpu_buffer_rsrc_t rsrc;
     int lane_off;  // tid * 8
-    __device__ inline void init(const KParams& P, int tid) {
-        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P.Z, 0, (int)((size_t)P.nm * P.zstride * sizeof(double)), 0x00020000);
+    __device__ inline void init_v(const double* Z, int nm, int zstride, int tid) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Z, 0, (int)((size_t)nm * zstride * sizeof(double)), 0x00020000);
         lane_off = tid * (int)sizeof(double);
     }
+    __device__ inline void init(const KParams& P, int tid) { init_v(P.Z, P.nm, P.zstride, tid); }
 };
 // chunk ch of moment k
-__device__ inline void sim_load_chunk(const ZBuf& zb, const KParams& P, int k, int ch, double (&z)[ZU]) {
-    const int row0 = (k * P.zstride + ((P.dbg & 8) ? 0 : ch) * (ZU * WG)) * (int)sizeof(double);  // dbg 8: timing experiment
+__device__ inline void sim_load_chunk_v(const ZBuf& zb, const int zstride, const bool dbg8, int k, int ch, double (&z)[ZU]) {
+    const int row0 = (k * zstride + (dbg8 ? 0 : ch) * (ZU * WG)) * (int)sizeof(double);  // dbg 8: timing experiment
 #pragma unroll
     for (int u = 0; u < ZU; ++u)
         z[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(zb.rsrc, zb.lane_off, row0 + u * WG * (int)sizeof(double), 0));
 }
+__device__ inline void sim_load_chunk(const ZBuf& zb, const KParams& P, int k, int ch, double (&z)[ZU]) { sim_load_chunk_v(zb, P.zstride, (P.dbg & 8) != 0, k, ch, z); }
 
 // zc: chunk 0 of moment 0 (already loaded).  s_theta [CT][np], s_part [WG/64][CT][nm] in LDS.
 // Moments are reduced in groups of G = 16/CT: one transposed reduction of G*CT accumulators has the
 // same number of dependent shuffle steps as one of CT, so grouping halves that latency for CT = 8.
 // A moment is nch chunks; the last one may be ragged (rows masked per lane).  Two chunks per trip, the
 // two register buffers trade places; the chunk after a moment's last is chunk 0 of the next moment.
+// (the problem's sizes by value: the persistent tile kernel has no KParams)
 template <int CT>
-__device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const double* s_theta, double* s_part, int tid, double (&zc)[ZU]) {
+__device__ inline void simulate_tile_v(const int ns, const int nm, const int np, const int zstride, const bool dbg8, const ZBuf& zb, const double* s_theta, double* s_part,
+                                       int tid, double (&zc)[ZU]) {
     constexpr int G = (CT >= 16) ? 1 : 16 / CT;
     const int lane = tid & 63, wave = tid >> 6;
-    const int ns = P.ns, nm = P.nm;
     const int nch = (ns + ZU * WG - 1) / (ZU * WG);
     const int last_draws = ns - (nch - 1) * (ZU * WG);   // draws of the last chunk, 1 .. ZU*WG
     const bool ragged = last_draws < ZU * WG;
@@ -115,7 +118,7 @@ __device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const dou
             if (k < nm) {
                 double mu[CT];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) mu[c] = s_theta[c * P.np + k];
+                for (int c = 0; c < CT; ++c) mu[c] = s_theta[c * np + k];
                 auto add_full = [&](const double (&z)[ZU]) {
 #pragma unroll
                     for (int u = 0; u < ZU; ++u) {
@@ -143,14 +146,14 @@ __device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const dou
                 double zn[ZU];
                 int ch = 0;
                 for (; ch + 2 <= nch; ch += 2) {
-                    sim_load_chunk(zb, P, k, ch + 1, zn);
+                    sim_load_chunk_v(zb, zstride, dbg8, k, ch + 1, zn);
                     add_full(zc);
                     const bool last = (ch + 2 == nch);
-                    sim_load_chunk(zb, P, last ? knext : k, last ? 0 : ch + 2, zc);
+                    sim_load_chunk_v(zb, zstride, dbg8, last ? knext : k, last ? 0 : ch + 2, zc);
                     if (last) add_last(zn); else add_full(zn);
                 }
                 if (ch < nch) {  // odd count: the last chunk is in zc; afterwards the buffers are swapped by copy
-                    sim_load_chunk(zb, P, knext, 0, zn);
+                    sim_load_chunk_v(zb, zstride, dbg8, knext, 0, zn);
                     add_last(zc);
 #pragma unroll
                     for (int u = 0; u < ZU; ++u) zc[u] = zn[u];
@@ -164,6 +167,11 @@ __device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const dou
             if (k0 + kk < nm) s_part[(wave * CT + c) * nm + k0 + kk] = tot;
         }
     }
+}
+
+template <int CT>
+__device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const double* s_theta, double* s_part, int tid, double (&zc)[ZU]) {
+    simulate_tile_v<CT>(P.ns, P.nm, P.np, P.zstride, (P.dbg & 8) != 0, zb, s_theta, s_part, tid, zc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,34 +188,72 @@ __device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const dou
 typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int DENSE_D = SMM_DENSE_D;
 
-template <int CT>
-__device__ inline void dense_tile(const KParams& P, const double* s_theta, double* s_part, int tid) {
+// (inlined into its kernels — out of line the operands came through generic pointers, one dependent load per MFMA —; the operand
+// fragments of a product are requested TOGETHER, ahead of the MFMAs that consume them: the B fragments of both hidden-unit tiles of the
+// wave before the first product, the A fragments of a tile before its tanh — an MFMA never waits for a load of its own)
+// OUT OF LINE, one copy for every kernel (its ~170 live registers — operand fragments of a whole tile, accumulators, tanh — are then
+// its own, not the callers'); the tile's proposals and partial sums are named by their byte offsets in the dynamic LDS (a generic pointer
+// would make every access a flat one).  NPS4: the products of the first GEMM in groups of four (np <= 16 NPS4) — straight-line code:
+// fragments past the last parameter are read again from the last one (any finite value) and meet a zero of the proposal's side.
+template <int CT, int NPS4>
+__device__ __attribute__((noinline)) void dense_tile_n(const int np_, const int nOt_, const double* dense_Bf_, const double* dense_Af_,
+                                                       const uint32_t theta_off_, const uint32_t part_off_, const int tid) {
     static_assert(CT == 16, "the dense objective tiles 16 chains (MFMA N dimension)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char dense_lds[];
+    // (the arguments of an out-of-line function arrive in vector registers: what is uniform goes back into scalar ones, and the
+    // matrices are GLOBAL memory, not "somewhere")
+    typedef const __attribute__((address_space(1))) double* gptr_t;
+    const int np = __builtin_amdgcn_readfirstlane(np_), nOt = __builtin_amdgcn_readfirstlane(nOt_);
+    const uint32_t theta_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)theta_off_), part_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)part_off_);
+    auto uniform_ptr = [](const double* p) {
+        const unsigned long long u = (unsigned long long)p;
+        return (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)u));
+    };
+    const gptr_t dense_Bf = uniform_ptr(dense_Bf_), dense_Af = uniform_ptr(dense_Af_);
+    const double* s_theta = (const double*)(dense_lds + theta_off);
+    double* s_part = (double*)(dense_lds + part_off);
+    constexpr int PS = 4 * NPS4;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int np = P.np, nPs = (np + 3) / 4, nOt = P.dense_nOt, nmp = nOt * 16;
+    const int nPs = (np + 3) / 4, nmp = nOt * 16;
     d4_t yacc[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) yacc[o] = d4_t{0.0, 0.0, 0.0, 0.0};
+    double bfr[2][PS];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const gptr_t bf = dense_Bf + (size_t)(2 * wave + tt) * nPs * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < PS; ++s) bfr[tt][s] = bf[(size_t)min(s, nPs - 1) * 64];
+    }
+    double th[PS];   // the proposal's components k = 4 s + lk of chain li (zero past the last parameter)
+#pragma unroll
+    for (int s = 0; s < PS; ++s) {
+        const int p = 4 * s + lk;
+        const double v = s_theta[li * np + min(p, np - 1)];
+        th[s] = p < np ? v : 0.0;
+    }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         const int T = 2 * wave + tt;
-        d4_t xacc = d4_t{0.0, 0.0, 0.0, 0.0};
-        const double* __restrict__ bf = P.dense_Bf + (size_t)T * nPs * 64 + lane;
-        for (int s = 0; s < nPs; ++s) {
-            const int p = 4 * s + lk;
-            const double b = (p < np) ? s_theta[li * np + p] : 0.0;
-            xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[(size_t)s * 64], b, xacc, 0, 0, 0);
+        double afr[4][4];   // requested before the first product: there when the tanh is over
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const gptr_t af = dense_Af + ((size_t)(min(o, nOt - 1) * (DENSE_D / 16) + T) * 4) * 64 + lane;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) afr[o][s4] = af[s4 * 64];
         }
+        d4_t xacc = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < PS; ++s) xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[tt][s], th[s], xacc, 0, 0, 0);
         double h[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = tanh(xacc[r]);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             if (o < nOt) {
-                const double* __restrict__ af = P.dense_Af + ((size_t)(o * (DENSE_D / 16) + T) * 4) * 64 + lane;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s4 * 64], h[s4], yacc[o], 0, 0, 0);
+                for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[o][s4], h[s4], yacc[o], 0, 0, 0);
             }
         }
     }
@@ -218,6 +264,20 @@ __device__ inline void dense_tile(const KParams& P, const double* s_theta, doubl
             for (int r = 0; r < 4; ++r) s_part[((size_t)wave * nmp + 16 * o + lk + 4 * r) * 16 + li] = yacc[o][r];
         }
     }
+}
+template <int CT>
+__device__ __forceinline__ void dense_tile_v(const int np, const int nOt, const double* dense_Bf, const double* dense_Af, const uint32_t theta_off, const uint32_t part_off, const int tid) {
+    const int g = (np + 15) / 16;   // (uniform)
+    if (g <= 1) dense_tile_n<CT, 1>(np, nOt, dense_Bf, dense_Af, theta_off, part_off, tid);
+    else if (g == 2) dense_tile_n<CT, 2>(np, nOt, dense_Bf, dense_Af, theta_off, part_off, tid);
+    else if (g == 3) dense_tile_n<CT, 3>(np, nOt, dense_Bf, dense_Af, theta_off, part_off, tid);
+    else dense_tile_n<CT, 4>(np, nOt, dense_Bf, dense_Af, theta_off, part_off, tid);
+}
+
+template <int CT>
+__device__ __forceinline__ void dense_tile(const KParams& P, const double* s_theta, double* s_part, int tid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dense_lds_base[];
+    dense_tile_v<CT>(P.np, P.dense_nOt, P.dense_Bf, P.dense_Af, (uint32_t)((const unsigned char*)s_theta - dense_lds_base), (uint32_t)((const unsigned char*)s_part - dense_lds_base), tid);
 }
 
 // value / simulated moments / status for one chain from its reduced sums
@@ -1010,7 +1070,6 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             const int npar = min(min(NR, P.rb_tries), max_tries);  // tries evaluated side by side
             const double sg = S.cs[cl * CSW + CS_SIGMA];
             const double* zz = S.rb + cl * RBW + 1;  // [tries][np]
-            const int lane = tid & 63;
             // mapto_01 (mprob.jl:248) once per chain and parameter — one division each, shared by all tries —, computed by the
             // NR lanes of the chain and kept in the (still unused) output record block
             double* m01 = S.rout + cl * RW;
@@ -1022,208 +1081,11 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             const bool coop = bs >= SMM_COOP_MIN_BATCH && !P.chol_L;   // (uniform)
             if (coop) {
                 __syncthreads();   // the blocks the control wave staged (records, state, randomness) are every wave's now
-                const int nwv = (int)blockDim.x / (64 * TPW);   // (one wave per tile in the slim launch)
-                const int LPC = 64 * nwv / CT;                   // lanes per chain: 4 .. 64, a power of two
-                const int cc = tid / LPC, sl = tid % LPC;
-                const int cg = tile * CT + cc;
-                const bool vld = cg < N;
-                const int sh = (lane / LPC) * LPC;
-                const unsigned long long seg = (LPC == 64 ? ~0ull : ((1ull << LPC) - 1ull)) << sh;   // this chain's lanes in the wave
-                const double* rcc = S.rec + cc * RW;
-                double* m01c = S.rout + cc * RW;
-                double* thc = S.theta + cc * np;
-                const double sgc = S.cs[cc * CSW + CS_SIGMA];
-                const uint32_t gcc = (uint32_t)(P.offset + cg);
-                if (vld)
-                    for (int k = sl; k < np; k += LPC) {   // mapto_01 (mprob.jl:248) once per chain and parameter
-                        const double lbk = S.lb[k];
-                        m01c[k] = (rcc[3 + k] - lbk) / (S.ub[k] - lbk);
-                    }
-                // (a word every tile of the workgroup sees: the number of the last round of shared tries somebody asked for)
-                unsigned long long* round_word = (unsigned long long*)(S.h - (size_t)st * ((tile_smem_doubles(CT, np, nm, RW, HW, RBW, KIND) + 1) & ~(size_t)1)) + 2;
-                if (threadIdx.x == 0) *round_word = 0ull;
-                unsigned long long round_id = 0ull;
-                __syncthreads();   // (a lane reads the m01 of its pairs, which other lanes of the chain may have written)
-                // one try of chain `u` (its lanes: this half-wave or whatever segment serves it), components of the batch
-                // [b0, b0 + bs): the point into `out`, true when inside the unit box
-                auto one_try = [&](const int u, const uint32_t gu, const double sgu, const int rr, const int b0, double* out) -> bool {
-                    const double* m01u = S.rout + u * RW;
-                    const double* zzu = S.rb + u * RBW + 1;
-                    bool okl = true;
-                    for (int q = sl; 2 * q < b0 + bs; q += LPC) {
-                        if (2 * q + 1 < b0) continue;
-                        double z0, z1;
-                        if (rr < P.rb_tries) { z0 = zzu[rr * np + 2 * q]; z1 = 2 * q + 1 < np ? zzu[rr * np + 2 * q + 1] : 0.0; }
-                        else { const double2 zz2 = rng_prop_normal2_outofline(P.seed, gu, (uint32_t)t, (uint32_t)rr, (uint32_t)q); z0 = zz2.x; z1 = zz2.y; }
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int k = 2 * q + e;
-                            if (k < b0 || k >= b0 + bs) continue;
-                            const double lbk = S.lb[k];
-                            const double span = S.ub[k] - lbk;
-                            const double step = sgu * (e ? z1 : z0);   // MvNormal(mu01, sigma): x = mu + sigma*z
-                            const double x = m01u[k] + step;
-                            if (!(x >= 0.0 && x <= 1.0)) okl = false;  // inclusive bounds, :405
-                            const double sc = x * span;
-                            out[k] = sc + lbk;   // mapto_ab, mprob.jl:271
-                        }
-                    }
-                    return okl;
-                };
-                const int n_pre = min(P.rb_tries, max_tries);   // tries whose normals are in the randomness block
-                for (int b0 = 0; b0 < np; b0 += bs) {
-                    bool done = !vld;
-                    for (int rr = 0; rr < n_pre && __ballot(!done) != 0ull; ++rr) {   // mysample, :400-410, try rr
-                        const bool okl = done || one_try(cc, gcc, sgc, rr, b0, thc);   // (kept if this try wins or is the last one)
-                        const unsigned long long m = __ballot(okl);
-                        if ((m & seg) == seg) done = true;
-                    }
-                    // Later tries come from the generator (~1.4 us each: Philox4x32-10 + Box-Muller per component pair), and a
-                    // launch lasts as long as its unluckiest chain — with 50 parameters and adapted sigmas regularly 5-15 tries,
-                    // now and then 50 (C5: 26 us per launch early in a run, 36 us on average, spikes of 130).  So the tile's CT
-                    // lane segments ("slots") all work for the chains still open: open chain number i of n gets the slots
-                    // i, i + n, i + 2n, ..., each evaluating one further try, and the lowest successful try wins — the tries,
-                    // their order and the winner are those of the serial loop.  Scratch: the (still unused) history rows of the
-                    // tile: slot s keeps its candidate in row s, chain u its success mask in the head of row u.
-                    int base = n_pre;
-                    for (int rounds = 0;; ++rounds) {
-                        unsigned long long* head = (unsigned long long*)(S.h + cc * HW);   // [0]: open, [1]: successful offsets
-                        ++round_id;
-                        if (sl == 0) { head[0] = done ? 0ull : 1ull; head[1] = 0ull; if (!done) *round_word = round_id; }
-                        __syncthreads();
-                        if (*round_word != round_id || base >= max_tries || rounds >= P.scout_after) break;   // (uniform over the workgroup: nobody open, no try left, or the stubborn chains' turn below)
-                        const unsigned long long open = __ballot(lane < CT && *(const unsigned long long*)(S.h + lane * HW) != 0ull);
-                        const int n_open = __popcll(open);
-                        const int per = n_open ? CT / n_open : 0;      // tries per open chain in this round (>= 1)
-                        const int off = n_open ? cc / n_open : 0;
-                        unsigned long long mm = open;
-                        for (int i = n_open ? cc % n_open : 0; i > 0; --i) mm &= mm - 1ull;
-                        const int u = mm ? __ffsll((long long)mm) - 1 : 0;
-                        const int rr = base + off;
-                        const bool active = n_open && off < per && rr < max_tries;
-                        double* cand = S.h + cc * HW + H_PARAMS;
-                        bool okl = true;
-                        if (active) okl = one_try(u, (uint32_t)(P.offset + tile * CT + u), S.cs[u * CSW + CS_SIGMA], rr, b0, cand);
-                        const unsigned long long m = __ballot(okl);
-                        if (active && (m & seg) == seg && sl == 0) atomicOr((unsigned long long*)(S.h + u * HW) + 1, 1ull << off);
-                        __syncthreads();
-                        if (active) {
-                            const unsigned long long won = ((const unsigned long long*)(S.h + u * HW))[1];
-                            if (won ? (__ffsll((long long)won) - 1 == off) : (rr == max_tries - 1)) {   // the winner (or the last try of all)
-                                double* thu = S.theta + u * np;
-                                for (int q = sl; 2 * q < b0 + bs; q += LPC)
-                                    for (int e = 0; e < 2; ++e) {
-                                        const int k = 2 * q + e;
-                                        if (k >= b0 && k < b0 + bs) thu[k] = cand[k];
-                                    }
-                            }
-                        }
-                        if (!done && head[1] != 0ull) done = true;
-                        __syncthreads();
-                        base += max(per, 1);
-                    }
-                    // The chains still open after those rounds are the stubborn ones (adapted sigmas, 50 parameters: one try in hundreds or
-                    // thousands is inside the box late in a run — C5: 38 us per iteration in the first 200 of 2000, 244 in the last, at 16
-                    // tries per 1.5 us and tile).  A try that fails fails EARLY, so the remaining tries are scouted by groups of 16 lanes, 16
-                    // pairs at a time, and given up at the first group of pairs with a component outside the box: 32 tries in flight
-                    // per tile instead of 16, most of them one trip long.  The groups TAKE their tries — a counter per chain hands them
-                    // out in order — from whichever chain of the tile still has tries worth making (below its lowest successful one),
-                    // so that the tile's unluckiest chain ends up with all 32 groups; a try that gets through all its pairs enters the
-                    // chain's minimum.  The lowest successful try wins — the tries, their order and the winner are the serial loop's —
-                    // and is then evaluated once more, in full, by the chain's own lanes (one_try: the same arithmetic as ever).
-                    // Scratch: the head of the chain's (still unused) history row — [0]: open, [1]: lowest successful try, [3]: next try
-                    // to hand out ([2] of row 0 is the workgroup's round word); double 4 of rows 0 .. CT / 8 - 1: the open chains' numbers, a byte each.
-                    {
-                        unsigned long long* head = (unsigned long long*)(S.h + cc * HW);
-                        ++round_id;
-                        const bool more = !done && base < max_tries;
-                        if (sl == 0) { head[0] = more ? 1ull : 0ull; head[1] = ~0ull; head[3] = (unsigned long long)base; if (more) *round_word = round_id; }
-                        __syncthreads();
-                        if (*round_word == round_id) {   // (uniform over the workgroup: somebody is open)
-                            const unsigned long long open = __ballot(lane < CT && *(const unsigned long long*)(S.h + lane * HW) != 0ull);
-                            const int n_open = __popcll(open);
-                            // (a BYTE per open chain, eight to double 4 of each of the first CT / 8 rows — a word no head uses: sixteen ints in
-                            // a row of HW = 10, one parameter and one moment, reached into row 1's head words; nothing any
-                            // wave reads in its ballot above lies there)
-                            static_assert(CT <= 64 && CT % 8 == 0, "olist: a byte per chain of the tile");
-                            auto olist = [&](const int idx) -> unsigned char* { return (unsigned char*)(S.h + (idx >> 3) * HW + 4) + (idx & 7); };
-                            if (tid < CT && ((open >> tid) & 1ull)) *olist(__popcll(open & ((1ull << tid) - 1ull))) = (unsigned char)tid;
-                            __syncthreads();
-                            if (n_open) {
-                                const int GLr = 64 * nwv >= 128 ? P.scout_gl : 4;   // lanes of a group (one try at a time; the slim launch: one wave per tile)
-                                const int G = tid / GLr, gj = tid - G * GLr;
-                                const int g_lead = lane & ~(GLr - 1);
-                                const unsigned long long gseg = ((1ull << GLr) - 1ull) << g_lead;   // the group's lanes in the wave
-                                const int qlo = b0 >> 1, qhi = (min(b0 + bs, np) + 1) >> 1;   // the pairs with a component of this batch
-                                const unsigned long long cap = (unsigned long long)max_tries;
-                                int oi = G % n_open;        // where the group looks first
-                                int u = 0, q0 = qlo;
-                                unsigned long long rr = 0ull;
-                                uint32_t gu = 0u;
-                                double sgu = 0.0;
-                                const double* m01u = S.rout;
-                                bool have = false, quit = false;
-                                while (__ballot(!quit) != 0ull) {
-                                    if (!quit && !have) {   // the group's next try: from a chain that has tries below its lowest successful one
-                                        int found = -1;
-                                        unsigned long long r0 = 0ull;
-                                        if (gj == 0) {
-                                            for (int sft = 0; sft < n_open && found < 0; ++sft) {
-                                                const int idx = oi + sft < n_open ? oi + sft : oi + sft - n_open;
-                                                const int v = (int)*olist(idx);
-                                                unsigned long long* hv = (unsigned long long*)(S.h + v * HW);
-                                                const unsigned long long lim = min(__hip_atomic_load(hv + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), cap);
-                                                if (__hip_atomic_load(hv + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < lim) {
-                                                    r0 = __hip_atomic_fetch_add(hv + 3, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                                    if (r0 < lim) { found = v; oi = idx; }
-                                                }
-                                            }
-                                        }
-                                        found = __shfl(found, g_lead, 64);
-                                        r0 = (unsigned long long)(unsigned)__shfl((int)(unsigned)r0, g_lead, 64) | ((unsigned long long)(unsigned)__shfl((int)(unsigned)(r0 >> 32), g_lead, 64) << 32);
-                                        if (found < 0) quit = true;
-                                        else {
-                                            u = found; rr = r0; q0 = qlo; have = true;
-                                            gu = (uint32_t)(P.offset + tile * CT + u);
-                                            sgu = S.cs[u * CSW + CS_SIGMA];
-                                            m01u = S.rout + u * RW;
-                                        }
-                                    }
-                                    bool okp = true;
-                                    const int q = q0 + gj;
-                                    if (have && q < qhi) {
-                                        const double2 zz2 = rng_prop_normal2_outofline(P.seed, gu, (uint32_t)t, (uint32_t)rr, (uint32_t)q);
-#pragma unroll
-                                        for (int e = 0; e < 2; ++e) {
-                                            const int k = 2 * q + e;
-                                            if (k >= b0 && k < b0 + bs && k < np) {
-                                                const double step = sgu * (e ? zz2.y : zz2.x);   // MvNormal(mu01, sigma): x = mu + sigma*z
-                                                const double x = m01u[k] + step;
-                                                if (!(x >= 0.0 && x <= 1.0)) okp = false;         // inclusive bounds, :405
-                                            }
-                                        }
-                                    }
-                                    const bool gok = (__ballot(okp) & gseg) == gseg;   // all pairs of the trip inside the box
-                                    if (have) {
-                                        if (gok && q0 + GLr >= qhi) {   // the try's last pairs: a candidate for the chain's first successful try
-                                            if (gj == 0) atomicMin((unsigned long long*)(S.h + u * HW) + 1, rr);
-                                            have = false;
-                                        } else if (gok) q0 += GLr;
-                                        else have = false;
-                                    }
-                                }
-                            }
-                            __syncthreads();
-                            if (more) {   // the chain's own lanes: its winning try in full (or, when none got through, the last one: :409 below)
-                                const unsigned long long won = head[1];
-                                (void)one_try(cc, gcc, sgc, won != ~0ull ? (int)won : max_tries - 1, b0, thc);
-                                if (won != ~0ull) done = true;
-                            }
-                        }
-                        __syncthreads();
-                    }
-                    if (!done && sl == 0) report_error(P, 2, t, (int)gcc);  // :409
-                }
+                // (smm_propose.hpp: every wave of the tile works, 64 * waves / CT lanes per chain)
+                const CoopProp X{S.rec, RW, S.rout, RW, S.theta, np, S.h, HW, S.rb, RBW, S.cs, CSW, S.lb, S.ub,
+                                 (unsigned long long*)(S.h - (size_t)st * ((tile_smem_doubles(CT, np, nm, RW, HW, RBW, KIND) + 1) & ~(size_t)1)) + 2, P.err,
+                                 P.seed, P.offset, N, bs, P.rb_tries, P.user_n, P.smpl_iters, P.scout_after, P.scout_gl};
+                coop_mysample<CT>(X, t, tile, tid, (int)blockDim.x / (64 * TPW), threadIdx.x == 0, CoopSyncThreads());
             } else if (ctl) {
             if (valid)
                 for (int k = r; k < np; k += NR) {

@@ -55,12 +55,14 @@ using namespace smm;
 
 #include "smm_params.hpp"
 #include "smm_walk_lean.hpp"
+#include "smm_propose.hpp"
 #include "smm_chain.hpp"
 #include "smm_p2p.hpp"
 #include "smm_chain_norm.hpp"
 #include "smm_chain_persist.hpp"
 #include "smm_chain_persist_gen.hpp"
 #include "smm_chain_persist_loc.hpp"
+#include "smm_chain_persist_tile.hpp"
 #include "smm_lookahead.hpp"
 #include "smm_exchange.hpp"
 #include "smm_cone_big.hpp"
@@ -185,7 +187,7 @@ bool user_persist_compile(UserObjective& u) {   // (g_user_mutex held)
         "        const double* udata, int n_udata, double* sim_moments, double* value, int* status);\n";
     tu += u.source;
     tu += "\n#define SMM_GEN_USER 1\n#include \"smmhip.h\"\n#include \"smm_rng.hpp\"\nusing namespace smm;\n#include \"smm_params.hpp\"\n"
-          "#include \"smm_walk_lean.hpp\"\n#include \"smm_chain.hpp\"\n#include \"smm_p2p.hpp\"\n#include \"smm_chain_norm.hpp\"\n"
+          "#include \"smm_walk_lean.hpp\"\n#include \"smm_propose.hpp\"\n#include \"smm_chain.hpp\"\n#include \"smm_p2p.hpp\"\n#include \"smm_chain_norm.hpp\"\n"
           "#include \"smm_chain_persist.hpp\"\n#include \"smm_chain_persist_gen.hpp\"\n";
     std::vector<const char*> names, texts;
     for (const EmbeddedSource& e : g_embedded) { names.push_back(e.name); texts.push_back(e.text); }
@@ -327,6 +329,7 @@ struct Ctx {
     bool persist = false;                      // this context can run it (objfunc_norm np <= 2, single shard of at most one tile per CU, key walk)
     bool persist_gen = false;                  // ... its form for objectives without a simulation (smm_chain_persist_gen.hpp: banana, 4096 < N <= 8192)
     bool persist_loc = false;                  // ... on locally numbered cones (smm_chain_persist_loc.hpp): thresholds (min_improve > 0), shards
+    bool persist_tile = false;                 // ... its form for objectives a whole tile evaluates (smm_chain_persist_tile.hpp): objfunc_norm of any size, the dense simulation
     bool persist_wide = false;                 // ... its 16-byte slots: one min_improve > 0 (or NaN) for all chains
     unsigned char* prw = nullptr;              // persist_loc: the ring's window (pr_win_layout) — a single shard's own allocation, a shard's: inside its p2p window
     bool persist_sh = false;                   // ... as a SHARD of a sharded run: the ring lives in every rank's p2p window (smm_bgp_p2p_step)
@@ -1035,7 +1038,7 @@ bool persist_usable(const Ctx* c, int n_left) {
     if (c->iter < 1 || !c->prev_open || c->exch_done || (c->pending && !c->unresolved)) return false;
     const int t0 = c->iter + 1;
     // (the locally numbered form starts a new plan window at the pending exchange's iteration instead: launch_chain_persist)
-    if (!c->persist_loc && c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) return false;
+    if (!c->persist_loc && !c->persist_tile && c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) return false;
     return true;
 }
 // ... as a shard (smm_bgp_p2p_step): from the p2p state — the records after iteration `iter` in the windows, its exchange not resolved
@@ -1067,7 +1070,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
     const int t0 = c->iter + 1;
     // (k_chain_persist_norm and _gen draw in the kernel unless tables are injected)
     const bool pregen = c->persist_gen ? (c->P.user_ntab || c->P.user_utab) : !(c->norm_fast && !c->P.user_ntab && !c->P.user_utab);
-    if (c->persist_loc && c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) {
+    if ((c->persist_loc || c->persist_tile) && c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) {
         // the pending exchange's plan is not in a window that also reaches past this iteration: a new window from ITS iteration on (one
         // iteration planned twice per window; no per-iteration launch, no stand-alone resolution at the windows' ends)
         c->plan_w = 0;
@@ -1081,8 +1084,8 @@ int launch_chain_persist(Ctx* c, int n_left) {
     if (!c->snap_valid) persist_snapshot(c);
     ++c->pr_epoch;
     if ((c->pr_epoch & 0x7fu) == 0u) {   // the slot tags' epoch bits start over: nothing older may look current
-        if (c->persist_loc) {   // (a shard zeroes its own window's ring: its peers store into it only behind the launch's start barrier)
-            const PrWin WL = pr_win_layout(c->P.Ng, c->P.RW, c->persist_sh ? c->P.p2p_G : 1, (c->P.N + NORM_CT - 1) / NORM_CT);
+        if (c->persist_loc || c->persist_tile) {   // (a shard zeroes its own window's ring: its peers store into it only behind the launch's start barrier)
+            const PrWin WL = pr_win_layout(c->P.Ng, c->P.RW, c->persist_sh ? c->P.p2p_G : 1, (c->P.N + NORM_CT - 1) / NORM_CT);   // (PT_CT == NORM_CT)
             unsigned char* base = c->persist_sh ? c->p2p_mine + c->prw_off : c->prw;
             HIPCHK(hipMemsetAsync(base + WL.slot, 0, WL.total - WL.slot, c->stream));
         } else {
@@ -1136,6 +1139,31 @@ int launch_chain_persist(Ctx* c, int n_left) {
             if (wd) { if (sh) go(k_chain_persist_loc<2, true, true>); else go(k_chain_persist_loc<2, true, false>); }
             else { if (sh) go(k_chain_persist_loc<2, false, true>); else go(k_chain_persist_loc<2, false, false>); }
         }
+    } else if (c->persist_tile) {
+        PersistTileArgs A{};
+        const int tiles = (P.N + PT_CT - 1) / PT_CT;
+        const PrWin WL = pr_win_layout(P.Ng, P.RW, 1, tiles);
+        const int kind = obj_kind(c->obj);
+        A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
+        A.self = c->prw; A.o_ctl = WL.ctl; A.o_progress = WL.progress; A.o_rec = WL.rec;
+        A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
+        A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
+        A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp; A.dense_Bf = P.dense_Bf; A.dense_Af = P.dense_Af;
+        A.rb = pregen ? P.rb : nullptr;
+        A.N = P.N; A.Ng = P.Ng; A.np = P.np; A.nm = P.nm; A.ns = P.ns; A.zstride = P.zstride; A.RW = P.RW; A.HW = P.HW; A.RBW = P.RBW; A.dense_nOt = P.dense_nOt;
+        A.batch_size = P.batch_size; A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
+        A.plan_t0 = P.plan_t0; A.exch_from = c->exchange_from; A.sigma_update_steps = P.sigma_update_steps; A.smpl_iters = P.smpl_iters; A.t0 = t0; A.t1 = t1;
+        A.rb_t0 = P.rb_t0; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
+        A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks; A.walk_first = c->unresolved ? 1 : 0;
+        A.unit_sh = P.lean_unit == 16 ? 4 : (P.lean_unit == 8 ? 3 : 2); A.scout_after = P.scout_after; A.scout_gl = P.scout_gl;
+        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo;
+        const dim3 grid(tiles), block(WG);
+        const size_t smem = pt_layout(P.np, P.nm, P.RW, P.HW, P.RBW, kind, P.dense_nOt).total;
+        auto go = [&](auto kern) {
+            if (c->kev0) hipExtLaunchKernelGGL(kern, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
+            else hipLaunchKernelGGL(kern, grid, block, smem, c->stream, A);
+        };
+        if (kind == 2) go(k_chain_persist_tile<2>); else go(k_chain_persist_tile<1>);
     } else if (c->persist_gen) {
         PersistGenArgs A{};
         A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
@@ -1787,6 +1815,16 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                          ns <= WG * PR_ZR && P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && !c->deep_plan && N / NORM_CT <= n_cus &&
                                          P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0') &&
                                          (c->lds_exchange ? K <= XLDS_MAX : (c->big_exchange && Ng <= 32768 && K <= 65535 && (size_t)Ng * 4 <= (size_t)160 * 1024));
+            // ... and for the objectives a whole tile evaluates (smm_chain_persist_tile.hpp): objfunc_norm with any number of parameters — the
+            // reference's larger examples have 6 and 18, Examples.jl:210-230, 232-319 — and the dense simulation (BASELINE config 5); one
+            // threshold >= 0 (or NaN) for all chains, isotropic proposals, one 16-chain tile per workgroup, all of them resident
+            const char* ptile = SMM_HOOK("SMMHIP_PERSIST_TILE");   // test hook: "0" never
+            const int tile_kind = obj_kind(c->obj);
+            const bool want_persist_tile = (tile_kind == 1 || tile_kind == 2) && !(c->norm_fast && np <= 2 && ns <= WG * PR_ZR) && N == Ng && Ng >= 2 && c->lds_exchange &&
+                                           P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan &&
+                                           !opts->chol_L && P.dbg == 0 && !(pe && pe[0] == '0') && !(ptile && ptile[0] == '0') && P.RW <= PT_LPC * PT_NJ &&
+                                           (tile_kind == 1 || N % PT_CT == 0) && (N + PT_CT - 1) / PT_CT <= 2 * n_cus &&
+                                           pt_layout(np, nm, P.RW, P.HW, P.RBW, tile_kind, P.dense_nOt).total <= (size_t)160 * 1024;
             const size_t persist_tiles = (want_persist_gen || want_persist_gen_small || want_persist_user) ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             // large single shards of objfunc_norm (C3 on one GPU): the narrow chain kernel's tiles walk their own, locally numbered cones
             // (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two launches
@@ -1797,7 +1835,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                        (size_t)Ng * 4 <= (size_t)160 * 1024;
             const size_t plan_iter = (want_cone_big ? (size_t)(N / NORM_CT) * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + cone_big_scratch_words(Ng, K) * 4 : 0) + (size_t)K * 36 + (c->big_exchange ? BigPlanScratch::words(Ng, K) * 4 + (size_t)(XROWS_MAX + 1) * XWG * 4 : 0) +
                                      (size_t)lean_walk_Kp(K) * 4 + 1024 + (want_cone ? (size_t)(N / cone_ct) * (CONE_LEVELS * 64 + CONE_HDRW) * 4 + 4 : 0) +
-                                     ((want_persist_loc || want_persist_sh) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
+                                     ((want_persist_loc || want_persist_sh || want_persist_tile) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0) +
                                      ((want_persist_sh && c->big_exchange) ? cone_big_scratch_words(Ng, K) * 4 : 0) +
                                      (want_persist_gen ? persist_tiles * (CONE_GCAP * 2) : 0) +
                                      ((want_persist_gen_small || want_persist_user) ? persist_tiles * ((CONE_LEVELS * 64 + CONE_HDRW) * 4 + CONE_GCAP * 2) + 4 : 0);
@@ -1970,6 +2008,27 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                         if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
                         if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                     }
+                    if (want_persist_tile && !c->persist) {   // (the lean plan stands: k_exch_plan lists the tiles' cones and gather lists behind it)
+                        const size_t tiles = (size_t)(N + PT_CT - 1) / PT_CT;
+                        if (!P.cone_ok) {   // (the dense tiles of the per-iteration kernel walk the same cones: want_cone above)
+                            P.cone_tiles = (int)tiles; P.cone_ct = PT_CT;
+                            P.cone_ok = dalloc<uint32_t>(c, (size_t)c->plan_cap);
+                            P.cone_hdr = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * CONE_HDRW);
+                            P.cone_pairs = dalloc<uint32_t>(c, (size_t)c->plan_cap * tiles * (CONE_LEVELS * 64) + 1024);   // (+: whole 1 KB pieces are fetched)
+                            HIPCHK(hipMemset((void*)P.cone_ok, 0, (size_t)c->plan_cap * 4));
+                        }
+                        if (P.cone_ct == PT_CT && (size_t)P.cone_tiles == tiles) {
+                            P.cone_gather = dalloc<uint16_t>(c, (size_t)c->plan_cap * tiles * CONE_GCAP + 512);
+                            const PrWin WL = pr_win_layout(Ng, P.RW, 1, (int)tiles);
+                            c->prw = dalloc<unsigned char>(c, WL.total);
+                            HIPCHK(hipMemset(c->prw, 0, WL.total));
+                            c->persist = true; c->persist_tile = true; c->persist_wide = true;
+                            if (!c->inline_walk) c->defer_resolve = true;   // (the exchange of an iteration is left to the next launch: it may be this kernel's)
+                            if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
+                            if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
+                            if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
+                        }
+                    }
                 }
             }
         }
@@ -2042,6 +2101,17 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             c->persist_max_tiles = per_cu * cus;
             if ((N + NORM_CT - 1) / NORM_CT > per_cu * cus) { c->persist = false; c->persist_loc = false; c->persist_sh = false; }
+        }
+        if (c->persist_tile) {
+            const int kind = obj_kind(c->obj);
+            const size_t smem = pt_layout(np, nm, P.RW, P.HW, P.RBW, kind, P.dense_nOt).total;
+            const void* fn = kind == 2 ? (const void*)k_chain_persist_tile<2> : (const void*)k_chain_persist_tile<1>;
+            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            int per_cu = 0, cus = 0;
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WG, smem));
+            HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            c->persist_max_tiles = per_cu * cus;
+            if ((N + PT_CT - 1) / PT_CT > per_cu * cus) { c->persist = false; c->persist_tile = false; c->defer_resolve = false; }
         }
         if (c->persist) {
             c->snap_cs = dalloc<double>(c, (size_t)N * CSW);
@@ -2913,7 +2983,7 @@ int smm_describe(void* ctx, char* out, int32_t cap) {
     const char* pers = !c->persist ? "none" : c->persist_loc ? (c->persist_sh ? (c->persist_sh_big ? (c->persist_wide ? "loc_wide_shard_bigplan" : "loc_shard_bigplan")
                                                                                                     : (c->persist_wide ? "loc_wide_shard" : "loc_shard"))
                                                                               : (c->persist_wide ? "loc_wide" : "loc"))
-                     : c->persist_user ? "gen_user" : "gen";
+                     : c->persist_tile ? (c->obj == SMM_OBJ_DENSE ? "tile_dense" : "tile_sim") : c->persist_user ? "gen_user" : "gen";
     snprintf(out, (size_t)cap, "chain=%s walk=%s exchange=%s persistent=%s plan=%s window=%d", chain, walk, xk[c->xk], pers,
              c->big_exchange ? (c->plan_ahead ? "big_ahead" : "big") : c->lds_exchange ? "lds" : "none", c->plan_cap);
     return SMM_OK;

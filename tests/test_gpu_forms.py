@@ -38,12 +38,12 @@ TABLE = [
     ("8192 chains",                                             lambda S: norm(8192),               "iter_norm_narrow", "standalone", "lean", "none", "lds"),
     ("C3: 32768 chains on one GPU",                             lambda S: norm(32768),              "iter_norm_narrow_cone", "cone_local", "rows", "none", "big_ahead"),
     ("40000 chains",                                            lambda S: norm(40000),              "iter_norm_narrow", "standalone", "lvl_big", "none", "big"),
-    ("four parameters (general_normal)",                        lambda S: cm.general_normal(4, N=64, T=8, ns=64), "iter_norm", "inline_lean", "lean", "none", "lds"),
-    ("six parameters (the reference's snorm_standard)",         lambda S: cm.general_normal(6, N=64, T=8, ns=64), "iter<sim,8>", "inline_lean16", "lean", "none", "lds"),
+    ("four parameters (general_normal)",                        lambda S: cm.general_normal(4, N=64, T=8, ns=64), "iter_norm", "inline_lean", "lean", "tile_sim", "lds"),
+    ("six parameters (the reference's snorm_standard)",         lambda S: cm.general_normal(6, N=64, T=8, ns=64), "iter<sim,8>", "inline_lean16", "lean", "tile_sim", "lds"),
     ("C4: banana, 8192 chains",                                 lambda S: banana(S, 8192),          "iter<gen,16,2>", "inline_keys_cone", "lean", "gen", "lds"),
     ("banana, 2048 chains",                                     lambda S: banana(S, 2048),          "iter<gen,8>", "inline_lean16", "lean", "gen", "lds"),
     ("banana, 1000 chains (not whole groups of 32)",            lambda S: banana(S, 1000),          "iter<gen,8>", "inline_lean16", "lean", "none", "lds"),
-    ("C5: dense 50 parameters, 4096 chains",                    lambda S: dense(S, 4096),           "iter<dense,16>", "inline_keys_under_tile", "lean", "none", "lds"),
+    ("C5: dense 50 parameters, 4096 chains",                    lambda S: dense(S, 4096),           "iter<dense,16>", "inline_keys_under_tile", "lean", "tile_dense", "lds"),
 ]
 
 

@@ -1,0 +1,173 @@
+"""The persistent form of the objectives a whole tile evaluates (smm.jl_amd/csrc/smm_chain_persist_tile.hpp): objfunc_norm with MORE
+than two parameters — the reference's own larger examples have 6 and 18 (Examples.jl:210-230, 232-319) — and the dense simulation of
+BASELINE config 5 on the FP64 matrix cores, against the oracle and against the one-launch-per-iteration kernels (k_chain_iter<1, 8>,
+k_chain_iter<2, 16>, k_chain_iter_norm for 3 and 4 parameters): thresholds (the reference's default min_improve is 0.5,
+AlgoBGP.jl:522), proposal batches, injected tables, a failing objective, read-backs between steps, hard errors replayed, the short
+ring under skew, restart.  Replaces run!'s loop over computeNextIteration! (AlgoAbstract.jl:38-45, AlgoBGP.jl:589-640,
+exchangeMoves! :647-716)."""
+import numpy as np
+import pytest
+
+import common as cm
+from smm_jl_amd import _abi as A
+from test_gpu_parity import dense_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(S, O, prob, opts, tab=None):
+    h = S.hip_context(prob, opts, tab)
+    t = tab if tab is not None else S.Tables()
+    o = O.OracleContext(prob, opts, S.Tables(probs_acc=t.probs_acc, prop_normals=t.prop_normals, pairs=t.pairs, Z=h.Z()))
+    return h, o
+
+
+def _same(ha, hb, sa, sb):
+    cm.assert_history_equal(ha, hb, exact_floats=True)
+    cm.assert_state_equal(sa, sb, rtol=0)
+
+
+def _run(S, O, prob, opts, steps, tab=None, oracle=True, expect=None):
+    h, o = _pair(S, O, prob, opts, tab)
+    c = S.hip_context(prob, opts, tab)
+    c.set_persistent(False)
+    if expect is not None:
+        assert h.describe()["persistent"] == expect, h.describe()
+    for n in steps:
+        h.step(n); c.step(n)
+        if oracle:
+            o.step(n)
+    avail, launches, repairs = h.persistent_info()
+    assert launches >= 1 and repairs == 0, (launches, repairs, h.describe())
+    assert c.persistent_info()[1] == 0
+    _same(h.history(), c.history(), h.state(), c.state())
+    if oracle:
+        cm.assert_history_equal(h.history(), o.history())
+        cm.assert_state_equal(h.state(), o.state())
+    return h, o
+
+
+@pytest.mark.parametrize("npar,N,ns,mi,bs,steps", [(6, 48, 300, 0.0, None, [40]), (18, 70, 200, 0.0, None, [1, 5, 2, 20, 12]), (3, 100, 1000, 0.0, None, [30]),
+                                                  (4, 33, 10000, 0.05, None, [25, 25]), (6, 2, 100, 0.01, None, [30]), (18, 16, 100, 0.5, None, [30]),
+                                                  (32, 9, 150, 0.0, 16, [30]), (5, 1000, 64, 0.002, None, [40]), (6, 64, 300, np.nan, None, [20]),
+                                                  (6, 257, 333, 0.0, 3, [33]), (40, 40, 50, 0.0, None, [20])])
+def test_tile_form_objfunc_norm_against_oracle_and_per_iteration_kernels(S, O, npar, N, ns, mi, bs, steps):
+    T = sum(steps)
+    prob, opts = cm.general_normal(npar, N=N, T=T, ns=ns, batch_size=bs)
+    opts.min_improve[:] = mi
+    h, o = _run(S, O, prob, opts, steps, expect="tile_sim")
+    if mi == mi and mi < 0.4 and N > 2:
+        assert (h.history().exchanged != 0).any()
+    if mi != mi:
+        assert not (h.history().exchanged != 0).any()
+
+
+@pytest.mark.parametrize("npar,nm,N,mi,bs,steps", [(6, 5, 48, 0.0, None, [30]), (50, 50, 64, 0.0, None, [1, 5, 2, 12]), (50, 50, 112, 0.05, None, [20]),
+                                                  (17, 33, 32, 0.0, None, [25]), (56, 60, 16, 0.0, None, [20]), (50, 50, 48, 0.0, 25, [20]),
+                                                  (3, 2, 256, 0.5, None, [30])])
+def test_tile_form_dense_against_oracle_and_per_iteration_kernels(S, O, npar, nm, N, mi, bs, steps):
+    T = sum(steps)
+    prob, opts = dense_problem(S, O, npar, nm, N=N, T=T, **({"batch_size": bs} if bs else {}))
+    opts.min_improve[:] = mi
+    h, o = _pair(S, O, prob, opts)
+    c = S.hip_context(prob, opts)
+    c.set_persistent(False)
+    assert h.describe()["persistent"] == "tile_dense", h.describe()
+    for n in steps:
+        h.step(n); c.step(n); o.step(n)
+    assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 0, h.persistent_info()
+    _same(h.history(), c.history(), h.state(), c.state())
+    # (tanh: ocml against libm — the tolerances of the per-iteration kernel's own tests)
+    cm.assert_history_equal(h.history(), o.history(), rtol=1e-7)
+    cm.assert_state_equal(h.state(), o.state(), rtol=1e-7)
+
+
+def test_tile_form_c5_size(S, O):
+    # BASELINE config 5's shape: 50 parameters, 50 moments, 4096 chains — one 16-chain tile per compute unit
+    prob, opts = dense_problem(S, O, 50, 50, N=4096, T=40, smpl_iters=100000)
+    h = S.hip_context(prob, opts)
+    c = S.hip_context(prob, opts)
+    c.set_persistent(False)
+    h.step(40); c.step(40)
+    assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 0, h.persistent_info()
+    _same(h.history(), c.history(), h.state(), c.state())
+    assert 0.02 < (h.history().exchanged != 0).mean() < 0.5
+
+
+def test_tile_form_norm6_4096_chains_across_plan_windows(S, O):
+    # the reference's 6-parameter example at the headline's population, over more than one look-ahead window
+    prob, opts = cm.general_normal(6, N=4096, T=300, ns=2000)
+    h, o = _pair(S, O, prob, opts)
+    h.step(300); o.step(300)
+    assert h.persistent_info()[1] >= 2 and h.persistent_info()[2] == 0, h.persistent_info()
+    cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+    cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
+
+
+def test_tile_form_injected_tables_failbox_skew_and_restart(S, O, monkeypatch, hooks):
+    # injected tables (uniforms, normals of 7 tries, pair lists)
+    prob, opts = cm.general_normal(6, N=80, T=50, ns=700)
+    opts.sigma *= 0.3
+    tab = cm.random_tables(prob, opts, tries=7)
+    _run(S, O, prob, opts, [50], tab=tab)
+    # a failing objective (status -2) and mixed stepping with read-backs
+    rng = np.random.default_rng(5)
+    half = rng.uniform(1.0, 5.0, 5)
+    prob = S.Problem(init=rng.uniform(-0.5, 0.5, 5) * half, lb=-half, ub=half, mom=rng.uniform(-0.5, 0.5, 5) * half, w=rng.uniform(0.5, 2.0, 5), ns=300,
+                     objective_id=A.SMM_OBJ_NORM_FAILBOX, obj_params=[0.1, 1.5])
+    opts = S.BGPOpts(N=200, maxiter=64, sigma=0.3 * cm.temps(200, 3.0), acc_tuner=np.geomspace(10.0, 1.0, 200), min_improve=np.zeros(200), seed=7, N_global=200)
+    h, o = _pair(S, O, prob, opts)
+    for n in (7, 1, 20, 2, 34):
+        h.step(n); o.step(n)
+        cm.assert_history_equal(h.history(), o.history())
+    assert (h.history().status == -2).any()
+    assert h.persistent_info()[1] >= 3 and h.persistent_info()[2] == 0
+    cm.assert_state_equal(h.state(), o.state())
+    # save / restart in the middle of a run
+    prob, opts = cm.general_normal(6, N=96, T=60, ns=200)
+    h, o = _pair(S, O, prob, opts)
+    h.step(25); o.step(60)
+    h2 = S.hip_context(prob, opts)
+    h2.set_state(h.state(), h.history())
+    h2.step(35)
+    assert h2.persistent_info()[1] >= 1
+    cm.assert_history_equal(h2.history(), o.history())
+    # the short ring under skew
+    monkeypatch.setenv("SMMHIP_PR_RING", "2")
+    monkeypatch.setenv("SMMHIP_PR_SLOW_TILE", "3")
+    monkeypatch.setenv("SMMHIP_PR_SLOW_US", "25")
+    prob, opts = cm.general_normal(6, N=640, T=40, ns=300)
+    _run(S, O, prob, opts, [40])
+
+
+def test_tile_form_hard_errors_are_replayed(S, O):
+    # smpl_iters exhausted inside a persistent launch (AlgoBGP.jl:409), and a negative objective value (:341): the tiles run on, the
+    # host rolls back and replays on the per-iteration path, which stops at the failing iteration with the documented state
+    prob, opts = cm.general_normal(6, N=64, T=60, ns=100, smpl_iters=2)
+    opts.sigma[:] = 40.0
+    h = S.hip_context(prob, opts)
+    c = S.hip_context(prob, opts)
+    c.set_persistent(False)
+    errs = []
+    for ctx in (h, c):
+        with pytest.raises(A.SMMHipError) as ei:
+            ctx.step(60)
+        errs.append(str(ei.value))
+    assert errs[0] == errs[1], errs
+    assert "no draw in support" in errs[0]
+    assert h.persistent_info()[2] >= 1
+    _same(h.history(), c.history(), h.state(), c.state())
+
+
+def test_tile_form_late_tries_of_mysample(S, O):
+    # wide proposals in many dimensions: most chains need tries past the pre-generated ones (the shared rounds, then the scouting groups)
+    prob, opts = dense_problem(S, O, 50, 50, N=48, T=25)
+    opts.sigma[:] = 0.08
+    opts.smpl_iters = 100000
+    h, o = _pair(S, O, prob, opts)
+    c = S.hip_context(prob, opts)
+    c.set_persistent(False)
+    h.step(25); c.step(25); o.step(25)
+    assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 0
+    _same(h.history(), c.history(), h.state(), c.state())
+    cm.assert_history_equal(h.history(), o.history(), rtol=1e-7)
