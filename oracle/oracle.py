@@ -22,6 +22,7 @@ _ORC_ONLY = [
     ("orc_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("orc_max_threads", C.c_int, []),
     ("orc_gen_dense", None, [C.c_uint64, C.c_int, C.c_int, A.c_double_p]),
+    ("orc_tanh", None, [A.c_double_p, A.c_double_p, C.c_int]),
     ("orc_set_user_objective", None, [C.c_int, C.c_void_p]),
     ("orc_set_user_objective_lanes", None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
 ]
@@ -106,6 +107,14 @@ def gen_dense(seed, np_, nm):
     out = np.empty(A.SMM_DENSE_D * np_ + nm * A.SMM_DENSE_D)
     load().orc_gen_dense(seed, np_, nm, A.dptr(out))
     return out
+
+
+def dense_tanh(x):
+    """the dense objective's tanh as include/smmhip.h freezes it (smm_oracle.c: smm_tanh)"""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    load().orc_tanh(A.dptr(x), A.dptr(y), x.size)
+    return y
 
 
 _user_libs = []

@@ -179,7 +179,7 @@ __device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const dou
 // runs on the FP64 matrix cores.  A tile is 16 chains = the N dimension of v_mfma_f64_16x16x4; wave w
 // of the 8 owns the hidden units d in [32w, 32w+32):
 //   x tile [16 d x 16 chains]  = B[16 d x np] * theta[np x 16]        (ceil(np/4) MFMAs)
-//   h = tanh(x): the accumulator layout (row = (lane>>4) + 4r, col = lane&15) IS the B-operand layout
+//   h = tanh(x) (smm_tanh below): the accumulator layout (row = (lane>>4) + 4r, col = lane&15) IS the B-operand layout
 //   of the next product (k = 4s + (lane>>4)), so h feeds the second GEMM from registers;
 //   y tile [16 k x 16 chains] += A[16 k x 16 d] * h[16 d x 16]        (4 MFMAs per output tile)
 // B and A are stored in fragment order (one coalesced 8-byte load per lane per MFMA).  The wave's
@@ -187,6 +187,37 @@ __device__ inline void simulate_tile(const KParams& P, const ZBuf& zb, const dou
 // ------------------------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int DENSE_D = SMM_DENSE_D;
+
+// the hidden layer's tanh (include/smmhip.h, SMM_OBJ_DENSE): ONE exponential and ONE division — E = exp(2|x|) = 2^n (1 + p) with p = expm1(r)
+// on |r| <= ln2 / 2 (Taylor to r^13: 4e-18), tanh = (E - 1) / (E + 1) with E -+ 1 = fma(2^n, p, 2^n -+ 1) (2^n -+ 1 is exact) — about 45
+// instructions against ocml's ~165 (tools/dense_bench.hip: 4.4 -> 1.4 us of a tile's evaluation); at most 3 ulp from the true value.  Only
+// correctly rounded operations (fma, rint, ldexp, IEEE division), so the oracle's restatement (smm_oracle.c: smm_tanh) is BIT-IDENTICAL.
+__device__ __forceinline__ double smm_tanh(const double x) {
+    const double ax = __builtin_fabs(x);
+    const double z = ax + ax;
+    const double zc = z > 40.0 ? 40.0 : z;   // (tanh is 1 from 19.0625 on; a NaN stays one)
+    const double n = __builtin_rint(zc * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, zc);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, r, 1.0 / 479001600.0);
+    q = __builtin_fma(q, r, 1.0 / 39916800.0);
+    q = __builtin_fma(q, r, 1.0 / 3628800.0);
+    q = __builtin_fma(q, r, 1.0 / 362880.0);
+    q = __builtin_fma(q, r, 1.0 / 40320.0);
+    q = __builtin_fma(q, r, 1.0 / 5040.0);
+    q = __builtin_fma(q, r, 1.0 / 720.0);
+    q = __builtin_fma(q, r, 1.0 / 120.0);
+    q = __builtin_fma(q, r, 1.0 / 24.0);
+    q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    const double p = __builtin_fma(r * r, q, r);
+    const int ni = (n == n) ? (int)n : 0;
+    const double s = __builtin_ldexp(1.0, ni);
+    const double em1 = __builtin_fma(s, p, s - 1.0), ep1 = __builtin_fma(s, p, s + 1.0);
+    const double t = ax >= 19.0625 ? 1.0 : em1 / ep1;
+    return __builtin_copysign(t, x);
+}
 
 // (inlined into its kernels — out of line the operands came through generic pointers, one dependent load per MFMA —; the operand
 // fragments of a product are requested TOGETHER, ahead of the MFMAs that consume them: the B fragments of both hidden-unit tiles of the
@@ -233,27 +264,37 @@ __device__ __attribute__((noinline)) void dense_tile_n(const int np_, const int 
         const double v = s_theta[li * np + min(p, np - 1)];
         th[s] = p < np ? v : 0.0;
     }
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    // both first products ahead of the first tanh: the matrix pipe works on the second tile's product (and later on the first tile's second
+    // product) while the wave's vector instructions evaluate the tanh; the A fragments of a tile are requested a product ahead of their use
+    double afr[2][4][4];
+    auto load_a = [&](const int tt) {
         const int T = 2 * wave + tt;
-        double afr[4][4];   // requested before the first product: there when the tanh is over
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const gptr_t af = dense_Af + ((size_t)(min(o, nOt - 1) * (DENSE_D / 16) + T) * 4) * 64 + lane;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) afr[o][s4] = af[s4 * 64];
+            for (int s4 = 0; s4 < 4; ++s4) afr[tt][o][s4] = af[s4 * 64];
         }
-        d4_t xacc = d4_t{0.0, 0.0, 0.0, 0.0};
+    };
+    load_a(0);
+    d4_t xacc[2];
 #pragma unroll
-        for (int s = 0; s < PS; ++s) xacc = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[tt][s], th[s], xacc, 0, 0, 0);
+    for (int tt = 0; tt < 2; ++tt) {
+        xacc[tt] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < PS; ++s) xacc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[tt][s], th[s], xacc[tt], 0, 0, 0);
+        if (tt == 0) load_a(1);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
         double h[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = tanh(xacc[r]);
+        for (int r = 0; r < 4; ++r) h[r] = smm_tanh(xacc[tt][r]);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             if (o < nOt) {
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[o][s4], h[s4], yacc[o], 0, 0, 0);
+                for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[tt][o][s4], h[s4], yacc[o], 0, 0, 0);
             }
         }
     }

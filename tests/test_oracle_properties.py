@@ -294,3 +294,18 @@ def test_restart_resumes_bit_exactly(O):
     b.step(18)
     cm.assert_history_equal(full.history(), b.history(), exact_floats=True)
     cm.assert_state_equal(full.state(), b.state(), rtol=0)
+
+
+def test_dense_tanh_contract_against_libm(O):
+    # SMM_OBJ_DENSE's tanh is a frozen expression (include/smmhip.h): one exponential, one division, at most 3 ulp from the true value
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-1, 1, 200000) * s for s in (1e-3, 0.6, 3.0, 20.0, 45.0)] + [10.0 ** rng.uniform(-300, 0, 20000)])
+    y, ref = O.dense_tanh(x), np.tanh(x)
+    ulp = np.abs(y.view(np.int64) - ref.view(np.int64))
+    assert ulp.max() <= 4, (ulp.max(), x[ulp.argmax()])      # (numpy's tanh is itself within an ulp)
+    assert np.all(np.sign(y) == np.sign(x)) and np.all(np.abs(y) <= 1.0)
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, 19.0625, 700.0, 1e308, 5e-324])
+    assert np.array_equal(O.dense_tanh(sp), np.tanh(sp)) and np.signbit(O.dense_tanh(np.array([-0.0])))[0]
+    assert np.isnan(O.dense_tanh(np.array([np.nan])))[0]
+    xs = np.sort(rng.uniform(-6, 6, 100000))
+    assert np.all(np.diff(O.dense_tanh(xs)) >= -4.5e-16)       # monotone up to the last bits
