@@ -55,7 +55,7 @@ WORKLOADS = {
     # (13 + 16) MFMAs = 464 (np = 50 padded to 52, nm = 50 to 64), 2048 flop each => 59 392 EXECUTED flop per chain evaluation — what
     # SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 counts; the un-padded algorithm is 2*256*50 + 2*50*256 = 51 200 (0.862 of it)
     "c5": dict(chains=4096, total=False, flop=464 * 2048 // 16, useful_flop=2 * 256 * 50 + 2 * 50 * 256, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma",
-               peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_iter<2, 16",
+               peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_persist_tile<2>",
                label="synthetic dense simulation, 50 params -> 256 hidden units (tanh) -> 50 moments: the products 256x50 and 50x256 per evaluation "
                      "on FP64 MFMA, 4096 chains (BASELINE configs[4]; NOT a 256x256 product: see roofline.note)"),
 }
@@ -85,7 +85,8 @@ def profile_tag(workload):
 
 # the persistent launches + the single iterations at window boundaries, per workload
 CHAIN_KERNELS = {"c2": ("k_chain_persist_loc<2, false, false>", "k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>"),
-                 "c4": ("k_chain_persist_gen", "k_chain_iter<0, 16, 2, true>")}
+                 "c4": ("k_chain_persist_gen", "k_chain_iter<0, 16, 2, true>"),
+                 "c5": ("k_chain_persist_tile<2>", "k_chain_iter<2, 16, 1, true>", "k_chain_iter<2, 16, 1, false>")}
 
 
 def _profile_iterations(summary_path, which):
@@ -179,6 +180,14 @@ def mfma_counter(kernel, workload):
     f = newest_profile("r[0-9][0-9]_%spmc_summary.txt" % profile_tag(workload))
     if not f:
         return None, None
+    if kernel.startswith("k_chain_persist"):   # per ITERATION: the chain kernels' totals / the iterations of the counter passes' command
+        iters, tot = _profile_iterations(f, "pmc"), 0.0
+        for line in open(f):
+            if any(k in line for k in CHAIN_KERNELS.get(workload, ())) and "SQ_INSTS_VALU_MFMA_MOPS_F64" in line:
+                m = re.search(r"total=\s*([0-9.]+)", line)
+                if m:
+                    tot += float(m.group(1))
+        return (tot / iters, os.path.relpath(f, ROOT)) if iters and tot else (None, None)
     for line in open(f):
         if kernel in line and "SQ_INSTS_VALU_MFMA_MOPS_F64" in line:
             m = re.search(r"mean_per_launch=\s*([0-9.]+)", line)
@@ -548,10 +557,10 @@ def main():
             roof["note"] = ("achieved = EXECUTED MFMA flop (464 v_mfma_f64_16x16x4 per 16 chains, np / nm padded to 52 / 64) over the chain kernel's duration; "
                             "mfma_counter = the same from SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the committed PMC pass (must agree within 5 %); the objective is "
                             "x = B theta (256 x np), h = tanh x, y = A h (nm x 256): 51 200 useful flop per evaluation, not the 2*256*256 + ... = 156 672 of a "
-                            "256 x 256 product that rounds 2-3 credited (BASELINE.json's wording).  One launch per iteration (the tiles walk the key exchange in their prologue).  "
-                            "The run drifts as sigma adapts — the synthetic objective accepts 99 % of the proposals, so every sigma grows without bound and "
-                            "mysample needs ever more tries per proposal (late tries are scouted by groups of 16 lanes: tools/c5_tail.py) —: "
-                            "quote it at >= 1600 iterations (--steps 8, the default for this workload); per-launch p50 / p99 in profiles/rNN_c5_launches.txt")
+                            "256 x 256 product that rounds 2-3 credited (BASELINE.json's wording).  The persistent tile kernel (smm_chain_persist_tile.hpp): one launch per "
+                            "look-ahead window, every figure per ITERATION; the hidden layer's tanh is part of the numerical contract (include/smmhip.h: one exponential, "
+                            "one division; device and oracle bit-identical).  The instance (acc_tuner x 3000: cold chains accept 20-40 %, sigma stationary) is "
+                            "quoted at >= 1600 iterations (--steps 8, the default for this workload)")
         if args.workload in ("c2", "c3"):
             roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "
                             "(FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)")

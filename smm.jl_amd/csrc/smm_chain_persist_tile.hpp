@@ -416,21 +416,29 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         if (A.ts && tid == 0) ts4 = wall_clock64();
         // ---- the moments of a chain (wave totals -> mean -> squared weighted deviation) by its 32 lanes (ObjExamples.jl:79-100) ----
         const bool failed = KIND == 1 && A.failbox && valid && s_theta[cc * np] >= A.objp[0] && s_theta[cc * np] <= A.objp[1];   // mprob.jl:183-186
-        if (valid) {
-            for (int k = r2; k < nm; k += LPC) {
-                double tot, m;
-                if constexpr (KIND == 2) {
-                    const int nmp = A.dense_nOt * 16;
-                    tot = s_part[((size_t)0 * nmp + k) * 16 + cc];
+        if constexpr (KIND == 2) {
+            // (the dense tile's partial sums lie [wave][moment][chain]: the lanes run over the CHAINS of a moment — consecutive doubles, no
+            // bank conflict; the chain's own 32 lanes would stride 128 bytes and meet in one bank)
+            const int nmp = A.dense_nOt * 16;
+            const int c16 = tid & (CT - 1);
+            if (tile * CT + c16 < N) {
+                for (int k = tid / CT; k < nm; k += WG / CT) {
+                    double tot = s_part[((size_t)0 * nmp + k) * 16 + c16];
 #pragma unroll
-                    for (int wv = 1; wv < WG / 64; ++wv) tot = tot + s_part[((size_t)wv * nmp + k) * 16 + cc];
-                    m = tot;
-                } else {
-                    tot = s_part[(0 * CT + cc) * nm + k];
-#pragma unroll
-                    for (int wv = 1; wv < WG / 64; ++wv) tot = tot + s_part[(wv * CT + cc) * nm + k];
-                    m = tot / (double)A.ns;
+                    for (int wv = 1; wv < WG / 64; ++wv) tot = tot + s_part[((size_t)wv * nmp + k) * 16 + c16];
+                    double d = tot - s_mom[k];
+                    const double wk = s_w[k];
+                    if (!isnan(wk)) d = d / wk;
+                    s_sm[c16 * nm + k] = tot;
+                    s_vk[c16 * nm + k] = d * d;
                 }
+            }
+        } else if (valid) {
+            for (int k = r2; k < nm; k += LPC) {
+                double tot = s_part[(0 * CT + cc) * nm + k];
+#pragma unroll
+                for (int wv = 1; wv < WG / 64; ++wv) tot = tot + s_part[(wv * CT + cc) * nm + k];
+                const double m = tot / (double)A.ns;
                 double d = m - s_mom[k];
                 const double wk = s_w[k];
                 if (!isnan(wk)) d = d / wk;

@@ -27,6 +27,8 @@ PY
   # (C4's persistent chain kernel covers many iterations per launch: per-iteration figures = totals over the chain kernels / the iterations of the
   #  command; bench.py runs warmup + steps + one profiled step of 200 iterations each: 1 + 5 + 1 in the kernel trace, 1 + 2 + 1 in the counter passes)
   [ $cfg = c4 ] && echo "# iterations_kernel_trace=1400 iterations_pmc=800" >> $out/${cfg}_pmc_summary.txt
+  # (C5's persistent tile kernel alike; its default is --steps 8: 1 + 8 + 1 steps in the kernel trace)
+  [ $cfg = c5 ] && echo "# iterations_kernel_trace=2000 iterations_pmc=800" >> $out/${cfg}_pmc_summary.txt
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
     rm -rf /tmp/pm && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pm -- $B --steps 2 > /dev/null 2>&1
     python $GRAFT_REPO_ROOT/tools/summarise_pmc.py $(find /tmp/pm -name "*counter_collection.csv" | head -1) | grep -a "k_chain_iter\|k_chain_persist\|k_cone_\|k_exch_resolve\|k_exch_plan\|k_pregen\|^#" >> $out/${cfg}_pmc_summary.txt
