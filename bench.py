@@ -555,7 +555,8 @@ def main():
                 "achieved_at_rocprof_kernel_us": (mops * 512.0 / (prof_us * 1e-6) / 1e12) if prof_us else None,
                 "flop_per_launch_counted_over_assumed": mops * 512.0 / work}
             roof["note"] = ("achieved = EXECUTED MFMA flop (464 v_mfma_f64_16x16x4 per 16 chains, np / nm padded to 52 / 64) over the chain kernel's duration; "
-                            "mfma_counter = the same from SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the committed PMC pass (must agree within 5 %); the objective is "
+                            "mfma_counter = the same from SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the committed PMC pass: 1.10 x the assumed figure since round 5 — the first "
+                            "product runs in groups of four fragments (16 for np = 50, straight-line code), the 3 padded ones are NOT credited; the objective is "
                             "x = B theta (256 x np), h = tanh x, y = A h (nm x 256): 51 200 useful flop per evaluation, not the 2*256*256 + ... = 156 672 of a "
                             "256 x 256 product that rounds 2-3 credited (BASELINE.json's wording).  The persistent tile kernel (smm_chain_persist_tile.hpp): one launch per "
                             "look-ahead window, every figure per ITERATION; the hidden layer's tanh is part of the numerical contract (include/smmhip.h: one exponential, "
