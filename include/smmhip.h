@@ -338,7 +338,7 @@ int  smm_get_timing(void* ctx, smm_timing_t* out);
  * dispatch-begin to dispatch-end durations the command processor stamps, i.e. what rocprofv3
  * --kernel-trace reports; null_bracket_ms = 0.   on = 0: off. */
 int  smm_set_profiling(void* ctx, int32_t on);
-/* The persistent form of smm_bgp_step and smm_bgp_p2p_step (smm.jl_amd/csrc/smm_chain_persist_loc.hpp, smm_chain_persist_gen.hpp;
+/* The persistent form of smm_bgp_step and smm_bgp_p2p_step (smm.jl_amd/csrc/smm_chain_persist_loc.hpp, smm_chain_persist_gen.hpp, smm_chain_persist_tile.hpp;
  * replaces the loop of run!, AlgoAbstract.jl:38-45, over computeNextIteration!, AlgoBGP.jl:589-640): where a context qualifies a step of
  * n >= 2 iterations is ONE kernel launch per look-ahead window (<= 256 iterations) instead of one per iteration.  Results are
  * bit-identical.  A context qualifies with
@@ -351,9 +351,12 @@ int  smm_set_profiling(void* ctx, int32_t on);
  *   - the banana objective, or a USER objective in the one-thread-per-evaluation form (smm_register_user_objective: the library compiles
  *     the persistent kernel once more with the user's source inside, through hiprtc, when the first such context is created: ~1.5 s),
  *     with at most 16 parameters / moments (one proposal batch, isotropic, min_improve == 0) on a single shard of up to 8192 chains in
- *     whole groups of 32.
- * Per-chain thresholds, other dist_fun, more than two moments of objfunc_norm, Cholesky proposals, the dense objective, the map-reduce
- * form of user objectives: the per-iteration kernels.
+ *     whole groups of 32;
+ *   - objfunc_norm with MORE than two parameters (the reference's own larger examples have 6 and 18, Examples.jl:210-230, 232-319) or
+ *     the dense objective: one proposal batch or several, isotropic proposals, dist_fun = `-`, ONE min_improve >= 0 (or NaN) for all
+ *     chains, a single shard of at most two 16-chain tiles per compute unit whose blocks fit the LDS (np = nm = 50: yes; 64 + 64: no).
+ * Per-chain thresholds, other dist_fun, Cholesky proposals, the map-reduce form of user objectives, shards of anything but objfunc_norm
+ * with at most two parameters: the per-iteration kernels.
  * on = 0 keeps the one-launch-per-iteration kernels (default: on).  A hard error of the algorithm inside such a launch is found at
  * the next call that checks (smm_sync, smm_bgp_step, the state readers): the library then repeats those iterations from the state
  * it saved on the one-launch-per-iteration path, so that the context stands at the failing iteration exactly as documented above.

@@ -191,7 +191,7 @@ constexpr int DENSE_D = SMM_DENSE_D;
 // the hidden layer's tanh (include/smmhip.h, SMM_OBJ_DENSE): ONE exponential and ONE division — E = exp(2|x|) = 2^n (1 + p) with p = expm1(r)
 // on |r| <= ln2 / 2 (Taylor to r^13: 4e-18), tanh = (E - 1) / (E + 1) with E -+ 1 = fma(2^n, p, 2^n -+ 1) (2^n -+ 1 is exact) — about 45
 // instructions against ocml's ~165 (tools/dense_bench.hip: 4.4 -> 1.4 us of a tile's evaluation); at most 3 ulp from the true value.  Only
-// correctly rounded operations (fma, rint, ldexp, IEEE division), so the oracle's restatement (smm_oracle.c: smm_tanh) is BIT-IDENTICAL.
+// correctly rounded operations (fma, rint, ldexp, IEEE division), so a plain C restatement of the same expression is BIT-IDENTICAL (the tests hold one).
 __device__ __forceinline__ double smm_tanh(const double x) {
     const double ax = __builtin_fabs(x);
     const double z = ax + ax;
