@@ -774,9 +774,6 @@ __device__ inline bool exchange_walk_tile_keys(const KParams& P, const int tx, u
 // The level walk is latency, not bandwidth: a level with a handful of pairs costs almost what a level with a thousand does
 // (measured per level of the first form: 1784 cycles for 1000 pairs, ~850 for 50), so what counts is the dependent chain
 // per level.  FINAL_BARRIER = false: only the walking wave 0 reads the result (its own LDS operations complete in order).
-#ifndef SMM_EXP_WALK_SKIP
-#define SMM_EXP_WALK_SKIP 0
-#endif
 constexpr uint32_t XNOPAIR = 0xffffffffu;   // i == j == 0xffff never occurs (chain ids < XLVL_MAX)
 // (inline asm: left to itself the compiler reads only the 8 value bytes first and fetches src with a second, dependent LDS
 // read inside the swap branch — two round trips per level instead of one.  The asm's own LDS operations are invisible to the
@@ -816,11 +813,11 @@ __device__ inline void walk_levels(const KParams& P, const uint32_t slot, const 
         const uint32_t e3 = level_end(l + 2);
         uint32_t pw2 = XNOPAIR;
         double m2 = mi_v;
-        if (!SMM_EXP_WALK_SKIP || e + wbase < e2) {   // this thread's first pair of the next level
+        {   // this thread's first pair of the next level
             pw2 = (e + tid < e2) ? pairs[e + tid] : XNOPAIR;
             if constexpr (!MI_U) m2 = (e + tid < e2) ? g_mi[e + tid] : 0.0;
         }
-        if (!SMM_EXP_WALK_SKIP || b + wbase < e) {
+        {
             if (pw != XNOPAIR) walk_pair(slot, pw, m);
             for (uint32_t pos = b + tid + NT; pos < e; pos += NT) walk_pair(slot, pairs[pos], MI_U ? mi_v : g_mi[pos]);   // levels wider than the workgroup
         }

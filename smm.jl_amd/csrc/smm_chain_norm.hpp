@@ -19,22 +19,7 @@
 constexpr int NORM_CT = 16;           // chains per tile
 constexpr int NORM_NR = 4;            // lanes per chain in the control wave
 constexpr int NORM_WG = 2 * WG;       // 1024 lanes
-#ifndef SMM_EXP_SGPR_MU
-#define SMM_EXP_SGPR_MU 0
-#endif
-#ifndef SMM_EXP_SETPRIO
-#define SMM_EXP_SETPRIO 1
-#endif
-#ifndef SMM_EXP_P2P_PLAIN_FIRST
-#define SMM_EXP_P2P_PLAIN_FIRST 0
-#endif
-#ifndef SMM_EXP_NORM_ZU
-#define SMM_EXP_NORM_ZU 4
-#endif
-#ifndef SMM_EXP_DMA_STAGE
-#define SMM_EXP_DMA_STAGE 1
-#endif
-constexpr int NORM_ZU = SMM_EXP_NORM_ZU;   // shock rows per chunk (the 16 means sit in SGPRs: 16 accumulators + two chunk buffers = 64 VGPRs)
+constexpr int NORM_ZU = 4;   // shock rows per chunk (the 16 means sit in SGPRs: 16 accumulators + two chunk buffers = 64 VGPRs)
 
 template <int ZK>
 __device__ inline void sim_load_chunk_n(const ZBuf& zb, const KParams& P, int k, int ch, double (&z)[ZK]) {
@@ -98,14 +83,7 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
         double acc[CT], mu[CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            // the proposal's k-th component is the same in every lane: into a scalar register pair (v_add_f64 takes one SGPR operand)
-#if SMM_EXP_SGPR_MU
-            const unsigned long long um = __builtin_bit_cast(unsigned long long, s_theta[c * NP + k]);
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)um), hi = __builtin_amdgcn_readfirstlane((unsigned)(um >> 32));
-            mu[c] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-#else
-            mu[c] = s_theta[c * NP + k];
-#endif
+            mu[c] = s_theta[c * NP + k];   // (in a scalar register pair it was slower: EXPERIMENTS.md R4.5)
             acc[c] = 0.0;
         }
         auto add_full = [&](const double (&z)[ZU]) {
@@ -137,11 +115,9 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
         int ch = 0;
 #pragma clang loop unroll(disable)
         for (; ch + 2 <= nch; ch += 2) {
-#if SMM_EXP_SETPRIO
             // a wave that is ahead yields to the ones behind (the arbiter prefers the oldest wave: left alone, the four waves of
             // a SIMD finish one after the other and the last one issues FP64 on its own, at 57 % of the rate)
             if (ch == 0) __builtin_amdgcn_s_setprio(3); else if (ch == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
-#endif
             sim_load_chunk_n<ZU>(zb, P, k, ch + 1, zn);
             add_full(zc);
             const bool last = (ch + 2 == nch);
@@ -149,9 +125,7 @@ __device__ inline void simulate_tile16(const KParams& P, const ZBuf& zb0, const 
             if (last) add_last(zn); else add_full(zn);
         }
         if (ch < nch) {
-#if SMM_EXP_SETPRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
             sim_load_chunk_n<ZU>(zb, P, knext, 0, zn);
             add_last(zc);
 #pragma unroll
@@ -190,7 +164,6 @@ __device__ inline bool exchange_walk_lean(const KParams& P, const int tx, unsign
     // (everything is requested before anything is looked at: a load issued behind the first wait is a round trip of its own)
     const uint32_t wflags = P.walk_flags[tid & 3];   // (word 0 is looked at; a per-lane address keeps it a vector load among the others)
     const uint32_t ov = g_offp[min(lane, LV_OFFP - 1)];   // lane l: first word of level l; lane 33: levels; lane 34: the plan fits
-#if SMM_EXP_DMA_STAGE
     // (round 3, VERDICT r2 #4a) slots and pair list straight into LDS by LDS-DMA, no VGPR hop, no ds_write pass: staging 1.67 ->
     // 1.59 us, kernel -0.03..0.1 us (A/B on one box: small, never negative).  A wave's share
     // is contiguous in memory and in LDS alike (the image is lane-linear): two instructions for its 256 chains' slots, two for its
@@ -213,7 +186,6 @@ __device__ inline bool exchange_walk_lean(const KParams& P, const int tx, unsign
         lean_walk_levels<NORM_WG, 0>(P.vals, 1, pbase, ov, nlev_d, tid, ltail_d);
         return true;
     }
-#endif
     uint4 s0 = make_uint4(0u, 0u, 0u, 0u), s1 = s0;
     if (4 * tid < Ng) { s0 = ((const uint4*)P.slot8)[2 * tid]; s1 = ((const uint4*)P.slot8)[2 * tid + 1]; }
     uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0;
@@ -309,13 +281,8 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
     uint4 s_[2 * SR];
     {
         const int qc0 = min(tid, (Ng - 1) / 4), qc1 = min(tid + NT, (Ng - 1) / 4);   // (lanes past the end read the last piece: not used)
-#if SMM_EXP_P2P_PLAIN_FIRST
-        s_[0] = g_slots[2 * qc0]; s_[1] = g_slots[2 * qc0 + 1];
-        if constexpr (SR == 2) { s_[2] = g_slots[2 * qc1]; s_[3] = g_slots[2 * qc1 + 1]; }
-#else
         if constexpr (SR == 1) p2p_load16x2_sys(g_slots + 2 * qc0, g_slots + 2 * qc0 + 1, s_[0], s_[1]);
         else p2p_load16x4_sys(g_slots + 2 * qc0, g_slots + 2 * qc0 + 1, g_slots + 2 * qc1, g_slots + 2 * qc1 + 1, s_[0], s_[1], s_[2], s_[3]);
-#endif
     }
     const uint32_t want_hi = p2p_tag(P, tx) << 16;
     bool timed_out = false;
@@ -538,14 +505,9 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
                     const uint32_t tag = p2p_tag(P, t - 1);
                     uint4 q[RW];
                     static_assert(RW % 2 == 0, "records are an even number of doubles");
-#if SMM_EXP_P2P_PLAIN_FIRST
-#pragma unroll
-                    for (int i = 0; i < RW; ++i) q[i] = g_ll[i];
-#else
 #pragma unroll
                     for (int i = 0; i + 4 <= RW; i += 4) p2p_load16x4_sys(g_ll + i, g_ll + i + 1, g_ll + i + 2, g_ll + i + 3, q[i], q[i + 1], q[i + 2], q[i + 3]);
                     if constexpr (RW % 4 != 0) p2p_load16x2_sys(g_ll + RW - 2, g_ll + RW - 1, q[RW - 2], q[RW - 1]);
-#endif
                     bool ok = true;
 #pragma unroll
                     for (int i = 0; i < RW; ++i) ok = ok && p2p_ll_ok(q[i], tag);

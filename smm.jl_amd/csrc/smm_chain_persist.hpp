@@ -40,10 +40,7 @@
 constexpr int PR_K = 8;          // iterations in the ring
 constexpr int PR_ZR = 20;        // shocks per lane held in registers: ns <= 512 * PR_ZR
 constexpr int PR_MAX_ITERS = 4000;   // iterations per launch (12 bits of the tags count them)
-#ifndef SMM_EXP_PR_DELAY
-#define SMM_EXP_PR_DELAY 8
-#endif
-constexpr int PR_GATHER_DELAY = SMM_EXP_PR_DELAY;   // s_sleep units (64 clocks) between this tile's publication and the gather's first look
+constexpr int PR_GATHER_DELAY = 8;   // s_sleep units (64 clocks) between this tile's publication and the gather's first look
 constexpr int PR_STW = 12;       // doubles of chain state in front of the record in a tile's LDS line
 constexpr unsigned long long PERSIST_TMO_FIRST = 40000000ull;   // 0.4 s of the 100 MHz wall clock: the spins of a context's first launches (smmhip.hip, launch_chain_persist)
 
@@ -56,16 +53,10 @@ __device__ inline uint32_t pr_tag16(const uint32_t epoch, const int rel) { retur
 __device__ inline uint32_t pr_tag32(const uint32_t epoch, const int rel) { return 0x80000000u | ((epoch & 0x7ffffu) << 12) | ((uint32_t)rel & 0xfffu); }
 __device__ inline uint32_t pr_progress_word(const uint32_t epoch, const int rel) { return (epoch << 12) | (uint32_t)rel; }
 
-// The ring is written with write-through stores and read past the caches.  Scope: the tiles are workgroups of ONE device, so the
-// agent scope (sc1) is enough; SMM_EXP_PR_SYS=1 makes it the system scope (sc0 sc1) of the p2p windows, for comparison.
-#ifndef SMM_EXP_PR_SYS
-#define SMM_EXP_PR_SYS 1   // (round 5: the same words also travel between the ranks' windows, smm_chain_persist_loc.hpp — one scope for all; measured equal, EXPERIMENTS.md R4.3)
-#endif
-#if SMM_EXP_PR_SYS
+// The ring is written with write-through stores and read past the caches.  Scope: for the tiles of ONE device the agent scope (sc1) would
+// do, but the same words also travel between the ranks' windows (smm_chain_persist_loc.hpp): the system scope (sc0 sc1) for all — measured
+// equal on one device (EXPERIMENTS.md R4.3).
 #define PR_SC "sc0 sc1"
-#else
-#define PR_SC "sc1"
-#endif
 __device__ inline unsigned long long pr_load8_sys(const void* p) {
     unsigned long long v;
     asm volatile("global_load_dwordx2 %0, %1, off " PR_SC "\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");

@@ -132,9 +132,8 @@ struct PersistLocWalkValues {
         return pr_tie_value(W, ring, nullptr, tag, RW, NPV, t, g);
     }
 };
-// (the ring's words travel at the system scope — sc0 sc1: pr_store8 / pr_store_ll / pr_dma16 and the loads of smm_chain_persist.hpp with
-// SMM_EXP_PR_SYS = 1 — whether the tiles are one device's or the ranks': a remote store lands in this device's memory behind its L2)
-static_assert(SMM_EXP_PR_SYS == 1, "the ranks' windows need the system scope");
+// (the ring's words travel at the system scope — sc0 sc1: pr_store8 / pr_store_ll / pr_dma16 and the loads of smm_chain_persist.hpp —
+// whether the tiles are one device's or the ranks': a remote store lands in this device's memory behind its L2)
 
 // progress of the slowest tile of ALL ranks in this launch; a word of a LATER launch counts as "through" (its rank has left this
 // launch behind: nothing of it is waited for any more), of an earlier one as "not started"

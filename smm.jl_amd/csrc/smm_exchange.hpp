@@ -1013,9 +1013,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
     if constexpr (!WIN) {
         if (tid == 0) nan_flags[(t + 1) & 1] = 0u;   // (the next iteration's word: its accept step or k_exch_keys raises it)
         if (info[3] == 0u || nan_flags[t & 1] != 0u) {
-#ifndef SMM_EXP_NO_FALLBACK   // (inspection builds: the rows walk's own code without the fallback's)
             resolve_key_body<PLDS>(P, t, vals, slots16, xsm);
-#endif
             return;
         }
     }
