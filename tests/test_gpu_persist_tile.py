@@ -171,3 +171,49 @@ def test_tile_form_late_tries_of_mysample(S, O):
     assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 0
     _same(h.history(), c.history(), h.state(), c.state())
     cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
+
+
+MASKED_TILE = r"""
+import os, sys, time, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import smm_jl_amd as S, common as cm
+from oracle import oracle as O
+O.load()
+prob, opts = cm.general_normal(6, N=4096, T=24, ns=64)
+h = S.hip_context(prob, opts)
+form, avail0 = h.describe()["persistent"], h.persistent_info()[0]
+t0 = time.perf_counter()
+h.step(24)
+dt = time.perf_counter() - t0
+o = O.OracleContext(prob, opts, S.Tables(Z=h.Z()), threads=O.max_threads())
+o.step(24)
+cm.assert_history_equal(h.history(), o.history(), atol=1e-12)   # (a parameter or moment that crosses zero: an ulp of a normal is an absolute 1e-15)
+cm.assert_state_equal(h.state(), o.state(), atol=1e-12)
+print(json.dumps(dict(form=form, avail0=avail0, info=h.persistent_info(), seconds=dt)))
+"""
+
+
+@pytest.mark.parametrize("var,val", [("HSA_CU_MASK", "0:0-127")])
+def test_tile_form_on_a_device_with_masked_compute_units(S, tmp_path, var, val):
+    # 256 tiles that wait for each other on a device that shows the process half its compute units: the form is refused at creation, or
+    # its first launch gives up after 0.4 s, the step is replayed on the per-iteration kernels, the second time-out switches the form
+    # off — and the results are the oracle's either way (the path test_persistent_form_on_a_device_with_masked_compute_units pins for
+    # k_chain_persist_loc)
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "masked_tile.py"
+    script.write_text(MASKED_TILE.format(root=root))
+    env = dict(os.environ)
+    env[var] = val
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    avail, launches, repairs = d["info"]
+    if d["avail0"] and repairs == 0:
+        pytest.skip("%s=%s left all tiles resident on this box (launches %d, %.2f s): nothing to see" % (var, val, launches, d["seconds"]))
+    assert (not d["avail0"]) or repairs >= 1, d
+    assert d["seconds"] < 6.0, d
