@@ -36,7 +36,12 @@ extern "C" {
  * the ns simulated draws of one moment are summed as SMM_REDUCE_LANES lane-strided
  * sequential partial sums (lane l takes draws l, l+512, l+1024, ...), each group of 64
  * partials is combined by a halving tree (offsets 32,16,8,4,2,1) and the 8 group
- * totals are added left to right.  Replaces mean(X,dims=2), ObjExamples.jl:79. */
+ * totals are added left to right.  Replaces mean(X,dims=2), ObjExamples.jl:79.
+ * The elementary functions of the path are part of the contract too: the logarithm and the sine / cosine of the generator's
+ * Box-Muller transform and the exponential of the acceptance probability (AlgoBGP.jl:344) are fixed sequences of correctly
+ * rounded operations (smm.jl_amd/csrc/smm_rng.hpp: smm_log, smm_sincos2pi, smm_exp — after fdlibm; each within 1 ulp), the
+ * dense objective's tanh likewise (below).  Consequence: a run is reproduced BIT FOR BIT by any implementation of the contract —
+ * every floating-point field of the history, not only the bookkeeping. */
 #define SMM_REDUCE_LANES 512
 
 typedef enum {

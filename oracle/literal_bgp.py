@@ -23,6 +23,24 @@ implementations cannot be compared bit by bit.
 import copy
 import math
 
+
+def contract_exp(x):
+    """the exponential of the numerical contract (include/smmhip.h; after fdlibm's e_exp.c), in plain Python floats"""
+    if x != x:
+        return x
+    if x > 709.782712893383973096:
+        return math.inf
+    if x < -745.13321910194110842:
+        return 0.0
+    k = float(round(x * 1.44269504088896338700e+00))     # round half to even, as rint
+    hi = x - k * 6.93147180369123816490e-01
+    lo = k * 1.90821492927058770002e-10
+    r = hi - lo
+    t = r * r
+    c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 + t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))))
+    y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi)
+    return math.ldexp(y, int(k))
+
 REDUCE_LANES = 512   # include/smmhip.h: the ns draws of a moment are summed as 512 lane-strided partial sums, ...
 
 OBJ_NORM, OBJ_NORM_FAILBOX = 0, 2   # smm_objective_t (include/smmhip.h)
@@ -136,10 +154,7 @@ def doAcceptReject(c, eval_new):
         if not (eval_new.value >= 0):             # :341
             raise NegativeObjective("chain %d iteration %d" % (c.id, c.iter))
         x = c.acc_tuner * (eval_old.value - eval_new.value)
-        try:
-            e = math.exp(x)
-        except OverflowError:
-            e = math.inf                          # (Base.exp returns Inf)
+        e = contract_exp(x)                       # (Base.exp in the reference; the contract's exponential here: include/smmhip.h)
         eval_new.prob = e if e != e else min(1.0, e)   # minimum([1.0, e]) propagates NaN, :344
         if not math.isfinite(eval_new.prob):      # :350-353
             eval_new.prob = 0.0

@@ -23,6 +23,7 @@ _ORC_ONLY = [
     ("orc_max_threads", C.c_int, []),
     ("orc_gen_dense", None, [C.c_uint64, C.c_int, C.c_int, A.c_double_p]),
     ("orc_tanh", None, [A.c_double_p, A.c_double_p, C.c_int]),
+    ("orc_math", None, [C.c_int, A.c_double_p, A.c_double_p, C.c_int]),
     ("orc_set_user_objective", None, [C.c_int, C.c_void_p]),
     ("orc_set_user_objective_lanes", None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
 ]
@@ -107,6 +108,14 @@ def gen_dense(seed, np_, nm):
     out = np.empty(A.SMM_DENSE_D * np_ + nm * A.SMM_DENSE_D)
     load().orc_gen_dense(seed, np_, nm, A.dptr(out))
     return out
+
+
+def contract_math(what, x):
+    """the contract's elementary functions (smm_oracle.c): what = "log" | "exp" | "sin2pi" | "cos2pi"""
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    load().orc_math({"log": 0, "exp": 1, "sin2pi": 2, "cos2pi": 3}[what], A.dptr(x), A.dptr(y), x.size)
+    return y
 
 
 def dense_tanh(x):

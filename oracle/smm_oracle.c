@@ -148,14 +148,76 @@ static double u53_open0(uint32_t hi, uint32_t lo) {
     uint64_t w = ((uint64_t)hi << 32) | lo;
     return (double)((w >> 11) + 1) * 0x1.0p-53;
 }
+/* The elementary functions of the path are part of its numerical contract (include/smmhip.h; the device's copies: smm_rng.hpp): plain
+ * sequences of correctly rounded operations, compiled without contraction, each within 1 ulp of the true value (sine / cosine: 2^-53
+ * absolute) — tests/test_oracle_properties.py compares them with libm's.  After fdlibm's e_log.c, k_sin.c, k_cos.c, e_exp.c. */
+static double smm_log(const double x) {   /* a positive normal double */
+    uint64_t b;
+    memcpy(&b, &x, 8);
+    int e = (int)((b >> 52) & 0x7ffu) - 1023;
+    const uint64_t mb = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m;
+    memcpy(&m, &mb, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+static void smm_sincos2pi(const double u, double* sn, double* cs) {   /* u in [0, 1) */
+    const double t = 4.0 * u;
+    const double q = rint(t);
+    const double r = t - q;
+    const double x = r * 1.57079632679489655800e+00 + r * 6.12323399573676603587e-17;
+    const double z = x * x;
+    const double v = z * x;
+    const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s = x + v * (-1.66666666666666324348e-01 + z * rs);
+    const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * rc);
+    const int qi = (int)q & 3;
+    *sn = qi == 0 ? s : (qi == 1 ? c : (qi == 2 ? -s : -c));
+    *cs = qi == 0 ? c : (qi == 1 ? -s : (qi == 2 ? -c : s));
+}
+static double smm_exp(const double x) {
+    if (x != x) return x;
+    if (x > 709.782712893383973096) return INFINITY;
+    if (x < -745.13321910194110842) return 0.0;
+    const double k = rint(x * 1.44269504088896338700e+00);
+    const double hi = x - k * 6.93147180369123816490e-01;
+    const double lo = k * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 + t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return ldexp(y, (int)k);
+}
+/* (exported for the tests) what: 0 log, 1 exp, 2 sin(2 pi x), 3 cos(2 pi x) */
+void orc_math(int what, const double* x, double* y, int n) {
+    for (int i = 0; i < n; ++i) {
+        double s, c;
+        if (what == 0) y[i] = smm_log(x[i]);
+        else if (what == 1) y[i] = smm_exp(x[i]);
+        else { smm_sincos2pi(x[i], &s, &c); y[i] = what == 2 ? s : c; }
+    }
+}
+
 /* Box-Muller: two standard normals from one Philox block */
 static void box_muller(const uint32_t x[4], double z[2]) {
     double u1 = u53_open0(x[0], x[1]);
     double u2 = u53(x[2], x[3]);
-    double r = sqrt(-2.0 * log(u1));
-    double a = 6.283185307179586476925286766559 * u2;
-    z[0] = r * cos(a);
-    z[1] = r * sin(a);
+    double r = sqrt(-2.0 * smm_log(u1));
+    double s, c;
+    smm_sincos2pi(u2, &s, &c);
+    z[0] = r * c;
+    z[1] = r * s;
 }
 
 /* MH uniform of (global chain c, iteration t>=1): one entry of probs_acc = rand(n), AlgoBGP.jl:85 */
@@ -710,7 +772,7 @@ static int next_eval(orc_t* o, int c, int t, double* theta, double* simM, double
                          value, gc + 1, t);
                 return ORC_ERR_NEGATIVE_OBJECTIVE;
             }
-            double e = exp(o->acc_tuner[gc] * (old - value));
+            double e = smm_exp(o->acc_tuner[gc] * (old - value));
             prob = (e != e) ? e : (e < 1.0 ? e : 1.0);  /* minimum([1.0, e]) propagates NaN, :344 */
             if (!isfinite(prob)) { prob = 0.0; acc = 0; status = -1; }            /* :350-353 */
             else if (!isfinite(old)) { prob = 1.0; acc = 1; }                     /* :355-359 */

@@ -802,7 +802,6 @@ __device__ inline void walk_levels(const KParams& P, const uint32_t slot, const 
         return lc < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)ev, lc) : g_off[lc];
     };
     // (level ends and this wave's first position are scalars: a wave without a pair in a level runs no vector instruction for it)
-    const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63);
     uint32_t b = 0;
     uint32_t e = nlev > 0 ? level_end(0) : 0u;
     uint32_t e2 = nlev > 0 ? level_end(1) : 0u;
@@ -1279,7 +1278,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
             prob = 0.0; acc = false;
         } else {
             if (!(value >= 0.0)) report_error(P, 1, t, gc);  // :341
-            const double e = exp(atun * (old - value));
+            const double e = smm_exp(atun * (old - value));   // (the contract exponential, smm_rng.hpp)
             prob = (e != e) ? e : (e < 1.0 ? e : 1.0);  // minimum([1.0,e]), NaN propagates (:344)
             if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }  // :350-353
             else if (!isfinite(old)) { prob = 1.0; acc = true; }            // :355-359

@@ -781,7 +781,7 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
         prob = 0.0; acc = false;
     } else {
         if (!(value >= 0.0) && r == 0) report_error(P, 1, t, gc);   // :341
-        const double e = exp(atun * (old - value));
+        const double e = smm_exp(atun * (old - value));   // (the contract exponential, smm_rng.hpp)
         prob = (e != e) ? e : (e < 1.0 ? e : 1.0);   // minimum([1.0,e]), NaN propagates (:344)
         if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }   // :350-353
         else if (!isfinite(old)) { prob = 1.0; acc = true; }             // :355-359

@@ -189,7 +189,7 @@ struct PersistWalkValues {   // GUARD of the lean walk (smm_walk_lean.hpp)
 
 // exp() out of line: inlined, its polynomial's nine 64-bit coefficients are hoisted out of the iteration loop into registers, spilled
 // to scratch memory there, and fetched back from it in every accept step (the same code as the inlined one: identical results)
-__device__ __attribute__((noinline)) double pr_exp(const double x) { return exp(x); }
+__device__ __attribute__((noinline)) double pr_exp(const double x) { return smm_exp(x); }   // (the contract exponential, smm_rng.hpp)
 
 // the slowest tile's progress in this launch (lanes of one wave; words of another launch count as "not started")
 __device__ inline int pr_min_progress(const uint32_t* pr_progress, const uint32_t epoch, const int tiles, const int lane) {

@@ -61,19 +61,75 @@ __host__ __device__ inline double u53_open0(uint32_t hi, uint32_t lo) {
     return (double)((w >> 11) + 1) * 0x1.0p-53;
 }
 
+// ------------------------------------------------------------------------------------------
+// The elementary functions of the path are part of its NUMERICAL CONTRACT (include/smmhip.h): the logarithm and the sine / cosine of
+// Box-Muller, the exponential of the acceptance probability (AlgoBGP.jl:344).  Plain sequences of correctly rounded operations (+ - * /,
+// rint, ldexp; compiled without contraction), so that every implementation of the contract — device, host, a C restatement — produces
+// the same bits; each within 1 ulp of the true value (sine and cosine: within 2^-53 absolute).  After fdlibm's e_log.c, k_sin.c, k_cos.c,
+// e_exp.c (Sun Microsystems 1993, freely distributable): the argument reductions are exact here because of what the arguments are.
+// ------------------------------------------------------------------------------------------
+// log of a positive normal double
+// (SMM_NOINLINE_DEV — out of line in device code: inlined next to the sine / cosine into the persistent kernels, this compiler (ROCm 7.2) emits an
+// instruction its own verifier refuses, "Operand has incorrect register class")
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMM_NOINLINE_DEV __attribute__((noinline))
+#else
+#define SMM_NOINLINE_DEV
+#endif
+__host__ __device__ SMM_NOINLINE_DEV inline double smm_log(const double x) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, x);
+    int e = (int)((b >> 52) & 0x7ffu) - 1023;
+    double m = __builtin_bit_cast(double, (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+// sine and cosine of 2 pi u, u in [0, 1): the quadrant is exact (t = 4 u, q = rint(t), r = t - q with |r| <= 1/2)
+__host__ __device__ inline void smm_sincos2pi(const double u, double& sn, double& cs) {
+    const double t = 4.0 * u;
+    const double q = __builtin_rint(t);
+    const double r = t - q;
+    const double x = r * 1.57079632679489655800e+00 + r * 6.12323399573676603587e-17;
+    const double z = x * x;
+    const double v = z * x;
+    const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s = x + v * (-1.66666666666666324348e-01 + z * rs);
+    const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * rc);
+    const int qi = (int)q & 3;
+    sn = qi == 0 ? s : (qi == 1 ? c : (qi == 2 ? -s : -c));
+    cs = qi == 0 ? c : (qi == 1 ? -s : (qi == 2 ? -c : s));
+}
+// exp of any double: a NaN stays one, overflow to +inf, the subnormal results through ldexp's rounding
+__host__ __device__ inline double smm_exp(const double x) {
+    if (x != x) return x;
+    if (x > 709.782712893383973096) return __builtin_huge_val();
+    if (x < -745.13321910194110842) return 0.0;
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    const double hi = x - k * 6.93147180369123816490e-01;
+    const double lo = k * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 + t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return __builtin_ldexp(y, (int)k);
+}
+
 __host__ __device__ inline void box_muller(const U4& x, double& z0, double& z1) {
     const double u1 = u53_open0(x.x, x.y);
     const double u2 = u53(x.z, x.w);
-    const double r = sqrt(-2.0 * log(u1));
+    const double r = __builtin_sqrt(-2.0 * smm_log(u1));   // (IEEE square root: correctly rounded everywhere)
     double s, c;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // angle 2*pi*u2 in units of pi: exact argument reduction, no large-argument (Payne-Hanek) code in the kernel
-    sincospi(2.0 * u2, &s, &c);
-#else
-    const double a = 6.283185307179586476925286766559 * u2;
-    s = sin(a);
-    c = cos(a);
-#endif
+    smm_sincos2pi(u2, s, c);
     z0 = r * c;
     z1 = r * s;
 }

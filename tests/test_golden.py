@@ -63,7 +63,7 @@ CASES["g5_banana10"] = g5
 def test_oracle_reproduces_golden_run(O, name):
     z = load(name)
     prob, opts, T = CASES[name]()
-    check_run(O.OracleContext(prob, opts, tables_of(z)), z, T, rtol=1e-13)
+    check_run(O.OracleContext(prob, opts, tables_of(z)), z, T, rtol=0)
 
 
 def test_oracle_reproduces_golden_objective(O):
@@ -83,8 +83,7 @@ def test_oracle_reproduces_golden_objective(O):
 def test_default_shock_matrix_fingerprint(O):
     z = load("g1b_default_Z")
     Zd = O.gen_Z(12, 2, 10000)
-    np.testing.assert_allclose(Zd[:, :32], z["head"], rtol=1e-14)
-    np.testing.assert_allclose(Zd[:, ::997], z["strided"], rtol=1e-14)
+    assert np.array_equal(Zd[:, :32], z["head"]) and np.array_equal(Zd[:, ::997], z["strided"])   # (the generator's functions are the contract's: no libm in it)
     np.testing.assert_allclose(Zd.sum(1), z["col_sums"], rtol=1e-12)
 
 
@@ -99,7 +98,7 @@ def test_golden_exchange_case_has_multi_pair_chains():
 def test_hip_reproduces_golden_run(name):
     z = load(name)
     prob, opts, T = CASES[name]()
-    check_run(S.hip_context(prob, opts, tables_of(z)), z, T, rtol=1e-12)  # exp(): ocml vs libm
+    check_run(S.hip_context(prob, opts, tables_of(z)), z, T, rtol=0)   # bit for bit: the exponential is part of the numerical contract (include/smmhip.h)
 
 
 @pytest.mark.gpu

@@ -309,3 +309,32 @@ def test_dense_tanh_contract_against_libm(O):
     assert np.isnan(O.dense_tanh(np.array([np.nan])))[0]
     xs = np.sort(rng.uniform(-6, 6, 100000))
     assert np.all(np.diff(O.dense_tanh(xs)) >= -4.5e-16)       # monotone up to the last bits
+
+
+def test_contract_elementary_functions_against_libm(O):
+    # include/smmhip.h: log / sin, cos(2 pi u) / exp are fixed sequences of correctly rounded operations, each within 1 ulp (sine, cosine:
+    # 2^-53 absolute) — what makes a run reproducible to the bit by every implementation of the contract
+    rng = np.random.default_rng(9)
+    k = rng.integers(0, 1 << 53, 400000, dtype=np.uint64)
+    u1 = (k + np.uint64(1)).astype(np.float64) * 2.0 ** -53
+    u1[::7] = np.ldexp(u1[::7], -rng.integers(0, 50, u1[::7].size))
+    u1[::11] = 1.0 - rng.integers(0, 100000, u1[::11].size) * 2.0 ** -53
+    ulp = lambda a, b: np.abs(a.view(np.int64) - b.view(np.int64))
+    assert ulp(O.contract_math("log", u1), np.log(u1)).max() <= 2          # (numpy's own log is within an ulp)
+    assert O.contract_math("log", np.array([1.0]))[0] == 0.0
+    u2 = k.astype(np.float64) * 2.0 ** -53
+    a = 2 * np.longdouble("3.14159265358979323846264338327950288") * u2.astype(np.longdouble)   # (64-bit significand: good to 2^-61 here)
+    for what, ref in (("sin2pi", np.sin(a)), ("cos2pi", np.cos(a))):
+        assert np.abs(O.contract_math(what, u2).astype(np.longdouble) - ref).max() <= 2.5 * 2.0 ** -53
+    assert np.array_equal(O.contract_math("sin2pi", np.array([0.0, 0.25, 0.5, 0.75])), [0.0, 1.0, -0.0, -1.0])
+    assert np.array_equal(O.contract_math("cos2pi", np.array([0.0, 0.25, 0.5, 0.75])), [1.0, -0.0, -1.0, 0.0])
+    x = np.concatenate([rng.uniform(-745, 709, 200000), rng.uniform(-30, 5, 200000), rng.uniform(-1, 1, 100000) * 1e-3])
+    assert ulp(O.contract_math("exp", x), np.exp(x)).max() <= 2
+    sp = np.array([-np.inf, -800.0, -745.2, 0.0, 709.79, 800.0, np.inf])
+    with np.errstate(over="ignore"):
+        assert np.array_equal(O.contract_math("exp", sp), np.exp(sp))
+    assert np.isnan(O.contract_math("exp", np.array([np.nan])))[0]
+    # the literal restatement's exponential (plain Python floats) is the same function
+    from oracle import literal_bgp as LB
+    xs = rng.uniform(-60, 3, 20000)
+    assert np.array_equal(np.array([LB.contract_exp(float(v)) for v in xs]), O.contract_math("exp", xs))
