@@ -39,7 +39,7 @@ extern "C" {
  * totals are added left to right.  Replaces mean(X,dims=2), ObjExamples.jl:79.
  * The elementary functions of the path are part of the contract too: the logarithm and the sine / cosine of the generator's
  * Box-Muller transform and the exponential of the acceptance probability (AlgoBGP.jl:344) are fixed sequences of correctly
- * rounded operations (smm.jl_amd/csrc/smm_rng.hpp: smm_log, smm_sincos2pi, smm_exp — after fdlibm; each within 1 ulp), the
+ * rounded operations (smm.jl_amd/csrc/smm_rng.hpp: smm_log, smm_sincos2pi — after fdlibm —, smm_exp; each within 1 ulp), the
  * dense objective's tanh likewise (below).  Consequence: a run is reproduced BIT FOR BIT by any implementation of the contract —
  * every floating-point field of the history, not only the bookkeeping. */
 #define SMM_REDUCE_LANES 512

@@ -24,8 +24,15 @@ import copy
 import math
 
 
+def _fma(a, b, c):
+    """a * b + c with ONE rounding (exact rational arithmetic, then the correctly rounded conversion): Python 3.10 has no math.fma"""
+    from fractions import Fraction
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
 def contract_exp(x):
-    """the exponential of the numerical contract (include/smmhip.h; after fdlibm's e_exp.c), in plain Python floats"""
+    """the exponential of the numerical contract (include/smmhip.h: range reduction, the Taylor coefficients 1/2! .. 1/13! by Estrin's
+    scheme in fma, ldexp), in plain Python floats"""
     if x != x:
         return x
     if x > 709.782712893383973096:
@@ -33,13 +40,17 @@ def contract_exp(x):
     if x < -745.13321910194110842:
         return 0.0
     k = float(round(x * 1.44269504088896338700e+00))     # round half to even, as rint
-    hi = x - k * 6.93147180369123816490e-01
-    lo = k * 1.90821492927058770002e-10
-    r = hi - lo
-    t = r * r
-    c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 + t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))))
-    y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi)
-    return math.ldexp(y, int(k))
+    r = _fma(-k, 6.93147180369123816490e-01, x)
+    r = _fma(-k, 1.90821492927058770002e-10, r)
+    r2 = r * r
+    r4 = r2 * r2
+    r8 = r4 * r4
+    a0, a1, a2 = _fma(1.0 / 6.0, r, 0.5), _fma(1.0 / 120.0, r, 1.0 / 24.0), _fma(1.0 / 5040.0, r, 1.0 / 720.0)
+    a3, a4, a5 = _fma(1.0 / 362880.0, r, 1.0 / 40320.0), _fma(1.0 / 39916800.0, r, 1.0 / 3628800.0), _fma(1.0 / 6227020800.0, r, 1.0 / 479001600.0)
+    b0, b1, b2 = _fma(a1, r2, a0), _fma(a3, r2, a2), _fma(a5, r2, a4)
+    q = _fma(b2, r8, _fma(b1, r4, b0))
+    p = _fma(r2, q, r)
+    return math.ldexp(1.0 + p, int(k))
 
 REDUCE_LANES = 512   # include/smmhip.h: the ns draws of a moment are summed as 512 lane-strided partial sums, ...
 

@@ -191,13 +191,16 @@ static double smm_exp(const double x) {
     if (x > 709.782712893383973096) return INFINITY;
     if (x < -745.13321910194110842) return 0.0;
     const double k = rint(x * 1.44269504088896338700e+00);
-    const double hi = x - k * 6.93147180369123816490e-01;
-    const double lo = k * 1.90821492927058770002e-10;
-    const double r = hi - lo;
-    const double t = r * r;
-    const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 + t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
-    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-    return ldexp(y, (int)k);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    /* exp(r) - 1 = r + r^2 q(r), q = the Taylor coefficients 1/2! .. 1/13! (|r| <= ln2 / 2: 4e-18), Estrin's scheme: four levels of fma */
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = fma(1.0 / 6.0, r, 0.5), a1 = fma(1.0 / 120.0, r, 1.0 / 24.0), a2 = fma(1.0 / 5040.0, r, 1.0 / 720.0);
+    const double a3 = fma(1.0 / 362880.0, r, 1.0 / 40320.0), a4 = fma(1.0 / 39916800.0, r, 1.0 / 3628800.0), a5 = fma(1.0 / 6227020800.0, r, 1.0 / 479001600.0);
+    const double b0 = fma(a1, r2, a0), b1 = fma(a3, r2, a2), b2 = fma(a5, r2, a4);
+    const double q = fma(b2, r8, fma(b1, r4, b0));
+    const double p = fma(r2, q, r);
+    return ldexp(1.0 + p, (int)k);
 }
 /* (exported for the tests) what: 0 log, 1 exp, 2 sin(2 pi x), 3 cos(2 pi x) */
 void orc_math(int what, const double* x, double* y, int n) {

@@ -65,18 +65,11 @@ __host__ __device__ inline double u53_open0(uint32_t hi, uint32_t lo) {
 // The elementary functions of the path are part of its NUMERICAL CONTRACT (include/smmhip.h): the logarithm and the sine / cosine of
 // Box-Muller, the exponential of the acceptance probability (AlgoBGP.jl:344).  Plain sequences of correctly rounded operations (+ - * /,
 // rint, ldexp; compiled without contraction), so that every implementation of the contract — device, host, a C restatement — produces
-// the same bits; each within 1 ulp of the true value (sine and cosine: within 2^-53 absolute).  After fdlibm's e_log.c, k_sin.c, k_cos.c,
-// e_exp.c (Sun Microsystems 1993, freely distributable): the argument reductions are exact here because of what the arguments are.
+// the same bits; each within 1 ulp of the true value (sine and cosine: within 2^-53 absolute).  After fdlibm's e_log.c, k_sin.c, k_cos.c
+// (Sun Microsystems 1993, freely distributable); the exponential: range reduction + Taylor by fma: the argument reductions are exact here because of what the arguments are.
 // ------------------------------------------------------------------------------------------
 // log of a positive normal double
-// (SMM_NOINLINE_DEV — out of line in device code: inlined next to the sine / cosine into the persistent kernels, this compiler (ROCm 7.2) emits an
-// instruction its own verifier refuses, "Operand has incorrect register class")
-#if defined(__HIP_DEVICE_COMPILE__)
-#define SMM_NOINLINE_DEV __attribute__((noinline))
-#else
-#define SMM_NOINLINE_DEV
-#endif
-__host__ __device__ SMM_NOINLINE_DEV inline double smm_log(const double x) {
+__host__ __device__ inline double smm_log(const double x) {
     const uint64_t b = __builtin_bit_cast(uint64_t, x);
     int e = (int)((b >> 52) & 0x7ffu) - 1023;
     double m = __builtin_bit_cast(double, (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
@@ -105,33 +98,50 @@ __host__ __device__ inline void smm_sincos2pi(const double u, double& sn, double
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double c = w + (((1.0 - w) - hz) + z * rc);
-    const int qi = (int)q & 3;
-    sn = qi == 0 ? s : (qi == 1 ? c : (qi == 2 ? -s : -c));
-    cs = qi == 0 ? c : (qi == 1 ? -s : (qi == 2 ? -c : s));
+    // quadrant qi: (sin, cos) = (s, c), (c, -s), (-s, -c), (-c, s) — one swap, two sign bits (no chain of selects)
+    const uint32_t qi = (uint32_t)(int)q & 3u;
+    const bool odd = (qi & 1u) != 0u;
+    const uint64_t sb = __builtin_bit_cast(uint64_t, odd ? c : s) ^ ((uint64_t)(qi & 2u) << 62);
+    const uint64_t cb = __builtin_bit_cast(uint64_t, odd ? s : c) ^ ((uint64_t)((qi + 1u) & 2u) << 62);
+    sn = __builtin_bit_cast(double, sb);
+    cs = __builtin_bit_cast(double, cb);
 }
-// exp of any double: a NaN stays one, overflow to +inf, the subnormal results through ldexp's rounding
+// exp of any double: a NaN stays one, overflow to +inf, the subnormal results through ldexp's rounding; no division (it sits on the
+// accept step's critical path: fdlibm's form with its quotient cost banana at 8192 chains 2 %)
 __host__ __device__ inline double smm_exp(const double x) {
     if (x != x) return x;
     if (x > 709.782712893383973096) return __builtin_huge_val();
     if (x < -745.13321910194110842) return 0.0;
     const double k = __builtin_rint(x * 1.44269504088896338700e+00);
-    const double hi = x - k * 6.93147180369123816490e-01;
-    const double lo = k * 1.90821492927058770002e-10;
-    const double r = hi - lo;
-    const double t = r * r;
-    const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 + t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
-    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-    return __builtin_ldexp(y, (int)k);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    // exp(r) - 1 = r + r^2 q(r), q = the Taylor coefficients 1/2! .. 1/13! (|r| <= ln2 / 2: 4e-18), Estrin's scheme: four levels of fma
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = __builtin_fma(1.0 / 6.0, r, 0.5), a1 = __builtin_fma(1.0 / 120.0, r, 1.0 / 24.0), a2 = __builtin_fma(1.0 / 5040.0, r, 1.0 / 720.0);
+    const double a3 = __builtin_fma(1.0 / 362880.0, r, 1.0 / 40320.0), a4 = __builtin_fma(1.0 / 39916800.0, r, 1.0 / 3628800.0), a5 = __builtin_fma(1.0 / 6227020800.0, r, 1.0 / 479001600.0);
+    const double b0 = __builtin_fma(a1, r2, a0), b1 = __builtin_fma(a3, r2, a2), b2 = __builtin_fma(a5, r2, a4);
+    const double q = __builtin_fma(b2, r8, __builtin_fma(b1, r4, b0));
+    const double p = __builtin_fma(r2, q, r);
+    return __builtin_ldexp(1.0 + p, (int)k);
 }
 
-__host__ __device__ inline void box_muller(const U4& x, double& z0, double& z1) {
-    const double u1 = u53_open0(x.x, x.y);
-    const double u2 = u53(x.z, x.w);
+// the transform itself, OUT OF LINE in device code: inlined into the persistent kernels (k_chain_persist_loc<2, true, true>), the logarithm next to
+// the sine / cosine makes this compiler (ROCm 7.2) emit an instruction its own verifier refuses ("Operand has incorrect register class")
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMM_NOINLINE_DEV __attribute__((noinline))
+#else
+#define SMM_NOINLINE_DEV
+#endif
+struct BM2 { double z0, z1; };   // (returned by value: in registers — results by reference would travel through scratch memory)
+__host__ __device__ SMM_NOINLINE_DEV inline BM2 box_muller_u(const double u1, const double u2) {
     const double r = __builtin_sqrt(-2.0 * smm_log(u1));   // (IEEE square root: correctly rounded everywhere)
     double s, c;
     smm_sincos2pi(u2, s, c);
-    z0 = r * c;
-    z1 = r * s;
+    return BM2{r * c, r * s};
+}
+__host__ __device__ inline void box_muller(const U4& x, double& z0, double& z1) {
+    const BM2 z = box_muller_u(u53_open0(x.x, x.y), u53(x.z, x.w));
+    z0 = z.z0; z1 = z.z1;
 }
 
 __host__ __device__ inline double rng_u(uint64_t seed, uint32_t chain, uint32_t iter) {
