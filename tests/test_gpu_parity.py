@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def make_pair(S, O, prob, opts, tables=None, **okw):
     """a HIP context and an oracle context fed with identical inputs.  The shock matrix Z (the
     seed-1234 draws of ObjExamples.jl:74-79) is injected randomness: when the caller gives none the
-    library's default Z is read back and handed to the oracle (host libm builds may differ by an ulp)."""
+    library's default Z is read back and handed to the oracle (identical since round 5: the generator's functions are the contract's)."""
     h = S.hip_context(prob, opts, tables)
     t = tables if tables is not None else S.Tables()
     to = S.Tables(probs_acc=t.probs_acc, prop_normals=t.prop_normals, pairs=t.pairs, Z=h.Z())
@@ -34,7 +34,7 @@ def run_both(S, O, prob, opts, tables, T=None):
 def test_eval_batch_matches_oracle(S, O):
     prob, opts = cm.serial_normal(N=3, T=2)
     h, o = make_pair(S, O, prob, opts)
-    np.testing.assert_allclose(h.Z(), O.gen_Z(opts.seed, 2, prob.ns), rtol=1e-14)  # same generator, libm builds differ by <= 1ulp
+    assert np.array_equal(h.Z(), O.gen_Z(opts.seed, 2, prob.ns))   # same generator, the contract's own log / sine / cosine (include/smmhip.h)
     rng = np.random.default_rng(0)
     for M in (1, 7, 8, 9, 100):
         p = np.stack([rng.uniform(-3, 3, M), rng.uniform(-20, 20, M)])
@@ -74,7 +74,7 @@ def test_injected_tables_exact(S, O, N):
     h, o = run_both(S, O, prob, opts, tab)
     hh, ho = h.history(), o.history()
     cm.assert_history_equal(hh, ho, rtol=1e-12)
-    # with injected normals/uniforms/pairs/Z only exp() differs between libm and ocml
+    # (tolerances from before round 5, when exp() was libm's / ocml's: the runs are bit-identical now, tests/test_gpu_bitexact.py)
     for f in ("value", "params", "sim_moments", "curr_val", "best_val"):
         assert np.array_equal(getattr(hh, f), getattr(ho, f), equal_nan=True), f
     cm.assert_state_equal(h.state(), o.state(), rtol=1e-12)
@@ -547,7 +547,7 @@ def test_c3_real_workload_32768_chains_ns10000(S, O):
     h.step(T); o.step(T)
     hh = h.history()
     # (atol: a simulated moment is a mean of O(1) draws and can come out at 1e-7; a one-ulp difference of the proposal --
-    # ocml vs glibc sincos/log in the built-in generator -- is 1e-16 absolute there)
+    # the generator's sincos/log before round 5 -- was 1e-16 absolute there; bit-identical now: tests/test_gpu_bitexact.py)
     cm.assert_history_equal(hh, o.history(), atol=1e-13)
     cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
     ex = hh.exchanged
@@ -786,7 +786,7 @@ def test_dense_generated_matrices_match_oracle(S, O):
     prob, opts = dense_problem(S, O, 7, 9, N=4, T=2, explicit=False)
     h, o = make_pair(S, O, prob, opts)
     p = np.random.default_rng(2).uniform(-1, 1, (7, 40))
-    # (the matrices themselves come from Box-Muller: log / sincos of ocml against libm's)
+    # (tolerance from before round 5; the generated matrices are bit-identical now: test_failing_objective_and_batches_bit_identical)
     np.testing.assert_allclose(h.eval_batch(p)[1], o.eval_batch(p)[1], rtol=1e-9, atol=1e-12)
 
 
@@ -804,7 +804,7 @@ def test_c5_dense_4096_chains(S, O):
     h, o = make_pair(S, O, prob, opts, threads=16)
     h.step(20); o.step(20)
     # (the objective itself is bit-identical — its tanh is part of the numerical contract —; the proposals' normals go through log /
-    # sincos, ocml against libm: an ulp of a parameter shows up as an absolute 1e-16 where a simulated moment crosses zero)
+    # sincos — ocml's against libm's before round 5, the contract's own now (tests/test_gpu_bitexact.py holds array_equal) —: the tolerance of then)
     cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
     cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
 

@@ -64,7 +64,7 @@ def test_persistent_form_injected_tables_and_one_parameter(S, O, npar):
     for n in (2, 30, 18):
         h.step(n); o.step(n)
     assert h.persistent_info()[1] >= 2 and h.persistent_info()[2] == 0
-    cm.assert_history_equal(h.history(), o.history())   # (exp of the accept step: ocml against glibc, <= 1 ulp)
+    cm.assert_history_equal(h.history(), o.history())   # (bit-identical since round 5: tests/test_gpu_bitexact.py)
     cm.assert_state_equal(h.state(), o.state())
 
 

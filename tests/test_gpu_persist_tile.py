@@ -77,7 +77,7 @@ def test_tile_form_dense_against_oracle_and_per_iteration_kernels(S, O, npar, nm
         h.step(n); c.step(n); o.step(n)
     assert h.persistent_info()[1] >= 1 and h.persistent_info()[2] == 0, h.persistent_info()
     _same(h.history(), c.history(), h.state(), c.state())
-    # (the dense objective itself is bit-identical, its tanh being part of the contract; the proposals' normals are ocml's against libm's)
+    # (the dense objective itself is bit-identical, its tanh being part of the contract; the tolerance dates from before the generator's functions were)
     cm.assert_history_equal(h.history(), o.history(), atol=1e-13)
     cm.assert_state_equal(h.state(), o.state(), atol=1e-13)
 
