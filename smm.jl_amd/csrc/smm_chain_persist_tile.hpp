@@ -105,6 +105,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
     unsigned* const s_flags = (unsigned*)(lds + L.fbase);
     int* const s_minprog = (int*)(s_flags + 0);
     unsigned* const s_abort = s_flags + 1;
+    unsigned* const s_rngctr = s_flags + 2;   // chunks of 64 draws of the next iteration's randomness handed out so far (fetch_rb_dyn)
     unsigned long long* const s_ts = (unsigned long long*)(lds + L.fbase + 64);   // [8]
     double* const dbl = (double*)(lds + L.dbase);
     double* const s_cs = dbl + L.o_cs;        // [16][PR_STW]
@@ -164,6 +165,29 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
             const uint32_t dst = (uint32_t)((unsigned char*)s_rb - lds);
             for (int p0 = 0; p0 < pieces; p0 += WG)
                 if (p0 + wave * 64 < pieces && p0 + tid < pieces) lds_dma16(src + p0 + tid, dst + (uint32_t)(p0 + wave * 64) * 16u);
+        }
+    };
+    // ... drawn here, in chunks of 64 draws that the waves take from an LDS counter as they become free: the waves with entries of the gather list
+    // poll for their peers' publications first, the others start drawing at once (the draws in the shadow of the stores' visibility latency)
+    auto fetch_rb_dyn = [&](const int tn) {
+        const int Q = (np + 1) / 2, per = 1 + A.rb_tries * Q, total = CT * per, nchunk = (total + 63) / 64;
+        for (;;) {
+            int k = 0;
+            if (lane == 0) k = (int)atomicAdd(s_rngctr, 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= nchunk) break;
+            const int it = 64 * k + lane;
+            if (it >= total) continue;
+            const int cl = it / per, what = it - cl * per, c1 = tile * CT + cl;
+            if (c1 >= N) continue;
+            double* o = s_rb + cl * RBW;
+            if (what == 0) o[0] = rng_u(A.seed, (uint32_t)c1, (uint32_t)tn);       // probs_acc[iter], AlgoBGP.jl:85
+            else {
+                const int rr = (what - 1) / Q, q = (what - 1) - rr * Q;
+                const double2 zz2 = rng_prop_normal2_outofline(A.seed, (uint32_t)c1, (uint32_t)tn, (uint32_t)rr, (uint32_t)q);   // rand(RAND, d), :404
+                o[1 + rr * np + 2 * q] = zz2.x;
+                if (2 * q + 1 < np) o[1 + rr * np + 2 * q + 1] = zz2.y;
+            }
         }
     };
     // the lists of exchange tx by LDS-DMA (pairs: a KB per wave; gather list: wave 3)
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
     }
     for (int k = tid; k < np; k += WG) { s_lb[k] = A.lb[k]; s_ub[k] = A.ub[k]; }
     for (int k = tid; k < nm; k += WG) { s_mom[k] = A.mom[k]; s_w[k] = A.w[k]; }
-    if (tid == 0) { *s_minprog = 0; *s_abort = 0u; }
+    if (tid == 0) { *s_minprog = 0; *s_abort = 0u; *s_rngctr = 0u; }
     if (tid >= 64 && tid < 72) s_ts[tid - 64] = 0ull;
     if (wave == 3 && lane < CONE_HDRW) {
         if (A.walk_first) s_hdr[((t0 - 1) & 3) * 16 + lane] = A.cone_hdr[((size_t)(t0 - 1 - A.plan_t0) * tiles + tile) * CONE_HDRW + lane];
@@ -337,7 +361,10 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         }
         if (chain_lane) s_cs[cc * PR_STW + CS_PARTNER] = (double)partner;
         PR_BARRIER();   // B2: every read of the ring's last entry, of the walk's lists and slots is done
-        if (tid == 0) __hip_atomic_store(pr_progress + tile, pr_progress_word(epoch, rel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(pr_progress + tile, pr_progress_word(epoch, rel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_rngctr = 0u;   // (the last iteration's draws ended before B0; the next ones start behind B5)
+        }
         // the next exchange's lists and header; the progress of the slowest tile, the abort word (consumed behind the objective)
         uint32_t nhdr = 0u;
         const bool want_hdr = wave == 3 && lane < CONE_HDRW && t + 1 < t1 && exch_on(t + 1);
@@ -541,7 +568,6 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         // ================= behind the publication =================
         // (what nobody waits for, while the other tiles' publications travel: the next randomness, the next walk's pair words on local
         // numbers, the history row's arrays; then the gather for the NEXT iteration's walk, then the row's stores)
-        if (t < t1 && rng_here) fetch_rb(t + 1);
         if (lists) fix_lists(t, t + 1);
         if (valid) {
             copy_strided(s_hrow + cc * HW + H_PARAMS, s_theta + cc * np, np, r2, LPC);
@@ -551,6 +577,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (valid) coop_store_n(A.hrec + ((size_t)(t - 1) * N + c) * HW, s_hrow + cc * HW, HW, r2, LPC);
+        if (t < t1 && rng_here) fetch_rb_dyn(t + 1);
         if (A.ts && tid == 0) {   // (slot 0: from the publication to the next iteration's B0 — rows, gather, the wait for the tile's other waves)
             s_ts[1] += ts1 - ts0; s_ts[2] += ts2 - ts1; s_ts[3] += ts3 - ts2; s_ts[4] += ts4 - ts3; s_ts[5] += ts4b - ts4; s_ts[6] += ts5 - ts4b; s_ts[7] = ts5;
         }

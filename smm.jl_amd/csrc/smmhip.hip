@@ -457,7 +457,7 @@ void ensure_windows(Ctx* c, int t, bool rng = true) {
         // (k_chain_persist_gen draws in the kernel too: blocks only for the iterations between its launches)
         // — and only where such launches are really being made: a caller that steps one iteration at a time (the reference's run! loop
         // over computeNextIteration!, AlgoAbstract.jl:38-45) never takes the persistent form and keeps its full windows
-        if (c->persist_gen && c->persist && c->persist_on && !c->persist_broken && !c->in_repair && !P.user_ntab && !P.user_utab &&
+        if ((c->persist_gen || c->persist_tile) && c->persist && c->persist_on && !c->persist_broken && !c->in_repair && !P.user_ntab && !P.user_utab &&
             c->persist_launches != c->pregen_seen_launches) W = std::min(W, 2);
         c->pregen_seen_launches = c->persist_launches;
         const size_t Q = (size_t)(P.np + 1) / 2;
@@ -1069,7 +1069,9 @@ void persist_snapshot(Ctx* c) {
 int launch_chain_persist(Ctx* c, int n_left) {
     const int t0 = c->iter + 1;
     // (k_chain_persist_norm and _gen draw in the kernel unless tables are injected)
-    const bool pregen = c->persist_gen ? (c->P.user_ntab || c->P.user_utab) : !(c->norm_fast && !c->P.user_ntab && !c->P.user_utab);
+    // (k_chain_persist_tile too, since round 5: its 512 lanes draw the next iteration's randomness behind the publication, where the tile waits for
+    // its peers' stores anyway — k_pregen_rng was 2.2 us per iteration of C5 on the main stream)
+    const bool pregen = (c->persist_gen || c->persist_tile) ? (c->P.user_ntab || c->P.user_utab) : !(c->norm_fast && !c->P.user_ntab && !c->P.user_utab);
     if ((c->persist_loc || c->persist_tile) && c->unresolved && !(t0 - 1 >= c->plan_t0 && t0 + 1 < c->plan_t0 + c->plan_w)) {
         // the pending exchange's plan is not in a window that also reaches past this iteration: a new window from ITS iteration on (one
         // iteration planned twice per window; no per-iteration launch, no stand-alone resolution at the windows' ends)
