@@ -852,7 +852,9 @@ int check_device_error(Ctx* c) {
             if (kind == 3 && ++c->persist_strikes >= 2) c->persist_broken = true;
             // a hard error (AlgoBGP.jl:341,409): every rank replays up to and including the failing iteration — which completes for all
             // chains, as everywhere — and stands there; a time-out or a cone that did not fit: the whole step again, on the other forms
-            persist_repair(c, (kind == 1 || kind == 2) ? it - c->snap_iter : -1);
+            // (a hard error raised BEFORE the first of these launches — by a one-iteration launch ahead of them on the stream —: they saw the word at
+            // their entry and stored nothing; n = 0 puts the host's bookkeeping back to the snapshot and replays nothing)
+            persist_repair(c, (kind == 1 || kind == 2) ? std::max(0, it - c->snap_iter) : -1);
             HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
             if (kind == 1 || kind == 2) e = std::min(e, eg);   // (the first failing chain of the POPULATION — maybe another rank's: every rank reports the same)
         }
@@ -863,9 +865,19 @@ int check_device_error(Ctx* c) {
         // state before the first of them, and the same iterations again on the one-launch-per-iteration path, which does.
         // (a tile gave up waiting, or a cone did not fit.  Once may be somebody else's doing — another context or process held compute
         // units while the tiles wanted to be resident together —: the form is tried again; the second time it is off for the context)
-        if ((e & 3) == 3 && ++c->persist_strikes >= 2) c->persist_broken = true;
-        persist_repair(c);
-        HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
+        if ((e & 3) != 3 && (int)(e >> 34) <= c->snap_iter) {
+            // ... unless the word was raised BEFORE the first of them, by a one-iteration launch ahead of them on the stream that nobody had
+            // looked at yet: they saw the word at their entry and stored nothing.  Nothing to replay — rolling back, clearing the word and
+            // running on LOST the error (tools/fuzz_errors.py, 2 of 600 cases) —: the host's bookkeeping back to the snapshot, the word stays
+            const unsigned long long keep = e;
+            persist_repair(c, 0);
+            HIPCHK(hipMemcpy(c->P.err, &keep, sizeof keep, hipMemcpyHostToDevice));
+            e = keep;
+        } else {
+            if ((e & 3) == 3 && ++c->persist_strikes >= 2) c->persist_broken = true;
+            persist_repair(c);
+            HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
+        }
     }
     if (!c->in_repair) {
         if (e == ERR_NONE && c->snap_valid) c->persist_proven = true;   // launches of the persistent form came through: its tiles ARE resident together

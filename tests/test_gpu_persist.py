@@ -182,3 +182,36 @@ def test_persistent_form_hard_error_in_a_step_across_a_plan_window(S, O):
     for f in cm.INT_FIELDS:
         np.testing.assert_array_equal(getattr(hh, f)[:tfail - 1], getattr(ho, f)[:tfail - 1], err_msg=f)
     np.testing.assert_allclose(hh.value[:tfail - 1], ho.value[:tfail - 1], rtol=1e-9)
+
+
+@pytest.mark.parametrize("ahead", [0, 3])
+def test_hard_error_of_a_single_iteration_ahead_of_a_persistent_launch_on_the_stream(S, O, ahead):
+    # found by tools/fuzz_errors.py (2 of 600 cases, round 5): AlgoBGP.jl:409 raised by a ONE-LAUNCH-PER-ITERATION kernel (the first iteration
+    # behind a read-back) with a persistent launch enqueued right behind it, before anybody has looked at the error word.  That launch sees
+    # the word at its entry and stores nothing — there is nothing to replay: the library used to roll back to the snapshot (taken behind the
+    # failing iteration), clear the word and run on, and the error was LOST.  `ahead`: iterations between the failing one and the snapshot.
+    N, T, tfail = 40, 60, 21
+    prob, opts = cm.serial_normal(N=N, T=T, ns=200, sigma0=0.01)
+    tab = cm.random_tables(prob, opts, tries=8)
+    tab.prop_normals[tfail - 1] = 1e9
+    h, o = _pair(S, O, prob, opts, tab)
+    h.step(tfail - 1); o.step(tfail - 1)
+    cm.assert_state_equal(h.state(), o.state())     # (the read-back settles the exchange: iteration tfail is a launch of its own)
+    with pytest.raises(A.SMMHipError) as eh:
+        h.step_async(1)                              # iteration tfail: fails on the device, nobody looks
+        for _ in range(ahead):
+            h.step_async(1)                          # ... further single launches: they see the word and store nothing
+        h.step_async(8)                              # a persistent launch behind them (a snapshot is taken in front of it)
+        h.step_async(5)
+        h.sync()
+    with pytest.raises(A.SMMHipError):
+        o.step(20)
+    assert eh.value.code == A.SMM_ERR_NO_DRAW_IN_SUPPORT and "iteration %d" % tfail in str(eh.value)
+    assert h.state().iter == tfail
+    hh, ho = h.history(0, T), o.history(0, T)
+    for f in cm.INT_FIELDS:
+        np.testing.assert_array_equal(getattr(hh, f)[:tfail - 1], getattr(ho, f)[:tfail - 1], err_msg=f)
+    assert np.array_equal(hh.value[:tfail - 1], ho.value[:tfail - 1])
+    assert np.isnan(hh.value[tfail:]).all() and (hh.status[tfail:] == 0).all()
+    with pytest.raises(A.SMMHipError):
+        h.step(1)   # sticky

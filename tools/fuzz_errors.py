@@ -12,6 +12,7 @@ from oracle import oracle as O
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 A.use_test_hooks(True)
 for it in range(cases):
     os.environ.pop("SMMHIP_PLAN_CAP", None)
@@ -37,16 +38,20 @@ for it in range(cases):
     o = O.OracleContext(prob, opts, S.Tables(probs_acc=tab.probs_acc, prop_normals=tab.prop_normals, pairs=tab.pairs, Z=h.Z()), threads=16)
     eh = None
     done = 0
+    log = []
     try:
         while done < T:
             n = int(min(T - done, rng.choice([1, 2, 7, 50, 120, 300])))
             h.step_async(n)
-            if rng.random() < 0.6: h.sync()
-            if rng.random() < 0.2: h.state()
+            r1, r2 = rng.random(), rng.random()
+            log.append("step_async(%d)%s%s -> %d" % (n, " sync" if r1 < 0.6 else "", " state" if r2 < 0.2 else "", done + n))
+            if r1 < 0.6: h.sync()
+            if r2 < 0.2: h.state()
             done += n
         h.sync()
     except A.SMMHipError as e:
         eh = e
+    log.append("hip: %s | iter %d | info %s | %s" % (eh, h.state().iter, h.persistent_info(), h.describe()))
     eo = None
     try:
         o.step(T)
@@ -64,6 +69,8 @@ for it in range(cases):
         ok = ok and np.allclose(hh.value[:tfail - 1], ho.value[:tfail - 1], rtol=1e-9, equal_nan=True)
     info = h.persistent_info()
     print("case %3d N %4d T %3d tfail %3d: %s (persistent launches %d, repairs %d)%s" % (it, N, T, tfail, "ok" if ok else "FAILED", info[1], info[2], "" if ok else "  oracle: iter %d %s | " % (it_o, str(eo)[:60]) + str(eh)[:100]), flush=True)
+    if not ok or only == it:
+        print("   seed-independent replay: N=%d T=%d tfail=%d prob/opts seed=%d | " % (N, T, tfail, opts.seed) + " ; ".join(log), flush=True)
     bad += 0 if ok else 1
     del h, o
 print("%d of %d cases failed" % (bad, cases))
