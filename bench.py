@@ -30,14 +30,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ITERS_PER_STEP = 200
 NS = 10000
 PEAK_FP64_ADD_TFLOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 39.3: 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz (adds cannot be FMA'd)
 PEAK_FP64_MFMA_TFLOPS = 78.6                         # dense FP64 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-C5_ACC_SCALE = 3000.0    # the dense instance's acc_tuner = C5_ACC_SCALE * geomspace(20, 1, N): see build_problem
 
 # per workload: chains per GPU (weak) or in total (fixed), algorithmic work per chain evaluation and the roofline that bounds it
 WORKLOADS = {
@@ -51,13 +49,19 @@ WORKLOADS = {
     # ~80 flop vs (2*10 + 10 + 8) * 8 = 304 B per chain evaluation: an HBM / latency stream
     "c4": dict(chains=8192, total=False, flop=80, bytes=304, bound="hbm", peak=PEAK_HBM_GBS, unit="GB/s", kernel="k_chain_persist_gen",
                label="banana / Rosenbrock 10 params / 10 moments, 8192 chains (BASELINE configs[3])"),
-    # dense simulation x = B theta (256 x np), h = tanh(x), y = A h (nm x 256) on v_mfma_f64_16x16x4: per 16-chain tile 16 tiles of hidden units x
-    # (13 + 16) MFMAs = 464 (np = 50 padded to 52, nm = 50 to 64), 2048 flop each => 59 392 EXECUTED flop per chain evaluation — what
-    # SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 counts; the un-padded algorithm is 2*256*50 + 2*50*256 = 51 200 (0.862 of it)
-    "c5": dict(chains=4096, total=False, flop=464 * 2048 // 16, useful_flop=2 * 256 * 50 + 2 * 50 * 256, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma",
-               peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_persist_tile<2>",
-               label="synthetic dense simulation, 50 params -> 256 hidden units (tanh) -> 50 moments: the products 256x50 and 50x256 per evaluation "
-                     "on FP64 MFMA, 4096 chains (BASELINE configs[4]; NOT a 256x256 product: see roofline.note)"),
+    # BASELINE configs[4] AS WORDED (SMM_OBJ_DENSE2, round 6): x = B theta (256 x np), h1 = tanh x, g = A2 h1 (256 x 256), h2 = tanh g, y = A h2 (nm x 256) on
+    # v_mfma_f64_16x16x4.  Per 16-chain tile: 16 row tiles x (13 + 64 + 16) = 1488 credited MFMAs (np = 50 padded to 52, nm = 50 to 64; the kernel EXECUTES
+    # 16 x (16 + 64 + 16) = 1536: the first product runs in groups of four fragments), 2048 flop each => 190 464 flop per chain evaluation;
+    # the un-padded algorithm is 2*256*50 + 2*256*256 + 2*50*256 = 182 272
+    "c5": dict(chains=4096, total=False, flop=1488 * 2048 // 16, useful_flop=2 * 256 * 50 + 2 * 256 * 256 + 2 * 50 * 256, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma",
+               peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_persist_tile<2>", mfma_per_tile=(1488, 1536),
+               label="synthetic dense simulation, 50 params -> 256 hidden units (tanh) -> 256 x 256 matvec -> 256 hidden units (tanh) -> 50 moments on FP64 MFMA, "
+                     "4096 chains (BASELINE configs[4] as worded: a 256x256 matvec per evaluation; SMM_OBJ_DENSE2)"),
+    # the instance of rounds 2-5 (SMM_OBJ_DENSE, no 256 x 256 stage): 16 x (13 + 16) = 464 credited MFMAs per tile, 59 392 flop per evaluation; un-padded 51 200
+    "c5v1": dict(chains=4096, total=False, flop=464 * 2048 // 16, useful_flop=2 * 256 * 50 + 2 * 50 * 256, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma",
+                 peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_persist_tile<2>", mfma_per_tile=(464, 512),
+                 label="synthetic dense simulation WITHOUT the 256 x 256 stage (SMM_OBJ_DENSE, the instance of rounds 2-5): 50 params -> 256 hidden units (tanh) -> 50 "
+                       "moments on FP64 MFMA, 4096 chains"),
 }
 
 
@@ -86,7 +90,8 @@ def profile_tag(workload):
 # the persistent launches + the single iterations at window boundaries, per workload
 CHAIN_KERNELS = {"c2": ("k_chain_persist_loc<2, false, false>", "k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>"),
                  "c4": ("k_chain_persist_gen", "k_chain_iter<0, 16, 2, true>"),
-                 "c5": ("k_chain_persist_tile<2>", "k_chain_iter<2, 16, 1, true>", "k_chain_iter<2, 16, 1, false>")}
+                 "c5": ("k_chain_persist_tile<2>", "k_chain_iter<2, 16, 1, true>", "k_chain_iter<2, 16, 1, false>"),
+                 "c5v1": ("k_chain_persist_tile<2>", "k_chain_iter<2, 16, 1, true>", "k_chain_iter<2, 16, 1, false>")}
 
 
 def _profile_iterations(summary_path, which):
@@ -214,7 +219,7 @@ def cpu_baseline(threads):
     upper bound for any CPU run of the reference path, which redraws its 2 x 10000 normals inside every evaluation
     (ObjExamples.jl:74-79).  regen_value: a bounded sample with those draws regenerated per evaluation by the port's
     generator (Philox + Box-Muller, both outputs used): a lower bound (Julia's ziggurat randn is several times cheaper)."""
-    import common as cm
+    from smm_jl_amd import workloads as cm
     from oracle import oracle as O
     n, t = 4096, ITERS_PER_STEP
     reps_max = 400
@@ -241,34 +246,9 @@ def cpu_baseline(threads):
 
 
 def build_problem(workload, n_loc, n_glob, rank, T, device):
-    """Problem / BGPOpts of one shard of the workload (the same constructions as tests/ and tools/run_objective.py)"""
-    import numpy as np
-    import smm_jl_amd as S
-    import common as cm
-    from smm_jl_amd import _abi as A
-    kw = dict(N=n_loc, maxiter=T, N_global=n_glob, chain_offset=rank * n_loc, device=device)
-    if workload == "c2":
-        return cm.serial_normal(N=n_glob, T=T, N_local=n_loc, chain_offset=rank * n_loc, device=device)
-    if workload == "c3":   # 8 temperature levels x (n_glob / 8) replicas (SURVEY 8d): chain id = level * replicas + r
-        prob, _ = cm.serial_normal(N=3, T=T)
-        L, R = 8, n_glob // 8
-        return prob, S.BGPOpts(sigma=np.repeat(0.05 * np.linspace(1, 5, L), R), acc_tuner=np.repeat(np.geomspace(20, 1, L), R),
-                               min_improve=np.zeros(n_glob), **kw)
-    if workload == "c4":
-        npar = 10
-        prob = S.Problem(init=np.zeros(npar), lb=-2 * np.ones(npar), ub=2 * np.ones(npar), mom=np.zeros(npar), w=np.ones(npar), ns=1,
-                         objective_id=A.SMM_OBJ_BANANA)
-        return prob, S.BGPOpts(sigma=0.01 * cm.temps(n_glob, 4), acc_tuner=np.geomspace(2.0, 0.1, n_glob), min_improve=np.zeros(n_glob),
-                               seed=3, smpl_iters=100000, **kw)
-    npar = nm = 50
-    rng = np.random.default_rng(3)
-    prob = S.Problem(init=rng.uniform(-0.3, 0.3, npar), lb=-np.ones(npar), ub=np.ones(npar), mom=rng.uniform(-0.5, 0.5, nm),
-                     w=rng.uniform(0.5, 2.0, nm), ns=1, objective_id=A.SMM_OBJ_DENSE)
-    # (round 5, VERDICT r4 "Next #4": acc_tuner 60000 .. 3000 instead of 20 .. 1.  With 20 .. 1 the synthetic objective accepted 99 % of the
-    # proposals, every sigma grew at every update, and the run measured mysample's rejection loop in 50 dimensions; now the cold chains
-    # accept 46 / 16 / 12 / 20 % by quarter of 2000 iterations and sigma stays within its initial range: tools/exp/c5_instance.py, oracle)
-    return prob, S.BGPOpts(sigma=0.004 * cm.temps(n_glob, 3), acc_tuner=C5_ACC_SCALE * np.geomspace(20, 1, n_glob), min_improve=np.zeros(n_glob), seed=3,
-                           smpl_iters=100000, **kw)
+    """Problem / BGPOpts of one shard of the workload: smm.jl_amd/workloads.py (the package's own builders; tests/ and tools/ use the same)"""
+    from smm_jl_amd import workloads
+    return workloads.build_problem(workload, n_loc, n_glob, rank, T, device)
 
 
 def free_port():
@@ -402,7 +382,7 @@ def main():
     import torch
     import torch.distributed as dist
     import smm_jl_amd as S
-    import common as cm
+    from smm_jl_amd import workloads as cm
 
     W = WORKLOADS[args.workload]
     device = 0 if args.same_device else local_rank
@@ -425,7 +405,7 @@ def main():
         n_loc = args.chains or (W["chains"] // world if args.same_device else W["chains"])
         n_glob = n_loc * world
     if args.steps is None:
-        args.steps = 8 if args.workload == "c5" else 5
+        args.steps = 8 if args.workload in ("c5", "c5v1") else 5
     K, Wm = args.steps, args.warmup
 
     # the self-check runs the form the timed run will use: the same N_global and chains per rank (at least 1024: the large-population
@@ -495,7 +475,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # outside the clock: do the shards agree on the exchange of the last iterations?
-    xok, xnote = cross_rank_check(ctx, torch, dist, rank, world, n_loc, args.same_device) if args.workload in ("c2", "c3", "c4", "c5") else (True, None)
+    xok, xnote = cross_rank_check(ctx, torch, dist, rank, world, n_loc, args.same_device) if args.workload in ("c2", "c3", "c4", "c5", "c5v1") else (True, None)
     if not xok:
         raise RuntimeError("cross-rank check failed: " + xnote)
     evals = n_glob * ITERS_PER_STEP * K
@@ -548,20 +528,24 @@ def main():
         if W["bound"] == "mfma":
             mops, msrc = mfma_counter(kernel, args.workload)
             roof["useful"] = {"flop_per_launch": n_loc * W["useful_flop"], "achieved": n_loc * W["useful_flop"] / (k_us * 1e-6) / 1e12,
-                              "frac": n_loc * W["useful_flop"] / (k_us * 1e-6) / 1e12 / W["peak"], "note": "the un-padded algorithm: 2*256*np + 2*nm*256 flop per evaluation"}
+                              "frac": n_loc * W["useful_flop"] / (k_us * 1e-6) / 1e12 / W["peak"],
+                              "note": "the un-padded algorithm: %d flop per evaluation" % W["useful_flop"]}
             roof["mfma_counter"] = None if mops is None else {
                 "SQ_INSTS_VALU_MFMA_MOPS_F64_per_launch": mops, "flop_per_launch": mops * 512.0, "source": msrc,
                 "achieved_at_avg_kernel_us": mops * 512.0 / (k_us * 1e-6) / 1e12,
                 "achieved_at_rocprof_kernel_us": (mops * 512.0 / (prof_us * 1e-6) / 1e12) if prof_us else None,
-                "flop_per_launch_counted_over_assumed": mops * 512.0 / work}
-            roof["note"] = ("achieved = EXECUTED MFMA flop (464 v_mfma_f64_16x16x4 per 16 chains, np / nm padded to 52 / 64) over the chain kernel's duration; "
-                            "mfma_counter = the same from SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the committed PMC pass: 1.10 x the assumed figure since round 5 — the first "
-                            "product runs in groups of four fragments (16 for np = 50, straight-line code), the 3 padded ones are NOT credited; the objective is "
-                            "x = B theta (256 x np), h = tanh x, y = A h (nm x 256): 51 200 useful flop per evaluation, not the 2*256*256 + ... = 156 672 of a "
-                            "256 x 256 product that rounds 2-3 credited (BASELINE.json's wording).  The persistent tile kernel (smm_chain_persist_tile.hpp): one launch per "
-                            "look-ahead window, every figure per ITERATION; the hidden layer's tanh is part of the numerical contract (include/smmhip.h: one exponential, "
-                            "one division; device and oracle bit-identical).  The instance (acc_tuner x 3000: cold chains accept 20-40 %, sigma stationary) is "
-                            "quoted at >= 1600 iterations (--steps 8, the default for this workload)")
+                "flop_per_launch_counted_over_assumed": mops * 512.0 / work,
+                "executed_over_credited_by_construction": W["mfma_per_tile"][1] / W["mfma_per_tile"][0]}
+            roof["note"] = ("achieved = CREDITED MFMA flop (%d v_mfma_f64_16x16x4 per 16 chains: np / nm padded to 52 / 64; the kernel executes %d — the first product runs in "
+                            "groups of four fragments, straight-line code, the padded ones are NOT credited) over the chain kernel's duration; mfma_counter = the same from "
+                            "SQ_INSTS_VALU_MFMA_MOPS_F64 x 512 of the committed PMC pass.  " % W["mfma_per_tile"]
+                            + ("The objective is BASELINE configs[4] as worded since round 6: x = B theta (256 x np), h1 = tanh x, g = A2 h1 (256 x 256; A2 streamed from L2 in fragment "
+                               "order, 512 KB per tile and evaluation), h2 = tanh g, y = A h2 (nm x 256): 182 272 useful flop per evaluation (rounds 2-5 measured the instance "
+                               "without the 256 x 256 stage: --workload c5v1).  " if args.workload == "c5" else
+                               "The objective is x = B theta (256 x np), h = tanh x, y = A h (nm x 256): 51 200 useful flop per evaluation, NOT BASELINE's 256 x 256 matvec (--workload c5 is).  ")
+                            + "The persistent tile kernel (smm_chain_persist_tile.hpp): one launch per look-ahead window, every figure per ITERATION; the hidden layers' tanh is part "
+                              "of the numerical contract (include/smmhip.h: one exponential, one division; device and oracle bit-identical).  The instance (acc_tuner x 3000: sigma "
+                              "stationary) is quoted at >= 1600 iterations (--steps 8, the default for this workload)")
         if args.workload in ("c2", "c3"):
             roof["note"] = ("2p/2m objfunc_norm is FP64-add bound (313 flop/B, SURVEY.md 8d): peak = 256CU x 4SIMD x 16 lanes x 2.4GHz adds/s "
                             "(FMA peak 78.6 TF is unreachable: no multiplies in the algorithm)")

@@ -64,7 +64,7 @@ typedef enum {
     SMM_OBJ_NORM_FAILBOX = 2, /* objfunc_norm that "throws" (status=-2, mprob.jl:183-186)
                                 when obj_params[0] <= theta_0 <= obj_params[1]; the role of
                                 Testobj_fails, ObjExamples.jl:27-32 */
-    SMM_OBJ_DENSE = 3   /* synthetic dense simulation (BASELINE config 5, no reference counterpart):
+    SMM_OBJ_DENSE = 3,  /* synthetic dense simulation (BASELINE config 5, no reference counterpart):
                            x = B*theta (B: SMM_DENSE_D x np), h = tanh(x), y = A*h (A: nm x SMM_DENSE_D),
                            simM = y, value = mean(((simM-mom)/w)^2).  obj_params = [B row-major, A row-major]
                            (SMM_DENSE_D*np + nm*SMM_DENSE_D doubles) or empty = generated from the seed.
@@ -73,6 +73,16 @@ typedef enum {
                            tanh (numerical contract, at most 3 ulp from the true value): with z = 2|x|, n = rint(z log2 e),
                            r = z - n ln2 (two fma), p = expm1(r) by its Taylor series to r^13 (Horner, fma):
                            tanh|x| = fma(2^n, p, 2^n - 1) / fma(2^n, p, 2^n + 1), 1 from |x| = 19.0625 on. */
+    /* (4 is SMM_OBJ_USER, the internal kind of every user objective) */
+    SMM_OBJ_DENSE2 = 5  /* BASELINE config 5 AS WORDED — "256x256 matvec per eval" (spec v2 of the synthetic dense simulation; SMM_OBJ_DENSE
+                           keeps its id and its goldens):
+                               x = B*theta (B: 256 x np), h1 = tanh(x), g = A2*h1 (A2: 256 x 256), h2 = tanh(g), y = A*h2 (A: nm x 256),
+                           simM = y, value = mean(((simM-mom)/w)^2): 2*256*np + 2*256*256 + 2*nm*256 flop per evaluation (1.8e5 at
+                           np = nm = 50).  obj_params = [B row-major, A2 row-major, A row-major] (256*np + 65536 + nm*256 doubles) or
+                           empty = generated from the seed (N(0,1)/sqrt(fan-in), counter stream 5, in that order).
+                           Summation order (numerical contract): x_d = fma chain over p; g_j = ONE fma chain over d = 0..255 (the
+                           accumulator of a row tile's 64 v_mfma_f64_16x16x4); y_k = 8 fma chains over d in [32w, 32w+32), added
+                           left to right; the tanh above.  The plugin seam it exercises: MProb.objfunc, mprob.jl:159,182. */
 } smm_objective_t;
 #define SMM_DENSE_D 256
 

@@ -22,6 +22,7 @@ _ORC_ONLY = [
     ("orc_philox4x32_10", None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("orc_max_threads", C.c_int, []),
     ("orc_gen_dense", None, [C.c_uint64, C.c_int, C.c_int, A.c_double_p]),
+    ("orc_gen_dense2", None, [C.c_uint64, C.c_int, C.c_int, A.c_double_p]),
     ("orc_tanh", None, [A.c_double_p, A.c_double_p, C.c_int]),
     ("orc_math", None, [C.c_int, A.c_double_p, A.c_double_p, C.c_int]),
     ("orc_set_user_objective", None, [C.c_int, C.c_void_p]),
@@ -107,6 +108,12 @@ def max_threads():
 def gen_dense(seed, np_, nm):
     out = np.empty(A.SMM_DENSE_D * np_ + nm * A.SMM_DENSE_D)
     load().orc_gen_dense(seed, np_, nm, A.dptr(out))
+    return out
+
+
+def gen_dense2(seed, np_, nm):
+    out = np.empty(A.SMM_DENSE_D * np_ + A.SMM_DENSE_D * A.SMM_DENSE_D + nm * A.SMM_DENSE_D)
+    load().orc_gen_dense2(seed, np_, nm, A.dptr(out))
     return out
 
 

@@ -40,6 +40,7 @@
 #define ORC_OBJ_BANANA 1
 #define ORC_OBJ_NORM_FAILBOX 2
 #define ORC_OBJ_DENSE 3
+#define ORC_OBJ_DENSE2 5   /* spec v2: with the 256 x 256 stage (include/smmhip.h) */
 #define ORC_OBJ_USER_BASE 1000
 #define ORC_MAX_USER 64
 typedef void (*orc_user_fn)(const double* theta, int np, const double* mom, const double* w, int nm, const double* udata,
@@ -471,11 +472,52 @@ static void objfunc_dense(int np, int nm, const double* theta, const double* Bm 
     *status = 1;
 }
 
+/* spec v2 (SMM_OBJ_DENSE2, include/smmhip.h; BASELINE config 5 as worded — a 256 x 256 matvec per evaluation; no reference counterpart,
+ * PARITY UNPINNED; the plugin seam: MProb.objfunc, mprob.jl:159,182): x = B*theta, h1 = tanh(x), g = A2*h1, h2 = tanh(g), y = A*h2.
+ * Summation order: g_j is ONE fma chain over d = 0..255 (a row tile's accumulator through its 64 matrix instructions); x and y as above. */
+static void objfunc_dense2(int np, int nm, const double* theta, const double* Bm /*[D][np]*/, const double* A2 /*[D][D]*/,
+                           const double* Am /*[nm][D]*/, const double* mom, const double* w, double* simM, double* value, int8_t* status) {
+    double h1[ORC_DENSE_D], h2[ORC_DENSE_D];
+    for (int d = 0; d < ORC_DENSE_D; ++d) {
+        double acc = 0.0;
+        for (int p = 0; p < np; ++p) acc = fma(Bm[(size_t)d * np + p], theta[p], acc);
+        h1[d] = smm_tanh(acc);
+    }
+    for (int j = 0; j < ORC_DENSE_D; ++j) {
+        double acc = 0.0;
+        for (int d = 0; d < ORC_DENSE_D; ++d) acc = fma(A2[(size_t)j * ORC_DENSE_D + d], h1[d], acc);
+        h2[j] = smm_tanh(acc);
+    }
+    double vsum = 0.0;
+    for (int k = 0; k < nm; ++k) {
+        double tot = 0.0;
+        for (int wv = 0; wv < 8; ++wv) {
+            double acc = 0.0;
+            for (int d = 32 * wv; d < 32 * wv + 32; ++d) acc = fma(Am[(size_t)k * ORC_DENSE_D + d], h2[d], acc);
+            tot = (wv == 0) ? acc : tot + acc;
+        }
+        simM[k] = tot;
+        double dd = tot - mom[k];
+        if (!isnan(w[k])) dd = dd / w[k];
+        double v = dd * dd;
+        vsum = (k == 0) ? v : vsum + v;
+    }
+    *value = vsum / (double)nm;
+    *status = 1;
+}
+
 /* default matrices of the dense objective: N(0,1)/sqrt(fan-in) from the counter RNG (stream 5) */
+static void gen_dense_n(uint64_t seed, int np, size_t nB, size_t nA, double* out);
 void orc_gen_dense(uint64_t seed, int np, int nm, double* out /* [D*np + nm*D] */) {
+    gen_dense_n(seed, np, (size_t)ORC_DENSE_D * np, (size_t)nm * ORC_DENSE_D, out);
+}
+/* spec v2: [B, A2, A]: every entry behind B has fan-in D */
+void orc_gen_dense2(uint64_t seed, int np, int nm, double* out /* [D*np + D*D + nm*D] */) {
+    gen_dense_n(seed, np, (size_t)ORC_DENSE_D * np, (size_t)ORC_DENSE_D * ORC_DENSE_D + (size_t)nm * ORC_DENSE_D, out);
+}
+static void gen_dense_n(uint64_t seed, int np, size_t nB, size_t nA, double* out) {
     uint32_t key[2];
     stream_key(seed, 5, key);
-    const size_t nB = (size_t)ORC_DENSE_D * np, nA = (size_t)nm * ORC_DENSE_D;
     for (size_t i = 0; i < nB + nA; i += 2) {
         uint32_t ctr[4] = {(uint32_t)(i >> 1), (uint32_t)((i >> 1) >> 32), 0, 0}, x[4];
         double z[2];
@@ -525,6 +567,10 @@ static void evaluate_objective(const orc_t* o, const double* theta, double* simM
     case ORC_OBJ_DENSE:
         objfunc_dense(p->np, p->nm, theta, o->obj_params, o->obj_params + (size_t)ORC_DENSE_D * p->np, o->mom, o->w, simM,
                       value, status);
+        break;
+    case ORC_OBJ_DENSE2:
+        objfunc_dense2(p->np, p->nm, theta, o->obj_params, o->obj_params + (size_t)ORC_DENSE_D * p->np,
+                       o->obj_params + (size_t)ORC_DENSE_D * p->np + (size_t)ORC_DENSE_D * ORC_DENSE_D, o->mom, o->w, simM, value, status);
         break;
     case ORC_OBJ_NORM_FAILBOX:
         if (o->obj_params && theta[0] >= o->obj_params[0] && theta[0] <= o->obj_params[1]) {
@@ -629,6 +675,10 @@ int orc_ctx_create(const orc_problem_t* prob, const orc_opts_t* opts, const orc_
     if (prob->objective_id == ORC_OBJ_DENSE && !o->obj_params) {
         o->obj_params = (double*)malloc(((size_t)ORC_DENSE_D * np + (size_t)nm * ORC_DENSE_D) * sizeof(double));
         orc_gen_dense(opts->seed, np, nm, o->obj_params);
+    }
+    if (prob->objective_id == ORC_OBJ_DENSE2 && !o->obj_params) {
+        o->obj_params = (double*)malloc(((size_t)ORC_DENSE_D * np + (size_t)ORC_DENSE_D * ORC_DENSE_D + (size_t)nm * ORC_DENSE_D) * sizeof(double));
+        orc_gen_dense2(opts->seed, np, nm, o->obj_params);
     }
     o->acc_tuner = dupd(opts->acc_tuner, Ng); o->min_improve = dupd(opts->min_improve, Ng);
     if (opts->chol_L) {

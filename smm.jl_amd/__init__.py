@@ -10,7 +10,7 @@ from ._abi import SMMHipError
 from .backend import BGPContext, BGPOpts, Problem, Tables, hip_context, register_user_objective
 from .host import (CI, BGPChain, Eval, MAlgoBGP, MProb, addEvalFunc, addMoment, addParam, addSampledParam, allAccepted,
                    banana, best, computeNextIteration, dataMoment, dataMomentd, dataMomentW, dataMomentWd,
-                   evaluateObjective, fill, dense_sim, history, mean, median, ms_names, objfunc_norm, param, paramd, params,
+                   evaluateObjective, fill, dense_sim, dense_sim2, history, mean, median, ms_names, objfunc_norm, param, paramd, params,
                    ps2s_names, ps_names, readMalgo, restart, run, save, serialNormal, setMoments, setValue, snorm_impl,
                    summary, user_objective)
 from .callers import (FD_gradient, Slice, doSlices, evaluateObjectives, getSigma, get_stdErrors, optSlices, range_length)

@@ -36,6 +36,7 @@ SMM_OBJ_NORM = 0
 SMM_OBJ_BANANA = 1
 SMM_OBJ_NORM_FAILBOX = 2
 SMM_OBJ_DENSE = 3
+SMM_OBJ_DENSE2 = 5   # spec v2 of the dense simulation: with the 256 x 256 stage (BASELINE config 5 as worded)
 SMM_DIST_MINUS, SMM_DIST_ABSDIFF, SMM_DIST_RELDIFF = 0, 1, 2   # smm_dist_fun_t
 SMM_OBJ_USER_BASE = 1000   # objective ids >= this are handles of smm_register_user_objective
 SMM_DENSE_D = 256

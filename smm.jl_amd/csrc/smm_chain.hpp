@@ -306,9 +306,128 @@ __device__ __attribute__((noinline)) void dense_tile_n(const int np_, const int 
         }
     }
 }
+// ------------------------------------------------------------------------------------------
+// SMM_OBJ_DENSE2 (spec v2, BASELINE config 5 AS WORDED: a 256 x 256 matvec per evaluation): x = B theta, h1 = tanh x, g = A2 h1, h2 = tanh g,
+// y = A h2.  The first and the last product are spec v1's; between them wave w owns the rows [32w, 32w + 32) of g — two row tiles, each ONE
+// accumulator through 64 v_mfma_f64_16x16x4 (the contract's single fma chain over d = 0..255):
+//   * h1 crosses the waves through LDS: [d][16 chains] = 32 KB in the region of the partial sums (free until the last product is done) —
+//     the accumulator layout (row lk + 4r of tile T, chain li) lands at 256 T + 64 r + lane, and the B operand of k-step s (d = 4s + lk) is
+//     read back at 64 s + lane: both conflict-free, one 8-byte LDS access per lane;
+//   * A2 (512 KB, L2-resident; every tile streams all of it per evaluation: 134 MB of L2 reads per iteration at 256 tiles) lies in fragment
+//     order [wave][k-step][lane][the wave's two row tiles]: ONE global_load_dwordx4 per lane feeds both MFMAs of a k-step; the loads run
+//     D2_DEPTH k-steps ahead of the MFMAs that consume them (a register ring; the loop is straight-line code);
+//   * two workgroup barriers: h1 complete before the first k-step; every wave done reading h1 before the partial sums overwrite it.
+// 192 MFMAs per wave (32 + 128 + 32), 1536 per tile of 16 chains: 10.2 us of the matrix pipe at two waves per SIMD.
+// ------------------------------------------------------------------------------------------
+constexpr int D2_DEPTH = 12;
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+template <int CT, int NPS4>
+__device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int nOt_, const double* dense_Bf_, const double* dense_A2f_, const double* dense_Af_,
+                                                        const uint32_t theta_off_, const uint32_t part_off_, const int tid) {
+    static_assert(CT == 16, "the dense objective tiles 16 chains (MFMA N dimension)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char dense_lds[];
+    typedef const __attribute__((address_space(1))) double* gptr_t;
+    typedef const __attribute__((address_space(1))) d2v_t* g2ptr_t;
+    const int np = __builtin_amdgcn_readfirstlane(np_), nOt = __builtin_amdgcn_readfirstlane(nOt_);
+    const uint32_t theta_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)theta_off_), part_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)part_off_);
+    auto uniform_ptr = [](const double* p) {
+        const unsigned long long u = (unsigned long long)p;
+        return (gptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)u));
+    };
+    const gptr_t dense_Bf = uniform_ptr(dense_Bf_), dense_Af = uniform_ptr(dense_Af_);
+    const double* s_theta = (const double*)(dense_lds + theta_off);
+    double* s_part = (double*)(dense_lds + part_off);
+    double* s_h1 = s_part;   // [256 hidden units][16 chains]
+    constexpr int PS = 4 * NPS4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int nPs = (np + 3) / 4, nmp = nOt * 16;
+    const g2ptr_t a2 = (g2ptr_t)uniform_ptr(dense_A2f_) + (size_t)wave * 64 * 64 + lane;
+    // the first k-steps of A2 are requested ahead of everything: they arrive under the first product and the tanh
+    d2v_t ring[D2_DEPTH];
+#pragma unroll
+    for (int s = 0; s < D2_DEPTH; ++s) ring[s] = a2[s * 64];
+    double bfr[2][PS];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const gptr_t bf = dense_Bf + (size_t)(2 * wave + tt) * nPs * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < PS; ++s) bfr[tt][s] = bf[(size_t)min(s, nPs - 1) * 64];
+    }
+    double th[PS];
+#pragma unroll
+    for (int s = 0; s < PS; ++s) {
+        const int p = 4 * s + lk;
+        const double v = s_theta[li * np + min(p, np - 1)];
+        th[s] = p < np ? v : 0.0;
+    }
+    d4_t xacc[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        xacc[tt] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < PS; ++s) xacc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(bfr[tt][s], th[s], xacc[tt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_h1[256 * (2 * wave + tt) + 64 * r + lane] = smm_tanh(xacc[tt][r]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // h1 stands
+    d4_t gacc[2] = {d4_t{0.0, 0.0, 0.0, 0.0}, d4_t{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const d2v_t a = ring[s % D2_DEPTH];
+        if (s + D2_DEPTH < 64) ring[s % D2_DEPTH] = a2[(s + D2_DEPTH) * 64];
+        const double hb = s_h1[64 * s + lane];
+        gacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, hb, gacc[0], 0, 0, 0);
+        gacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, hb, gacc[1], 0, 0, 0);
+    }
+    // the last product: spec v1's, on h2 = tanh(g) straight from the accumulators
+    d4_t yacc[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) yacc[o] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int T = 2 * wave + tt;
+        double afr[4][4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const gptr_t af = dense_Af + ((size_t)(min(o, nOt - 1) * (DENSE_D / 16) + T) * 4) * 64 + lane;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) afr[o][s4] = af[s4 * 64];
+        }
+        double h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = smm_tanh(gacc[tt][r]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o < nOt) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[o][s4], h[s4], yacc[o], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave has read h1: its region becomes the partial sums'
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (o < nOt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_part[((size_t)wave * nmp + 16 * o + lk + 4 * r) * 16 + li] = yacc[o][r];
+        }
+    }
+}
+
 template <int CT>
-__device__ __forceinline__ void dense_tile_v(const int np, const int nOt, const double* dense_Bf, const double* dense_Af, const uint32_t theta_off, const uint32_t part_off, const int tid) {
+__device__ __forceinline__ void dense_tile_v(const int np, const int nOt, const double* dense_Bf, const double* dense_Af, const double* dense_A2f, const uint32_t theta_off, const uint32_t part_off, const int tid) {
     const int g = (np + 15) / 16;   // (uniform)
+    if (dense_A2f) {   // (uniform: spec v2)
+        if (g <= 1) dense2_tile_n<CT, 1>(np, nOt, dense_Bf, dense_A2f, dense_Af, theta_off, part_off, tid);
+        else if (g == 2) dense2_tile_n<CT, 2>(np, nOt, dense_Bf, dense_A2f, dense_Af, theta_off, part_off, tid);
+        else if (g == 3) dense2_tile_n<CT, 3>(np, nOt, dense_Bf, dense_A2f, dense_Af, theta_off, part_off, tid);
+        else dense2_tile_n<CT, 4>(np, nOt, dense_Bf, dense_A2f, dense_Af, theta_off, part_off, tid);
+        return;
+    }
     if (g <= 1) dense_tile_n<CT, 1>(np, nOt, dense_Bf, dense_Af, theta_off, part_off, tid);
     else if (g == 2) dense_tile_n<CT, 2>(np, nOt, dense_Bf, dense_Af, theta_off, part_off, tid);
     else if (g == 3) dense_tile_n<CT, 3>(np, nOt, dense_Bf, dense_Af, theta_off, part_off, tid);
@@ -318,7 +437,7 @@ __device__ __forceinline__ void dense_tile_v(const int np, const int nOt, const 
 template <int CT>
 __device__ __forceinline__ void dense_tile(const KParams& P, const double* s_theta, double* s_part, int tid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dense_lds_base[];
-    dense_tile_v<CT>(P.np, P.dense_nOt, P.dense_Bf, P.dense_Af, (uint32_t)((const unsigned char*)s_theta - dense_lds_base), (uint32_t)((const unsigned char*)s_part - dense_lds_base), tid);
+    dense_tile_v<CT>(P.np, P.dense_nOt, P.dense_Bf, P.dense_Af, P.dense_A2f, (uint32_t)((const unsigned char*)s_theta - dense_lds_base), (uint32_t)((const unsigned char*)s_part - dense_lds_base), tid);
 }
 
 // value / simulated moments / status for one chain from its reduced sums
@@ -419,7 +538,9 @@ struct TileSmem {
     }
 };
 __host__ __device__ inline size_t tile_smem_doubles(int CT, int np, int nm, int RW, int HW, int RBW, int kind) {
-    const size_t part = kind == 1 ? (size_t)(WG / 64) * CT * nm : kind == 2 ? (size_t)(WG / 64) * (((nm + 15) / 16) * 16) * 16 : 0;
+    // (kind 3: the dense objective's spec v2 — its partial sums' region also stages the first hidden layer, [256][16])
+    size_t part = kind == 1 ? (size_t)(WG / 64) * CT * nm : kind >= 2 ? (size_t)(WG / 64) * (((nm + 15) / 16) * 16) * 16 : 0;
+    if (kind == 3 && part < (size_t)DENSE_D * 16) part = (size_t)DENSE_D * 16;
     return (size_t)CT * (CSW + RBW + 2 * RW + 2 * HW + np) + 3 * np + 2 * nm + part + 2;
 }
 

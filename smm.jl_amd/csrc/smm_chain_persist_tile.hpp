@@ -35,7 +35,7 @@ struct PersistTileArgs {
     uint32_t o_ctl, o_progress, o_rec;
     double* cs; const double* rec_in; double* rec_out; double* vals_out; uint2* slot8_out; uint32_t* walk_flags;
     double* hrec; unsigned long long* err; unsigned long long* ts;
-    const double *Z, *lb, *ub, *mom, *w, *objp, *dense_Bf, *dense_Af;
+    const double *Z, *lb, *ub, *mom, *w, *objp, *dense_Bf, *dense_Af, *dense_A2f;
     const double* rb;                  // randomness blocks of the window (null: drawn in the kernel)
     int N, Ng, np, nm, ns, zstride, RW, HW, RBW, dense_nOt, batch_size, failbox;
     int plan_t0, exch_from, sigma_update_steps, smpl_iters, t0, t1, rb_t0, rb_tries, user_n;
@@ -66,7 +66,8 @@ __host__ __device__ inline PtLayout pt_layout(const int np, const int nm, const 
     L.o_vk = o; o += (PT_CT * nm + 1) & ~1;
     L.o_rb = o; o += PT_CT * RBW;
     L.o_B = o;
-    const uint32_t part = kind == 2 ? (uint32_t)(WG / 64) * (uint32_t)(nOt * 16) * 16u : (uint32_t)(WG / 64) * PT_CT * (uint32_t)nm;
+    uint32_t part = kind >= 2 ? (uint32_t)(WG / 64) * (uint32_t)(nOt * 16) * 16u : (uint32_t)(WG / 64) * PT_CT * (uint32_t)nm;
+    if (kind == 3 && part < (uint32_t)DENSE_D * 16u) part = (uint32_t)DENSE_D * 16u;   // (spec v2 of the dense objective stages its first hidden layer there)
     const uint32_t rows = 2u * PT_CT * (uint32_t)HW;
     o += part > rows ? part : rows;
     L.total = (size_t)L.dbase + (size_t)o * 8;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         if (t < t1 && !rng_here) fetch_rb(t + 1);
         // ---- the objective: all 512 lanes ----
         if constexpr (KIND == 1) simulate_tile_v<CT>(A.ns, nm, np, A.zstride, false, zb, s_theta, s_part, tid, za);
-        else dense_tile_v<CT>(np, A.dense_nOt, A.dense_Bf, A.dense_Af, (uint32_t)((unsigned char*)s_theta - lds), (uint32_t)((unsigned char*)s_part - lds), tid);
+        else dense_tile_v<CT>(np, A.dense_nOt, A.dense_Bf, A.dense_Af, A.dense_A2f, (uint32_t)((unsigned char*)s_theta - lds), (uint32_t)((unsigned char*)s_part - lds), tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA (lists, randomness) has landed
         if (want_hdr) s_hdr[((t + 1) & 3) * 16 + lane] = nhdr;
         if (wave == 2) {

@@ -42,6 +42,7 @@ struct KParams {
     // dense objective (SMM_OBJ_DENSE): B and A in MFMA fragment order
     const double* dense_Bf;  // [D/16][ceil(np/4)][64]
     const double* dense_Af;  // [nOt][D/16][4][64]
+    const double* dense_A2f; // SMM_OBJ_DENSE2 (the 256 x 256 stage; null: spec v1): [8 waves][64 k-steps][64 lanes][2 row tiles of the wave]
     int dense_nOt;           // ceil(nm/16)
     // block widths (doubles, even)
     int RW, HW, RBW;

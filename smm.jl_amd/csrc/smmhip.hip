@@ -384,6 +384,9 @@ T* dupload(Ctx* c, const T* h, size_t n) {
 
 bool is_sim(int obj) { return obj == SMM_OBJ_NORM || obj == SMM_OBJ_NORM_FAILBOX; }
 int obj_kind(int obj) { return is_sim(obj) ? 1 : obj == SMM_OBJ_DENSE ? 2 : 0; }
+// ... as the LDS layouts see it: 3 = the dense objective's spec v2 (SMM_OBJ_DENSE2: internally SMM_OBJ_DENSE with the 256 x 256 stage's
+// operand set; its first hidden layer is staged in the partial sums' region)
+int lay_kind(const Ctx* c);
 
 // the two value arrays (and slot arrays) alternate by iteration: reads of iteration t_read's values, writes of iteration t_write's
 void point_values(const Ctx* c, KParams& P, int t_read, int t_write) {
@@ -393,8 +396,9 @@ void point_values(const Ctx* c, KParams& P, int t_read, int t_write) {
 
 size_t tile_smem_base(const Ctx* c, int ct) {
     const KParams& P = c->P;
-    return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, obj_kind(c->obj)) * sizeof(double);
+    return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, lay_kind(c)) * sizeof(double);
 }
+int lay_kind(const Ctx* c) { const int k = obj_kind(c->obj); return k == 2 && c->P.dense_A2f ? 3 : k; }
 size_t norm_smem(const Ctx* c) {   // k_chain_iter_norm: [walk: chain slots | pair list] theta, partial sums, parked state
     const size_t b = (size_t)c->P.tile_off * sizeof(double) + norm_tile_doubles(c->P.np) * sizeof(double);
     return c->cone_big ? std::max(b, cone_local_lds_bytes()) : b;   // (the local cone walk lies UNDER the tile's blocks)
@@ -1162,7 +1166,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.self = c->prw; A.o_ctl = WL.ctl; A.o_progress = WL.progress; A.o_rec = WL.rec;
         A.cs = P.cs; A.rec_in = c->rec[c->cur]; A.rec_out = c->rec[c->cur ^ 1]; A.vals_out = P.vals_out; A.slot8_out = P.slot8_out; A.walk_flags = P.walk_flags;
         A.hrec = P.hrec; A.err = P.err; A.ts = P.ts;
-        A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp; A.dense_Bf = P.dense_Bf; A.dense_Af = P.dense_Af;
+        A.Z = P.Z; A.lb = P.lb; A.ub = P.ub; A.mom = P.mom; A.w = P.w; A.objp = P.objp; A.dense_Bf = P.dense_Bf; A.dense_Af = P.dense_Af; A.dense_A2f = P.dense_A2f;
         A.rb = pregen ? P.rb : nullptr;
         A.N = P.N; A.Ng = P.Ng; A.np = P.np; A.nm = P.nm; A.ns = P.ns; A.zstride = P.zstride; A.RW = P.RW; A.HW = P.HW; A.RBW = P.RBW; A.dense_nOt = P.dense_nOt;
         A.batch_size = P.batch_size; A.failbox = (P.obj == SMM_OBJ_NORM_FAILBOX && P.objp) ? 1 : 0;
@@ -1172,7 +1176,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.unit_sh = P.lean_unit == 16 ? 4 : (P.lean_unit == 8 ? 3 : 2); A.scout_after = P.scout_after; A.scout_gl = P.scout_gl;
         A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo;
         const dim3 grid(tiles), block(WG);
-        const size_t smem = pt_layout(P.np, P.nm, P.RW, P.HW, P.RBW, kind, P.dense_nOt).total;
+        const size_t smem = pt_layout(P.np, P.nm, P.RW, P.HW, P.RBW, lay_kind(c), P.dense_nOt).total;
         auto go = [&](auto kern) {
             if (c->kev0) hipExtLaunchKernelGGL(kern, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
             else hipLaunchKernelGGL(kern, grid, block, smem, c->stream, A);
@@ -1542,7 +1546,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         std::lock_guard<std::mutex> lock(g_user_mutex);
         if (prob->objective_id - SMM_OBJ_USER_BASE >= (int)g_user_objectives.size())
             return fail(nullptr, SMM_ERR_INVALID_ARG, "unknown user objective handle");
-    } else if (prob->objective_id < 0 || prob->objective_id > SMM_OBJ_DENSE)
+    } else if (prob->objective_id < 0 || (prob->objective_id > SMM_OBJ_DENSE && prob->objective_id != SMM_OBJ_DENSE2))
         return fail(nullptr, SMM_ERR_INVALID_ARG, "unknown objective_id");
     if (is_sim(prob->objective_id) && np != nm)
         return fail(nullptr, SMM_ERR_INVALID_ARG, "objfunc_norm needs one moment per parameter (ObjExamples.jl:66-78)");
@@ -1580,7 +1584,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         HIPCHK(hipEventCreate(&c->ev0));
         HIPCHK(hipEventCreate(&c->ev1));
         KParams& P = c->P;
-        c->obj = user_obj ? SMM_OBJ_USER : prob->objective_id;
+        c->obj = user_obj ? SMM_OBJ_USER : prob->objective_id == SMM_OBJ_DENSE2 ? SMM_OBJ_DENSE : prob->objective_id;   // (spec v2: the dense kind with P.dense_A2f set)
         c->exchange_from = opts->exchange_from_iter;
         P.exch_from = opts->exchange_from_iter;
         {
@@ -1615,18 +1619,20 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             P.u_value = dalloc<double>(c, N);
             P.u_status = dalloc<int>(c, N);
         }
-        if (prob->objective_id == SMM_OBJ_DENSE) {
-            const size_t nB = (size_t)DENSE_D * np, nA = (size_t)nm * DENSE_D;
-            if (prob->n_obj_params != 0 && (size_t)prob->n_obj_params != nB + nA)
-                throw std::string("SMM_OBJ_DENSE: obj_params must hold B (256 x np) and A (nm x 256), or be empty");
-            std::vector<double> M(nB + nA);
+        if (prob->objective_id == SMM_OBJ_DENSE || prob->objective_id == SMM_OBJ_DENSE2) {
+            const bool v2 = prob->objective_id == SMM_OBJ_DENSE2;   // [B, A2, A]: with the 256 x 256 stage
+            const size_t nB = (size_t)DENSE_D * np, n2 = v2 ? (size_t)DENSE_D * DENSE_D : 0, nA = (size_t)nm * DENSE_D;
+            if (prob->n_obj_params != 0 && (size_t)prob->n_obj_params != nB + n2 + nA)
+                throw std::string(v2 ? "SMM_OBJ_DENSE2: obj_params must hold B (256 x np), A2 (256 x 256) and A (nm x 256), or be empty"
+                                     : "SMM_OBJ_DENSE: obj_params must hold B (256 x np) and A (nm x 256), or be empty");
+            std::vector<double> M(nB + n2 + nA);
             if (prob->n_obj_params) memcpy(M.data(), prob->obj_params, M.size() * 8);
             else {  // N(0,1)/sqrt(fan-in) from the counter RNG, stream 5
-                for (size_t i = 0; i < nB + nA; i += 2) {
+                for (size_t i = 0; i < M.size(); i += 2) {
                     double z0, z1;
                     box_muller(philox_stream(opts->seed, 5, (uint32_t)(i >> 1), (uint32_t)((i >> 1) >> 32), 0, 0), z0, z1);
                     M[i] = z0 / sqrt(i < nB ? (double)np : (double)DENSE_D);
-                    if (i + 1 < nB + nA) M[i + 1] = z1 / sqrt(i + 1 < nB ? (double)np : (double)DENSE_D);
+                    if (i + 1 < M.size()) M[i + 1] = z1 / sqrt(i + 1 < nB ? (double)np : (double)DENSE_D);
                 }
             }
             const int nPs = (np + 3) / 4, nOt = (nm + 15) / 16;
@@ -1642,11 +1648,22 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                     for (int s = 0; s < 4; ++s)
                         for (int l = 0; l < 64; ++l) {
                             const int k = 16 * o + (l & 15), d = 16 * T + 4 * s + (l >> 4);
-                            if (k < nm) Af[(((size_t)o * (DENSE_D / 16) + T) * 4 + s) * 64 + l] = M[nB + (size_t)k * DENSE_D + d];
+                            if (k < nm) Af[(((size_t)o * (DENSE_D / 16) + T) * 4 + s) * 64 + l] = M[nB + n2 + (size_t)k * DENSE_D + d];
                         }
             P.dense_Bf = dupload(c, Bf.data(), Bf.size());
             P.dense_Af = dupload(c, Af.data(), Af.size());
             P.dense_nOt = nOt;
+            if (v2) {   // A2 in fragment order [wave][k-step][lane][the wave's two row tiles] (smm_chain.hpp: dense2_tile_n)
+                std::vector<double> A2f((size_t)DENSE_D * DENSE_D);
+                for (int wv = 0; wv < 8; ++wv)
+                    for (int s = 0; s < DENSE_D / 4; ++s)
+                        for (int l = 0; l < 64; ++l)
+                            for (int tt = 0; tt < 2; ++tt) {
+                                const int j = 16 * (2 * wv + tt) + (l & 15), d = 4 * s + (l >> 4);
+                                A2f[(((size_t)wv * (DENSE_D / 4) + s) * 64 + l) * 2 + tt] = M[nB + (size_t)j * DENSE_D + d];
+                            }
+                P.dense_A2f = dupload(c, A2f.data(), A2f.size());
+            }
         }
         {
             const int rows = (ns + WG - 1) / WG;
@@ -1838,7 +1855,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                                            P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan &&
                                            !opts->chol_L && P.dbg == 0 && !(pe && pe[0] == '0') && !(ptile && ptile[0] == '0') && P.RW <= PT_LPC * PT_NJ &&
                                            (tile_kind == 1 || N % PT_CT == 0) && (N + PT_CT - 1) / PT_CT <= 2 * n_cus &&
-                                           pt_layout(np, nm, P.RW, P.HW, P.RBW, tile_kind, P.dense_nOt).total <= (size_t)160 * 1024;
+                                           pt_layout(np, nm, P.RW, P.HW, P.RBW, lay_kind(c), P.dense_nOt).total <= (size_t)160 * 1024;
             const size_t persist_tiles = (want_persist_gen || want_persist_gen_small || want_persist_user) ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             // large single shards of objfunc_norm (C3 on one GPU): the narrow chain kernel's tiles walk their own, locally numbered cones
             // (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two launches
@@ -2118,7 +2135,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         }
         if (c->persist_tile) {
             const int kind = obj_kind(c->obj);
-            const size_t smem = pt_layout(np, nm, P.RW, P.HW, P.RBW, kind, P.dense_nOt).total;
+            const size_t smem = pt_layout(np, nm, P.RW, P.HW, P.RBW, lay_kind(c), P.dense_nOt).total;
             const void* fn = kind == 2 ? (const void*)k_chain_persist_tile<2> : (const void*)k_chain_persist_tile<1>;
             HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             int per_cu = 0, cus = 0;
@@ -2989,7 +3006,7 @@ int smm_describe(void* ctx, char* out, int32_t cap) {
     else if (c->norm_fast)
         chain = c->cone_big ? "iter_norm_narrow_cone" : (!c->win_lv_pairs_p || c->deep_plan || c->nan_values) && c->inline_walk ? "iter_norm_any"
               : (P.lean_wide && c->inline_walk) ? "iter_norm_wide" : c->norm_narrow ? "iter_norm_narrow" : "iter_norm";
-    else chain = c->obj == SMM_OBJ_DENSE ? "iter<dense,16>" : is_sim(c->obj) ? (c->tpw == 2 ? "iter<sim,8,2>" : "iter<sim,8>")
+    else chain = c->obj == SMM_OBJ_DENSE ? (P.dense_A2f ? "iter<dense2,16>" : "iter<dense,16>") : is_sim(c->obj) ? (c->tpw == 2 ? "iter<sim,8,2>" : "iter<sim,8>")
                : (c->gen_keys ? "iter<gen,16,2>" : c->tpw == 2 ? "iter<gen,8,2>" : "iter<gen,8>");
     static const char* xk[] = {"lean", "lvl", "lvl_soa", "tickets", "rows", "key", "lvl_big", "any"};
     const char* walk = c->cone_big ? "cone_local" : !c->inline_walk ? "standalone" : c->dense_keys ? "inline_keys_under_tile" : c->gen_keys ? (c->cone ? "inline_keys_cone" : "inline_keys")
@@ -2997,7 +3014,7 @@ int smm_describe(void* ctx, char* out, int32_t cap) {
     const char* pers = !c->persist ? "none" : c->persist_loc ? (c->persist_sh ? (c->persist_sh_big ? (c->persist_wide ? "loc_wide_shard_bigplan" : "loc_shard_bigplan")
                                                                                                     : (c->persist_wide ? "loc_wide_shard" : "loc_shard"))
                                                                               : (c->persist_wide ? "loc_wide" : "loc"))
-                     : c->persist_tile ? (c->obj == SMM_OBJ_DENSE ? "tile_dense" : "tile_sim") : c->persist_user ? "gen_user" : "gen";
+                     : c->persist_tile ? (c->obj == SMM_OBJ_DENSE ? (P.dense_A2f ? "tile_dense2" : "tile_dense") : "tile_sim") : c->persist_user ? "gen_user" : "gen";
     snprintf(out, (size_t)cap, "chain=%s walk=%s exchange=%s persistent=%s plan=%s window=%d", chain, walk, xk[c->xk], pers,
              c->big_exchange ? (c->plan_ahead ? "big_ahead" : "big") : c->lds_exchange ? "lds" : "none", c->plan_cap);
     return SMM_OK;

@@ -51,7 +51,8 @@ def user_objective(source, name="user_objective", n_sums=None, lanes=256):
 
 objfunc_norm = DeviceObjective("objfunc_norm", A.SMM_OBJ_NORM, needs_square=True)   # ObjExamples.jl:59-116
 banana = DeviceObjective("banana", A.SMM_OBJ_BANANA, ns=1)                           # ObjExamples.jl:251-265
-dense_sim = DeviceObjective("dense_sim", A.SMM_OBJ_DENSE, ns=1)                     # BASELINE config 5 (include/smmhip.h)
+dense_sim = DeviceObjective("dense_sim", A.SMM_OBJ_DENSE, ns=1)                     # synthetic dense simulation (include/smmhip.h)
+dense_sim2 = DeviceObjective("dense_sim2", A.SMM_OBJ_DENSE2, ns=1)                  # ... with the 256 x 256 stage: BASELINE config 5 as worded
 
 
 class MProb:

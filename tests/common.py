@@ -5,38 +5,7 @@ import smm_jl_amd as S
 from smm_jl_amd import _abi as A
 
 
-def temps(N, maxtemp):
-    # range(1.0, stop=maxtemp, length=N), AlgoBGP.jl:508
-    return np.linspace(1.0, maxtemp, N) if N > 1 else np.ones(1)
-
-
-def serial_normal(N=3, T=200, ns=10000, acc_tuners=None, min_improve=0.0, maxtemp=5.0, sigma0=0.05, seed=12,
-                  p2_bounds=(-20.0, 20.0), mom=(-1.0, 10.0), w=(1.0, 1.0), objective_id=A.SMM_OBJ_NORM,
-                  obj_params=None, **kw):
-    """serialNormal(2, T): Examples.jl:118-153 + snorm_impl :373-416 (N=3, acc_tuners=[20,2,1])."""
-    if acc_tuners is None:
-        acc_tuners = [20.0, 2.0, 1.0] if N == 3 else np.geomspace(20.0, 1.0, N)
-    prob = S.Problem(init=[0.2, -0.2], lb=[-3.0, p2_bounds[0]], ub=[3.0, p2_bounds[1]], mom=list(mom), w=list(w),
-                     ns=ns, objective_id=objective_id, obj_params=obj_params)
-    opts = S.BGPOpts(N=kw.pop("N_local", N), maxiter=T, sigma=sigma0 * temps(N, maxtemp),
-                     acc_tuner=np.broadcast_to(np.asarray(acc_tuners, float), (N,)).copy(),
-                     min_improve=np.broadcast_to(np.asarray(min_improve, float), (N,)).copy(), seed=seed,
-                     N_global=N, **kw)
-    return prob, opts
-
-
-def general_normal(npar, N, T, ns=1000, seed=7, batch_size=None, **kw):
-    """an np-dimensional objfunc_norm problem in the spirit of snorm_impl(npar>2), Examples.jl:392-405"""
-    rng = np.random.default_rng(seed)
-    half = rng.uniform(1.0, 5.0, npar)
-    init = rng.uniform(-0.5, 0.5, npar) * half
-    mom = rng.uniform(-0.5, 0.5, npar) * half
-    w = rng.uniform(0.5, 2.0, npar)
-    prob = S.Problem(init=init, lb=-half, ub=half, mom=mom, w=w, ns=ns)
-    opts = S.BGPOpts(N=kw.pop("N_local", N), maxiter=T, sigma=0.05 * temps(N, 3.0),
-                     acc_tuner=np.geomspace(10.0, 1.0, N) if N > 1 else np.array([2.0]),
-                     min_improve=np.zeros(N), seed=seed, batch_size=batch_size, N_global=N, **kw)
-    return prob, opts
+from smm_jl_amd.workloads import general_normal, serial_normal, temps  # noqa: E402,F401  (the builders live in the package: bench.py does not depend on tests/)
 
 
 def random_tables(prob, opts, tries=24, seed=99, pairs=True, Z=True):

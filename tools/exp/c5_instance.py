@@ -4,10 +4,11 @@ import smm_jl_amd as S, common as cm
 from smm_jl_amd import _abi as A
 from oracle import oracle as O
 O.load()
+OBJ = A.SMM_OBJ_DENSE2 if "v1" not in sys.argv else A.SMM_OBJ_DENSE
 def run(N, T, accs, wscale=1.0, sig0=0.004):
     npar=nm=50
     rng=np.random.default_rng(3)
-    prob=S.Problem(init=rng.uniform(-0.3,0.3,npar), lb=-np.ones(npar), ub=np.ones(npar), mom=rng.uniform(-0.5,0.5,nm), w=wscale*rng.uniform(0.5,2.0,nm), ns=1, objective_id=A.SMM_OBJ_DENSE)
+    prob=S.Problem(init=rng.uniform(-0.3,0.3,npar), lb=-np.ones(npar), ub=np.ones(npar), mom=rng.uniform(-0.5,0.5,nm), w=wscale*rng.uniform(0.5,2.0,nm), ns=1, objective_id=OBJ)
     opts=S.BGPOpts(N=N, maxiter=T, sigma=sig0*cm.temps(N,3), acc_tuner=accs, min_improve=np.zeros(N), seed=3, smpl_iters=100000)
     o=O.OracleContext(prob, opts, S.Tables(), threads=O.max_threads())
     o.step(T)
