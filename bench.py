@@ -356,8 +356,10 @@ def cross_rank_check(ctx, torch, dist, rank, world, n_loc, same_device, last=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps of 200 iterations (default 5; c5: 8 = the steady state past 1600 iterations)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps of 200 iterations per repetition (default: c2 20, c5 8 = the steady state past 1600 iterations, else 5)")
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=None, help="repetitions of the K timed steps, each bracketed by barrier + synchronize (default: as many as make the "
+                                                            "timed regions add up to >= 0.6 s, between 3 and 12, within 32 GB of history); value = the MEDIAN repetition")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
     ap.add_argument("--protocol", choices=["auto", "p2p", "records", "values"], default=os.environ.get("SMM_BENCH_PROTOCOL", "auto"))
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the workload's)")
@@ -405,7 +407,7 @@ def main():
         n_loc = args.chains or (W["chains"] // world if args.same_device else W["chains"])
         n_glob = n_loc * world
     if args.steps is None:
-        args.steps = 8 if args.workload in ("c5", "c5v1") else 5
+        args.steps = 8 if args.workload in ("c5", "c5v1") else 20 if args.workload == "c2" else 5   # (c2: the driver's own --steps 20; 12 repetitions = 0.6 s of timed region)
     K, Wm = args.steps, args.warmup
 
     # the self-check runs the form the timed run will use: the same N_global and chains per rank (at least 1024: the large-population
@@ -421,7 +423,11 @@ def main():
     elif not sharded:
         protocol = None
 
-    T = ITERS_PER_STEP * (K + Wm + 2)   # + the two profiled steps
+    # history capacity: every repetition's K steps + warm-up + the two profiled steps; the repetitions bounded by 32 GB of history rows
+    prob0, _ = build_problem(args.workload, n_loc, n_glob, rank, 1, device)
+    row_bytes = n_loc * ((8 + prob0.np + prob0.nm + 1) & ~1) * 8
+    reps_cap = max(1, min(args.reps or 12, int(32e9 // (row_bytes * ITERS_PER_STEP * K))))
+    T = ITERS_PER_STEP * (reps_cap * K + Wm + 2)
 
     def barrier():
         if world > 1:
@@ -445,17 +451,27 @@ def main():
         for _ in range(Wm):
             run_step()
         sync(); torch.cuda.synchronize(); barrier()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            run_step()
-        sync(); torch.cuda.synchronize(); barrier()
-        return ctx, run_step, sync, time.perf_counter() - t0
+        times, want = [], (args.reps or 3)
+        while len(times) < min(want, reps_cap):
+            t0 = time.perf_counter()
+            for _ in range(K):
+                run_step()
+            sync(); torch.cuda.synchronize(); barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:   # (outside the clock: the MAX over the ranks, which also makes every rank take the same number of repetitions)
+                tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.same_device else "cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            times.append(dt)
+            if args.reps is None and len(times) == 1:
+                want = max(3, min(12, int(0.6 / dt) + 1))
+        return ctx, run_step, sync, times
 
     # the p2p windows meet real links here for the first time in earnest: a failure (a peer's stores never arrive: SMM_ERR_HIP after
     # ~4 s) must not kill the bench — every rank learns of it, the contexts are made anew, and the run is repeated on the collective form
     err = None
     try:
-        ctx, run_step, sync, dt = timed_run(protocol)
+        ctx, run_step, sync, times = timed_run(protocol)
     except Exception as e:   # noqa: BLE001
         if not (sharded and protocol == "p2p"):
             raise
@@ -467,13 +483,10 @@ def main():
             proto_note = "%s; TIMED RUN on p2p failed (%s): repeated on the record all-gather" % (proto_note, err or "on another rank")
             protocol = "records"
             barrier()
-            ctx, run_step, sync, dt = timed_run(protocol)
+            ctx, run_step, sync, times = timed_run(protocol)
     elif err is not None:
         raise RuntimeError(err)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.same_device else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = sorted(times)[len(times) // 2]   # the median repetition (each already the max over the ranks)
     # outside the clock: do the shards agree on the exchange of the last iterations?
     xok, xnote = cross_rank_check(ctx, torch, dist, rank, world, n_loc, args.same_device) if args.workload in ("c2", "c3", "c4", "c5", "c5v1") else (True, None)
     if not xok:
@@ -605,7 +618,12 @@ def main():
         out = {"metric": "chain-evals/sec (whole node), serialNormal 2p/2m, 4096 chains x 200 iters" if args.workload == "c2"
                          else "chain-evals/sec (whole node), %s" % args.workload,
                "value": value, "unit": "chain-evals/s", "n_gpus": world, "steps": K, "warmup": Wm,
-               "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong" if (W["total"] or (world > 1 and args.same_device and not args.chains)) else "weak", "vs_baseline": None,
+               "ms_per_step": dt / K * 1e3,
+               "repetitions": {"n": len(times), "ms_per_step_min": min(times) / K * 1e3, "ms_per_step_median": dt / K * 1e3, "ms_per_step_max": max(times) / K * 1e3,
+                               "timed_region_s_total": sum(times), "value_best": evals / min(times),
+                               "note": "each repetition = EXACTLY --steps steps bracketed by barrier + synchronize (max over the ranks); value and ms_per_step are the MEDIAN repetition's"},
+               "iterations_run": ITERS_PER_STEP * (Wm + len(times) * K + 1),   # warm-up + repetitions + the profiled step, on the timed context
+               "higher_is_better": True, "scaling": "strong" if (W["total"] or (world > 1 and args.same_device and not args.chains)) else "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s, %d BGP chains per GPU (%d total) x %d iterations per step" % (W["label"], n_loc, n_glob, ITERS_PER_STEP),
                           "chains_per_gpu": n_loc, "chains_total": n_glob, "iters_per_step": ITERS_PER_STEP, "ns": NS if args.workload in ("c2", "c3") else None,
@@ -617,6 +635,9 @@ def main():
                           "world_seen": (dist.get_world_size() if dist.is_initialized() else 1),
                           "backend": (str(dist.get_backend()) if dist.is_initialized() else None),
                           "same_device": bool(args.same_device), "forced_sharded": force_sharded},
+               "vs_cpu_baseline": (None if cpu is None else {"cached_shocks_upper_bound": value / cpu["value"], "regenerated_draws_lower_bound": value / cpu["regen_value"],
+                                                              "note": "value / the C port of the reference path on this box's host cores (cpu_baseline; parity unpinned: not the Julia "
+                                                                      "reference).  vs_baseline stays null: BASELINE.md holds no published number for this metric"}),
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist.is_initialized():

@@ -316,11 +316,15 @@ int  smm_bgp_sharded_finish(void* ctx, const void* gathered_dev);
  *        first publication rewrites the windows with a new epoch, and a rank still in its finish would find the words of the
  *        last iteration replaced (a time-out in the tagged forms, other records without notice in the generic one).
  *        smm.jl_amd/dist.py::ShardedBGP.sync does it.
- *   Which of the three forms a context steps in is decided from what every rank knows (population, objective, thresholds),
+ *   Which of the forms a context steps in is decided from what every rank knows (population, objective, thresholds),
  *   never from a shard's own values.  A NaN value in an uploaded state (smm_set_state) reaches every window with the first
  *   publication: the rows form resolves such iterations on the exact values, the one-launch form (N_global <= 8192) has no
  *   second walk and reports SMM_ERR_HIP on every rank in the same iteration — step such a state once with smm_bgp_sharded_step
- *   (or as a single shard) first. */
+ *   (or as a single shard) first.  The persistent form reports it from inside its launch; the ranks agree on that at their
+ *   rendezvous and replay the step on the forms above.
+ *   What a shard in the persistent form sends per chain, iteration and PEER: the parameters and the value of its last accepted
+ *   record as self-validating granules — (np + 1) x 16 bytes, 48 at two parameters; the rest of a record (prob, status, simulated
+ *   moments) stays in the owner's window and is fetched by the one chain that continues from it (swap_ev_ij!, AlgoBGP.jl:734-749). */
 #define SMM_P2P_HANDLE_BYTES 64
 int  smm_bgp_p2p_init(void* ctx, void* ipc_handle_out, void** window_dev_out);
 int  smm_bgp_p2p_attach(void* ctx, int32_t rank, const void* ipc_handle, void* window_dev);

@@ -215,7 +215,9 @@ __device__ __forceinline__ double smm_tanh(const double x) {
     const int ni = (n == n) ? (int)n : 0;
     const double s = __builtin_ldexp(1.0, ni);
     const double em1 = __builtin_fma(s, p, s - 1.0), ep1 = __builtin_fma(s, p, s + 1.0);
-    const double t = ax >= 19.0625 ? 1.0 : em1 / ep1;
+    // (1 from 19.0625 on: the select sits on the NUMERATOR — ep1 / ep1 is exactly 1 — so that the division stays unconditional: selecting between
+    // 1.0 and the quotient made the compiler branch around the division: four branches per lane and tile in the middle of the matrix instructions)
+    const double t = (ax >= 19.0625 ? ep1 : em1) / ep1;
     return __builtin_copysign(t, x);
 }
 
@@ -319,8 +321,8 @@ __device__ __attribute__((noinline)) void dense_tile_n(const int np_, const int 
 //   * two workgroup barriers: h1 complete before the first k-step; every wave done reading h1 before the partial sums overwrite it.
 // 192 MFMAs per wave (32 + 128 + 32), 1536 per tile of 16 chains: 10.2 us of the matrix pipe at two waves per SIMD.
 // ------------------------------------------------------------------------------------------
-constexpr int D2_DEPTH = 12;
 typedef double d2v_t __attribute__((ext_vector_type(2)));
+constexpr int D2_DEPTH = 12;
 template <int CT, int NPS4>
 __device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int nOt_, const double* dense_Bf_, const double* dense_A2f_, const double* dense_Af_,
                                                         const uint32_t theta_off_, const uint32_t part_off_, const int tid) {
@@ -343,7 +345,6 @@ __device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int
     const int li = lane & 15, lk = lane >> 4;
     const int nPs = (np + 3) / 4, nmp = nOt * 16;
     const g2ptr_t a2 = (g2ptr_t)uniform_ptr(dense_A2f_) + (size_t)wave * 64 * 64 + lane;
-    // the first k-steps of A2 are requested ahead of everything: they arrive under the first product and the tanh
     d2v_t ring[D2_DEPTH];
 #pragma unroll
     for (int s = 0; s < D2_DEPTH; ++s) ring[s] = a2[s * 64];
@@ -383,7 +384,6 @@ __device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int
         gacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, hb, gacc[0], 0, 0, 0);
         gacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, hb, gacc[1], 0, 0, 0);
     }
-    // the last product: spec v1's, on h2 = tanh(g) straight from the accumulators
     d4_t yacc[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) yacc[o] = d4_t{0.0, 0.0, 0.0, 0.0};
@@ -408,7 +408,7 @@ __device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int
             }
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave has read h1: its region becomes the partial sums'
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         if (o < nOt) {

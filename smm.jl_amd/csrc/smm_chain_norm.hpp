@@ -298,7 +298,7 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
                 do {
                     __builtin_amdgcn_s_sleep(1);
                     q = p2p_load16_sys(g_slots + (g >> 1));
-                    if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { timed_out = true; break; }
+                    if (p2p_spin_over(P, t0, tx + 1)) { timed_out = true; break; }
                 } while (!ok());
             }
         }
@@ -518,7 +518,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
                             ok = true;
 #pragma unroll
                             for (int i = 0; i < RW; ++i) { q[i] = p2p_load16_sys(g_ll + i); ok = ok && p2p_ll_ok(q[i], tag); }
-                            if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { report_error(P, 3, t, gc); break; }
+                            if (p2p_spin_over(P, t0, t)) { report_error(P, 3, t, gc); break; }
                         } while (!ok);
                     }
 #pragma unroll

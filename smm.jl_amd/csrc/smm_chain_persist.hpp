@@ -91,6 +91,13 @@ __device__ inline void pr_store_ll(void* p, const double2 v, const uint32_t tag)
                  :: "v"(p), "v"(q0), "v"((unsigned char*)p + 16), "v"(q1) : "memory");
 }
 
+// ... one granule: 8 bytes of payload as 16 self-validating bytes
+__device__ inline void pr_store_ll1(void* p, const double v, const uint32_t tag) {
+    const unsigned long long a = __builtin_bit_cast(unsigned long long, v);
+    const p2p_u32x4 q0 = {(unsigned)a, tag, (unsigned)(a >> 32), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off " PR_SC "\n\ts_nop 1" :: "v"(p), "v"(q0) : "memory");
+}
+
 // The ring holds a record's doubles in its own order — parameters first, so that the gather fetches them together with the walk
 // slot: theta[NP], value, prob, status, sim_moments[NP], pad — one uint4 {lo, tag, hi, tag} per double.
 template <int NP> __device__ constexpr int pr_ring_index(const int classic) {   // classic: value, prob, status, theta[NP], sim_moments[NP], pad

@@ -14,10 +14,14 @@
 //     between two publications); k_cone_tiles' (N_global > 8192) are local already;
 //   * WIDE = one min_improve > 0 for all chains (dist_fun = -): 16-byte slots {value, local | stamp << 16}, the test is the
 //     subtraction itself (lean_walk_levels<., ., true>), the gathered value is the record's own self-validating copy;
-//   * SH = a shard of a sharded run (one process per GPU, smm_p2p.hpp's windows): the ring lives in every rank's window, a tile
-//     publishes into ALL of them (fire-and-forget stores over xGMI), gathers from its own, announces its progress to all; launches
-//     of different ranks meet in a start barrier built from one word per rank (a rank arrives at launch e only when its launch
-//     e - 1 has ended: nothing of the ring's last use is still being read).
+//   * SH = a shard of a sharded run (one process per GPU, smm_p2p.hpp's windows): the ring lives in every rank's window; a tile
+//     publishes its chains' WHOLE records into its own rank's window and, into every PEER's (fire-and-forget stores over xGMI), only
+//     what every walk consumes — the parameters and the value, NP + 1 self-validating granules = 48 bytes per chain and peer at two
+//     parameters (round 5 pushed the 8-byte slot and all RW granules: 136) —; a tile gathers its cone from its own window (the walk
+//     slot's key is derived from the gathered value), and only an EXCHANGED chain fetches the rest of its donor's record (prob,
+//     status, simulated moments: swap_ev_ij!, AlgoBGP.jl:734-749) from the donor's OWNER's window by LDS-DMA, under the simulation;
+//     progress is announced to all; launches of different ranks meet in a start barrier built from one word per rank (a rank
+//     arrives at launch e only when its launch e - 1 has ended: nothing of the ring's last use is still being read).
 // The launch's FIRST walk (an exchange the previous kernel left pending) is fed like every other: the tiles publish the records
 // they start from as "iteration 0" of the launch, so there is no plain-memory path for it and a shard needs none for its peers.
 // Everything else — roles of the waves, barriers, ring, tags, overrun guard, numerical contract, error convention — is
@@ -218,6 +222,10 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
             for (int i = r; i < NPC; i += 4) st2[PR_STW / 2 + i] = g_rec[i];
             if (r == 0) {
                 const double v0 = g_rec[0].x;
+                // (a NaN value — only an uploaded state can hold one, smm_set_state — orders under no key: the shard's form is chosen from
+                // what every rank knows, never from a shard's own values, so the launch itself says it; the ranks agree on the word at their
+                // next rendezvous and replay the step on the per-iteration forms, which resolve or report such a state: include/smmhip.h)
+                if (SH && v0 != v0) pr_report(A.err, 3, t0, (int)c0g + cl);
                 if constexpr (WIDE) ((uint4*)lds)[cl] = make_uint4((uint32_t)__double2loint(v0), (uint32_t)__double2hiint(v0), (uint32_t)cl, 0u);
                 else ((uint2*)lds)[cl] = make_uint2(order_key32(v0), (uint32_t)cl);
                 for (int k = 0; k < NP; ++k) Y.s_gth[cl * NP + k] = A.rec_in[(size_t)c * RW + 3 + k];
@@ -333,8 +341,9 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
         for (int e = tid - 256; e < ngat; e += 256) {
             const int g = (int)gl[e];
             const uint32_t loc = (uint32_t)(CT + e);
-            if constexpr (WIDE) {
+            if constexpr (WIDE || SH) {
                 // the record's parameters and its value (the ring's doubles 0 .. NP), self-validating, requested together
+                // (a shard's peers push exactly these: the 8-byte slot's key is derived from the value here)
                 p2p_u32x4 q0, q1, q2;
                 asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off sc0 sc1\n\tglobal_load_dwordx4 %2, %5, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
                              : "=&v"(q0), "=&v"(q1), "=&v"(q2) : "v"(rr + (size_t)g * RW), "v"(rr + (size_t)g * RW + (NP - 1)), "v"(rr + (size_t)g * RW + NP) : "memory");
@@ -343,7 +352,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
                     const PlGather3 w3 = pl_wait_gather3(W, rr + (size_t)g * RW, rr + (size_t)g * RW + (NP - 1), rr + (size_t)g * RW + NP, tag, t_report, g);
                     u0 = w3.q0; u1 = w3.q1; u2 = w3.q2;
                 }
-                ((uint4*)lds)[loc] = make_uint4(u2.x, u2.z, loc, 0u);
+                if constexpr (WIDE) ((uint4*)lds)[loc] = make_uint4(u2.x, u2.z, loc, 0u);
+                else ((uint2*)lds)[loc] = make_uint2(order_key32(p2p_ll_double(u2)), loc);
                 Y.s_gth[loc * NP] = p2p_ll_double(u0);
                 if constexpr (NP > 1) Y.s_gth[loc * NP + 1] = p2p_ll_double(u1);
             } else {
@@ -380,14 +390,19 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
         const size_t so = (size_t)A.o_slot + ((size_t)(rel & rmask) * (A.Ng + 4) + (size_t)c_glob) * 8;
         const size_t ro_ = (size_t)A.o_rec + ((size_t)(rel & rmask) * A.Ng + (size_t)c_glob) * RW * 16 + (size_t)r * 32;
         if constexpr (SH) {
+            // the whole record into this rank's own window; into the peers' the ring's doubles 0 .. NP only (parameters, value):
+            // lane r holds doubles 2r and 2r + 1
+            constexpr int need = NP + 1;
+            if (r < NPC) pr_store_ll(mine + ro_, pv, tag);
 #pragma unroll
             for (int p = 0; p < P2P_MAXG; ++p) {
-                if (p < A.G) {
+                if (p < A.G && p != A.rank) {
                     unsigned char* w = A.win[p];
-                    if (!WIDE && r == 0) pr_store8(w + so, sw);
-                    if (r < NPC) pr_store_ll(w + ro_, pv, tag);
+                    if (2 * r + 1 < need) pr_store_ll(w + ro_, pv, tag);
+                    else if (2 * r < need) pr_store_ll1(w + ro_, pv.x, tag);
                 }
             }
+            (void)sw; (void)so;
         } else {
             if (!WIDE && r == 0) pr_store8(mine + so, sw);
             if (r < NPC) pr_store_ll(mine + ro_, pv, tag);
@@ -601,7 +616,13 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
             const uint32_t src_g = src < (uint32_t)CT ? c0g + src : (uint32_t)gl[src - CT];
             // the donor's whole record (swap_ev_ij!, :734-749), requested now and looked at behind the simulation (LDS-DMA, past the caches)
             if (donor) {
-                const uint4* g_ll = (const uint4*)(mine + A.o_rec) + ((size_t)((rel - 1) & rmask) * A.Ng + src_g) * RW;
+                const unsigned char* dwin = mine;
+                if constexpr (SH) {   // (the donor's OWNER holds the whole record: equal shards of A.N chains)
+                    const int owner = (int)src_g / A.N;
+#pragma unroll
+                    for (int p = 0; p < P2P_MAXG; ++p) dwin = owner == p ? A.win[p] : dwin;
+                }
+                const uint4* g_ll = (const uint4*)(dwin + A.o_rec) + ((size_t)((rel - 1) & rmask) * A.Ng + src_g) * RW;
                 const uint32_t dbase = (uint32_t)((unsigned char*)Y.s_donor - lds);
                 pr_dma16(g_ll + r, dbase);
                 if (4 + r < RW) pr_dma16(g_ll + 4 + r, dbase + 64 * 16);
@@ -703,7 +724,13 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
                 if (__builtin_expect(!ok, 0)) {   // (the gather validated the parameters only: the other pieces of the same publication may still be on their way)
                     const uint16_t* gl = (const uint16_t*)(lds + Y.gbase) + ((t - 1) & 1) * CONE_GCAP;
                     const uint32_t src_g = (uint32_t)src < (uint32_t)CT ? c0g + (uint32_t)src : (uint32_t)gl[src - CT];
-                    const uint4* g_ll = (const uint4*)(mine + A.o_rec) + ((size_t)((rel - 1) & rmask) * A.Ng + src_g) * RW;
+                    const unsigned char* dwin = mine;
+                    if constexpr (SH) {
+                        const int owner = (int)src_g / A.N;
+#pragma unroll
+                        for (int p = 0; p < P2P_MAXG; ++p) dwin = owner == p ? A.win[p] : dwin;
+                    }
+                    const uint4* g_ll = (const uint4*)(dwin + A.o_rec) + ((size_t)((rel - 1) & rmask) * A.Ng + src_g) * RW;
 #pragma unroll
                     for (int f = 0; f < RW; f += 2) {
                         const PrLL2 w2 = pr_wait_ll2(W, g_ll + f, g_ll + f + 1, tag, t, (int)c0g + cl);

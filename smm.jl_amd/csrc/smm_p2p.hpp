@@ -85,6 +85,13 @@ __device__ inline void p2p_store4(void* p, const uint32_t v) { __hip_atomic_stor
 constexpr int P2P_UNIT = 16;
 __host__ __device__ inline int p2p_units(const int N) { return (N + P2P_UNIT - 1) / P2P_UNIT; }
 constexpr unsigned long long P2P_TIMEOUT_TICKS = 400000000ull;   // 4 s of the 100 MHz wall clock: a peer is gone, not late
+// a spin for tagged words of iteration t_launch - 1 is over: timed out, or the run failed in an EARLIER iteration than t_launch — the launch that
+// should have stored those words saw the error word at its entry and stored nothing (error convention, include/smmhip.h), and this launch is
+// poisoned itself and will store nothing either: a failed run drains at once instead of waiting 4 s in every remaining launch of its step
+// (a NaN uploaded into a shard of N_global <= 8192, reported in its first exchange: 168 s for a step of 19 iterations before)
+__device__ inline bool p2p_spin_over(const KParams& P, const unsigned long long t0, const int t_launch) {
+    return wall_clock64() - t0 > P2P_TIMEOUT_TICKS || error_before(__hip_atomic_load(P.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t_launch);
+}
 
 // Stores into a window are system-scope stores (sc0 sc1: written through, acknowledged once visible to every agent), so
 // "s_waitcnt vmcnt(0)" after them is the release (generic form).  A system-scope release fence would write back the whole L2 per
@@ -145,7 +152,7 @@ __device__ inline double p2p_ll_value(const KParams& P, const int t, const uint3
         do {
             __builtin_amdgcn_s_sleep(1);
             q = p2p_load16_sys(a);   // (past the caches: the stale line must not be served again)
-            if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { report_error(P, 3, t + 1, (int)g); break; }
+            if (p2p_spin_over(P, t0, t + 1)) { report_error(P, 3, t + 1, (int)g); break; }
         } while (!p2p_ll_ok(q, tag));
     }
     return p2p_ll_double(q);
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256) void k_p2p_unpack(const KParams P, const int t
         while (!p2p_ll_ok(q, tag)) {
             __builtin_amdgcn_s_sleep(1);
             q = p2p_load16_sys(src + i);
-            if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) { report_error(P, 3, t, g); return; }
+            if (p2p_spin_over(P, t0, t + 1)) { report_error(P, 3, t, g); return; }
         }
         dst[i] = p2p_ll_double(q);
     }

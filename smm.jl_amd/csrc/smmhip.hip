@@ -844,6 +844,16 @@ unsigned long long p2p_agree_error(Ctx* c, unsigned long long e_local) {
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
 }
+// the second launch of the persistent form that gave up (its tiles not resident together: a masked or shared device; a cone that did not fit;
+// a state the form cannot walk): the form is off for this context from here on — said ONCE on stderr, since nothing else changes for the
+// caller but the speed (smm_get_persistent / smm_describe report it too)
+void persist_give_up(Ctx* c) {
+    if (!c->persist_broken)
+        fprintf(stderr, "libsmmhip: context %p (device %d, chains %d of %d): the persistent form gave up twice (iteration %d) and is OFF for this context; "
+                        "the per-iteration kernels run instead (same results, more launches). smm_get_persistent reports it.\n",
+                (void*)c, c->device, c->P.N, c->P.Ng, c->iter);
+    c->persist_broken = true;
+}
 int check_device_error(Ctx* c) {
     if (c->failed) return c->failed;   // err holds the message of the first failure
     unsigned long long e = ERR_NONE;
@@ -853,7 +863,7 @@ int check_device_error(Ctx* c) {
         const unsigned long long eg = p2p_agree_error(c, e);
         if (eg != ERR_NONE) {
             const int kind = (int)(eg & 3), it = (int)(eg >> 34);
-            if (kind == 3 && ++c->persist_strikes >= 2) c->persist_broken = true;
+            if (kind == 3 && ++c->persist_strikes >= 2) persist_give_up(c);
             // a hard error (AlgoBGP.jl:341,409): every rank replays up to and including the failing iteration — which completes for all
             // chains, as everywhere — and stands there; a time-out or a cone that did not fit: the whole step again, on the other forms
             // (a hard error raised BEFORE the first of these launches — by a one-iteration launch ahead of them on the stream —: they saw the word at
@@ -878,7 +888,7 @@ int check_device_error(Ctx* c) {
             HIPCHK(hipMemcpy(c->P.err, &keep, sizeof keep, hipMemcpyHostToDevice));
             e = keep;
         } else {
-            if ((e & 3) == 3 && ++c->persist_strikes >= 2) c->persist_broken = true;
+            if ((e & 3) == 3 && ++c->persist_strikes >= 2) persist_give_up(c);
             persist_repair(c);
             HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
         }
@@ -1060,7 +1070,10 @@ bool persist_usable(const Ctx* c, int n_left) {
 // ... as a shard (smm_bgp_p2p_step): from the p2p state — the records after iteration `iter` in the windows, its exchange not resolved
 // yet — or behind a launch of its own; the first iteration of a run, the iteration behind a settled state are the per-iteration forms'
 bool persist_sh_usable(const Ctx* c, int n_left) {
-    if (!(c->persist_sh && c->persist_on && !c->persist_broken && !c->in_repair && !c->nan_values && n_left >= 2 && c->p2p_mine)) return false;
+    // (NOT c->nan_values: that flag is this shard's own — smm_set_state saw a NaN among ITS values — and the form must be chosen from what every
+    // rank knows, or one rank would take the per-iteration kernels while its peers wait at the launches' start barrier.  The launch reports such a
+    // state itself — kind 3 at its first iteration, smm_chain_persist_loc.hpp —, the ranks agree on the word and replay the step on the other forms)
+    if (!(c->persist_sh && c->persist_on && !c->persist_broken && !c->in_repair && n_left >= 2 && c->p2p_mine)) return false;
     if (c->p2p_ranks_here * ((c->P.N + NORM_CT - 1) / NORM_CT) > c->persist_max_tiles) return false;   // (ranks sharing this device: not resident together)
     if (c->iter < 1 || !c->prev_open || c->exch_done || c->a2a_open) return false;
     if (c->p2p_current) return c->rec_external && (c->pending_ext || !exchange_active(c, c->iter));
@@ -2100,8 +2113,13 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 h[H_CURR] = INFINITY; h[H_BEST] = INFINITY; h[H_BESTID] = -1.0; h[H_EXCH] = 0.0; h[H_ACC] = 0.0; h[H_STATUS] = 0.0;
             }
             P.hrec = dalloc<double>(c, TN * P.HW);
-            for (int t = 0; t < T; ++t)
-                HIPCHK(hipMemcpy(P.hrec + (size_t)t * N * P.HW, row.data(), row.size() * 8, hipMemcpyHostToDevice));
+            // (one row from the host, then doubling copies on the device: a long history — bench.py's repetitions hold 50 000 iterations — is filled
+            // at HBM speed instead of row by row over PCIe)
+            HIPCHK(hipMemcpy(P.hrec, row.data(), row.size() * 8, hipMemcpyHostToDevice));
+            for (size_t have = 1; have < (size_t)T; have *= 2) {
+                const size_t n = std::min(have, (size_t)T - have);
+                HIPCHK(hipMemcpy(P.hrec + have * N * P.HW, P.hrec, n * N * P.HW * 8, hipMemcpyDeviceToDevice));
+            }
         }
         P.err = dalloc<unsigned long long>(c, 1);
         {

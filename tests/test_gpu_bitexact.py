@@ -3,7 +3,7 @@ only the bookkeeping: the elementary functions of the path (the logarithm, sine 
 exponential of the acceptance probability, AlgoBGP.jl:344; the dense objective's tanh) are part of the numerical contract
 (include/smmhip.h), fixed sequences of correctly rounded operations in smm_rng.hpp / smm_chain.hpp and in the oracle.  north_star asks for
 bit-exact accept / swap bookkeeping and 1e-6 relative on the objective; this holds array_equal on everything, at every BASELINE
-configuration's shape and in every form of the chain kernels (persistent: loc, loc_wide, gen, tile_sim, tile_dense; one launch per
+configuration's shape and in every form of the chain kernels (persistent: loc, loc_wide, gen, tile_sim, tile_dense, tile_dense2; one launch per
 iteration; large shards).  Replaces run!'s loop over computeNextIteration! (AlgoAbstract.jl:38-45, AlgoBGP.jl:589-640)."""
 import numpy as np
 import pytest
@@ -67,7 +67,13 @@ def test_c4_bit_identical(S, O):
 
 def test_c5_bit_identical(S, O):
     import bench
-    prob, opts = bench.build_problem("c5", 4096, 4096, 0, 60, 0)            # BASELINE configs[4]: dense, 50 parameters, FP64 MFMA
+    prob, opts = bench.build_problem("c5", 4096, 4096, 0, 60, 0)            # BASELINE configs[4] AS WORDED: dense, 50 parameters, a 256 x 256 matvec per evaluation, FP64 MFMA
+    _exact(S, O, prob, opts, [60], form="tile_dense2")
+
+
+def test_c5_without_the_256x256_stage_bit_identical(S, O):
+    import bench
+    prob, opts = bench.build_problem("c5v1", 4096, 4096, 0, 60, 0)          # the instance of rounds 2-5 (SMM_OBJ_DENSE)
     _exact(S, O, prob, opts, [60], form="tile_dense")
 
 

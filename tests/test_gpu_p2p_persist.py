@@ -53,11 +53,25 @@ try:
         if kind == "chunks" and k == 2:
             c.p2p_finish(); c.sync(); put("mid"); [get("mid", r) for r in range(G)]     # a read-back in the middle (the ranks meet: include/smmhip.h)
             assert c.history().value.shape[0] == 10
+        if kind == "nanstate" and k == 1:
+            # an uploaded state with a NaN value in ONE shard (ADVICE r5): the flag smm_set_state derives from it is that rank's own
+            c.p2p_finish(); c.sync(); put("mid"); [get("mid", r) for r in range(G)]
+            st0, h0 = c.state(), c.history()
+            if rank == G - 1:
+                st0.la_value[3] = np.nan
+            c.set_state(st0, h0)
+            put("up"); [get("up", r) for r in range(G)]
+            t_nan = time.time()
     c.p2p_finish(); c.sync()
 except A.SMMHipError as e:
     err = str(e)
-h, st = c.history(), c.state()
-put("result", pickle.dumps(({{f: getattr(h, f) for f in h.FIELDS}}, {{f: getattr(st, f) for f in st.FIELDS}}, c.persistent_info(), err, st.iter)))
+    if kind == "nanstate":
+        err += " | %.1f s" % (time.time() - t_nan)
+if kind == "nanstate":     # (the form could not resolve the NaN state: SMM_ERR_HIP leaves the records in the windows; nothing to read back)
+    put("result", pickle.dumps((None, None, c.persistent_info(), err, -1)))
+else:
+    h, st = c.history(), c.state()
+    put("result", pickle.dumps(({{f: getattr(h, f) for f in h.FIELDS}}, {{f: getattr(st, f) for f in st.FIELDS}}, c.persistent_info(), err, st.iter)))
 [get("result", r) for r in range(G)]            # nobody unmaps a window a peer may still store into
 """
 
@@ -161,3 +175,20 @@ def test_sharded_persistent_form_hard_error_is_replayed_on_every_rank_to_the_sam
         for f in A.HistoryBuffers.FIELDS:
             assert np.array_equal(h[f], getattr(hs, f)[..., r * n:(r + 1) * n], equal_nan=True), (f, r)
     assert its == {single.state().iter}, its
+
+
+def test_a_nan_in_one_shards_uploaded_state_reaches_every_rank_together(S, tmp_path):
+    # smm_set_state's NaN flag is the shard's own.  Round 5 chose the shard's form from it: the rank holding the NaN took
+    # the per-iteration kernels while its peers launched the persistent kernel, waited 4 s at the start barrier and 30 s in the error
+    # rendezvous.  Now every rank launches the same form, the launch reports the NaN (kind 3), the ranks agree and replay the step on the
+    # windows' per-iteration forms — which, at N_global <= 8192, report such a state on EVERY rank in the same iteration (include/smmhip.h)
+    G, N, T, ns = 2, 1024, 30, 100
+    res = _run(tmp_path, G, N, T, ns, 0.0, "nanstate")
+    its = set()
+    for r in range(G):
+        h, st, pinfo, err, it = res[r]
+        assert err is not None and "could not be resolved" in err, (r, err)
+        assert float(err.split("|")[-1].split()[0]) < 15.0, err      # (no 4 s + 30 s of time-outs)
+        import re
+        its.add(re.search(r"iteration (\d+)", err).group(1))
+    assert len(its) == 1, its            # the same iteration on every rank (the chain named is the reporting tile's first: the rank's own)

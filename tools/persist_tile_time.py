@@ -21,8 +21,8 @@ IT = 200
 lib = S._abi.load()
 hist = {}
 for on in (1, 0, 1):
-    if what == "c5":
-        prob, opts = bench.build_problem("c5", N, N, 0, IT * blocks, 0)
+    if what in ("c5", "c5v1"):
+        prob, opts = bench.build_problem(what, N, N, 0, IT * blocks, 0)
     else:
         prob, opts = cm.general_normal(int(what[4:]), N=N, T=IT * blocks, ns=10000)
     ctx = S.hip_context(prob, opts)
