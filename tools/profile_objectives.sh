@@ -8,7 +8,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for cfg in c3 c4 c5; do
-  B="python $GRAFT_REPO_ROOT/bench.py --workload $cfg --no-cpu-baseline --no-unfused"
+  B="python $GRAFT_REPO_ROOT/bench.py --workload $cfg --reps 1 --no-cpu-baseline --no-unfused"
   rm -rf /tmp/kt && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $B > $out/${cfg}_run.txt 2>&1
   cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $out/${cfg}_kernel_stats.csv
   python - $(find /tmp/kt -name "*kernel_trace.csv" | head -1) > $out/${cfg}_launches.txt <<'PY'
@@ -33,6 +33,8 @@ PY
     rm -rf /tmp/pm && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pm -- $B --steps 2 > /dev/null 2>&1
     python $GRAFT_REPO_ROOT/tools/summarise_pmc.py $(find /tmp/pm -name "*counter_collection.csv" | head -1) | grep -a "k_chain_iter\|k_chain_persist\|k_cone_\|k_exch_resolve\|k_exch_plan\|k_pregen\|^#" >> $out/${cfg}_pmc_summary.txt
   done
+  rm -rf /tmp/pm && timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/pm -- $B --steps 2 > /dev/null 2>&1
+  python $GRAFT_REPO_ROOT/tools/clock_from_pmc.py /tmp/pm | grep -a "k_chain_iter\|k_chain_persist" >> $out/${cfg}_pmc_summary.txt
   grep -a "^{" $out/${cfg}_run.txt > $out/bench_${cfg}.json
   head -4 $out/${cfg}_kernel_stats.csv | cut -c1-200
   cat $out/${cfg}_launches.txt | cut -c1-220
