@@ -348,6 +348,10 @@ int  smm_eval_batch_noseed(void* ctx, const double* params, int32_t M, uint64_t 
 
 int  smm_get_history(void* ctx, int32_t t0, int32_t t1, smm_history_t* out);
 int  smm_get_state(void* ctx, smm_state_t* out);
+/* smm_set_state is also the recovery from a hard error (AlgoBGP.jl:341,409): the context steps again from the uploaded state.  A failure that
+ * no entry point has handed to the caller yet — raised on the device by asynchronous steps nobody synchronised; the state readers do not
+ * raise — is returned by THIS call, once, and nothing is uploaded: an error never disappears into a recovery the caller did not know it was
+ * making.  The next smm_set_state goes through. */
 int  smm_set_state(void* ctx, const smm_state_t* in, const smm_history_t* hist /* iterations 0..iter-1 */);
 int  smm_get_timing(void* ctx, smm_timing_t* out);
 /* on = 1: bracket every kernel of smm_bgp_step with hipEvents on the ctx stream so that

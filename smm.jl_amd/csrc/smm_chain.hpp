@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
                             th[k] = sc + lbk;
                         }
                     }
-                    if (!ok2) report_error(P, 2, t, gc);  // :409
+                    if (!ok2) report_error(P, ERRK_NO_DRAW, t, gc);  // :409
                 }
             }
             }
@@ -1398,7 +1398,7 @@ __global__ __launch_bounds__(WG * TPW, 4) void k_chain_iter(const KParams P, con
         } else if (status < 0) {  // :336-338
             prob = 0.0; acc = false;
         } else {
-            if (!(value >= 0.0)) report_error(P, 1, t, gc);  // :341
+            if (!(value >= 0.0)) report_error(P, ERRK_NEGATIVE, t, gc);  // :341
             const double e = smm_exp(atun * (old - value));   // (the contract exponential, smm_rng.hpp)
             prob = (e != e) ? e : (e < 1.0 ? e : 1.0);  // minimum([1.0,e]), NaN propagates (:344)
             if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }  // :350-353

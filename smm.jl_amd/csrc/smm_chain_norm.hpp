@@ -285,7 +285,7 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
         else p2p_load16x4_sys(g_slots + 2 * qc0, g_slots + 2 * qc0 + 1, g_slots + 2 * qc1, g_slots + 2 * qc1 + 1, s_[0], s_[1], s_[2], s_[3]);
     }
     const uint32_t want_hi = p2p_tag(P, tx) << 16;
-    bool timed_out = false;
+    bool timed_out = false, gave_up = false;   // (gave_up: the slots never came — timed out, or the run has failed already)
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
 #pragma unroll
@@ -298,11 +298,12 @@ __device__ inline bool exchange_walk_lean_p2p(const KParams& P, const int tx, un
                 do {
                     __builtin_amdgcn_s_sleep(1);
                     q = p2p_load16_sys(g_slots + (g >> 1));
-                    if (p2p_spin_over(P, t0, tx + 1)) { timed_out = true; break; }
+                    if (const int o = p2p_spin_over(P, t0, tx)) { timed_out = timed_out || o == 1; gave_up = true; break; }
                 } while (!ok());
             }
         }
     }
+    (void)gave_up;
     if (timed_out) report_error(P, 3, tx + 1, P.offset);   // (everybody goes on to the barriers below; the failure is reported)
     const int nlev = __builtin_amdgcn_readlane((int)ov, 33);
     bool form_ok = __builtin_amdgcn_readlane((int)ov, 34) != 0 && __builtin_amdgcn_readfirstlane((int)wflags) == 0 && (uint32_t)(size_t)lds == 0u;
@@ -518,7 +519,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
                             ok = true;
 #pragma unroll
                             for (int i = 0; i < RW; ++i) { q[i] = p2p_load16_sys(g_ll + i); ok = ok && p2p_ll_ok(q[i], tag); }
-                            if (p2p_spin_over(P, t0, t)) { report_error(P, 3, t, gc); break; }
+                            if (const int o = p2p_spin_over(P, t0, t - 1)) { if (o == 1) report_error(P, 3, t, gc); break; }
                         } while (!ok);
                     }
 #pragma unroll
@@ -636,7 +637,7 @@ __device__ __forceinline__ void chain_iter_norm_body(const KParams& P, const int
                     found = true;
                 }
             }
-            if (!found && r == 0) report_error(P, 2, t, gc);   // :409
+            if (!found && r == 0) report_error(P, ERRK_NO_DRAW, t, gc);   // :409
         }
         if (r == 0) {
 #pragma unroll
@@ -780,7 +781,7 @@ __device__ inline void epilogue_norm(const KParams& P, const int t, double* __re
     } else if (status < 0) {   // :336-338
         prob = 0.0; acc = false;
     } else {
-        if (!(value >= 0.0) && r == 0) report_error(P, 1, t, gc);   // :341
+        if (!(value >= 0.0) && r == 0) report_error(P, ERRK_NEGATIVE, t, gc);   // :341
         const double e = smm_exp(atun * (old - value));   // (the contract exponential, smm_rng.hpp)
         prob = (e != e) ? e : (e < 1.0 ? e : 1.0);   // minimum([1.0,e]), NaN propagates (:344)
         if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }   // :350-353

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
                     done = true;
                 }
             }
-            if (!done && r == 0) pr_report(A.err, 2, t, c);   // :409
+            if (!done && r == 0) pr_report(A.err, ERRK_NO_DRAW, t, c);   // :409
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(1024, 4) void k_chain_persist_gen(const PersistGenA
             bool acc;
             if (failed) { prob = 0.0; acc = false; }                     // :336-338
             else {
-                if (!(value >= 0.0) && r == 0) pr_report(A.err, 1, t, c);   // :341
+                if (!(value >= 0.0) && r == 0) pr_report(A.err, ERRK_NEGATIVE, t, c);   // :341
                 const double e = pr_exp(atun * (old - value));
                 prob = (e != e) ? e : (e < 1.0 ? e : 1.0);   // minimum([1.0,e]), NaN propagates (:344)
                 if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }   // :350-353

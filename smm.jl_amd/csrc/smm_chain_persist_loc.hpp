@@ -668,7 +668,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
 #pragma unroll
                 for (int k = 0; k < NP; ++k) th[k] = lt.th[k];
                 found = lt.found;
-                if (!found && r == 0) pr_report(A.err, 2, t, (int)c0g + cl);   // :409
+                if (!found && r == 0) pr_report(A.err, ERRK_NO_DRAW, t, (int)c0g + cl);   // :409
             }
             if (r == 0) {
 #pragma unroll
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
             if (status < 0) {   // :336-338
                 prob = 0.0; acc = false;
             } else {
-                if (!(value >= 0.0) && r == 0) pr_report(A.err, 1, t, (int)c0g + cl);   // :341
+                if (!(value >= 0.0) && r == 0) pr_report(A.err, ERRK_NEGATIVE, t, (int)c0g + cl);   // :341
                 const double e = pr_exp(atun * (old - value));
                 prob = (e != e) ? e : (e < 1.0 ? e : 1.0);   // minimum([1.0,e]), NaN propagates (:344)
                 if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }   // :350-353

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
             if (status < 0) {   // :336-338
                 prob = 0.0; acc = false;
             } else {
-                if (!(value >= 0.0)) pr_report(A.err, 1, t, c);   // :341
+                if (!(value >= 0.0)) pr_report(A.err, ERRK_NEGATIVE, t, c);   // :341
                 const double e = pr_exp(atun * (old - value));
                 prob = (e != e) ? e : (e < 1.0 ? e : 1.0);   // minimum([1.0,e]), NaN propagates (:344)
                 if (!isfinite(prob)) { prob = 0.0; acc = false; status = -1; }   // :350-353

@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(XWG) void k_exch_resolve_rows(const KParams P, cons
                         __builtin_amdgcn_s_sleep(1);
                         const uint4 q4 = p2p_load16_sys(g_slots + pc);
                         q = p2p_u32x4{q4.x, q4.y, q4.z, q4.w};
-                        if (p2p_spin_over(P, t0, t + 1)) { report_error(P, 3, t + 1, g); odd = true; break; }
+                        if (const int o = p2p_spin_over(P, t0, t)) { if (o == 1) report_error(P, 3, t + 1, g); odd = true; break; }
                     } while (!ok());
                 }
                 const p2p_u32x4 w4 = {slot17(q.x, (uint32_t)g), g + 1 < Ng ? slot17(q.y, (uint32_t)g + 1u) : 0u,

@@ -85,12 +85,18 @@ __device__ inline void p2p_store4(void* p, const uint32_t v) { __hip_atomic_stor
 constexpr int P2P_UNIT = 16;
 __host__ __device__ inline int p2p_units(const int N) { return (N + P2P_UNIT - 1) / P2P_UNIT; }
 constexpr unsigned long long P2P_TIMEOUT_TICKS = 400000000ull;   // 4 s of the 100 MHz wall clock: a peer is gone, not late
-// a spin for tagged words of iteration t_launch - 1 is over: timed out, or the run failed in an EARLIER iteration than t_launch — the launch that
-// should have stored those words saw the error word at its entry and stored nothing (error convention, include/smmhip.h), and this launch is
-// poisoned itself and will store nothing either: a failed run drains at once instead of waiting 4 s in every remaining launch of its step
-// (a NaN uploaded into a shard of N_global <= 8192, reported in its first exchange: 168 s for a step of 19 iterations before)
-__device__ inline bool p2p_spin_over(const KParams& P, const unsigned long long t0, const int t_launch) {
-    return wall_clock64() - t0 > P2P_TIMEOUT_TICKS || error_before(__hip_atomic_load(P.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t_launch);
+// a spin for tagged words of iteration t_data is over — 1: timed out (the caller reports it); 2: the run has FAILED and those words will never come:
+// the launch that should have stored them was poisoned (an error of an EARLIER iteration: it saw the word at its entry and stored nothing — error
+// convention, include/smmhip.h), or it gave up itself (kind 3 IN that iteration: a form that could not resolve its exchange returns without storing; a hard
+// error of the algorithm, kinds 1 / 2, does not count: that iteration completes and its words arrive).  Nothing is reported then — the first error stands —
+// and a failed run drains at once instead of waiting 4 s in every remaining launch of its step (a NaN uploaded into a shard of N_global <= 8192,
+// reported in its first exchange: 168 s for a step of 19 iterations before)
+__device__ inline int p2p_spin_over(const KParams& P, const unsigned long long t0, const int t_data) {
+    if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) return 1;
+    const unsigned long long e = __hip_atomic_load(P.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e == ERR_NONE) return 0;
+    const int it = (int)(e >> 34), kind = (int)(e & 3ull);
+    return (it < t_data || (it == t_data && kind == 3)) ? 2 : 0;
 }
 
 // Stores into a window are system-scope stores (sc0 sc1: written through, acknowledged once visible to every agent), so
@@ -152,7 +158,7 @@ __device__ inline double p2p_ll_value(const KParams& P, const int t, const uint3
         do {
             __builtin_amdgcn_s_sleep(1);
             q = p2p_load16_sys(a);   // (past the caches: the stale line must not be served again)
-            if (p2p_spin_over(P, t0, t + 1)) { report_error(P, 3, t + 1, (int)g); break; }
+            if (const int o = p2p_spin_over(P, t0, t)) { if (o == 1) report_error(P, 3, t + 1, (int)g); break; }
         } while (!p2p_ll_ok(q, tag));
     }
     return p2p_ll_double(q);
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(256) void k_p2p_unpack(const KParams P, const int t
         while (!p2p_ll_ok(q, tag)) {
             __builtin_amdgcn_s_sleep(1);
             q = p2p_load16_sys(src + i);
-            if (p2p_spin_over(P, t0, t + 1)) { report_error(P, 3, t, g); return; }
+            if (const int o = p2p_spin_over(P, t0, t)) { if (o == 1) report_error(P, 3, t, g); return; }
         }
         dst[i] = p2p_ll_double(q);
     }

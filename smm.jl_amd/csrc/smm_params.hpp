@@ -183,6 +183,11 @@ __host__ __device__ inline uint32_t order_key17(const double v) {
 // has an iteration BEFORE t raised a hard error?  (Not "is the word set": a workgroup of iteration t that starts late may find the
 // word set by a faster workgroup of the same launch — the failing iteration itself completes for every chain.)
 __device__ inline bool error_before(const unsigned long long err_word, const int t) { return (err_word >> 34) < (unsigned long long)t; }
+// the kinds of the sticky error word (its two low bits; atomicMin keeps the smallest key = the first failing iteration, the first failing chain of it,
+// and for ONE chain in ONE iteration the error the reference would have raised first: its proposal (mysample, AlgoBGP.jl:409, called at :280) precedes its
+// objective's value check (:341, inside doAcceptReject! at :287) — the enumeration of tests/test_gpu_error_enumeration.py found the two the other way
+// round: a chain without a draw evaluates whatever its lanes hold, the value may be NaN, and "negative objective" used to win)
+constexpr int ERRK_CAPACITY = 0, ERRK_NO_DRAW = 1, ERRK_NEGATIVE = 2, ERRK_FORM = 3;
 __device__ inline void report_error(const KParams& P, int kind, int t, int gchain) {
     const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)gchain << 2) | (unsigned)kind;
     atomicMin(P.err, key);

@@ -231,7 +231,7 @@ __device__ __forceinline__ void coop_mysample(const CoopProp X, const int t, con
             bar();
         }
         if (!done && sl == 0) {   // :409
-            const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)gcc << 2) | 2u;
+            const unsigned long long key = ((unsigned long long)t << 34) | ((unsigned long long)gcc << 2) | (unsigned)ERRK_NO_DRAW;
             atomicMin(X.err, key);
         }
     }

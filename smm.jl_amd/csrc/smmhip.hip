@@ -345,6 +345,7 @@ struct Ctx {
     int persist_launches = 0, persist_repairs = 0;
     int pregen_seen_launches = 0;              // persist_launches when the last window of randomness blocks was made (ensure_windows)
     int pr_ring_k = PR_K, pr_slow_tile = -1, pr_slow_ticks = 0;   // (test build: SMMHIP_PR_RING, SMMHIP_PR_SLOW_TILE, SMMHIP_PR_SLOW_US)
+    bool failed_told = false;   // `failed` has been returned to the caller by some entry point
     bool in_repair = false;
     // ... and what persist_repair restores when a launch of it ends with the error word set: the state before the FIRST such launch
     // since the last check of the error word
@@ -854,6 +855,9 @@ void persist_give_up(Ctx* c) {
                 (void*)c, c->device, c->P.N, c->P.Ng, c->iter);
     c->persist_broken = true;
 }
+// (an entry point hands the sticky failure to its caller)
+int told(Ctx* c) { c->failed_told = true; return c->failed; }
+int told(Ctx* c, int rc) { if (rc != SMM_OK && rc == c->failed) c->failed_told = true; return rc; }
 int check_device_error(Ctx* c) {
     if (c->failed) return c->failed;   // err holds the message of the first failure
     unsigned long long e = ERR_NONE;
@@ -863,14 +867,14 @@ int check_device_error(Ctx* c) {
         const unsigned long long eg = p2p_agree_error(c, e);
         if (eg != ERR_NONE) {
             const int kind = (int)(eg & 3), it = (int)(eg >> 34);
-            if (kind == 3 && ++c->persist_strikes >= 2) persist_give_up(c);
+            if (kind == ERRK_FORM && ++c->persist_strikes >= 2) persist_give_up(c);
             // a hard error (AlgoBGP.jl:341,409): every rank replays up to and including the failing iteration — which completes for all
             // chains, as everywhere — and stands there; a time-out or a cone that did not fit: the whole step again, on the other forms
             // (a hard error raised BEFORE the first of these launches — by a one-iteration launch ahead of them on the stream —: they saw the word at
             // their entry and stored nothing; n = 0 puts the host's bookkeeping back to the snapshot and replays nothing)
-            persist_repair(c, (kind == 1 || kind == 2) ? std::max(0, it - c->snap_iter) : -1);
+            persist_repair(c, (kind == ERRK_NO_DRAW || kind == ERRK_NEGATIVE) ? std::max(0, it - c->snap_iter) : -1);
             HIPCHK(hipMemcpy(&e, c->P.err, sizeof e, hipMemcpyDeviceToHost));
-            if (kind == 1 || kind == 2) e = std::min(e, eg);   // (the first failing chain of the POPULATION — maybe another rank's: every rank reports the same)
+            if (kind == ERRK_NO_DRAW || kind == ERRK_NEGATIVE) e = std::min(e, eg);   // (the first failing chain of the POPULATION — maybe another rank's: every rank reports the same)
         }
         c->snap_valid = false;
         if (eg == ERR_NONE) c->persist_proven = true;
@@ -901,14 +905,14 @@ int check_device_error(Ctx* c) {
     const int kind = (int)(e & 3), chain = (int)((e >> 2) & 0xffffffffu), it = (int)(e >> 34);
     char b[256];
     int rc;
-    if (kind == 3) {
+    if (kind == ERRK_FORM) {
         snprintf(b, sizeof b, "internal error: the exchange of iteration %d could not be resolved in the form chosen for it (chain %d)", it, chain + 1);
         rc = SMM_ERR_HIP;
-    } else if (kind == 0) {
+    } else if (kind == ERRK_CAPACITY) {
         snprintf(b, sizeof b, "values form of the sharded exchange: more than %d records between one pair of ranks (chain %d, iteration %d): "
                  "use the record all-gather (smm_bgp_exchange_dev / smm_bgp_sharded_step)", c->a2a_cap, chain + 1, it);
         rc = SMM_ERR_EXCHANGE_CAPACITY;
-    } else if (kind == 1) {
+    } else if (kind == ERRK_NEGATIVE) {
         snprintf(b, sizeof b, "AlgoBGP assumes that your objective function returns a non-negative number "
                  "(chain %d, iteration %d)", chain + 1, it);
         rc = SMM_ERR_NEGATIVE_OBJECTIVE;
@@ -921,7 +925,7 @@ int check_device_error(Ctx* c) {
     // The reference aborts inside the failing iteration (AlgoBGP.jl:341,409).  Here that iteration completes for all chains
     // and every later launch of the step sees the error word and stores nothing: the run stands at the failing iteration,
     // its exchange is never applied, and the context refuses to go on until smm_set_state.
-    if (kind != 3 && it >= 1 && it <= c->iter) {   // (kind 0, a block of the values form overflowed: the exchange of iteration `it` was not applied either)
+    if (kind != ERRK_FORM && it >= 1 && it <= c->iter) {   // (kind 0, a block of the values form overflowed: the exchange of iteration `it` was not applied either)
         c->iter = it;
         c->pending = false; c->prev_open = false; c->unresolved = false; c->pending_ext = false; c->rec_external = false;
         c->a2a_open = false; c->p2p_current = false;
@@ -2308,7 +2312,7 @@ int smm_sync(void* ctx) {
             }
             c->pev_iters = 0;
         }
-        return check_device_error(c);
+        return told(c, check_device_error(c));
     } catch (const std::string& m) {
         return fail(c, SMM_ERR_HIP, m);
     }
@@ -2317,7 +2321,7 @@ int smm_sync(void* ctx) {
 int smm_bgp_step_async(void* ctx, int32_t n_iters) {
     Ctx* c = (Ctx*)ctx;
     if (!c || n_iters < 0) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (c->P.N != c->P.Ng) return fail(c, SMM_ERR_STATE, "smm_bgp_step needs a single shard (N == N_global); use the sharded calls");
     if (c->iter + n_iters > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
@@ -2354,14 +2358,14 @@ int smm_bgp_step(void* ctx, int32_t n_iters) {
 int smm_bgp_local_step(void* ctx) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
     if (c->a2a_open) return fail(c, SMM_ERR_STATE, "smm_bgp_a2a_pack_dev without smm_bgp_a2a_apply_dev: the exchange of this iteration would be dropped");
     if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         const int t = c->iter + 1;
         // smm_bgp_step leaves the exchange of its last iteration to the next chain kernel (inline walk): the three-phase
         // form reads P.xres, so resolve it now (local_step after step read an unresolved xres)
@@ -2385,7 +2389,7 @@ int smm_bgp_local_step(void* ctx) {
 int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathered_next_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !gathered_next_dev) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (c->iter + 1 > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
     if (c->rec_external && !gathered_prev_dev) return fail(c, SMM_ERR_INVALID_ARG, "gathered_prev required: the last records live there");
     if (c->unresolved) return fail(c, SMM_ERR_STATE, "mixing smm_bgp_step and smm_bgp_sharded_step without a flush");
@@ -2393,7 +2397,7 @@ int smm_bgp_sharded_step(void* ctx, const void* gathered_prev_dev, void* gathere
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         const int t = c->iter + 1;
         const KParams& P = c->P;
         int flags = (c->prev_open ? F_CLOSE_PREV : 0);
@@ -2458,7 +2462,7 @@ int smm_bgp_sharded_finish(void* ctx, const void* gathered_dev) {
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         const KParams& P = c->P;
         int flags = (c->prev_open ? F_CLOSE_PREV : 0) | F_GLOBAL_REC;
         if (c->pending_ext) {
@@ -2579,7 +2583,7 @@ int smm_bgp_p2p_attach(void* ctx, int32_t rank, const void* ipc_handle, void* wi
 int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
     Ctx* c = (Ctx*)ctx;
     if (!c || n_iters < 0) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (!c->p2p_mine) return fail(c, SMM_ERR_STATE, "smm_bgp_p2p_init comes first");
     if (c->p2p_attached != (1u << c->P.p2p_G) - 1u) return fail(c, SMM_ERR_STATE, "smm_bgp_p2p_step: not every rank's window is attached");
     if (c->iter + n_iters > c->P.T) return fail(c, SMM_ERR_MAXITER, "step beyond maxiter (history capacity)");
@@ -2590,7 +2594,7 @@ int smm_bgp_p2p_step(void* ctx, int32_t n_iters) {
         // (launches of the persistent form that this step simply continues are looked at — and agreed upon by the ranks — when the run is
         // synchronised, not between two steps: the host stays out of the way)
         if (!(!c->p2p_current && persist_sh_usable(c, n_iters))) settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         KParams& P = c->P;
         if (c->profiling == 2) {
             while ((int)c->pev.size() < 4 * n_iters) {
@@ -2622,7 +2626,7 @@ int smm_bgp_p2p_finish(void* ctx) {
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         p2p_publish(c);   // (behind a launch of the persistent form: the records after `iter` into the windows, their exchange still to be resolved)
         const KParams& P = c->P;
         const P2PLayout L = p2p_layout(P.Ng, P.RW);
@@ -2653,12 +2657,12 @@ int smm_bgp_record_doubles(void* ctx) {
 int smm_bgp_export_records_dev(void* ctx, void* rec_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !rec_dev) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         // after smm_bgp_step the exchange of the last iteration is still pending (resolved or not): the exported records must
         // be the ones AFTER that exchange, as the three-phase protocol defines them
         if (c->pending || c->unresolved) flush(c);
@@ -2673,13 +2677,13 @@ int smm_bgp_export_records_dev(void* ctx, void* rec_dev) {
 int smm_bgp_exchange_dev(void* ctx, const void* gathered_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !gathered_dev) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (c->iter < 1) return fail(c, SMM_ERR_STATE, "exchange before the first local step");
     if (c->pending || c->exch_done || c->a2a_open) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         c->exch_done = true;
         if (exchange_active(c, c->iter)) {
             const KParams& P = c->P;
@@ -2704,13 +2708,13 @@ int smm_bgp_a2a_capacity(void* ctx) {
 int smm_bgp_export_values_dev(void* ctx, void* vals_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !vals_dev) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (c->rec_external) return fail(c, SMM_ERR_STATE, "records are in the gather buffer: call smm_bgp_sharded_finish first");
     if (c->iter < 1) return fail(c, SMM_ERR_STATE, "no iteration yet");
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         if (c->pending || c->unresolved) flush(c);
         HIPCHK(hipMemcpyAsync(vals_dev, c->vals_buf[c->iter & 1], (size_t)c->P.N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     } catch (const std::string& m) {
@@ -2722,14 +2726,14 @@ int smm_bgp_export_values_dev(void* ctx, void* vals_dev) {
 int smm_bgp_a2a_pack_dev(void* ctx, const void* vals_all_dev, void* send_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !vals_all_dev || !send_dev) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (c->a2a_cap <= 0) return fail(c, SMM_ERR_STATE, "the values form needs equal shards (N_global a multiple of N, chain_offset a multiple of N)");
     if (c->iter < 1) return fail(c, SMM_ERR_STATE, "exchange before the first local step");
     if (c->pending || c->a2a_open || c->exch_done) return fail(c, SMM_ERR_STATE, "exchange already resolved for this iteration");
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         if (exchange_active(c, c->iter)) {
             KParams P1 = c->P;
             P1.RW = 1;   // (the resolve kernels read value s at gathered[s * RW])
@@ -2752,12 +2756,12 @@ int smm_bgp_a2a_pack_dev(void* ctx, const void* vals_all_dev, void* send_dev) {
 int smm_bgp_a2a_apply_dev(void* ctx, const void* recv_dev) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !recv_dev) return SMM_ERR_INVALID_ARG;
-    if (c->failed) return c->failed;
+    if (c->failed) return told(c);
     if (!c->a2a_open) return fail(c, SMM_ERR_STATE, "smm_bgp_a2a_pack_dev comes first");
     try {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
-        if (c->failed) return c->failed;
+        if (c->failed) return told(c);
         if (exchange_active(c, c->iter)) {
             const KParams& P = c->P;
             hipLaunchKernelGGL(k_a2a_apply, dim3((P.N + 255) / 256), dim3(256), 0, c->stream, P, c->iter, (const double*)recv_dev,
@@ -2936,6 +2940,11 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         HIPCHK(hipSetDevice(c->device));
         settle_persist(c);
         HIPCHK(hipStreamSynchronize(c->stream));
+        // a hard error nobody has been TOLD of yet (raised on the device by steps this caller enqueued and never synchronised; the state readers
+        // do not raise): this call is the recovery from a failure, it must not be the place where one disappears — it reports it, once, and uploads
+        // nothing; the caller's next smm_set_state goes through (tests/test_gpu_error_enumeration.py: every `... step ss` sequence lost its error here)
+        (void)check_device_error(c);
+        if (c->failed && !c->failed_told) { c->failed_told = true; return c->failed; }
         KParams& P = c->P;
         const size_t N = P.N, RW = P.RW, HW = P.HW, np = P.np, nm = P.nm;
         std::vector<double> cs(N * CSW), rec(N * RW, 0.0);
@@ -2975,7 +2984,7 @@ int smm_set_state(void* ctx, const smm_state_t* s, const smm_history_t* h) {
         if (c->failed) {   // a state from before the failure: the run may go on
             const unsigned long long e = ERR_NONE;
             HIPCHK(hipMemcpy(P.err, &e, 8, hipMemcpyHostToDevice));
-            c->failed = 0;
+            c->failed = 0; c->failed_told = false;
         }
         c->rec_external = false; c->pending_ext = false; c->unresolved = false;
         c->pending = false;
