@@ -375,11 +375,16 @@ int  smm_set_profiling(void* ctx, int32_t on);
  *     the persistent kernel once more with the user's source inside, through hiprtc, when the first such context is created: ~1.5 s),
  *     with at most 16 parameters / moments (one proposal batch, isotropic, min_improve == 0) on a single shard of up to 8192 chains in
  *     whole groups of 32;
- *   - objfunc_norm with MORE than two parameters (the reference's own larger examples have 6 and 18, Examples.jl:210-230, 232-319) or
- *     the dense objective: one proposal batch or several, isotropic proposals, dist_fun = `-`, ONE min_improve >= 0 (or NaN) for all
- *     chains, a single shard of at most two 16-chain tiles per compute unit whose blocks fit the LDS (np = nm = 50: yes; 64 + 64: no).
- * Per-chain thresholds, other dist_fun, Cholesky proposals, the map-reduce form of user objectives, shards of anything but objfunc_norm
- * with at most two parameters: the per-iteration kernels.
+ *   - objfunc_norm with MORE than two parameters (the reference's own larger examples have 6 and 18, Examples.jl:210-230, 232-319), the
+ *     dense objectives (SMM_OBJ_DENSE, SMM_OBJ_DENSE2), or a USER objective in its MAP-REDUCE form (smm_register_user_objective_lanes with
+ *     64, 128, 256 or 512 lanes per evaluation: the library compiles the persistent tile kernel once more with the user's source inside,
+ *     through hiprtc, when the first such context is created; a tile's 512 lanes then evaluate 512 / lanes chains at a time with the
+ *     stand-alone kernel's reduction order — the same bits; it pays while an evaluation is short beside the ~40 us of three launches per
+ *     iteration: a long simulation fills the device better from its own launches, smm_set_persistent(ctx, 0)):
+ *     one proposal batch or several, isotropic proposals, dist_fun = `-`, ONE min_improve >= 0 (or NaN) for all chains, a single shard of
+ *     at most two 16-chain tiles per compute unit whose blocks fit the LDS (np = nm = 50: yes; 64 + 64: no).
+ * Per-chain thresholds, other dist_fun, Cholesky proposals, user objectives with 1024 lanes, shards of anything but objfunc_norm with at
+ * most two parameters: the per-iteration kernels.
  * on = 0 keeps the one-launch-per-iteration kernels (default: on).  A hard error of the algorithm inside such a launch is found at
  * the next call that checks (smm_sync, smm_bgp_step, the state readers): the library then repeats those iterations from the state
  * it saved on the one-launch-per-iteration path, so that the context stands at the failing iteration exactly as documented above.

@@ -44,12 +44,14 @@ struct PersistTileArgs {
     double sigma_adjust_by, thr;
     uint64_t seed;
     unsigned long long tmo;            // ticks a spin may last
+    int u_lanes, n_udata;              // a user objective in its map-reduce form (SMM_TILE_USER below): lanes per evaluation, doubles of its data (objp)
 };
 
 // LDS: [slots 16 B x PL_LOCN | pair words | gather list | 4 headers | re-numbering table | flags, stamps] doubles: cs rec[2] theta
 // const sm vk rb | region B: the objective's partial sums / the two history rows
-struct PtLayout { uint32_t pbase, gbase, hbase, tbase, fbase, dbase; uint32_t o_cs, o_rec, o_theta, o_const, o_sm, o_vk, o_rb, o_B; size_t total; };
-__host__ __device__ inline PtLayout pt_layout(const int np, const int nm, const int RW, const int HW, const int RBW, const int kind, const int nOt) {
+struct PtLayout { uint32_t pbase, gbase, hbase, tbase, fbase, dbase; uint32_t o_cs, o_rec, o_theta, o_const, o_sm, o_vk, o_uv, o_rb, o_B; size_t total; };
+// (kind: 1 objfunc_norm, 2 the dense simulation, 3 its spec v2, 4 a user objective in its map-reduce form: user_part doubles of wave totals)
+__host__ __device__ inline PtLayout pt_layout(const int np, const int nm, const int RW, const int HW, const int RBW, const int kind, const int nOt, const int user_part = 0) {
     PtLayout L;
     L.pbase = PL_PBASE;
     L.gbase = L.pbase + (uint32_t)CONE_LEVELS * 64 * 4;
@@ -64,10 +66,12 @@ __host__ __device__ inline PtLayout pt_layout(const int np, const int nm, const 
     L.o_const = o; o += (2 * np + 2 * nm + 1) & ~1;
     L.o_sm = o; o += (PT_CT * nm + 1) & ~1;
     L.o_vk = o; o += (PT_CT * nm + 1) & ~1;
+    L.o_uv = o; o += 2 * PT_CT;   // a user objective's value and status per chain
     L.o_rb = o; o += PT_CT * RBW;
     L.o_B = o;
     uint32_t part = kind >= 2 ? (uint32_t)(WG / 64) * (uint32_t)(nOt * 16) * 16u : (uint32_t)(WG / 64) * PT_CT * (uint32_t)nm;
-    if (kind == 3 && part < (uint32_t)DENSE_D * 16u) part = (uint32_t)DENSE_D * 16u;   // (spec v2 of the dense objective stages its first hidden layer there)
+    if (kind == 3 && part < (uint32_t)DENSE_D * 16u) part = (uint32_t)DENSE_D * 16u;
+    if (kind == 4) part = (uint32_t)user_part;   // (spec v2 of the dense objective stages its first hidden layer there)
     const uint32_t rows = 2u * PT_CT * (uint32_t)HW;
     o += part > rows ? part : rows;
     L.total = (size_t)L.dbase + (size_t)o * 8;
@@ -90,9 +94,20 @@ __device__ __attribute__((noinline)) uint4 pt_wait_ll(const PrWait W, const uint
     return q;
 }
 
+// A USER OBJECTIVE IN ITS MAP-REDUCE FORM in this loop (round 6; MProb.objfunc, mprob.jl:159,182 — the form a real simulation objective takes: a sum over
+// many independent units): the library compiles THIS FILE once more with hiprtc, together with the user's source (smm_register_user_objective_lanes:
+// SMM_USER_PARTIAL / SMM_USER_FINISH, SMM_NSUMS sums), as SMM_TILE_USER — the kernel is then smm_user_persist_tile_kernel, KIND 4: the tile's 512 lanes
+// evaluate 512 / lanes chains at a time, `lanes` lanes per chain exactly as the stand-alone smm_user_eval_kernel does (lane l of n_lanes, the halving tree
+// inside each group of 64, the groups' totals left to right: the numerical contract of include/smmhip.h — results are bit-identical), the chain's lane
+// calls the user's finish, and a failing evaluation (status < 0) is the rejection of mprob.jl:183-186 / AlgoBGP.jl:336-338.
+#ifdef SMM_TILE_USER
+extern "C" __global__ __launch_bounds__(WG) void smm_user_persist_tile_kernel(const PersistTileArgs A) {
+    constexpr int KIND = 4;
+#else
 template <int KIND>
 __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs A) {
     static_assert(KIND == 1 || KIND == 2, "objfunc_norm (shocks streamed) or the dense simulation");
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int CT = PT_CT, LPC = PT_LPC;
     const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -118,6 +133,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
     double* const s_w = s_mom + nm;
     double* const s_sm = dbl + L.o_sm;        // [16][nm]: simulated moments of the proposals
     double* const s_vk = dbl + L.o_vk;        // [16][nm]: their squared weighted deviations
+    double* const s_uv = dbl + L.o_uv;        // [2][16]: a user objective's value / status of the proposals (KIND 4)
     double* const s_rb = dbl + L.o_rb;        // [16][RBW]: u, z[try][np] of the iteration
     double* const s_part = dbl + L.o_B;       // region B: the objective's partial sums ...
     double* const s_hrow = dbl + L.o_B;       // ... / [16][HW] the history rows of iteration t
@@ -418,8 +434,30 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         if (A.ts && tid == 0) ts3 = wall_clock64();
         if (t < t1 && !rng_here) fetch_rb(t + 1);
         // ---- the objective: all 512 lanes ----
+#ifdef SMM_TILE_USER
+        {   // evaluateObjective(m, p) (mprob.jl:175-188) -> the user's partial sums: WG / u_lanes chains at a time, u_lanes lanes (whole waves) per chain
+            const int UL = A.u_lanes, per = WG / UL, nwv = UL / 64;
+            for (int c0r = 0; c0r < CT; c0r += per) {
+                const int cr = c0r + tid / UL, ll = tid % UL;
+                if (tile * CT + cr < N) {   // (wave-uniform: a chain's lanes are whole waves)
+                    double part[SMM_NSUMS];
+#pragma unroll
+                    for (int i = 0; i < SMM_NSUMS; ++i) part[i] = 0.0;
+                    smm_user_partial(s_theta + cr * np, np, A.objp, A.n_udata, ll, UL, part);
+#pragma unroll
+                    for (int i = 0; i < SMM_NSUMS; ++i) {
+                        double a = part[i];
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1) a = a + __shfl_xor(a, off, 64);
+                        if (lane == 0) s_part[(cr * nwv + (ll >> 6)) * SMM_NSUMS + i] = a;
+                    }
+                }
+            }
+        }
+#else
         if constexpr (KIND == 1) simulate_tile_v<CT>(A.ns, nm, np, A.zstride, false, zb, s_theta, s_part, tid, za);
         else dense_tile_v<CT>(np, A.dense_nOt, A.dense_Bf, A.dense_Af, A.dense_A2f, (uint32_t)((unsigned char*)s_theta - lds), (uint32_t)((unsigned char*)s_part - lds), tid);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA (lists, randomness) has landed
         if (want_hdr) s_hdr[((t + 1) & 3) * 16 + lane] = nhdr;
         if (wave == 2) {
@@ -444,6 +482,22 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         if (A.ts && tid == 0) ts4 = wall_clock64();
         // ---- the moments of a chain (wave totals -> mean -> squared weighted deviation) by its 32 lanes (ObjExamples.jl:79-100) ----
         const bool failed = KIND == 1 && A.failbox && valid && s_theta[cc * np] >= A.objp[0] && s_theta[cc * np] <= A.objp[1];   // mprob.jl:183-186
+#ifdef SMM_TILE_USER
+        if (chain_lane) {   // the groups' totals left to right (numerical contract), then the user's finish: moments, value, status
+            const int nwv = A.u_lanes / 64;
+            double tot[SMM_NSUMS];
+#pragma unroll
+            for (int i = 0; i < SMM_NSUMS; ++i) {
+                double a = s_part[(cc * nwv) * SMM_NSUMS + i];
+                for (int wv = 1; wv < nwv; ++wv) a = a + s_part[(cc * nwv + wv) * SMM_NSUMS + i];
+                tot[i] = a;
+            }
+            int st_u = 1;
+            double v_u = 0.0;
+            smm_user_finish(s_theta + cc * np, np, tot, SMM_NSUMS, s_mom, s_w, nm, A.objp, A.n_udata, s_sm + cc * nm, &v_u, &st_u);
+            s_uv[cc] = v_u; s_uv[CT + cc] = (double)st_u;
+        }
+#else
         if constexpr (KIND == 2) {
             // (the dense tile's partial sums lie [wave][moment][chain]: the lanes run over the CHAINS of a moment — consecutive doubles, no
             // bank conflict; the chain's own 32 lanes would stride 128 bytes and meet in one bank)
@@ -474,6 +528,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
                 s_vk[cc * nm + k] = d * d;
             }
         }
+#endif
         if (lists) build_table(t);
         PR_BARRIER();   // B5: the partial sums are consumed (the rows' region is free), the re-numbering table stands
         unsigned long long ts4b = 0;
@@ -484,7 +539,11 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
             const double* vk = s_vk + cc * nm;
             double value;
             int status;
+#ifdef SMM_TILE_USER
+            if (true) { value = s_uv[cc]; status = (int)s_uv[CT + cc]; (void)vk; (void)failed; }   // the user's own (a failing evaluation: status < 0, :336-338 below)
+#else
             if (failed) { value = -1.0; status = -2; }   // Eval() default, Eval.jl:84
+#endif
             else {
                 double vsum = 0.0;
                 int k = 0;

@@ -91,6 +91,10 @@ struct UserObjective {
     std::vector<char> persist_code;        // k_chain_persist_gen with the user's objective inside (smm_chain_persist_gen.hpp, SMM_GEN_USER)
     int persist_state = 0;                 // 0: not tried yet, 1: persist_code stands, -1: did not compile (persist_log)
     std::string persist_log;
+    int n_sums = 1;                        // map-reduce form: partial sums per lane
+    std::vector<char> tile_code;           // k_chain_persist_tile with the user's map-reduce objective inside (smm_chain_persist_tile.hpp, SMM_TILE_USER)
+    int tile_state = 0;                    // 0: not tried yet, 1: tile_code stands, -1: did not compile (tile_log)
+    std::string tile_log;
 };
 // the device headers the persistent kernel is made of, as text: hiprtc compiles them together with the user's source
 struct EmbeddedSource { const char* name; const char* text; };
@@ -223,6 +227,54 @@ bool user_persist_compile(UserObjective& u) {   // (g_user_mutex held)
     return true;
 }
 
+// k_chain_persist_tile with a user objective in its MAP-REDUCE form inside (smm_register_user_objective_lanes; SMM_TILE_USER in
+// smm_chain_persist_tile.hpp): the same recipe, on demand, once per registered objective
+bool user_tile_compile(UserObjective& u) {   // (g_user_mutex held)
+    if (u.tile_state != 0) return u.tile_state > 0;
+    u.tile_state = -1;
+    if (u.source.empty() || u.lanes == 0) { u.tile_log = "not the map-reduce form"; return false; }
+    std::string err;
+    if (!g_rtc.load(err)) { u.tile_log = err; return false; }
+    std::string tu = "#include <type_traits>\n#include <stdint.h>\n#include <math.h>\n";
+    tu += USER_PRELUDE_LANES;
+    tu += u.source;
+    tu += "\n#define SMM_TILE_USER 1\n#include \"smmhip.h\"\n#include \"smm_rng.hpp\"\nusing namespace smm;\n#include \"smm_params.hpp\"\n"
+          "#include \"smm_walk_lean.hpp\"\n#include \"smm_propose.hpp\"\n#include \"smm_chain.hpp\"\n#include \"smm_p2p.hpp\"\n#include \"smm_chain_norm.hpp\"\n"
+          "#include \"smm_chain_persist.hpp\"\n#include \"smm_chain_persist_loc.hpp\"\n#include \"smm_chain_persist_tile.hpp\"\n";
+    std::vector<const char*> names, texts;
+    for (const EmbeddedSource& e : g_embedded) { names.push_back(e.name); texts.push_back(e.text); }
+    static const char* stub_stdint = "typedef unsigned int uint32_t; typedef unsigned long uint64_t; typedef int int32_t; typedef long int64_t;\n"
+                                     "typedef unsigned short uint16_t; typedef unsigned char uint8_t; typedef signed char int8_t; typedef short int16_t;\n";
+    static const char* stub_math = "#ifndef INFINITY\n#define INFINITY __builtin_huge_val()\n#endif\n#ifndef NAN\n#define NAN __builtin_nan(\"\")\n#endif\n";
+    names.push_back("hip/hip_runtime.h"); texts.push_back("\n");
+    names.push_back("stdint.h"); texts.push_back(stub_stdint);
+    names.push_back("math.h"); texts.push_back(stub_math);
+    hiprtcProgram prog = nullptr;
+    if (g_rtc.create(&prog, tu.c_str(), "smm_user_persist_tile.hip", (int)names.size(), texts.data(), names.data()) != HIPRTC_SUCCESS) {
+        u.tile_log = "hiprtcCreateProgram failed";
+        return false;
+    }
+    const std::string nsd = "-DSMM_NSUMS=" + std::to_string(u.n_sums);
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", nsd.c_str()};
+    const hiprtcResult rc = g_rtc.compile(prog, 6, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        g_rtc.log_size(prog, &n);
+        std::string log(n, ' ');
+        if (n) g_rtc.log(prog, &log[0]);
+        u.tile_log = log;
+        g_rtc.destroy(&prog);
+        return false;
+    }
+    size_t cs = 0;
+    g_rtc.code_size(prog, &cs);
+    u.tile_code.resize(cs);
+    g_rtc.code(prog, u.tile_code.data());
+    g_rtc.destroy(&prog);
+    u.tile_state = 1;
+    return true;
+}
+
 struct Ctx {
     KParams P{};
     int obj = 0, device = 0, exchange_from = 2;
@@ -298,6 +350,9 @@ struct Ctx {
     hipFunction_t ufn = nullptr;
     hipModule_t upmod = nullptr;    // ... and the persistent kernel compiled with it inside (smm_chain_persist_gen.hpp, SMM_GEN_USER)
     hipFunction_t upfn = nullptr;
+    hipModule_t utmod = nullptr;    // ... and the persistent TILE kernel with its map-reduce form inside (smm_chain_persist_tile.hpp, SMM_TILE_USER)
+    hipFunction_t utfn = nullptr;
+    int u_nsums = 1;                // ... its partial sums per lane
     bool persist_user = false;      // persist_gen launches upfn
     bool defer_resolve = false;     // the exchange of an iteration is left unresolved until somebody needs it (the next launch may be the persistent kernel's)
     bool rec_external = false;  // the records after the last accept step were written to the caller's gather buffer (sharded_step)
@@ -399,7 +454,12 @@ size_t tile_smem_base(const Ctx* c, int ct) {
     const KParams& P = c->P;
     return tile_smem_doubles(ct, P.np, P.nm, P.RW, P.HW, P.RBW, lay_kind(c)) * sizeof(double);
 }
-int lay_kind(const Ctx* c) { const int k = obj_kind(c->obj); return k == 2 && c->P.dense_A2f ? 3 : k; }
+int lay_kind(const Ctx* c) { const int k = obj_kind(c->obj); return k == 2 && c->P.dense_A2f ? 3 : (c->obj == SMM_OBJ_USER && c->u_lanes > 0) ? 4 : k; }
+// dynamic LDS of k_chain_persist_tile for this context (a user objective's wave totals: 16 chains x lanes / 64 groups x its sums)
+size_t persist_tile_smem(const Ctx* c) {
+    const KParams& P = c->P;
+    return pt_layout(P.np, P.nm, P.RW, P.HW, P.RBW, lay_kind(c), P.dense_nOt, PT_CT * (c->u_lanes / 64) * c->u_nsums).total;
+}
 size_t norm_smem(const Ctx* c) {   // k_chain_iter_norm: [walk: chain slots | pair list] theta, partial sums, parked state
     const size_t b = (size_t)c->P.tile_off * sizeof(double) + norm_tile_doubles(c->P.np) * sizeof(double);
     return c->cone_big ? std::max(b, cone_local_lds_bytes()) : b;   // (the local cone walk lies UNDER the tile's blocks)
@@ -1193,12 +1253,17 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.unit_sh = P.lean_unit == 16 ? 4 : (P.lean_unit == 8 ? 3 : 2); A.scout_after = P.scout_after; A.scout_gl = P.scout_gl;
         A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo;
         const dim3 grid(tiles), block(WG);
-        const size_t smem = pt_layout(P.np, P.nm, P.RW, P.HW, P.RBW, lay_kind(c), P.dense_nOt).total;
+        A.u_lanes = c->u_lanes; A.n_udata = c->n_objp;
+        const size_t smem = persist_tile_smem(c);
         auto go = [&](auto kern) {
             if (c->kev0) hipExtLaunchKernelGGL(kern, grid, block, smem, c->stream, c->kev0, c->kev1, 0, A);
             else hipLaunchKernelGGL(kern, grid, block, smem, c->stream, A);
         };
-        if (kind == 2) go(k_chain_persist_tile<2>); else go(k_chain_persist_tile<1>);
+        if (c->utfn) {   // the same kernel, compiled with the user's map-reduce objective inside (user_tile_compile)
+            void* args[] = {(void*)&A};
+            if (c->kev0) HIPCHK(hipExtModuleLaunchKernel(c->utfn, grid.x * (unsigned)WG, 1, 1, WG, 1, 1, smem, c->stream, args, nullptr, c->kev0, c->kev1, 0));
+            else HIPCHK(hipModuleLaunchKernel(c->utfn, grid.x, 1, 1, WG, 1, 1, (unsigned)smem, c->stream, args, nullptr));
+        } else if (kind == 2) go(k_chain_persist_tile<2>); else go(k_chain_persist_tile<1>);
     } else if (c->persist_gen) {
         PersistGenArgs A{};
         A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
@@ -1501,6 +1566,7 @@ static int register_user_source(const std::string& src, int n_sums, int lanes, i
     UserObjective u;
     u.code.resize(cs);
     u.lanes = lanes;
+    u.n_sums = n_sums > 0 ? n_sums : 1;
     if (user_text) u.source = user_text;
     g_rtc.code(prog, u.code.data());
     g_rtc.destroy(&prog);
@@ -1520,7 +1586,7 @@ int smm_register_user_objective_lanes(const char* hip_source, int32_t n_sums, in
         g_create_err = "smm_register_user_objective_lanes: need 1 <= n_sums <= 64 and lanes a multiple of 64 in [64, 1024]";
         return SMM_ERR_INVALID_ARG;
     }
-    return register_user_source(std::string(USER_PRELUDE_LANES) + hip_source + USER_KERNEL_LANES, n_sums, lanes, objective_id_out);
+    return register_user_source(std::string(USER_PRELUDE_LANES) + hip_source + USER_KERNEL_LANES, n_sums, lanes, objective_id_out, hip_source);
 }
 
 int smm_device_count(void) {
@@ -1544,6 +1610,7 @@ void smm_ctx_destroy(void* ctx) {
     if (c->p2p_mine) (void)hipFree(c->p2p_mine);
     if (c->umod) (void)hipModuleUnload(c->umod);
     if (c->upmod) (void)hipModuleUnload(c->upmod);
+    if (c->utmod) (void)hipModuleUnload(c->utmod);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->pev) (void)hipEventDestroy(e);
@@ -1628,7 +1695,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 std::lock_guard<std::mutex> lock(g_user_mutex);
                 const UserObjective& u = g_user_objectives[prob->objective_id - SMM_OBJ_USER_BASE];
                 HIPCHK(hipModuleLoadData(&c->umod, u.code.data()));
-                c->u_lanes = u.lanes;
+                c->u_lanes = u.lanes; c->u_nsums = u.n_sums;
             }
             HIPCHK(hipModuleGetFunction(&c->ufn, c->umod, "smm_user_eval_kernel"));
             P.u_theta = dalloc<double>(c, (size_t)N * np);
@@ -1868,11 +1935,13 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             // threshold >= 0 (or NaN) for all chains, isotropic proposals, one 16-chain tile per workgroup, all of them resident
             const char* ptile = SMM_HOOK("SMMHIP_PERSIST_TILE");   // test hook: "0" never
             const int tile_kind = obj_kind(c->obj);
-            const bool want_persist_tile = (tile_kind == 1 || tile_kind == 2) && !(c->norm_fast && np <= 2 && ns <= WG * PR_ZR) && N == Ng && Ng >= 2 && c->lds_exchange &&
+            // ... and a USER objective in its map-reduce form (smm_register_user_objective_lanes) whose lanes are a whole share of the tile's 512
+            const bool user_tile = user_obj && c->u_lanes > 0 && c->u_lanes <= WG && WG % c->u_lanes == 0 && PT_CT % (WG / c->u_lanes) == 0;
+            const bool want_persist_tile = (tile_kind == 1 || tile_kind == 2 || user_tile) && !(c->norm_fast && np <= 2 && ns <= WG * PR_ZR) && N == Ng && Ng >= 2 && c->lds_exchange &&
                                            P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan &&
                                            !opts->chol_L && P.dbg == 0 && !(pe && pe[0] == '0') && !(ptile && ptile[0] == '0') && P.RW <= PT_LPC * PT_NJ &&
-                                           (tile_kind == 1 || N % PT_CT == 0) && (N + PT_CT - 1) / PT_CT <= 2 * n_cus &&
-                                           pt_layout(np, nm, P.RW, P.HW, P.RBW, lay_kind(c), P.dense_nOt).total <= (size_t)160 * 1024;
+                                           (tile_kind != 2 || N % PT_CT == 0) && (N + PT_CT - 1) / PT_CT <= 2 * n_cus &&
+                                           persist_tile_smem(c) <= (size_t)160 * 1024;
             const size_t persist_tiles = (want_persist_gen || want_persist_gen_small || want_persist_user) ? (size_t)N / PG_CT : (size_t)(N + NORM_CT - 1) / NORM_CT;
             // large single shards of objfunc_norm (C3 on one GPU): the narrow chain kernel's tiles walk their own, locally numbered cones
             // (smm_cone_big.hpp) instead of waiting for the one-workgroup resolution between two launches
@@ -2056,7 +2125,19 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                         if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
                         if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
                     }
-                    if (want_persist_tile && !c->persist) {   // (the lean plan stands: k_exch_plan lists the tiles' cones and gather lists behind it)
+                    bool tile_ok = want_persist_tile && !c->persist;
+                    if (tile_ok && user_tile) {   // the tile kernel with the user's map-reduce objective inside: compiled now (once per registered objective)
+                        std::lock_guard<std::mutex> lock(g_user_mutex);
+                        UserObjective& u = g_user_objectives[prob->objective_id - SMM_OBJ_USER_BASE];
+                        if (user_tile_compile(u)) {
+                            HIPCHK(hipModuleLoadData(&c->utmod, u.tile_code.data()));
+                            HIPCHK(hipModuleGetFunction(&c->utfn, c->utmod, "smm_user_persist_tile_kernel"));
+                        } else {
+                            tile_ok = false;
+                            if (getenv("SMMHIP_VERBOSE")) fprintf(stderr, "libsmmhip: the persistent form of this user objective is not available:\n%s\n", u.tile_log.c_str());
+                        }
+                    }
+                    if (tile_ok) {   // (the lean plan stands: k_exch_plan lists the tiles' cones and gather lists behind it)
                         const size_t tiles = (size_t)(N + PT_CT - 1) / PT_CT;
                         if (!P.cone_ok) {   // (the dense tiles of the per-iteration kernel walk the same cones: want_cone above)
                             P.cone_tiles = (int)tiles; P.cone_ct = PT_CT;
@@ -2157,11 +2238,17 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         }
         if (c->persist_tile) {
             const int kind = obj_kind(c->obj);
-            const size_t smem = pt_layout(np, nm, P.RW, P.HW, P.RBW, lay_kind(c), P.dense_nOt).total;
-            const void* fn = kind == 2 ? (const void*)k_chain_persist_tile<2> : (const void*)k_chain_persist_tile<1>;
-            HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            const size_t smem = persist_tile_smem(c);
             int per_cu = 0, cus = 0;
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WG, smem));
+            if (c->utfn) {
+                (void)hipFuncSetAttribute((const void*)c->utfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   // (a module's function: not every runtime takes it this way; the launch asks for what it needs)
+                (void)hipGetLastError();
+                HIPCHK(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->utfn, WG, smem));
+            } else {
+                const void* fn = kind == 2 ? (const void*)k_chain_persist_tile<2> : (const void*)k_chain_persist_tile<1>;
+                HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WG, smem));
+            }
             HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             c->persist_max_tiles = per_cu * cus;
             if ((N + PT_CT - 1) / PT_CT > per_cu * cus) { c->persist = false; c->persist_tile = false; c->defer_resolve = false; }
@@ -3041,7 +3128,7 @@ int smm_describe(void* ctx, char* out, int32_t cap) {
     const char* pers = !c->persist ? "none" : c->persist_loc ? (c->persist_sh ? (c->persist_sh_big ? (c->persist_wide ? "loc_wide_shard_bigplan" : "loc_shard_bigplan")
                                                                                                     : (c->persist_wide ? "loc_wide_shard" : "loc_shard"))
                                                                               : (c->persist_wide ? "loc_wide" : "loc"))
-                     : c->persist_tile ? (c->obj == SMM_OBJ_DENSE ? (P.dense_A2f ? "tile_dense2" : "tile_dense") : "tile_sim") : c->persist_user ? "gen_user" : "gen";
+                     : c->persist_tile ? (c->utfn ? "tile_user" : c->obj == SMM_OBJ_DENSE ? (P.dense_A2f ? "tile_dense2" : "tile_dense") : "tile_sim") : c->persist_user ? "gen_user" : "gen";
     snprintf(out, (size_t)cap, "chain=%s walk=%s exchange=%s persistent=%s plan=%s window=%d", chain, walk, xk[c->xk], pers,
              c->big_exchange ? (c->plan_ahead ? "big_ahead" : "big") : c->lds_exchange ? "lds" : "none", c->plan_cap);
     return SMM_OK;

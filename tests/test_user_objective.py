@@ -93,9 +93,9 @@ def test_user_objective_compile_error_is_reported(S):
     assert "compile" in str(e.value)
 
 
-def panel_problem(S, oid, N, T, seed=9):
+def panel_problem(S, oid, N, T, seed=9, fail_above=0.85):
     prob = S.Problem(init=[0.3, 1.0], lb=[-0.95, 0.1], ub=[0.95, 3.0], mom=[0.0, 0.12, 0.06], w=[0.05, 0.05, 0.05], ns=1,
-                     objective_id=oid, obj_params=[40.0, 1000.0, 0.85])   # 40 periods x 1000 agents; fails above rho = 0.85
+                     objective_id=oid, obj_params=[40.0, 1000.0] + ([fail_above] if fail_above is not None else []))   # 40 periods x 1000 agents; fails above rho = 0.85
     opts = S.BGPOpts(N=N, maxiter=T, sigma=0.05 * cm.temps(N, 4.0), acc_tuner=np.geomspace(3.0, 0.5, N) if N > 1 else [2.0],
                      min_improve=np.zeros(N), seed=seed, N_global=N)
     return prob, opts
@@ -188,7 +188,7 @@ def test_user_objective_persistent_form_hard_error_and_where_it_does_not_apply(S
     oid = S.register_user_objective(AR1_SOURCE)
     prob, opts = ar1_problem(S, oid, N=100, T=10)            # not whole groups of 32
     assert S.hip_context(prob, opts).persistent_info()[0] is False
-    oid2 = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=64)   # the map-reduce form: its own launches
+    oid2 = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=1024)   # the map-reduce form with more lanes than a tile has: its own launches
     p2, o2 = panel_problem(S, oid2, N=64, T=10)
     assert S.hip_context(p2, o2).persistent_info()[0] is False
     # a hard error inside a launch (AlgoBGP.jl:409): replayed on the per-iteration launches to the failing iteration
@@ -206,3 +206,39 @@ def test_user_objective_persistent_form_hard_error_and_where_it_does_not_apply(S
     assert errs[0] == errs[1] and "no draw in support" in errs[0], errs
     assert h.persistent_info()[2] >= 1
     cm.assert_history_equal(h.history(), c.history(), exact_floats=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes,N,steps,fail_above,mi", [(256, 64, [1, 20, 9], None, 0.0), (64, 48, [30], 0.5, 0.0), (512, 40, [2, 3, 15], 0.5, 0.05), (128, 256, [25], None, 0.5),
+                                                    (256, 1000, [12], 0.6, 0.0)])
+def test_map_reduce_user_objective_in_the_persistent_loop(S, O, lanes, N, steps, fail_above, mi):
+    # VERDICT r5 "Next #4": the form a real SIMULATION objective takes (MProb.objfunc, mprob.jl:159,182: a sum over many independent units —
+    # SMM_USER_PARTIAL / SMM_USER_FINISH, `lanes` lanes per evaluation) inside the persistent loop: the library compiles k_chain_persist_tile
+    # once more, with the user's source inside (hiprtc, on demand); a tile's 512 lanes evaluate 512 / lanes chains at a time with the reduction
+    # order of the stand-alone kernel.  Against the three launches per iteration (proposal / the user's kernel / accept) to the bit, and against
+    # the oracle (gcc build of the same text); failing evaluations (status -2), thresholds (the reference's default 0.5 included), partial tiles
+    T = sum(steps)
+    oid = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=lanes)
+    O.register_user_objective(PANEL_SOURCE, oid, n_sums=3, lanes=lanes)
+    prob, opts = panel_problem(S, oid, N=N, T=T, fail_above=fail_above)
+    opts.min_improve[:] = mi
+    h = S.hip_context(prob, opts)
+    assert h.describe()["persistent"] == "tile_user", h.describe()
+    c = S.hip_context(prob, opts)
+    c.set_persistent(False)
+    o = O.OracleContext(prob, opts, threads=O.max_threads())
+    for n in steps:
+        h.step(n); c.step(n); o.step(n)
+    avail, launches, repairs = h.persistent_info()
+    assert launches >= 1 and repairs == 0, (launches, repairs)
+    assert c.persistent_info()[1] == 0
+    hh = h.history()
+    cm.assert_history_equal(hh, c.history(), exact_floats=True)
+    cm.assert_state_equal(h.state(), c.state(), rtol=0)
+    cm.assert_history_equal(hh, o.history(), exact_floats=True)
+    cm.assert_state_equal(h.state(), o.state(), rtol=0)
+    assert hh.accepted[1:].any()
+    if mi < 0.4:
+        assert (hh.exchanged != 0).any()
+    if fail_above is not None:
+        assert (hh.status == -2).any()

@@ -38,10 +38,10 @@ def main():
     npar = nm = 50; N = 4096
     rng = np.random.default_rng(3)
     prob = S.Problem(init=rng.uniform(-0.3, 0.3, npar), lb=-np.ones(npar), ub=np.ones(npar), mom=rng.uniform(-0.5, 0.5, nm),
-                     w=rng.uniform(0.5, 2.0, nm), ns=1, objective_id=A.SMM_OBJ_DENSE)
+                     w=rng.uniform(0.5, 2.0, nm), ns=1, objective_id=A.SMM_OBJ_DENSE2)
     opts = S.BGPOpts(N=N, maxiter=T, sigma=0.004 * cm.temps(N, 3), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N),
                      N_global=N, seed=3, smpl_iters=100000)
-    rows.append(("C5 dense np=nm=50 (FP64 MFMA), N=4096", rate(S.hip_context(prob, opts), N)))
+    rows.append(("C5 dense2 (256x256 stage) np=nm=50 (FP64 MFMA), acc_tuner 20..1 (not the bench instance), N=4096", rate(S.hip_context(prob, opts), N)))
     opts = S.BGPOpts(N=N, maxiter=T, sigma=0.0004 * cm.temps(N, 3), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N),
                      N_global=N, seed=3, smpl_iters=100000)
     rows.append(("C5 dense, 10x smaller proposal steps, N=4096", rate(S.hip_context(prob, opts), N)))
@@ -70,7 +70,20 @@ def main():
     oid = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=256)
     prob = S.Problem(init=[0.3, 1.0], lb=[-0.95, 0.1], ub=[0.95, 3.0], mom=[0.0, 0.12, 0.06], w=[0.05, 0.05, 0.05], ns=1,
                      objective_id=oid, obj_params=[40.0, 4096.0])
-    rows.append(("user map-reduce panel 4096x40, N=4096", rate(S.hip_context(prob, opts), N, iters=100)))
+    cu = S.hip_context(prob, opts)
+    rows.append(("user map-reduce panel 4096x40, 256 lanes, persistent loop (%s), N=4096" % cu.describe()["persistent"], rate(cu, N, iters=100)))
+    cu = S.hip_context(prob, opts)
+    cu.set_persistent(False)
+    rows.append(("user map-reduce panel 4096x40, 256 lanes, three launches per iteration, N=4096", rate(cu, N, iters=100)))
+    for agents, lanes in ((256, 64), (1024, 256)):   # cheaper simulations: what the loop itself costs
+        oid = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=lanes)
+        prob = S.Problem(init=[0.3, 1.0], lb=[-0.95, 0.1], ub=[0.95, 3.0], mom=[0.0, 0.12, 0.06], w=[0.05, 0.05, 0.05], ns=1,
+                         objective_id=oid, obj_params=[40.0, float(agents)])
+        cu = S.hip_context(prob, opts)
+        rows.append(("user map-reduce panel %dx40, %d lanes, persistent loop, N=4096" % (agents, lanes), rate(cu, N, iters=100)))
+        cu = S.hip_context(prob, opts)
+        cu.set_persistent(False)
+        rows.append(("user map-reduce panel %dx40, %d lanes, three launches per iteration, N=4096" % (agents, lanes), rate(cu, N, iters=100)))
     for name, r in rows:
         print("%-88s %8.1f M chain-evals/s  (%.1f us per iteration)" % (name, r / 1e6, 1e6 / (r / int(name.split("N=")[1]))))
 
