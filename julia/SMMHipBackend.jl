@@ -194,6 +194,9 @@ function run!(algo::MAlgoBGPHip)
     maxiter = Int(algo.opts["maxiter"])
     sf = get(algo.opts, "save_frequency", 0)
     fn = get(algo.opts, "filename", "")
+    # (iterations somebody already asked for through computeNextIteration! — enqueued or still counted — are part of the run: `algo.i` alone would
+    # step past maxiter when the caller had not advanced it itself, ADVICE r5)
+    algo.i = max(algo.i, getfield(algo, :stepped) + getfield(algo, :deferred))
     while algo.i < maxiter
         n = maxiter - algo.i
         if sf > 0 && fn != ""

@@ -43,7 +43,10 @@ function shard_create(m::MProb, opts::Dict, rank::Int, G::Int)
     N = Int(opts["N"])
     N % G == 0 || throw(ArgumentError("opts[\"N\"] = $N chains do not split into $G equal shards"))
     n = N ÷ G
-    hip, = SMMHipBackend.hip_context(m, opts; N_local = n, chain_offset = rank * n, device = rank)
+    # the HIP device of this rank: opts["devices"] (one ordinal per rank) where given, else the rank itself
+    devs = get(opts, "devices", nothing)
+    dev = devs === nothing ? rank : Int(devs[rank + 1])
+    hip, = SMMHipBackend.hip_context(m, opts; N_local = n, chain_offset = rank * n, device = dev)
     SHARD[] = hip
     return SMMHip.hip_p2p_init(hip)
 end

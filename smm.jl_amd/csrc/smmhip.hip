@@ -900,7 +900,14 @@ unsigned long long p2p_agree_error(Ctx* c, unsigned long long e_local) {
             if (s_r != seq) { all = false; break; }
             e = std::min(e, e_r);
         }
-        if (all) return e;
+        if (all) {
+            // (word and number arrive by two copies and are read by one unfenced DMA: a number seen with the word of the launch before is
+            // possible in theory — ADVICE r5 —: every number is there now, so one more look holds every word that was written before its number)
+            HIPCHK(hipMemcpy(buf.data(), c->p2p_mine + c->prw_off + WL.fin, buf.size(), hipMemcpyDeviceToHost));
+            e = e_local;
+            for (int r = 0; r < G; ++r) { unsigned long long e_r; memcpy(&e_r, buf.data() + 128 * (size_t)r, 8); e = std::min(e, e_r); }
+            return e;
+        }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) throw std::string("sharded run: a rank did not report the end of its step within 30 s (is every rank calling smm_sync / smm_bgp_p2p_finish?)");
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
