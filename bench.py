@@ -443,8 +443,9 @@ def main():
     # history capacity: every repetition's K steps + warm-up + the two profiled steps; the repetitions bounded by 32 GB of history rows
     prob0, _ = build_problem(args.workload, n_loc, n_glob, rank, 1, device)
     row_bytes = n_loc * ((8 + prob0.np + prob0.nm + 1) & ~1) * 8
-    reps_cap = max(1, min(args.reps or 12, int(32e9 // (row_bytes * ITERS_PER_STEP * K))))
-    T = ITERS_PER_STEP * (reps_cap * K + Wm + 2)
+    # (a single shard repeats the SAME K steps from the state behind the warm-up: one repetition's worth of history; shards continue their chains)
+    reps_cap = max(1, min(args.reps or 12, int(32e9 // (row_bytes * ITERS_PER_STEP * K)))) if sharded else (args.reps or 12)
+    T = ITERS_PER_STEP * ((reps_cap if sharded else 1) * K + Wm + 2)
 
     def barrier():
         if world > 1:
@@ -468,8 +469,15 @@ def main():
         for _ in range(Wm):
             run_step()
         sync(); torch.cuda.synchronize(); barrier()
+        # every repetition times THE SAME K steps (the iterations behind the warm-up): the state after the warm-up is read back once and uploaded
+        # again before each further repetition, outside the clock (a single shard; the generator is counter-based, so the iterations are the
+        # same to the bit).  Continuing the chains instead measures another workload every time: over tens of thousands of iterations sigma keeps
+        # adapting, more proposals leave the box, and a step of 200 iterations drifts from 2.55 to 2.80 ms (round 6, 12 x 20 steps in a row)
+        restore = (ctx.state(), ctx.history()) if not sharded else None
         times, want = [], (args.reps or 3)
         while len(times) < min(want, reps_cap):
+            if restore is not None and times:
+                ctx.set_state(*restore); ctx.sync(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(K):
                 run_step()
@@ -630,8 +638,8 @@ def main():
         del c2
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(host_cores())   # (the other ranks idle at the barrier below)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # (at N = 1 only: the contract's cpu_baseline leg)
+        cpu = cpu_baseline(host_cores())
     barrier()
 
     if rank == 0:
@@ -644,9 +652,10 @@ def main():
                "value": value, "unit": "chain-evals/s", "n_gpus": world, "steps": K, "warmup": Wm,
                "ms_per_step": dt / K * 1e3,
                "repetitions": {"n": len(times), "ms_per_step_min": min(times) / K * 1e3, "ms_per_step_median": dt / K * 1e3, "ms_per_step_max": max(times) / K * 1e3,
-                               "timed_region_s_total": sum(times), "value_best": evals / min(times),
-                               "note": "each repetition = EXACTLY --steps steps bracketed by barrier + synchronize (max over the ranks); value and ms_per_step are the MEDIAN repetition's"},
-               "iterations_run": ITERS_PER_STEP * (Wm + len(times) * K + 1),   # warm-up + repetitions + the profiled step, on the timed context
+                               "ms_per_step_all": [round(x / K * 1e3, 4) for x in times], "timed_region_s_total": sum(times), "value_best": evals / min(times),
+                               "note": "each repetition = EXACTLY --steps steps bracketed by barrier + synchronize (max over the ranks); value and ms_per_step are the MEDIAN repetition's; "
+                                       "a single shard repeats the SAME steps (the state behind the warm-up uploaded again before each repetition, outside the clock), shards continue their chains"},
+               "iterations_run": ITERS_PER_STEP * (Wm + (len(times) if sharded else 1) * K + 1),   # warm-up + the repetitions' iterations + the profiled step: where the timed context stands
                "higher_is_better": True, "scaling": "strong" if (W["total"] or (world > 1 and args.same_device and not args.chains)) else "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s, %d BGP chains per GPU (%d total) x %d iterations per step" % (W["label"], n_loc, n_glob, ITERS_PER_STEP),

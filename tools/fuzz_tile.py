@@ -34,12 +34,17 @@ def main():
             if rng.random() < 0.25:
                 d = [k for k in range(1, npar) if npar % k == 0]
                 bs = int(rng.choice(d)) if d else None
-            prob, opts = dense_problem(S, O, npar, nm, N=N, T=T, seed=seed, **({"batch_size": bs} if bs else {}))
+            v2 = rng.random() < 0.5        # SMM_OBJ_DENSE2: with the 256 x 256 stage (round 6)
+            if v2:
+                from test_dense2 import dense2_problem
+                prob, opts = dense2_problem(npar, nm, N=N, T=T, seed=seed, **({"batch_size": bs} if bs else {}))
+            else:
+                prob, opts = dense_problem(S, O, npar, nm, N=N, T=T, seed=seed, **({"batch_size": bs} if bs else {}))
             if rng.random() < 0.5:
                 opts.sigma = opts.sigma * float(rng.choice([3.0, 10.0]))   # late tries of mysample
                 opts.smpl_iters = 100000
-            note = "dense np %2d nm %2d bs %s" % (npar, nm, bs)
-            rtol, expect = 1e-9, "tile_dense"
+            note = "dense%s np %2d nm %2d bs %s" % ("2" if v2 else " ", npar, nm, bs)
+            rtol, expect = 1e-9, "tile_dense2" if v2 else "tile_dense"
         else:
             npar = int(rng.choice([3, 4, 5, 6, 6, 18, 18, 32, 40]))
             N = int(rng.choice([2, 16, 17, 48, 333, 1000, 4096, int(rng.integers(3, 2049))]))
