@@ -208,7 +208,9 @@ def profiled_clock(kernel, workload):
     f = newest_profile("r[0-9][0-9]_%spmc_summary.txt" % profile_tag(workload))
     if not f:
         return None, None
-    names = CHAIN_KERNELS.get(workload, (kernel,)) if kernel.startswith("k_chain_persist") else (kernel,)
+    if not kernel.startswith("k_chain_persist"):
+        return None, None   # (a dispatch of one iteration is too short: the counter's window is a few microseconds wider than the dispatch's timestamps)
+    names = CHAIN_KERNELS.get(workload, (kernel,))
     cyc = ns = 0.0
     for line in open(f):
         if "GRBM_GUI_ACTIVE" in line and "effective_clock_MHz" in line and any(k in line for k in names):

@@ -79,6 +79,9 @@ def test_form_of_a_user_objective(S):
     oid = S.register_user_objective(AR1_SOURCE)
     d = S.hip_context(*ar1_problem(S, oid, N=256, T=8)).describe()
     assert (d["chain"], d["persistent"]) == ("user_3launches", "gen_user"), d
-    oid2 = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=64)
+    oid2 = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=64)     # the map-reduce form: compiled into the persistent TILE kernel (round 6)
     d = S.hip_context(*panel_problem(S, oid2, N=64, T=8)).describe()
+    assert (d["chain"], d["persistent"]) == ("user_lanes_3launches", "tile_user"), d
+    oid3 = S.register_user_objective(PANEL_SOURCE, n_sums=3, lanes=1024)   # more lanes than a tile has: its own launches
+    d = S.hip_context(*panel_problem(S, oid3, N=64, T=8)).describe()
     assert d["persistent"] == "none", d
