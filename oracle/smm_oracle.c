@@ -12,6 +12,10 @@
  *     test/test_algoBGP.jl (lifted into tests/test_oracle_properties.py),
  *   - the analytic anchor of ObjExamples.jl:90-101 (Z == 0 => value = mean(((mu-mom)/w)^2)),
  *   - Philox4x32-10 known-answer vectors (Random123 kat_vectors).
+ * The pin that would lift this status exists as a script nobody here could run: julia/reference_golden.jl drives the
+ * reference's OWN doAcceptReject! / set_eval! / exchangeMoves! / objfunc_norm with injected randomness and writes
+ * tests/golden/ref_bgp.json + ref_Z.bin; tests/test_golden.py::test_oracle_matches_reference_vectors replays them through
+ * this file (skipped until a maintainer with a julia binary commits those two files).
  * Every function cites the reference lines it restates (paths relative to /root/reference).
  *
  * All randomness is either INJECTED (tables) or drawn from a counter-based generator
