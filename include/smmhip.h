@@ -366,7 +366,8 @@ int  smm_set_profiling(void* ctx, int32_t on);
  * n >= 2 iterations is ONE kernel launch per look-ahead window (<= 256 iterations) instead of one per iteration.  Results are
  * bit-identical.  A context qualifies with
  *   - objfunc_norm with at most two parameters / moments and ns <= 10240, one proposal batch, isotropic proposals, dist_fun = `-`, ONE
- *     min_improve >= 0 (or NaN) for all chains — 0, or the reference's default 0.5 (AlgoBGP.jl:522) —, at most one 16-chain tile per
+ *     min_improve >= 0 (or NaN) for all chains — 0, or the reference's default 0.5 (AlgoBGP.jl:522); a single shard also one PER chain,
+ *     below —, at most one 16-chain tile per
  *     compute unit: a single shard of up to 4096 chains (smm_bgp_step), or a SHARD of a sharded run (smm_bgp_p2p_step: N a multiple
  *     of 16, N <= 4096 per rank, N_global <= 32768; the ring of tagged words then lives in every rank's window, a hard error inside
  *     such a launch is agreed upon by the ranks at their next smm_sync / smm_bgp_p2p_finish and replayed by every rank up to the
@@ -383,8 +384,11 @@ int  smm_set_profiling(void* ctx, int32_t on);
  *     iteration: a long simulation fills the device better from its own launches, smm_set_persistent(ctx, 0)):
  *     one proposal batch or several, isotropic proposals, dist_fun = `-`, ONE min_improve >= 0 (or NaN) for all chains, a single shard of
  *     at most two 16-chain tiles per compute unit whose blocks fit the LDS (np = nm = 50: yes; 64 + 64: no).
- * Per-chain thresholds, other dist_fun, Cholesky proposals, user objectives with 1024 lanes, shards of anything but objfunc_norm with at
- * most two parameters: the per-iteration kernels.
+ *   - (round 6) min_improve BY CHAIN, what the reference's API takes (a vector, AlgoBGP.jl:522; the pair (i, j) is tested against chain i's,
+ *     :688): single shards of the objfunc_norm and tile forms above walk one threshold per chain, every one >= 0 or NaN; a context's single
+ *     iterations keep the per-iteration kernels' walk on any thresholds.
+ * A negative threshold, other dist_fun, Cholesky proposals, user objectives with 1024 lanes, shards of anything but objfunc_norm with at
+ * most two parameters and one threshold: the per-iteration kernels.
  * on = 0 keeps the one-launch-per-iteration kernels (default: on).  A hard error of the algorithm inside such a launch is found at
  * the next call that checks (smm_sync, smm_bgp_step, the state readers): the library then repeats those iterations from the state
  * it saved on the one-launch-per-iteration path, so that the context stands at the failing iteration exactly as documented above.

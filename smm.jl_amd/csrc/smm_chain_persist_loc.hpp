@@ -65,11 +65,12 @@ struct PersistLocArgs {
     double sigma_adjust_by, thr;
     uint64_t seed;
     unsigned long long tmo;           // ticks a spin may last
+    const double* mi_g;               // WIDE: min_improve of every chain of the population (AlgoBGP.jl:522; the pair (i, j) is tested against chain i's, :688)
 };
 __host__ __device__ inline size_t persist_loc_smem_bytes(const int np) {
     const size_t hw = (size_t)((H_PARAMS + 2 * np + 1) & ~1);
     const size_t dbl = (size_t)NORM_CT * np + (size_t)np * 8 * NORM_CT + (size_t)NORM_CT * persist_line(np) + 2 * 64 * (size_t)(1 + 2 * np) +
-                       2 * NORM_CT * hw + (size_t)PR_ZR * 64 + 16 + 16 + 2 * 64 * 2 + (size_t)PL_LOCN * np;
+                       2 * NORM_CT * hw + (size_t)PR_ZR * 64 + 16 + 16 + 2 * 64 * 2 + (size_t)PL_LOCN * np + (size_t)PL_LOCN;   // (+ a threshold per local slot: the wide walk's)
     return (size_t)PL_PBASE + 2 * (size_t)CONE_LEVELS * 64 * 4 + 2 * (size_t)CONE_GCAP * 2 + 4 * 16 * 4 + 2 * (size_t)PL_HASH * 4 + dbl * 8;
 }
 
@@ -79,7 +80,7 @@ struct PersistLocLds {
     static constexpr int CT = NORM_CT, RW = L::RW, HW = L::HW, LW = PR_STW + RW, RNGW = 1 + 2 * NP;
     uint32_t pbase, gbase, hbase, tbase;
     uint32_t* s_hdr;
-    double *s_theta, *s_part, *s_st, *s_rng, *s_hrow, *s_xrow, *s_z0, *s_const, *s_gth;
+    double *s_theta, *s_part, *s_st, *s_rng, *s_hrow, *s_xrow, *s_z0, *s_const, *s_gth, *s_thr;
     uint4* s_donor;
     unsigned long long* s_ts;
     unsigned* s_arrived; int* s_minprog; unsigned* s_abort; unsigned* s_xmask; int* s_glready; int* s_pub; int* s_hready;
@@ -107,6 +108,7 @@ struct PersistLocLds {
         s_hready = (int*)(s_arrived + 6);     // the exchange whose re-numbering table is built
         s_donor = (uint4*)(s_const + 16 + 16);
         s_gth = s_const + 16 + 16 + 2 * 64 * 2;   // [PL_LOCN][NP]: the parameters of the cone's chains' last accepted records, by LOCAL number
+        s_thr = s_gth + PL_LOCN * NP;             // [PL_LOCN]: min_improve of the chain AT that local position (the wide walk's per-position thresholds)
     }
 };
 
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
                 if constexpr (WIDE) ((uint4*)lds)[cl] = make_uint4((uint32_t)__double2loint(v0), (uint32_t)__double2hiint(v0), (uint32_t)cl, 0u);
                 else ((uint2*)lds)[cl] = make_uint2(order_key32(v0), (uint32_t)cl);
                 for (int k = 0; k < NP; ++k) Y.s_gth[cl * NP + k] = A.rec_in[(size_t)c * RW + 3 + k];
+                if constexpr (WIDE) Y.s_thr[cl] = A.mi_g[c0g + (uint32_t)cl];
             }
         }
 #pragma unroll
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
                     const PlGather3 w3 = pl_wait_gather3(W, rr + (size_t)g * RW, rr + (size_t)g * RW + (NP - 1), rr + (size_t)g * RW + NP, tag, t_report, g);
                     u0 = w3.q0; u1 = w3.q1; u2 = w3.q2;
                 }
-                if constexpr (WIDE) ((uint4*)lds)[loc] = make_uint4(u2.x, u2.z, loc, 0u);
+                if constexpr (WIDE) { ((uint4*)lds)[loc] = make_uint4(u2.x, u2.z, loc, 0u); Y.s_thr[loc] = A.mi_g[g]; }
                 else ((uint2*)lds)[loc] = make_uint2(order_key32(p2p_ll_double(u2)), loc);
                 Y.s_gth[loc * NP] = p2p_ll_double(u0);
                 if constexpr (NP > 1) Y.s_gth[loc * NP + 1] = p2p_ll_double(u1);
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
         }
         if (tid == 256) {   // the dummy pair's slots behind the cone's: keys 1 < 2 / value 0 on both sides — "no swap"
             const uint32_t nloc = (uint32_t)(CT + ngat);
-            if constexpr (WIDE) ((uint4*)lds)[nloc] = make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (WIDE) { ((uint4*)lds)[nloc] = make_uint4(0u, 0u, 0u, 0u); Y.s_thr[nloc] = 0.0; }   // (0 - 0 > 0 is false)
             else { ((uint2*)lds)[nloc] = make_uint2(1u, 0u); ((uint2*)lds)[nloc + 1u] = make_uint2(2u, 0u); }
         }
     };
@@ -598,7 +601,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
             if (exch) {
                 const int nsub = (int)(Y.s_hdr[((t - 1) & 3) * 16] & 0xffffu);
                 if constexpr (WIDE) {
-                    lean_walk_levels<64, 0, true>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, A.thr);
+                    lean_walk_levels<64, 0, true, WalkNoGuard, true>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, A.thr, WalkNoGuard(),
+                                                                     (uint32_t)((unsigned char*)Y.s_thr - lds));
                 } else {
                     const PersistLocWalkValues values{W, (const uint4*)(mine + A.o_rec) + (size_t)((rel - 1) & rmask) * A.Ng * RW, gl, c0g, pr_tag32(epoch, rel - 1), RW, NP, t};
                     lean_walk_levels<64, 0, false, PersistLocWalkValues>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, 0.0, values);

@@ -44,12 +44,13 @@ struct PersistTileArgs {
     double sigma_adjust_by, thr;
     uint64_t seed;
     unsigned long long tmo;            // ticks a spin may last
+    const double* mi_g;                // min_improve of every chain of the population (the wide walk's per-position thresholds, AlgoBGP.jl:522, :688)
     int u_lanes, n_udata;              // a user objective in its map-reduce form (SMM_TILE_USER below): lanes per evaluation, doubles of its data (objp)
 };
 
 // LDS: [slots 16 B x PL_LOCN | pair words | gather list | 4 headers | re-numbering table | flags, stamps] doubles: cs rec[2] theta
 // const sm vk rb | region B: the objective's partial sums / the two history rows
-struct PtLayout { uint32_t pbase, gbase, hbase, tbase, fbase, dbase; uint32_t o_cs, o_rec, o_theta, o_const, o_sm, o_vk, o_uv, o_rb, o_B; size_t total; };
+struct PtLayout { uint32_t pbase, gbase, hbase, tbase, fbase, thbase, dbase; uint32_t o_cs, o_rec, o_theta, o_const, o_sm, o_vk, o_uv, o_rb, o_B; size_t total; };
 // (kind: 1 objfunc_norm, 2 the dense simulation, 3 its spec v2, 4 a user objective in its map-reduce form: user_part doubles of wave totals)
 __host__ __device__ inline PtLayout pt_layout(const int np, const int nm, const int RW, const int HW, const int RBW, const int kind, const int nOt, const int user_part = 0) {
     PtLayout L;
@@ -58,7 +59,8 @@ __host__ __device__ inline PtLayout pt_layout(const int np, const int nm, const 
     L.hbase = L.gbase + (uint32_t)CONE_GCAP * 2;
     L.tbase = L.hbase + 4u * 16 * 4;
     L.fbase = L.tbase + (uint32_t)PL_HASH * 4;
-    L.dbase = L.fbase + 128u;
+    L.thbase = L.fbase + 128u;                       // a threshold (double) per local slot
+    L.dbase = L.thbase + (uint32_t)PL_LOCN * 8u;
     uint32_t o = 0;   // doubles behind dbase
     L.o_cs = o; o += PT_CT * PR_STW;
     L.o_rec = o; o += 2 * PT_CT * RW;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
     unsigned* const s_abort = s_flags + 1;
     unsigned* const s_rngctr = s_flags + 2;   // chunks of 64 draws of the next iteration's randomness handed out so far (fetch_rb_dyn)
     unsigned long long* const s_ts = (unsigned long long*)(lds + L.fbase + 64);   // [8]
+    double* const s_thr = (double*)(lds + L.thbase);   // [PL_LOCN]: min_improve of the chain at that local position
     double* const dbl = (double*)(lds + L.dbase);
     double* const s_cs = dbl + L.o_cs;        // [16][PR_STW]
     double* const s_rec = dbl + L.o_rec;      // [2][16][RW]: parity of t = the record the chain continues from; the other = its last accepted record after t
@@ -260,8 +263,9 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
             uint4 q = pr_load16_sys(rr + (size_t)g * RW);
             if (__builtin_expect(!p2p_ll_ok(q, tag), 0)) q = pt_wait_ll(W, rr + (size_t)g * RW, tag, t_report, g);
             slots[CT + e] = make_uint4(q.x, q.z, (uint32_t)(CT + e), 0u);
+            s_thr[CT + e] = A.mi_g[g];
         }
-        if (tid == WG - 1) slots[CT + ngat] = make_uint4(0u, 0u, 0u, 0u);   // the dummy pair's slot: 0 - 0 > thr is false
+        if (tid == WG - 1) { slots[CT + ngat] = make_uint4(0u, 0u, 0u, 0u); s_thr[CT + ngat] = 0.0; }   // the dummy pair's slot: 0 - 0 > 0 is false
     };
     // a chain's record as iteration `rel` of the launch into the ring: self-validating granules, 32 lanes per chain
     // (lane r2 stores the granules r2, r2 + 32, ...: every store instruction writes 512 contiguous bytes per chain)
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         if (r2 == 0) {
             const double v0 = A.rec_in[(size_t)c * RW];
             slots[cc] = make_uint4((uint32_t)__double2loint(v0), (uint32_t)__double2hiint(v0), (uint32_t)cc, 0u);
+            s_thr[cc] = A.mi_g[c];
         }
     }
     for (int k = tid; k < np; k += WG) { s_lb[k] = A.lb[k]; s_ub[k] = A.ub[k]; }
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         // ---- the walk over the cone's sub-levels, on local slots: wave 0 alone, no barriers ----
         if (exch && wave == 0) {
             const int nsub = (int)(s_hdr[((t - 1) & 3) * 16] & 0xffffu);
-            lean_walk_levels<64, 0, true>(nullptr, 1, L.pbase, (uint32_t)(64 * lane), nsub, lane, 0, A.thr);
+            lean_walk_levels<64, 0, true, WalkNoGuard, true>(nullptr, 1, L.pbase, (uint32_t)(64 * lane), nsub, lane, 0, A.thr, WalkNoGuard(), L.thbase);
         }
         PR_BARRIER();   // B1
         unsigned long long ts1 = 0;

@@ -37,6 +37,7 @@ struct KParams {
     // user objective (objective_id >= SMM_OBJ_USER_BASE): proposals out, results in, [N][np] / [N][nm] / [N]
     double* u_theta; double* u_simM; double* u_value; int* u_status;
     int mi_uniform;               // all thresholds equal (the usual case): mi_value
+    int mi_pct;                   // thresholds DIFFER by chain, every one >= 0 or NaN, dist_fun = `-`: the persistent forms' wide walk reads one per slot position
     int tile_off;                 // doubles in front of the tile's LDS blocks (the inline walk's chain slots)
     double mi_value;
     // dense objective (SMM_OBJ_DENSE): B and A in MFMA fragment order

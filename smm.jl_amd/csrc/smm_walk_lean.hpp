@@ -62,17 +62,21 @@ __device__ inline double walk_value(const GUARD& g, const double* __restrict__ v
     if constexpr (std::is_same<GUARD, WalkNoGuard>::value) return vsrc[(size_t)s * vstride];
     else return g.value(s);
 }
+// PCT (the persistent forms' wide walk, round 6): the threshold is the COLDER chain's own (min_improve[i], AlgoBGP.jl:522, :688) — a double per slot
+// POSITION at LDS offset thr_base + 8 * position, read in the same LDS round trip as the slots (positions do not travel with the records a swap exchanges)
 // one pair, on its own (further words of a level wider than the workgroup)
-template <int US, bool WIDE = false, class GUARD = WalkNoGuard>
+template <int US, bool WIDE = false, class GUARD = WalkNoGuard, bool PCT = false>
 __device__ inline void lean_pair(const double* __restrict__ vsrc, const int vstride, const uint32_t pw, const uint32_t stamp, const double thr = 0.0,
-                                 const GUARD& guard = GUARD()) {
+                                 const GUARD& guard = GUARD(), const uint32_t thr_base = 0u) {
     uint32_t ai, aj;
     lean_decode<US>(pw, ai, aj);
     if constexpr (WIDE) {
         u32x4_t si, sj;
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
+        double thr_l = thr;
+        if constexpr (PCT) asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj), "=&v"(thr_l) : "v"(ai), "v"(aj), "v"(thr_base + (ai >> 1)) : "memory");
+        else asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(si), "=&v"(sj) : "v"(ai), "v"(aj) : "memory");
         const double vi = __hiloint2double((int)si.y, (int)si.x), vj = __hiloint2double((int)sj.y, (int)sj.x);
-        if (vi - vj > thr) {   // dist_fun = -, AlgoBGP.jl:688
+        if (vi - vj > thr_l) {   // dist_fun = -, AlgoBGP.jl:688
             const u32x4_t ni = {sj.x, sj.y, (sj.z & 0xffffu) | stamp, 0u}, nj = {si.x, si.y, (si.z & 0xffffu) | stamp, 0u};
             asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
         }
@@ -96,9 +100,10 @@ __device__ inline int lean_walk_tail(const uint32_t ov, const int nlev, const in
     const unsigned long long wide = __ballot(lane < nlev && nx - ov > 64u);
     return wide ? 64 - __builtin_clzll(wide) : 0;
 }
-template <int NT, int US, bool WIDE = false, class GUARD = WalkNoGuard>
+template <int NT, int US, bool WIDE = false, class GUARD = WalkNoGuard, bool PCT = false>
 __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const int vstride, const uint32_t pbase, const uint32_t ov,
-                                        const int nlev, const int tid, const int ltail, const double thr = 0.0, const GUARD& guard = GUARD()) {
+                                        const int nlev, const int tid, const int ltail, const double thr = 0.0, const GUARD& guard = GUARD(),
+                                        const uint32_t thr_base = 0u) {
     const uint32_t wbase = (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63);   // this wave's first word within a trip
     const uint32_t tid4p = pbase + 4u * (uint32_t)tid;
     const uint32_t tidst = ((uint32_t)tid + 1u) << 16;                           // this lane's stamp at position 0
@@ -119,10 +124,15 @@ __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const i
             uint32_t pwn;
             if constexpr (WIDE) {
                 u32x4_t si, sj;
-                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(si), "=&v"(sj), "=&v"(pwn) : "v"(ai), "v"(aj), "v"(nptr) : "memory");
+                double thr_l = thr;
+                if constexpr (PCT)   // (the threshold of position i rides in the same LDS round trip)
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(si), "=&v"(sj), "=&v"(pwn), "=&v"(thr_l) : "v"(ai), "v"(aj), "v"(nptr), "v"(thr_base + (ai >> 1)) : "memory");
+                else
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(si), "=&v"(sj), "=&v"(pwn) : "v"(ai), "v"(aj), "v"(nptr) : "memory");
                 const double vi = __hiloint2double((int)si.y, (int)si.x), vj = __hiloint2double((int)sj.y, (int)sj.x);
-                if (vi - vj > thr) {   // dist_fun = -, AlgoBGP.jl:688; swap_ev_ij!, :739-744; the stamp stands for set_exchanged!, :747-748
+                if (vi - vj > thr_l) {   // dist_fun = -, AlgoBGP.jl:688; swap_ev_ij!, :739-744; the stamp stands for set_exchanged!, :747-748
                     const u32x4_t ni = {sj.x, sj.y, (sj.z & 0xffffu) | stamp, 0u}, nj = {si.x, si.y, (si.z & 0xffffu) | stamp, 0u};
                     asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %1, %3" :: "v"(ai), "v"(aj), "v"(ni), "v"(nj) : "memory");
                 }
@@ -145,7 +155,7 @@ __device__ inline void lean_walk_levels(const double* __restrict__ vsrc, const i
                 for (uint32_t o = (uint32_t)NT; wbase + o < width; o += (uint32_t)NT) {
                     uint32_t pwx;
                     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pwx) : "v"(tid4p + 4u * (st + o)) : "memory");
-                    lean_pair<US, WIDE, GUARD>(vsrc, vstride, pwx, ((st + o) << 16) + tidst, thr, guard);
+                    lean_pair<US, WIDE, GUARD, PCT>(vsrc, vstride, pwx, ((st + o) << 16) + tidst, thr, guard, thr_base);
                 }
             }
         } else if (wbase < st2 - st1) {   // idle in this level, not in the next: its word

@@ -666,7 +666,7 @@ void launch_chain_iter_norm(Ctx* c, int t, int flags) {
     // the lean walks need a padded plan of at most 31 levels and values without NaN: where that is not given — per-chain or
     // negative thresholds (no padded plan), an injected pair list that goes deeper, an uploaded state with NaN values — the
     // kernel with the walk on 16-byte slots {value, src, partner} runs
-    if (walk && (!c->P.lv_pairs_p || c->deep_plan || c->nan_values)) {
+    if (walk && (!c->P.lv_pairs_p || c->deep_plan || c->nan_values || c->P.mi_pct)) {   // (mi_pct: the lean plan stands for the persistent launches only)
         switch (c->P.np) {
             case 1: launch_chain_iter_norm_any_t<1>(c, t, flags); break;
             case 2: launch_chain_iter_norm_any_t<2>(c, t, flags); break;
@@ -1226,7 +1226,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.walk_first = c->unresolved ? 1 : 0;
         A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks;
         A.tables_local = c->persist_sh_big ? 1 : 0; A.unit_sh = P.lean_unit == 16 ? 4 : (P.lean_unit == 8 ? 3 : 2);
-        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo;
+        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo; A.mi_g = P.min_improve_g;
         const dim3 grid(tiles), block(NORM_WG);
         const size_t smem = persist_loc_smem_bytes(P.np);
         auto go = [&](auto kern) {
@@ -1258,7 +1258,7 @@ int launch_chain_persist(Ctx* c, int n_left) {
         A.rb_t0 = P.rb_t0; A.rb_tries = P.rb_tries; A.user_n = P.user_n;
         A.ring_k = c->pr_ring_k; A.slow_tile = c->pr_slow_tile; A.slow_ticks = c->pr_slow_ticks; A.walk_first = c->unresolved ? 1 : 0;
         A.unit_sh = P.lean_unit == 16 ? 4 : (P.lean_unit == 8 ? 3 : 2); A.scout_after = P.scout_after; A.scout_gl = P.scout_gl;
-        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo;
+        A.epoch = c->pr_epoch; A.sigma_adjust_by = P.sigma_adjust_by; A.thr = P.mi_value; A.seed = P.seed; A.tmo = tmo; A.mi_g = P.min_improve_g;
         const dim3 grid(tiles), block(WG);
         A.u_lanes = c->u_lanes; A.n_udata = c->n_objp;
         const size_t smem = persist_tile_smem(c);
@@ -1777,6 +1777,14 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
         P.mi_uniform = 1; P.mi_value = opts->min_improve[0];
         for (int i = 1; i < Ng; ++i)
             if (!(opts->min_improve[i] == P.mi_value || (opts->min_improve[i] != opts->min_improve[i] && P.mi_value != P.mi_value))) P.mi_uniform = 0;   // (NaN everywhere is one threshold too: nothing ever swaps)
+        // per-chain thresholds (what the reference's API takes: opts["min_improve"] is a vector, AlgoBGP.jl:522): the persistent forms walk them too
+        // (a threshold per slot position, smm_walk_lean.hpp PCT) while this context's single iterations keep the forms they had (the level walk on any
+        // thresholds): every threshold >= 0 or NaN (the dummy pair's 0 - 0 must not exceed it), dist_fun = `-`
+        P.mi_pct = 0;
+        if (!P.mi_uniform && opts->dist_fun == SMM_DIST_MINUS) {
+            P.mi_pct = 1;
+            for (int i = 0; i < Ng; ++i) if (opts->min_improve[i] < 0.0) P.mi_pct = 0;
+        }
         const size_t TN = (size_t)T * N;
         if (tab && tab->probs_acc) P.user_utab = dupload(c, tab->probs_acc, TN);
         if (tab && tab->prop_normals && tab->prop_tries > 0) {
@@ -1929,7 +1937,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             // ... and on LOCALLY NUMBERED cones (smm_chain_persist_loc.hpp): the same objective with one threshold >= 0 (or NaN: nothing
             // ever swaps) for all chains — min_improve > 0 is the reference's default (AlgoBGP.jl:522) —, whatever the population's size
             // does to the tile's LDS
-            const bool want_persist_loc = c->norm_fast && np <= 2 && ns <= WG * PR_ZR && N == Ng && Ng >= 2 && c->inline_walk && P.mi_uniform && !(P.mi_value < 0.0) &&
+            const bool mi_ok = (P.mi_uniform && !(P.mi_value < 0.0)) || P.mi_pct;   // one threshold >= 0 (or NaN) for all chains, or one per chain, each >= 0 (or NaN)
+            const bool want_persist_loc = c->norm_fast && np <= 2 && ns <= WG * PR_ZR && N == Ng && Ng >= 2 && c->inline_walk && mi_ok &&
                                           opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan && (N + NORM_CT - 1) / NORM_CT <= n_cus &&
                                           P.dbg == 0 && !(pe && pe[0] == '0') && !(ploc && ploc[0] == '0');
             // ... and as a shard of a sharded run (one process per GPU: smm_bgp_p2p_step): the same kernel, the ring in the ranks' windows
@@ -1945,7 +1954,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             // ... and a USER objective in its map-reduce form (smm_register_user_objective_lanes) whose lanes are a whole share of the tile's 512
             const bool user_tile = user_obj && c->u_lanes > 0 && c->u_lanes <= WG && WG % c->u_lanes == 0 && PT_CT % (WG / c->u_lanes) == 0;
             const bool want_persist_tile = (tile_kind == 1 || tile_kind == 2 || user_tile) && !(c->norm_fast && np <= 2 && ns <= WG * PR_ZR) && N == Ng && Ng >= 2 && c->lds_exchange &&
-                                           P.mi_uniform && !(P.mi_value < 0.0) && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan &&
+                                           mi_ok && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan &&
                                            !opts->chol_L && P.dbg == 0 && !(pe && pe[0] == '0') && !(ptile && ptile[0] == '0') && P.RW <= PT_LPC * PT_NJ &&
                                            (tile_kind != 2 || N % PT_CT == 0) && (N + PT_CT - 1) / PT_CT <= 2 * n_cus &&
                                            persist_tile_smem(c) <= (size_t)160 * 1024;
@@ -2046,13 +2055,16 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 const char* kw = SMM_HOOK("SMMHIP_KEY_WALK");   // test hook: "0" keeps the walks on 16-byte / split slots
                 const bool keys = P.mi_uniform && P.mi_value == 0.0;
                 const bool wide = P.mi_uniform && !keys && !(P.mi_value < 0.0) && resolve_lean_bytes(Ng, K, true) <= (size_t)160 * 1024;
-                if ((keys || wide) && K <= XLDS_MAX && !(kw && kw[0] == '0') && opts->dist_fun == SMM_DIST_MINUS) {
-                    P.lean_wide = wide ? 1 : 0;
+                // (thresholds by chain: the lean PLAN — padded levels on 16-byte units, the tiles' cones behind it — is made for the persistent launches; the
+                // stand-alone lean resolution and the inline lean walks, which test ONE threshold, stay off: lean_resolve below, launch_chain_iter_norm)
+                const bool pct = P.mi_pct != 0 && (want_persist_loc || want_persist_tile) && !c->persist;
+                if ((keys || wide || pct) && K <= XLDS_MAX && !(kw && kw[0] == '0') && opts->dist_fun == SMM_DIST_MINUS) {
+                    P.lean_wide = (wide || pct) ? 1 : 0;
                     P.plan_Kp = lean_walk_Kp(K);
-                    P.lean_unit = wide ? lean_wide_unit(Ng) : lean_walk_unit(Ng);
+                    P.lean_unit = (wide || pct) ? lean_wide_unit(Ng) : lean_walk_unit(Ng);
                     c->win_lv_pairs_p = dalloc<uint32_t>(c, (size_t)c->plan_cap * P.plan_Kp + 512);   // (+512: whole 1 KB pieces may be read past the last iteration's words)
                     c->win_lv_offp = dalloc<uint32_t>(c, (size_t)c->plan_cap * LV_OFFP);
-                    c->lean_resolve = true;
+                    c->lean_resolve = !pct;
                     if (keys && ((c->norm_fast && c->inline_walk && Ng <= XLVL_MAX && K <= XLVL_MAX) || c->gen_keys)) {   // ... in the prologue of k_chain_iter_norm, or of k_chain_iter (key form)
                         for (int b = 0; b < 2; ++b) c->slot8_buf[b] = dalloc<uint2>(c, (size_t)N + 4 + 128);
                         P.slot8 = c->slot8_buf[0];
@@ -2127,7 +2139,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                             c->prw = dalloc<unsigned char>(c, WL.total);
                             HIPCHK(hipMemset(c->prw, 0, WL.total));
                         }
-                        c->persist = true; c->persist_loc = true; c->persist_wide = wide; c->persist_sh = want_persist_sh;
+                        c->persist = true; c->persist_loc = true; c->persist_wide = wide || pct; c->persist_sh = want_persist_sh;
                         if (const char* rk = SMM_HOOK("SMMHIP_PR_RING")) { const int k = atoi(rk); if (k == 2 || k == 4) c->pr_ring_k = k; }
                         if (const char* st = SMM_HOOK("SMMHIP_PR_SLOW_TILE")) c->pr_slow_tile = atoi(st);
                         if (const char* su = SMM_HOOK("SMMHIP_PR_SLOW_US")) c->pr_slow_ticks = 100 * atoi(su);
@@ -3125,13 +3137,13 @@ int smm_describe(void* ctx, char* out, int32_t cap) {
     const char* chain;
     if (c->obj == SMM_OBJ_USER) chain = c->u_lanes ? "user_lanes_3launches" : "user_3launches";
     else if (c->norm_fast)
-        chain = c->cone_big ? "iter_norm_narrow_cone" : (!c->win_lv_pairs_p || c->deep_plan || c->nan_values) && c->inline_walk ? "iter_norm_any"
+        chain = c->cone_big ? "iter_norm_narrow_cone" : (!c->win_lv_pairs_p || c->deep_plan || c->nan_values || P.mi_pct) && c->inline_walk ? "iter_norm_any"
               : (P.lean_wide && c->inline_walk) ? "iter_norm_wide" : c->norm_narrow ? "iter_norm_narrow" : "iter_norm";
     else chain = c->obj == SMM_OBJ_DENSE ? (P.dense_A2f ? "iter<dense2,16>" : "iter<dense,16>") : is_sim(c->obj) ? (c->tpw == 2 ? "iter<sim,8,2>" : "iter<sim,8>")
                : (c->gen_keys ? "iter<gen,16,2>" : c->tpw == 2 ? "iter<gen,8,2>" : "iter<gen,8>");
     static const char* xk[] = {"lean", "lvl", "lvl_soa", "tickets", "rows", "key", "lvl_big", "any"};
     const char* walk = c->cone_big ? "cone_local" : !c->inline_walk ? "standalone" : c->dense_keys ? "inline_keys_under_tile" : c->gen_keys ? (c->cone ? "inline_keys_cone" : "inline_keys")
-                     : c->norm_fast ? (P.lean_wide ? "inline_lean_wide" : c->win_lv_pairs_p ? "inline_lean" : "inline_slots") : c->gen_lean ? "inline_lean16" : "inline_slots";
+                     : c->norm_fast ? ((P.lean_wide && !P.mi_pct) ? "inline_lean_wide" : (c->win_lv_pairs_p && !P.mi_pct) ? "inline_lean" : "inline_slots") : c->gen_lean ? "inline_lean16" : "inline_slots";
     const char* pers = !c->persist ? "none" : c->persist_loc ? (c->persist_sh ? (c->persist_sh_big ? (c->persist_wide ? "loc_wide_shard_bigplan" : "loc_shard_bigplan")
                                                                                                     : (c->persist_wide ? "loc_wide_shard" : "loc_shard"))
                                                                               : (c->persist_wide ? "loc_wide" : "loc"))

@@ -33,7 +33,8 @@ TABLE = [
     ("C1: serialNormal, 3 chains",                              lambda S: norm(3),                  "iter_norm", "inline_lean", "lean", "loc", "lds"),
     ("C2: 4096 chains (the headline)",                          lambda S: norm(4096),               "iter_norm", "inline_lean", "lean", "loc", "lds"),
     ("C2 with the reference's default threshold 0.5",           lambda S: norm(4096, 0.5),          "iter_norm_wide", "inline_lean_wide", "lean", "loc_wide", "lds"),
-    ("per-chain thresholds",                                    lambda S: norm(64, np.linspace(0, 0.5, 64)), "iter_norm_any", "inline_slots", "lvl", "none", "lds"),
+    ("per-chain thresholds (round 6: the persistent form walks them)", lambda S: norm(64, np.linspace(0, 0.5, 64)), "iter_norm_any", "inline_slots", "lvl", "loc_wide", "lds"),
+    ("per-chain thresholds, one of them negative",              lambda S: norm(64, np.linspace(-0.1, 0.5, 64)), "iter_norm_any", "inline_slots", "lvl", "none", "lds"),
     ("4097 chains: more tiles than compute units",              lambda S: norm(4112),               "iter_norm_narrow", "standalone", "lean", "none", "lds"),
     ("8192 chains",                                             lambda S: norm(8192),               "iter_norm_narrow", "standalone", "lean", "none", "lds"),
     ("C3: 32768 chains on one GPU",                             lambda S: norm(32768),              "iter_norm_narrow_cone", "cone_local", "rows", "none", "big_ahead"),

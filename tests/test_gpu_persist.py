@@ -149,14 +149,19 @@ def test_persistent_form_can_be_switched_off_and_reports_itself(S):
     h.step(20)
     assert h.persistent_info()[1] == 0
     # one threshold > 0 for all chains (the reference's default, AlgoBGP.jl:522): the form on locally numbered cones (round 5,
-    # tests/test_gpu_persist_loc.py); more than two moments: the tile form (tests/test_gpu_persist_tile.py); per-chain thresholds: none
+    # tests/test_gpu_persist_loc.py); more than two moments: the tile form (tests/test_gpu_persist_tile.py); thresholds by chain (round 6): the same
+    # forms, a threshold per slot position — unless one of them is negative
     p2, o2 = cm.serial_normal(N=64, T=20, ns=300, min_improve=0.05)
     assert S.hip_context(p2, o2).persistent_info()[0] is True
     p4, o4 = cm.serial_normal(N=64, T=20, ns=300, min_improve=np.linspace(0.0, 0.5, 64))
+    assert S.hip_context(p4, o4).persistent_info()[0] is True
+    p4, o4 = cm.serial_normal(N=64, T=20, ns=300, min_improve=np.linspace(-0.1, 0.5, 64))
     assert S.hip_context(p4, o4).persistent_info()[0] is False
     p3, o3 = cm.general_normal(4, N=32, T=10, ns=200)
     assert S.hip_context(p3, o3).persistent_info()[0] is True
     o3.min_improve[:] = np.linspace(0.0, 0.5, 32)
+    assert S.hip_context(p3, o3).persistent_info()[0] is True
+    o3.min_improve[:] = np.linspace(-0.1, 0.5, 32)
     assert S.hip_context(p3, o3).persistent_info()[0] is False
 
 
