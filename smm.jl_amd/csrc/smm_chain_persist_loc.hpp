@@ -186,8 +186,11 @@ __device__ __attribute__((noinline)) PlGather3 pl_wait_gather3(const PrWait W, c
     return o;
 }
 
-template <int NP, bool WIDE, bool SH>
+// (PCT: thresholds by chain — WIDE single shards only; a form of its own so that ONE threshold for all chains pays nothing for it: 11.84 -> 12.06 us per iteration when
+// the per-position read was always there, 12.27 as a run-time branch)
+template <int NP, bool WIDE, bool SH, bool PCT = false>
 __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistLocArgs A) {
+    static_assert(!PCT || (WIDE && !SH), "thresholds by chain: the wide walk of a single shard");
     static_assert(NP == 1 || NP == 2, "one moment per half of the workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     using LY = PersistLocLds<NP>;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
                 if constexpr (WIDE) ((uint4*)lds)[cl] = make_uint4((uint32_t)__double2loint(v0), (uint32_t)__double2hiint(v0), (uint32_t)cl, 0u);
                 else ((uint2*)lds)[cl] = make_uint2(order_key32(v0), (uint32_t)cl);
                 for (int k = 0; k < NP; ++k) Y.s_gth[cl * NP + k] = A.rec_in[(size_t)c * RW + 3 + k];
-                if constexpr (WIDE) Y.s_thr[cl] = A.mi_g[c0g + (uint32_t)cl];
+                if constexpr (PCT) Y.s_thr[cl] = A.mi_g[c0g + (uint32_t)cl];
             }
         }
 #pragma unroll
@@ -355,7 +358,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
                     const PlGather3 w3 = pl_wait_gather3(W, rr + (size_t)g * RW, rr + (size_t)g * RW + (NP - 1), rr + (size_t)g * RW + NP, tag, t_report, g);
                     u0 = w3.q0; u1 = w3.q1; u2 = w3.q2;
                 }
-                if constexpr (WIDE) { ((uint4*)lds)[loc] = make_uint4(u2.x, u2.z, loc, 0u); Y.s_thr[loc] = A.mi_g[g]; }
+                if constexpr (PCT) Y.s_thr[loc] = A.mi_g[g];
+                if constexpr (WIDE) ((uint4*)lds)[loc] = make_uint4(u2.x, u2.z, loc, 0u);
                 else ((uint2*)lds)[loc] = make_uint2(order_key32(p2p_ll_double(u2)), loc);
                 Y.s_gth[loc * NP] = p2p_ll_double(u0);
                 if constexpr (NP > 1) Y.s_gth[loc * NP + 1] = p2p_ll_double(u1);
@@ -376,7 +380,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
         }
         if (tid == 256) {   // the dummy pair's slots behind the cone's: keys 1 < 2 / value 0 on both sides — "no swap"
             const uint32_t nloc = (uint32_t)(CT + ngat);
-            if constexpr (WIDE) { ((uint4*)lds)[nloc] = make_uint4(0u, 0u, 0u, 0u); Y.s_thr[nloc] = 0.0; }   // (0 - 0 > 0 is false)
+            if constexpr (PCT) Y.s_thr[nloc] = 0.0;   // (0 - 0 > 0 is false)
+            if constexpr (WIDE) ((uint4*)lds)[nloc] = make_uint4(0u, 0u, 0u, 0u);
             else { ((uint2*)lds)[nloc] = make_uint2(1u, 0u); ((uint2*)lds)[nloc + 1u] = make_uint2(2u, 0u); }
         }
     };
@@ -601,8 +606,8 @@ __global__ __launch_bounds__(NORM_WG, 4) void k_chain_persist_loc(const PersistL
             if (exch) {
                 const int nsub = (int)(Y.s_hdr[((t - 1) & 3) * 16] & 0xffffu);
                 if constexpr (WIDE) {
-                    lean_walk_levels<64, 0, true, WalkNoGuard, true>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, A.thr, WalkNoGuard(),
-                                                                     (uint32_t)((unsigned char*)Y.s_thr - lds));
+                    lean_walk_levels<64, 0, true, WalkNoGuard, PCT>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, A.thr, WalkNoGuard(),
+                                                                    (uint32_t)((unsigned char*)Y.s_thr - lds));
                 } else {
                     const PersistLocWalkValues values{W, (const uint4*)(mine + A.o_rec) + (size_t)((rel - 1) & rmask) * A.Ng * RW, gl, c0g, pr_tag32(epoch, rel - 1), RW, NP, t};
                     lean_walk_levels<64, 0, false, PersistLocWalkValues>(nullptr, 1, lbase, (uint32_t)(64 * lane), nsub, lane, 0, 0.0, values);

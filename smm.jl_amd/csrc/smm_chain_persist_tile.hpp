@@ -105,8 +105,9 @@ __device__ __attribute__((noinline)) uint4 pt_wait_ll(const PrWait W, const uint
 #ifdef SMM_TILE_USER
 extern "C" __global__ __launch_bounds__(WG) void smm_user_persist_tile_kernel(const PersistTileArgs A) {
     constexpr int KIND = 4;
+    constexpr bool PCT = false;   // (one threshold for all chains)
 #else
-template <int KIND>
+template <int KIND, bool PCT = false>   // PCT: thresholds by chain (a form of its own: see k_chain_persist_loc)
 __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs A) {
     static_assert(KIND == 1 || KIND == 2, "objfunc_norm (shocks streamed) or the dense simulation");
 #endif
@@ -263,9 +264,9 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
             uint4 q = pr_load16_sys(rr + (size_t)g * RW);
             if (__builtin_expect(!p2p_ll_ok(q, tag), 0)) q = pt_wait_ll(W, rr + (size_t)g * RW, tag, t_report, g);
             slots[CT + e] = make_uint4(q.x, q.z, (uint32_t)(CT + e), 0u);
-            s_thr[CT + e] = A.mi_g[g];
+            if constexpr (PCT) s_thr[CT + e] = A.mi_g[g];
         }
-        if (tid == WG - 1) { slots[CT + ngat] = make_uint4(0u, 0u, 0u, 0u); s_thr[CT + ngat] = 0.0; }   // the dummy pair's slot: 0 - 0 > 0 is false
+        if (tid == WG - 1) { slots[CT + ngat] = make_uint4(0u, 0u, 0u, 0u); if constexpr (PCT) s_thr[CT + ngat] = 0.0; }   // the dummy pair's slot: 0 - 0 > 0 is false
     };
     // a chain's record as iteration `rel` of the launch into the ring: self-validating granules, 32 lanes per chain
     // (lane r2 stores the granules r2, r2 + 32, ...: every store instruction writes 512 contiguous bytes per chain)
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         if (r2 == 0) {
             const double v0 = A.rec_in[(size_t)c * RW];
             slots[cc] = make_uint4((uint32_t)__double2loint(v0), (uint32_t)__double2hiint(v0), (uint32_t)cc, 0u);
-            s_thr[cc] = A.mi_g[c];
+            if constexpr (PCT) s_thr[cc] = A.mi_g[c];
         }
     }
     for (int k = tid; k < np; k += WG) { s_lb[k] = A.lb[k]; s_ub[k] = A.ub[k]; }
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(WG) void k_chain_persist_tile(const PersistTileArgs
         // ---- the walk over the cone's sub-levels, on local slots: wave 0 alone, no barriers ----
         if (exch && wave == 0) {
             const int nsub = (int)(s_hdr[((t - 1) & 3) * 16] & 0xffffu);
-            lean_walk_levels<64, 0, true, WalkNoGuard, true>(nullptr, 1, L.pbase, (uint32_t)(64 * lane), nsub, lane, 0, A.thr, WalkNoGuard(), L.thbase);
+            lean_walk_levels<64, 0, true, WalkNoGuard, PCT>(nullptr, 1, L.pbase, (uint32_t)(64 * lane), nsub, lane, 0, A.thr, WalkNoGuard(), L.thbase);
         }
         PR_BARRIER();   // B1
         unsigned long long ts1 = 0;

@@ -1118,7 +1118,8 @@ void launch_resolve_rows_window(Ctx* c, int t) {
     }
 }
 // ---- the persistent chain kernels (smm_chain_persist.hpp, smm_chain_persist_loc.hpp) ----
-const void* persist_loc_fn(int np, bool wide, bool sh) {
+const void* persist_loc_fn(int np, bool wide, bool sh, bool pct = false) {
+    if (pct) return np == 1 ? (const void*)k_chain_persist_loc<1, true, false, true> : (const void*)k_chain_persist_loc<2, true, false, true>;
     if (np == 1) return wide ? (sh ? (const void*)k_chain_persist_loc<1, true, true> : (const void*)k_chain_persist_loc<1, true, false>)
                              : (sh ? (const void*)k_chain_persist_loc<1, false, true> : (const void*)k_chain_persist_loc<1, false, false>);
     return wide ? (sh ? (const void*)k_chain_persist_loc<2, true, true> : (const void*)k_chain_persist_loc<2, true, false>)
@@ -1234,7 +1235,8 @@ int launch_chain_persist(Ctx* c, int n_left) {
             else hipLaunchKernelGGL(kern, grid, block, smem, c->stream, A);
         };
         const bool wd = c->persist_wide, sh = c->persist_sh;
-        if (P.np == 1) {
+        if (P.mi_pct) { if (P.np == 1) go(k_chain_persist_loc<1, true, false, true>); else go(k_chain_persist_loc<2, true, false, true>); }
+        else if (P.np == 1) {
             if (wd) { if (sh) go(k_chain_persist_loc<1, true, true>); else go(k_chain_persist_loc<1, true, false>); }
             else { if (sh) go(k_chain_persist_loc<1, false, true>); else go(k_chain_persist_loc<1, false, false>); }
         } else {
@@ -1270,7 +1272,8 @@ int launch_chain_persist(Ctx* c, int n_left) {
             void* args[] = {(void*)&A};
             if (c->kev0) HIPCHK(hipExtModuleLaunchKernel(c->utfn, grid.x * (unsigned)WG, 1, 1, WG, 1, 1, smem, c->stream, args, nullptr, c->kev0, c->kev1, 0));
             else HIPCHK(hipModuleLaunchKernel(c->utfn, grid.x, 1, 1, WG, 1, 1, (unsigned)smem, c->stream, args, nullptr));
-        } else if (kind == 2) go(k_chain_persist_tile<2>); else go(k_chain_persist_tile<1>);
+        } else if (P.mi_pct) { if (kind == 2) go(k_chain_persist_tile<2, true>); else go(k_chain_persist_tile<1, true>); }
+        else if (kind == 2) go(k_chain_persist_tile<2>); else go(k_chain_persist_tile<1>);
     } else if (c->persist_gen) {
         PersistGenArgs A{};
         A.cone_hdr = P.cone_hdr; A.cone_pairs = P.cone_pairs; A.cone_gather = P.cone_gather; A.cone_ok = P.cone_ok;
@@ -1952,7 +1955,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             const char* ptile = SMM_HOOK("SMMHIP_PERSIST_TILE");   // test hook: "0" never
             const int tile_kind = obj_kind(c->obj);
             // ... and a USER objective in its map-reduce form (smm_register_user_objective_lanes) whose lanes are a whole share of the tile's 512
-            const bool user_tile = user_obj && c->u_lanes > 0 && c->u_lanes <= WG && WG % c->u_lanes == 0 && PT_CT % (WG / c->u_lanes) == 0;
+            const bool user_tile = user_obj && c->u_lanes > 0 && c->u_lanes <= WG && WG % c->u_lanes == 0 && PT_CT % (WG / c->u_lanes) == 0 && !P.mi_pct;   // (compiled for ONE threshold)
             const bool want_persist_tile = (tile_kind == 1 || tile_kind == 2 || user_tile) && !(c->norm_fast && np <= 2 && ns <= WG * PR_ZR) && N == Ng && Ng >= 2 && c->lds_exchange &&
                                            mi_ok && opts->dist_fun == SMM_DIST_MINUS && K <= XLDS_MAX && Ng <= XLDS_MAX && !c->deep_plan &&
                                            !opts->chol_L && P.dbg == 0 && !(pe && pe[0] == '0') && !(ptile && ptile[0] == '0') && P.RW <= PT_LPC * PT_NJ &&
@@ -2247,7 +2250,7 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
             if (N / PG_CT > per_cu * cus) { c->persist = false; c->persist_gen = false; }
         } else if (c->persist_loc) {
             const size_t smem = persist_loc_smem_bytes(np);
-            const void* fn = persist_loc_fn(np, c->persist_wide, c->persist_sh);
+            const void* fn = persist_loc_fn(np, c->persist_wide, c->persist_sh, P.mi_pct != 0);
             HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             int per_cu = 0, cus = 0;
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NORM_WG, smem));
@@ -2264,7 +2267,8 @@ int smm_ctx_create(const smm_problem_t* prob, const smm_bgp_opts_t* opts, const 
                 (void)hipGetLastError();
                 HIPCHK(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, c->utfn, WG, smem));
             } else {
-                const void* fn = kind == 2 ? (const void*)k_chain_persist_tile<2> : (const void*)k_chain_persist_tile<1>;
+                const void* fn = P.mi_pct ? (kind == 2 ? (const void*)k_chain_persist_tile<2, true> : (const void*)k_chain_persist_tile<1, true>)
+                                          : (kind == 2 ? (const void*)k_chain_persist_tile<2> : (const void*)k_chain_persist_tile<1>);
                 HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
                 HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WG, smem));
             }
