@@ -41,7 +41,7 @@ PEAK_HBM_GBS = 8000.0
 WORKLOADS = {
     # 2*nm*ns FP64 adds + ~100 for proposal/objective/accept; 128 B of HBM traffic (state read 40 B + history record 88 B)
     "c2": dict(chains=4096, total=False, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
-               kernel="k_chain_persist_loc<2, false, false>",
+               kernel="k_chain_persist_loc<2, false, false, false>",
                label="serialNormal objfunc_norm 2 params / 2 moments, ns=10000 (BASELINE configs[1])"),
     "c3": dict(chains=32768, total=True, flop=2 * 2 * NS + 100, bytes=128, bound="valu_fp64", peak=PEAK_FP64_ADD_TFLOPS, unit="TFLOP/s",
                kernel="k_chain_iter_norm_narrow_cone<2>",
@@ -54,12 +54,12 @@ WORKLOADS = {
     # 16 x (16 + 64 + 16) = 1536: the first product runs in groups of four fragments), 2048 flop each => 190 464 flop per chain evaluation;
     # the un-padded algorithm is 2*256*50 + 2*256*256 + 2*50*256 = 182 272
     "c5": dict(chains=4096, total=False, flop=1488 * 2048 // 16, useful_flop=2 * 256 * 50 + 2 * 256 * 256 + 2 * 50 * 256, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma",
-               peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_persist_tile<2>", mfma_per_tile=(1488, 1536),
+               peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_persist_tile<2, false>", mfma_per_tile=(1488, 1536),
                label="synthetic dense simulation, 50 params -> 256 hidden units (tanh) -> 256 x 256 matvec -> 256 hidden units (tanh) -> 50 moments on FP64 MFMA, "
                      "4096 chains (BASELINE configs[4] as worded: a 256x256 matvec per evaluation; SMM_OBJ_DENSE2)"),
     # the instance of rounds 2-5 (SMM_OBJ_DENSE, no 256 x 256 stage): 16 x (13 + 16) = 464 credited MFMAs per tile, 59 392 flop per evaluation; un-padded 51 200
     "c5v1": dict(chains=4096, total=False, flop=464 * 2048 // 16, useful_flop=2 * 256 * 50 + 2 * 50 * 256, bytes=(3 * 50 + 50 + 8) * 8, bound="mfma",
-                 peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_persist_tile<2>", mfma_per_tile=(464, 512),
+                 peak=PEAK_FP64_MFMA_TFLOPS, unit="TFLOP/s", kernel="k_chain_persist_tile<2, false>", mfma_per_tile=(464, 512),
                  label="synthetic dense simulation WITHOUT the 256 x 256 stage (SMM_OBJ_DENSE, the instance of rounds 2-5): 50 params -> 256 hidden units (tanh) -> 50 "
                        "moments on FP64 MFMA, 4096 chains"),
 }
@@ -88,10 +88,10 @@ def profile_tag(workload):
 
 
 # the persistent launches + the single iterations at window boundaries, per workload
-CHAIN_KERNELS = {"c2": ("k_chain_persist_loc<2, false, false>", "k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>"),
+CHAIN_KERNELS = {"c2": ("k_chain_persist_loc<2, false, false, false>", "k_chain_persist_loc<2, false, true, false>", "k_chain_persist_norm<2>", "k_chain_iter_norm<2, true>", "k_chain_iter_norm<2, false>"),
                  "c4": ("k_chain_persist_gen", "k_chain_iter<0, 16, 2, true>"),
-                 "c5": ("k_chain_persist_tile<2>", "k_chain_iter<2, 16, 1, true>", "k_chain_iter<2, 16, 1, false>"),
-                 "c5v1": ("k_chain_persist_tile<2>", "k_chain_iter<2, 16, 1, true>", "k_chain_iter<2, 16, 1, false>")}
+                 "c5": ("k_chain_persist_tile<2, false>", "k_chain_iter<2, 16, 1, true>", "k_chain_iter<2, 16, 1, false>"),
+                 "c5v1": ("k_chain_persist_tile<2, false>", "k_chain_iter<2, 16, 1, true>", "k_chain_iter<2, 16, 1, false>")}
 
 
 def _profile_iterations(summary_path, which):
@@ -539,7 +539,7 @@ def main():
         norm_p2p = sharded and protocol == "p2p" and args.workload in ("c2", "c3")
         pinfo = ctx.persistent_info()
         shard_persist = norm_p2p and pinfo[1] > 0     # the shard ran the persistent form: the ring across the windows (smm_chain_persist_loc.hpp)
-        kernel = (W["kernel"] if not sharded else "k_chain_persist_loc<2, false, true>" if shard_persist
+        kernel = (W["kernel"] if not sharded else "k_chain_persist_loc<2, false, true, false>" if shard_persist
                   else "k_chain_iter_norm_p2p<2>" if norm_p2p and n_glob <= 8192      # the walk inline
                   else "k_chain_iter_norm_p2p_rows<2>" if norm_p2p and n_glob <= 32768                       # + k_exch_resolve_rows<., true>
                   else W["kernel"].replace("true", "false"))

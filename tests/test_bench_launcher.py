@@ -74,5 +74,5 @@ def test_two_ranks_on_one_device_take_the_persistent_form():
     cfg = d["config"]
     assert d["n_gpus"] == 2 and cfg["world_seen"] == 2 and cfg["protocol"] == "p2p"
     assert cfg["shard_form"].startswith("persistent"), cfg["shard_form"]
-    assert d["roofline"]["kernel"] == "k_chain_persist_loc<2, false, true>" and d["roofline"]["persistent"]["repairs"] == 0
+    assert d["roofline"]["kernel"] == "k_chain_persist_loc<2, false, true, false>" and d["roofline"]["persistent"]["repairs"] == 0
     assert "0 inconsistent partner marks across 2 rank(s)" in cfg["cross_rank_check"]
