@@ -169,31 +169,37 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
         }
     }
     __syncthreads();  // cnt / ep are free from here on
+    // (two copies of the levels, read from one and written to the other: ONE barrier per sweep; a pair's own level stays in a register)
     uint16_t* lvl = (uint16_t*)ep;          // [K]
+    uint16_t* lvl_b = lvl + K;               // [K]  (ep holds 2K words)
     uint32_t* lhist = cnt;                   // [nlev+1] <= Ng+2 entries
-    for (int q = tid; q < K; q += XWG) lvl[q] = 0;
+    for (int q = tid; q < K; q += XWG) { lvl[q] = 0; lvl_b[q] = 0; }
     __syncthreads();
-    int changed = 1;
-    while (changed) {  // Jacobi sweeps: converges after (number of levels) sweeps
-        int mine = 0;
-        uint16_t nl[MAXPP];
+    {
+        uint16_t own[MAXPP];
 #pragma unroll
-        for (int m = 0; m < MAXPP; ++m) {
-            const int q = tid + m * XWG;
-            nl[m] = 0;
-            if (q < K) {
-                const uint32_t a = prei[m] >= 0 ? lvl[prei[m]] : 0u, b = prej[m] >= 0 ? lvl[prej[m]] : 0u;
-                const bool known = (prei[m] < 0 || a) && (prej[m] < 0 || b);
-                nl[m] = known ? (uint16_t)(1u + (a > b ? a : b)) : (uint16_t)0;
+        for (int m = 0; m < MAXPP; ++m) own[m] = 0;
+        const uint16_t* cur = lvl;
+        uint16_t* nxt = lvl_b;
+        int changed = 1;
+        while (changed) {  // Jacobi sweeps: converges after (number of levels) sweeps
+            int mine = 0;
+#pragma unroll
+            for (int m = 0; m < MAXPP; ++m) {
+                const int q = tid + m * XWG;
+                if (q < K) {
+                    const uint32_t a = prei[m] >= 0 ? cur[prei[m]] : 0u, b = prej[m] >= 0 ? cur[prej[m]] : 0u;
+                    const bool known = (prei[m] < 0 || a) && (prej[m] < 0 || b);
+                    const uint16_t nl = known ? (uint16_t)(1u + (a > b ? a : b)) : (uint16_t)0;
+                    if (nl != own[m]) mine = 1;
+                    own[m] = nl;
+                    nxt[q] = nl;
+                }
             }
+            changed = __syncthreads_or(mine);
+            const uint16_t* x = cur; cur = nxt; nxt = (uint16_t*)x;
         }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < MAXPP; ++m) {
-            const int q = tid + m * XWG;
-            if (q < K && nl[m] != lvl[q]) { lvl[q] = nl[m]; mine = 1; }
-        }
-        changed = __syncthreads_or(mine);
+        // (converged: the last sweep changed nothing, both copies hold the levels; everything below reads lvl)
     }
     if (P.ts && blockIdx.x == 0 && tid == 0) P.ts[(size_t)8 * 60000 + 83] = wall_clock64();
     // counting sort of the pairs by level
@@ -343,14 +349,31 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
 #pragma unroll
             for (int m = 0; m < MAXPP; ++m) {
                 const int q = tid + m * XWG;
-                if (q < K && lvq[m] == l)
-                    for (int w = 0; w < wpp; ++w) {
-                        const uint32_t v = need[(size_t)q * wpp + w];
-                        if (v) {
-                            if (prei[m] >= 0) atomicOr(&need[(size_t)prei[m] * wpp + w], v);
-                            if (prej[m] >= 0) atomicOr(&need[(size_t)prej[m] * wpp + w], v);
+                if (q < K && lvq[m] == l) {
+                    // (the pair's words read together — 16 bytes at a time where the row is whole pieces —, then OR-ed into the predecessors' rows)
+                    uint32_t* ri = prei[m] >= 0 ? &need[(size_t)prei[m] * wpp] : nullptr;
+                    uint32_t* rj = prej[m] >= 0 ? &need[(size_t)prej[m] * wpp] : nullptr;
+                    if ((wpp & 3) == 0) {
+                        for (int w = 0; w < wpp; w += 8) {
+                            const uint4 v0 = *(const uint4*)&need[(size_t)q * wpp + w];
+                            const uint4 v1 = w + 4 < wpp ? *(const uint4*)&need[(size_t)q * wpp + w + 4] : make_uint4(0u, 0u, 0u, 0u);
+                            const uint32_t v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                            for (int x = 0; x < 8; ++x)
+                                if (v[x]) {
+                                    if (ri) atomicOr(&ri[w + x], v[x]);
+                                    if (rj) atomicOr(&rj[w + x], v[x]);
+                                }
                         }
-                    }
+                    } else
+                        for (int w = 0; w < wpp; ++w) {
+                            const uint32_t v = need[(size_t)q * wpp + w];
+                            if (v) {
+                                if (ri) atomicOr(&ri[w], v);
+                                if (rj) atomicOr(&rj[w], v);
+                            }
+                        }
+                }
             }
             __syncthreads();
         }
@@ -398,25 +421,37 @@ __global__ __launch_bounds__(XWG) void k_exch_plan(const KParams P, const int t0
             const int q = tid + m * XWG;
             if (q < K) {
                 const uint32_t word = (sc8 * ci[m]) | ((sc8 * cj[m]) << 16);
+                // (a pair of the first levels is in a hundred cones and its thread walks them one after the other: four cones per trip — their
+                // counters' atomics in flight together, then the stores — instead of one round trip to the LDS per cone)
+                const bool gi = o_gl && rri[m] == 0, gj = o_gl && rrj[m] == 0;
+                const uint32_t ti = ((uint32_t)ci[m] - (uint32_t)P.offset) / ct, tj = ((uint32_t)cj[m] - (uint32_t)P.offset) / ct;
                 for (int w = 0; w < wpp; ++w) {
                     uint32_t bits = need[(size_t)q * wpp + w];
                     while (bits) {
-                        const uint32_t b = (uint32_t)w * 32u + (uint32_t)__builtin_ctz(bits);
-                        bits &= bits - 1u;
-                        const uint32_t dst = atomicAdd(&lcnt[b * LS + lvq[m]], 1u);
-                        if (dst < (uint32_t)(CONE_LEVELS * 64)) o_cp[(size_t)(b0 + b) * (CONE_LEVELS * 64) + dst] = word;
-                        // a chain is in the cones its FIRST pair is in (the bits are monotone along a chain: an earlier pair of the
-                        // chain carries every bit of a later one) — that is where its initial slot is needed
-                        if (o_gl) {
-                            if (rri[m] == 0 && ((uint32_t)ci[m] - (uint32_t)P.offset) / ct != (uint32_t)b0 + b) {
-                                const uint32_t g = atomicAdd(&gcnt[b], 1u);
-                                if (g < (uint32_t)CONE_GCAP) o_gl[(size_t)(b0 + b) * CONE_GCAP + g] = ci[m];
-                            }
-                            if (rrj[m] == 0 && ((uint32_t)cj[m] - (uint32_t)P.offset) / ct != (uint32_t)b0 + b) {
-                                const uint32_t g = atomicAdd(&gcnt[b], 1u);
-                                if (g < (uint32_t)CONE_GCAP) o_gl[(size_t)(b0 + b) * CONE_GCAP + g] = cj[m];
+                        uint32_t bb[4], dst[4], g1[4], g2[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            bb[u] = 0xffffffffu;
+                            if (bits) { bb[u] = (uint32_t)w * 32u + (uint32_t)__builtin_ctz(bits); bits &= bits - 1u; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            dst[u] = 0u; g1[u] = 0xffffffffu; g2[u] = 0xffffffffu;
+                            if (bb[u] != 0xffffffffu) {
+                                dst[u] = atomicAdd(&lcnt[bb[u] * LS + lvq[m]], 1u);
+                                // a chain is in the cones its FIRST pair is in (the bits are monotone along a chain: an earlier pair of the
+                                // chain carries every bit of a later one) — that is where its initial slot is needed
+                                if (gi && ti != (uint32_t)b0 + bb[u]) g1[u] = atomicAdd(&gcnt[bb[u]], 1u);
+                                if (gj && tj != (uint32_t)b0 + bb[u]) g2[u] = atomicAdd(&gcnt[bb[u]], 1u);
                             }
                         }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (bb[u] != 0xffffffffu) {
+                                if (dst[u] < (uint32_t)(CONE_LEVELS * 64)) o_cp[(size_t)(b0 + bb[u]) * (CONE_LEVELS * 64) + dst[u]] = word;
+                                if (g1[u] < (uint32_t)CONE_GCAP) o_gl[(size_t)(b0 + bb[u]) * CONE_GCAP + g1[u]] = ci[m];
+                                if (g2[u] < (uint32_t)CONE_GCAP) o_gl[(size_t)(b0 + bb[u]) * CONE_GCAP + g2[u]] = cj[m];
+                            }
                     }
                 }
             }

@@ -1,7 +1,7 @@
 """The persistent chain kernel of simulation-free objectives (k_chain_persist_gen) against the one-launch-per-iteration kernel on
 BASELINE config 4 (banana, 10 parameters, 8192 chains): us per iteration over K steps of 200, the kernel's in-kernel phase times
 (SMMHIP_TS=1: accumulated wall-clock stamps of wave 0 of every workgroup), and a bit-exact comparison of the two histories.
-  python tools/persist_gen_time.py [steps] [chains] [parameters]"""
+  [PG_INSTANCE=bench] python tools/persist_gen_time.py [steps] [chains] [parameters]"""
 import ctypes as C
 import os
 import sys
@@ -21,8 +21,12 @@ IT = 200
 lib = S._abi.load()
 hist = {}
 for on in (1, 0, 1):
-    prob = S.Problem(init=np.full(NP, 1.2), lb=-2 * np.ones(NP), ub=2 * np.ones(NP), mom=np.zeros(NP), w=np.ones(NP), ns=1, objective_id=A.SMM_OBJ_BANANA)
-    opts = S.BGPOpts(N=N, maxiter=IT * (K + 1), sigma=0.02 * cm.temps(N, 5), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N), seed=3)
+    if os.environ.get("PG_INSTANCE") == "bench":   # bench.py's C4 instance (smm.jl_amd/workloads.py)
+        from smm_jl_amd.workloads import build_problem
+        prob, opts = build_problem("c4", N, N, 0, IT * (K + 1), 0)
+    else:
+      prob = S.Problem(init=np.full(NP, 1.2), lb=-2 * np.ones(NP), ub=2 * np.ones(NP), mom=np.zeros(NP), w=np.ones(NP), ns=1, objective_id=A.SMM_OBJ_BANANA)
+      opts = S.BGPOpts(N=N, maxiter=IT * (K + 1), sigma=0.02 * cm.temps(N, 5), acc_tuner=np.geomspace(20, 1, N), min_improve=np.zeros(N), seed=3)
     ctx = S.hip_context(prob, opts)
     ctx.set_persistent(on)
     ctx.step(IT)
