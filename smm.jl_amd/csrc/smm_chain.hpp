@@ -345,9 +345,7 @@ __device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int
     const int li = lane & 15, lk = lane >> 4;
     const int nPs = (np + 3) / 4, nmp = nOt * 16;
     const g2ptr_t a2 = (g2ptr_t)uniform_ptr(dense_A2f_) + (size_t)wave * 64 * 64 + lane;
-    d2v_t ring[D2_DEPTH];
-#pragma unroll
-    for (int s = 0; s < D2_DEPTH; ++s) ring[s] = a2[s * 64];
+    // (the first product's operands are asked for first: the second product's ring is not looked at before the first barrier)
     double bfr[2][PS];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -355,6 +353,9 @@ __device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int
 #pragma unroll
         for (int s = 0; s < PS; ++s) bfr[tt][s] = bf[(size_t)min(s, nPs - 1) * 64];
     }
+    d2v_t ring[D2_DEPTH];
+#pragma unroll
+    for (int s = 0; s < D2_DEPTH; ++s) ring[s] = a2[s * 64];
     double th[PS];
 #pragma unroll
     for (int s = 0; s < PS; ++s) {
@@ -376,10 +377,24 @@ __device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // h1 stands
     d4_t gacc[2] = {d4_t{0.0, 0.0, 0.0, 0.0}, d4_t{0.0, 0.0, 0.0, 0.0}};
+    // the last product's operands (A's fragments of this wave's two column tiles, out of L2) are requested UNDER the second product, as its ring drains:
+    // asked for where they are used, every group of four matrix instructions waited a round trip to the L2 of its own (eight per evaluation)
+    double afr[2][4][4];
+    auto load_afr = [&](const int tt) {
+        const int T = 2 * wave + tt;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const gptr_t af = dense_Af + ((size_t)(min(o, nOt - 1) * (DENSE_D / 16) + T) * 4) * 64 + lane;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) afr[tt][o][s4] = af[s4 * 64];
+        }
+    };
 #pragma unroll
     for (int s = 0; s < 64; ++s) {
         const d2v_t a = ring[s % D2_DEPTH];
         if (s + D2_DEPTH < 64) ring[s % D2_DEPTH] = a2[(s + D2_DEPTH) * 64];
+        if (s == 64 - D2_DEPTH) load_afr(0);
+        if (s == 64 - D2_DEPTH / 2) load_afr(1);
         const double hb = s_h1[64 * s + lane];
         gacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, hb, gacc[0], 0, 0, 0);
         gacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, hb, gacc[1], 0, 0, 0);
@@ -389,22 +404,23 @@ __device__ __attribute__((noinline)) void dense2_tile_n(const int np_, const int
     for (int o = 0; o < 4; ++o) yacc[o] = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-        const int T = 2 * wave + tt;
-        double afr[4][4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const gptr_t af = dense_Af + ((size_t)(min(o, nOt - 1) * (DENSE_D / 16) + T) * 4) * 64 + lane;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) afr[o][s4] = af[s4 * 64];
-        }
         double h[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = smm_tanh(gacc[tt][r]);
+        // (an accumulator's chain in the contract's order — column tile by column tile, k-step by k-step —, the four moments' chains side by side)
+        if (nOt == 4) {   // (uniform; straight-line code for the full four tiles of moments)
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            if (o < nOt) {
+            for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[o][s4], h[s4], yacc[o], 0, 0, 0);
+                for (int o = 0; o < 4; ++o) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[tt][o][s4], h[s4], yacc[o], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                if (o < nOt) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) yacc[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[tt][o][s4], h[s4], yacc[o], 0, 0, 0);
+                }
             }
         }
     }
